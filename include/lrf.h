@@ -1,0 +1,141 @@
+/* lrf.h -- C ABI of the MI355X-native localrf render path (liblrf_hip.so).
+ *
+ * The reference (facebookresearch/localrf) has no FFI layer: its hot path is a chain of
+ * ATen ops behind two Python call signatures.  This header is the boundary a maintainer
+ * binds instead (ctypes stub in INTEGRATION.md).  Each entry point names the reference
+ * lines (relative to /root/reference/localTensoRF) whose work it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous fp32 (unless typed
+ * otherwise) on the current HIP device; `stream` is a hipStream_t passed as void*;
+ * no allocation, no host synchronisation and no ownership transfer inside the library;
+ * all calls are asynchronous on `stream` and re-entrant per stream.  Return 0 on success,
+ * non-zero on error with a message available from lrf_last_error().
+ */
+#ifndef LRF_H_
+#define LRF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRF_ABI_VERSION 1
+
+/* Fixed shape of the VM field this build is specialised for (opt.py:117-119,155-157:
+ * n_lamb_sigma=[8,8,8], n_lamb_sh=[24,24,24], data_dim_color=27, featureC=128). */
+#define LRF_CD 8      /* density components per plane  */
+#define LRF_CA 24     /* appearance components per plane */
+#define LRF_APP_DIM 27
+#define LRF_FEATC 128
+
+/* flags for lrf_render_fwd / lrf_render_bwd */
+#define LRF_FLAG_WHITE_BG   1u   /* tensorBase.py:633-634 */
+#define LRF_FLAG_RELU_DENS  2u   /* fea2denseAct == "relu" (tensorBase.py:498-499) */
+#define LRF_FLAG_MLP_VALU   4u   /* debug engine: colour MLP on the vector ALU, natural-layout weights */
+
+/* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
+ * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with
+ * W_p = gridSize[matMode[p][0]], H_p = gridSize[matMode[p][1]]; line p is [1,C,L_p,1]
+ * with L_p = gridSize[vecMode[p]]. */
+typedef struct LrfParams {
+  const float* density_plane[3];
+  const float* density_line[3];
+  const float* app_plane[3];
+  const float* app_line[3];
+  const float* basis;      /* basis_mat.weight          [27,72]   */
+  const float* w1;         /* renderModule.mlp.0.weight [128,27]  */
+  const float* b1;         /* renderModule.mlp.0.bias   [128]     */
+  const float* w2;         /* renderModule.mlp.2.weight [128,128] */
+  const float* b2;         /* renderModule.mlp.2.bias   [128]     */
+  const float* w3;         /* renderModule.mlp_view.0.weight [3,131] */
+  const float* b3;         /* renderModule.mlp_view.0.bias   [3]     */
+  int32_t grid[3];         /* gridSize (x,y,z) */
+} LrfParams;
+
+/* Derived, kernel-friendly image of a field ("layout cache").  Built by lrf_pack_field
+ * into caller-owned memory of lrf_cache_bytes() bytes; must be rebuilt whenever a
+ * parameter changes (optimizer step, upsample_volume_grid models/tensoRF.py:224-233). */
+typedef struct LrfField {
+  const void*  cache;      /* device buffer written by lrf_pack_field */
+  const float* alpha_vol;  /* AlphaGridMask.alpha_volume [Z,Y,X] or NULL (tensorBase.py:36-58) */
+  int32_t alpha_dim[3];    /* X,Y,Z of alpha_vol */
+  float   alpha_aabb[6];   /* AlphaGridMask.aabb */
+  float   aabb[6];         /* field aabb (min xyz, max xyz) */
+  int32_t grid[3];
+  float   density_shift;   /* tensorBase.py:497 */
+  float   distance_scale;  /* tensorBase.py:610 */
+  float   weight_thres;    /* rayMarch_weight_thres, tensorBase.py:622 */
+  /* natural-layout MLP weights, used only by the LRF_FLAG_MLP_VALU debug engine */
+  const float* basis; const float* w1; const float* b1;
+  const float* w2; const float* b2; const float* w3; const float* b3;
+} LrfField;
+
+/* Gradients wrt the reference's parameters, in the reference's (state-dict) layout.
+ * Accumulated into (+=); caller zeroes. */
+typedef struct LrfGrads {
+  float* density_plane[3];
+  float* density_line[3];
+  float* app_plane[3];
+  float* app_line[3];
+  float* basis; float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
+} LrfGrads;
+
+int         lrf_abi_version(void);
+const char* lrf_last_error(void);
+
+/* Bytes of the layout cache for a grid (x,y,z). */
+size_t lrf_cache_bytes(const int32_t grid[3]);
+
+/* NCHW params -> channel-last planes/lines + MFMA-fragment-ordered MLP image. */
+int lrf_pack_field(const LrfParams* p, void* cache, void* stream);
+
+/* Bytes of scratch lrf_render_fwd / lrf_render_bwd need for R rays x S samples. */
+size_t lrf_workspace_bytes(int32_t R, int32_t S);
+
+/* TensorBase.forward (tensorBase.py:567-636) for one field, z schedule supplied
+ * (tensorBase.py:419-437 is ray-independent, so the host draws the jitter and keeps RNG
+ * parity).  rays [R,6] = (origin, un-normalised direction); z [S].
+ * Outputs rgb [R,3], depth [R].  Optional debug outputs (may be NULL): weight_out [R,S]
+ * (post floater filter, tensorBase.py:612/620), acc_out [R]. */
+int lrf_render_fwd(const LrfField* f, const float* rays, const float* z,
+                   int32_t R, int32_t S, uint32_t flags, float floater_thresh,
+                   float* rgb, float* depth, float* weight_out, float* acc_out,
+                   void* workspace, void* stream);
+
+/* Measurement variant of lrf_render_fwd (bench.py only): brackets each kernel with HIP
+ * events on `stream`, SYNCHRONISES, and returns ms_out[4] (host) = {march, shade, finalize,
+ * total} plus the number of shaded samples (sum over rays of weight > thres). */
+int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
+                           int32_t R, int32_t S, uint32_t flags, float floater_thresh,
+                           float* rgb, float* depth, void* workspace, void* stream,
+                           float* ms_out, int32_t* n_shaded_out);
+
+/* Backward of lrf_render_fwd (replaces autograd through tensorBase.py:567-636,
+ * tensoRF.py:112-196): recomputes the forward, scatters parameter gradients into `g`
+ * (reference layout) and writes d(loss)/d(rays) [R,6]. floater_thresh must be 0
+ * (the filter is eval-only, train.py:107,139). */
+int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, const float* z,
+                   int32_t R, int32_t S, uint32_t flags,
+                   const float* g_rgb, const float* g_depth,
+                   const LrfGrads* g, float* g_rays,
+                   void* workspace, void* stream);
+
+/* Pieces of the path exposed on their own (unit parity tests; also used by
+ * TensorVMSplit.compute_densityfeature / compute_appfeature / compute_alpha):
+ * u [P,3] are normalised coordinates in [-1,1] (tensorBase.py:342-345). */
+int lrf_density_feature(const LrfField* f, const float* u, int32_t P, float* sigma_feature, void* stream); /* tensoRF.py:112-151 */
+int lrf_app_feature(const LrfField* f, const float* u, int32_t P, float* app_features /*[P,27]*/, void* stream); /* tensoRF.py:153-196 */
+
+/* TensorBase.sample_ray (tensorBase.py:396-417): AABB march named by BASELINE.json's
+ * north_star (not on train.py's path).  jitter [R] or NULL.  Outputs pts [R,N,3],
+ * t [R,N], inside [R,N] (uint8). */
+int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size, float near_, float far_,
+                        const float* jitter, int32_t R, int32_t N,
+                        float* pts, float* t, uint8_t* inside, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRF_H_ */

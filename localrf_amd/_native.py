@@ -1,0 +1,94 @@
+"""ctypes binding of liblrf_hip.so (C ABI in include/lrf.h).
+
+There is no fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblrf_hip.so")
+
+LRF_FLAG_WHITE_BG = 1
+LRF_FLAG_RELU_DENS = 2
+LRF_FLAG_MLP_VALU = 4
+
+_f = C.c_void_p  # device float*
+
+
+class LrfParams(C.Structure):
+    _fields_ = [("density_plane", _f * 3), ("density_line", _f * 3),
+                ("app_plane", _f * 3), ("app_line", _f * 3),
+                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f),
+                ("grid", C.c_int32 * 3)]
+
+
+class LrfField(C.Structure):
+    _fields_ = [("cache", C.c_void_p), ("alpha_vol", _f), ("alpha_dim", C.c_int32 * 3),
+                ("alpha_aabb", C.c_float * 6), ("aabb", C.c_float * 6), ("grid", C.c_int32 * 3),
+                ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
+                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
+
+
+class LrfGrads(C.Structure):
+    _fields_ = [("density_plane", _f * 3), ("density_line", _f * 3),
+                ("app_plane", _f * 3), ("app_line", _f * 3),
+                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
+
+
+# every symbol include/lrf.h declares: (restype, argtypes)
+SYMBOLS = {
+    "lrf_abi_version": (C.c_int, []),
+    "lrf_last_error": (C.c_char_p, []),
+    "lrf_cache_bytes": (C.c_size_t, [C.POINTER(C.c_int32)]),
+    "lrf_pack_field": (C.c_int, [C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),
+    "lrf_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "lrf_render_fwd": (C.c_int, [C.POINTER(LrfField), _f, _f, C.c_int32, C.c_int32, C.c_uint32, C.c_float,
+                                 _f, _f, _f, _f, C.c_void_p, C.c_void_p]),
+    "lrf_render_fwd_profile": (C.c_int, [C.POINTER(LrfField), _f, _f, C.c_int32, C.c_int32, C.c_uint32,
+                                         C.c_float, _f, _f, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "lrf_render_bwd": (C.c_int, [C.POINTER(LrfField), C.POINTER(LrfParams), _f, _f, C.c_int32, C.c_int32,
+                                 C.c_uint32, _f, _f, C.POINTER(LrfGrads), _f, C.c_void_p, C.c_void_p]),
+    "lrf_density_feature": (C.c_int, [C.POINTER(LrfField), _f, C.c_int32, _f, C.c_void_p]),
+    "lrf_app_feature": (C.c_int, [C.POINTER(LrfField), _f, C.c_int32, _f, C.c_void_p]),
+    "lrf_sample_ray_aabb": (C.c_int, [_f, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _f,
+                                      C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"localrf_amd: {LIB_PATH} not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the render path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if h.lrf_abi_version() != 1:
+            raise NativeError("localrf_amd: ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed: {lib().lrf_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "native call needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,190 @@
+// lrf_common.h -- layout of the derived field cache and device helpers shared by the
+// gfx950 kernels.  Geometry helpers restate, per sample, what the reference does with
+// whole-tensor ATen ops (file:line relative to /root/reference/localTensoRF).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lrf.h"
+
+namespace lrf {
+
+// ------------------------------------------------------------------ cache layout
+// Planes are stored channel-last [H][W][C] so one bilinear tap is one contiguous
+// 32 B (density) / 96 B (appearance) read; lines are [L][C].  Offsets are in floats and
+// 64-float aligned.  The MLP image is in MFMA-fragment order (see lrf_mlp_image.h).
+constexpr int MAT0[3] = {0, 0, 1};   // matMode[p][0]  (tensorBase.py:274) -> plane W axis
+constexpr int MAT1[3] = {1, 2, 2};   // matMode[p][1]                      -> plane H axis
+constexpr int VEC[3]  = {2, 1, 0};   // vecMode[p]     (tensorBase.py:275)
+
+// MLP image (floats)
+constexpr int IMG_BAS  = 0;                       // [t'2][p3][lane64][8]  basis_mat, 6 of 8 used
+constexpr int IMG_W1   = IMG_BAS + 2 * 3 * 64 * 8;   // [t'8][t2][lane64][4]
+constexpr int IMG_W2   = IMG_W1 + 8 * 2 * 64 * 4;    // [t'8][t8][lane64][4]
+constexpr int IMG_W3H  = IMG_W2 + 8 * 8 * 64 * 4;    // [g4][f32][4]   mlp_view weight, hidden part
+constexpr int IMG_B1   = IMG_W3H + 4 * 32 * 4;       // [128]
+constexpr int IMG_B2   = IMG_B1 + 128;               // [128]
+constexpr int IMG_W3V  = IMG_B2 + 128;               // [o4][4] = (wx,wy,wz,bias) per colour
+constexpr int IMG_FLOATS = IMG_W3V + 16;             // 24336 floats = 97,344 B
+
+struct Layout {
+  size_t dplane[3], dline[3], aplane[3], aline[3], mlp, total;   // float offsets
+  int pw[3], ph[3], ll[3];
+};
+
+__host__ __device__ inline size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
+
+__host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
+  Layout L;
+  size_t off = 0;
+  for (int p = 0; p < 3; ++p) {
+    L.pw[p] = grid[MAT0[p]]; L.ph[p] = grid[MAT1[p]]; L.ll[p] = grid[VEC[p]];
+  }
+  for (int p = 0; p < 3; ++p) { L.dplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CD); }
+  for (int p = 0; p < 3; ++p) { L.dline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CD); }
+  for (int p = 0; p < 3; ++p) { L.aplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CA); }
+  for (int p = 0; p < 3; ++p) { L.aline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CA); }
+  L.mlp = off; off = align64(off + IMG_FLOATS);
+  L.total = off;
+  return L;
+}
+
+// Device-side view of a field, passed by value to kernels.
+struct DField {
+  const float* dplane[3]; const float* dline[3];
+  const float* aplane[3]; const float* aline[3];
+  const float* mlp;
+  int pw[3], ph[3], ll[3];
+  const float* alpha_vol; int ax, ay, az;
+  float m_lo[3], m_inv[3];     // alpha-mask aabb: lo and 2/size   (tensorBase.py:57-58)
+  float lo[3], inv[3];         // field aabb: lo and 2/size        (tensorBase.py:342-345)
+  float density_shift, distance_scale, weight_thres;
+  const float* basis; const float* w1; const float* b1; const float* w2; const float* b2;
+  const float* w3; const float* b3;
+};
+
+// ------------------------------------------------------------------ geometry
+// utils/ray_utils.py:9-12
+__device__ __forceinline__ void contract3(float& x, float& y, float& z) {
+  float m = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+  m = fmaxf(m, 1e-6f);
+  if (m > 1.0f) {
+    const float s = (2.0f * m - 1.0f) / (m * m);
+    x *= s; y *= s; z *= s;
+  }
+}
+
+// ATen grid_sampler_unnormalize(align_corners=True) + clip_coordinates (border padding):
+// returns the integer base tap and the fractional weight; the +1 tap is index-clamped
+// (its weight is 0 whenever it would fall outside).
+__device__ __forceinline__ void tap1d(float u, int size, int& i0, int& i1, float& t) {
+  float ix = ((u + 1.0f) * 0.5f) * (float)(size - 1);
+  ix = fminf(fmaxf(ix, 0.0f), (float)(size - 1));
+  const float f0 = floorf(ix);
+  t = ix - f0;
+  i0 = (int)f0;
+  i1 = min(i0 + 1, size - 1);
+}
+
+// tensorBase.py:495-499 (torch softplus: beta=1, threshold=20)
+__device__ __forceinline__ float feature2density(float f, float shift, bool relu) {
+  if (relu) return fmaxf(f, 0.0f);
+  const float y = f + shift;
+  return y > 20.0f ? y : log1pf(expf(y));
+}
+
+// F.grid_sample 3-D, zeros padding, align_corners=True (tensorBase.py:51-55)
+__device__ __forceinline__ float alpha_mask_sample(const DField& f, float x, float y, float z) {
+  const float ux = (x - f.m_lo[0]) * f.m_inv[0] - 1.0f;
+  const float uy = (y - f.m_lo[1]) * f.m_inv[1] - 1.0f;
+  const float uz = (z - f.m_lo[2]) * f.m_inv[2] - 1.0f;
+  const float ix = ((ux + 1.0f) * 0.5f) * (float)(f.ax - 1);
+  const float iy = ((uy + 1.0f) * 0.5f) * (float)(f.ay - 1);
+  const float iz = ((uz + 1.0f) * 0.5f) * (float)(f.az - 1);
+  const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  float out = 0.0f;
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+        if (xi >= 0 && xi < f.ax && yi >= 0 && yi < f.ay && zi >= 0 && zi < f.az) {
+          const float w = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
+          out += f.alpha_vol[((size_t)zi * f.ay + yi) * f.ax + xi] * w;
+        }
+      }
+  return out;
+}
+
+// Position of sample with distance zk on ray (o, dhat): tensorBase.py:438-440, then
+// normalize_coord tensorBase.py:342-345.  Returns contracted position in (x,y,z) and
+// the normalised coordinate in u[3].
+__device__ __forceinline__ void sample_point(const DField& f, const float o[3], const float dh[3],
+                                             float zk, float x[3], float u[3]) {
+  x[0] = o[0] + dh[0] * zk; x[1] = o[1] + dh[1] * zk; x[2] = o[2] + dh[2] * zk;
+  contract3(x[0], x[1], x[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) u[a] = (x[a] - f.lo[a]) * f.inv[a] - 1.0f;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+
+// sum_p sum_c bilerp(density_plane_p,c) * lerp(density_line_p,c)   (tensoRF.py:112-151)
+__device__ __forceinline__ float density_feature(const DField& f, const float u[3]) {
+  float feat = 0.0f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    const float* pl = f.dplane[p];
+    const float* q00 = pl + ((size_t)y0 * f.pw[p] + x0) * LRF_CD;
+    const float* q10 = pl + ((size_t)y0 * f.pw[p] + x1) * LRF_CD;
+    const float* q01 = pl + ((size_t)y1 * f.pw[p] + x0) * LRF_CD;
+    const float* q11 = pl + ((size_t)y1 * f.pw[p] + x1) * LRF_CD;
+    const float* r0 = f.dline[p] + (size_t)l0 * LRF_CD;
+    const float* r1 = f.dline[p] + (size_t)l1 * LRF_CD;
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
+    const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
+    const float wl0 = 1.0f - tl, wl1 = tl;
+    float sp = 0.0f;
+#pragma unroll
+    for (int h = 0; h < LRF_CD / 4; ++h) {
+      const float4 a = ld4(q00 + 4 * h), b = ld4(q10 + 4 * h), c = ld4(q01 + 4 * h), d = ld4(q11 + 4 * h);
+      const float4 e = ld4(r0 + 4 * h), g = ld4(r1 + 4 * h);
+      sp += (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + g.x * wl1);
+      sp += (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + g.y * wl1);
+      sp += (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + g.z * wl1);
+      sp += (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + g.w * wl1);
+    }
+    feat += sp;
+  }
+  return feat;
+}
+
+// Inclusive product scan across the 64 lanes of a wave; returns the exclusive product in
+// `excl` and the wave total in `total`.
+__device__ __forceinline__ void wave_scan_prod(float v, int lane, float& excl, float& total) {
+  float p = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(p, d, 64);
+    if (lane >= d) p *= t;
+  }
+  excl = __shfl_up(p, 1, 64);
+  if (lane == 0) excl = 1.0f;
+  total = __shfl(p, 63, 64);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+}  // namespace lrf

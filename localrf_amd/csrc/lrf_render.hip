@@ -1,0 +1,706 @@
+// lrf_render.hip -- gfx950 (MI355X / CDNA4) forward kernels of the localrf render path
+// and the C ABI declared in include/lrf.h.
+//
+// Pipeline of lrf_render_fwd (one field, R rays x S samples):
+//   k_march    one wavefront per ray: contracted sampling, density VM gather (channel-last
+//              planes, 2x float4 per tap), softplus, alpha, wave-level prefix product for
+//              transmittance, acc/depth, floater filter, and in-wave compaction of the
+//              samples that pass weight > thres into per-ray lists + a global work-item
+//              list (ITEM compact samples per item).
+//   k_shade    persistent, one 1024-thread workgroup per CU, the colour network's weights
+//              resident in LDS in MFMA-fragment order.  Each wave pulls items from a device
+//              queue; per 16-sample tile it gathers the 72 appearance products straight
+//              into the B-operand layout of v_mfma_f32_16x16x4_f32 and runs
+//              basis(72->27) -> 128 -> 128 as a register-resident MFMA chain (the D layout
+//              of one layer IS the B layout of the next after a K permutation folded into
+//              the packed weights), the 131->3 head + sigmoid + weighting on the VALU.
+//   k_finalize per-ray ordered sum of item partials + white background (deterministic).
+//
+// Reference lines (relative to /root/reference/localTensoRF) are cited at each step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include "lrf_common.h"
+
+namespace lrf {
+
+constexpr int ITEM = 32;          // compact samples per shade work item (2 MFMA tiles)
+constexpr int ITEM_TILES = ITEM / 16;
+
+thread_local char g_err[512] = "";
+static int set_err(const char* msg, hipError_t e = hipSuccess) {
+  if (e != hipSuccess) snprintf(g_err, sizeof(g_err), "%s: %s", msg, hipGetErrorString(e));
+  else snprintf(g_err, sizeof(g_err), "%s", msg);
+  return 1;
+}
+#define LRF_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(#call, e_); } while (0)
+
+// ---------------------------------------------------------------------------- pack
+// [C,H,W] -> [H,W,C]
+__global__ void k_pack_plane(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= W) return;
+  for (int c = 0; c < C; ++c)
+    dst[((size_t)y * W + x) * C + c] = src[((size_t)c * H + y) * W + x];
+}
+// [C,L] -> [L,C]
+__global__ void k_pack_line(const float* __restrict__ src, float* __restrict__ dst, int C, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * L) return;
+  const int l = i / C, c = i % C;
+  dst[i] = src[(size_t)c * L + l];
+}
+// colour network -> MFMA-fragment-ordered image (see lrf_common.h IMG_*).
+// Fragment lane l = (i = l & 15, g = l >> 4): A operand row 16t'+i, K-slot g.
+__global__ void k_pack_mlp(LrfParams p, float* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= IMG_FLOATS) return;
+  float v = 0.0f;
+  if (idx < IMG_W1) {                       // basis_mat.weight [27,72]   (tensoRF.py:25-27,196)
+    const int e = idx - IMG_BAS;
+    const int j = e & 7, lane = (e >> 3) & 63, tp = e >> 9;          // tp = t'*3 + p
+    const int t1 = tp / 3, pl = tp % 3;
+    const int row = 16 * t1 + (lane & 15), col = pl * LRF_CA + 6 * (lane >> 4) + j;
+    if (row < LRF_APP_DIM && j < 6) v = p.basis[row * 72 + col];
+  } else if (idx < IMG_W2) {                // mlp.0.weight [128,27]      (tensorBase.py:105)
+    const int e = idx - IMG_W1;
+    const int r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;            // tt = t'*2 + t
+    const int t1 = tt >> 1, t0 = tt & 1;
+    const int row = 16 * t1 + (lane & 15), col = 16 * t0 + 4 * (lane >> 4) + r;
+    if (col < LRF_APP_DIM) v = p.w1[row * LRF_APP_DIM + col];
+  } else if (idx < IMG_W3H) {               // mlp.2.weight [128,128]     (tensorBase.py:106)
+    const int e = idx - IMG_W2;
+    const int r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;            // tt = t'*8 + t
+    const int t1 = tt >> 3, t0 = tt & 7;
+    const int row = 16 * t1 + (lane & 15), col = 16 * t0 + 4 * (lane >> 4) + r;
+    v = p.w2[row * LRF_FEATC + col];
+  } else if (idx < IMG_B1) {                // mlp_view.0.weight[:, :128] (tensorBase.py:107)
+    const int e = idx - IMG_W3H;
+    const int o = e & 3, fidx = (e >> 2) & 31, g = e >> 7;
+    const int feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3);
+    if (o < 3) v = p.w3[o * (LRF_FEATC + 3) + feat];
+  } else if (idx < IMG_B2) {
+    v = p.b1[idx - IMG_B1];
+  } else if (idx < IMG_W3V) {
+    v = p.b2[idx - IMG_B2];
+  } else {                                  // view columns + bias of mlp_view.0
+    const int e = idx - IMG_W3V;
+    const int o = e >> 2, c = e & 3;
+    if (o < 3) v = (c < 3) ? p.w3[o * (LRF_FEATC + 3) + LRF_FEATC + c] : p.b3[o];
+  }
+  img[idx] = v;
+}
+
+// --------------------------------------------------------------------------- march
+// One wavefront per ray.  tensorBase.py:576-622 (sampling, density, alpha2weights,
+// acc/depth, floater filter, shading mask).
+__global__ __launch_bounds__(256) void k_march(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
+    uint32_t flags, float floater,
+    float* __restrict__ depth, float* __restrict__ acc_ws, float* __restrict__ w_all,
+    int* __restrict__ ncomp, uint16_t* __restrict__ cidx, float* __restrict__ cw,
+    int2* __restrict__ items, int* __restrict__ counters) {
+  extern __shared__ float s_alpha_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + wave;
+  if (ray >= R) return;
+  float* s_alpha = s_alpha_all + (size_t)wave * S;
+
+  const float* rp = rays + (size_t)ray * 6;
+  const float o[3] = {rp[0], rp[1], rp[2]};
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);      // :578-580
+  const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+  const bool relu = flags & LRF_FLAG_RELU_DENS;
+  const int nchunk = (S + 63) >> 6;
+
+  // pass A: alpha per sample -> LDS
+  for (int c = 0; c < nchunk; ++c) {
+    const int k = (c << 6) + lane;
+    float alpha = 0.0f;
+    if (k < S - 1) {                               // last sample is never valid (:600)
+      const float zk = z[k];
+      float x[3], u[3];
+      sample_point(f, o, dh, zk, x, u);
+      bool valid = true;
+      if (f.alpha_vol) valid = alpha_mask_sample(f, x[0], x[1], x[2]) > 0.0f;   // :593-598
+      if (valid) {
+        const float sigma = feature2density(density_feature(f, u), f.density_shift, relu);  // :603-608
+        const float dist = z[k + 1] - zk;                                          // :584-587
+        alpha = 1.0f - expf(-sigma * dist * f.distance_scale);                     // :610
+      }
+    }
+    if (k < S) s_alpha[k] = alpha;
+  }
+  // (each wave only touches its own LDS slice: no barrier needed, LDS ops are in order per wave)
+
+  float acc = 0.0f, dsum = 0.0f, kbar = 0.0f;
+  int nsh = 0;
+  const int npass = floater > 0.0f ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool emit = (pass == npass - 1);
+    float carry = 1.0f, a_acc = 0.0f, a_d = 0.0f, a_k = 0.0f;
+    for (int c = 0; c < nchunk; ++c) {
+      const int k = (c << 6) + lane;
+      float alpha = 0.0f;
+      if (k < S) {
+        alpha = s_alpha[k];
+        if (pass == 1 && (float)k < kbar * floater) alpha = 0.0f;                  // :617-619
+        if (k == S - 1) alpha = 1.0f;                                               // :24
+      }
+      const float v = (k < S) ? (1.0f - alpha + 1e-10f) : 1.0f;                    // :25-29
+      float excl, total;
+      wave_scan_prod(v, lane, excl, total);
+      const float T = carry * excl;
+      carry *= total;
+      const float w = alpha * T;                                                    // :31
+      if (pass == 0) {
+        a_acc += w;
+        a_d += (k < S) ? w * z[k] : 0.0f;
+        a_k += w * (float)k;
+      }
+      if (emit) {
+        if (w_all && k < S) w_all[(size_t)ray * S + k] = w;
+        const bool sh = (k < S) && (w > f.weight_thres);                            // :622
+        const unsigned long long m = __ballot(sh);
+        if (sh) {
+          const int pos = nsh + __popcll(m & ((1ull << lane) - 1ull));
+          cidx[(size_t)ray * S + pos] = (uint16_t)k;
+          cw[(size_t)ray * S + pos] = w;
+        }
+        nsh += __popcll(m);
+      }
+    }
+    if (pass == 0) {
+      acc = wave_sum(a_acc);                                                        // :614
+      dsum = wave_sum(a_d);
+      kbar = wave_sum(a_k);
+    }
+  }
+  const int nit = (nsh + ITEM - 1) / ITEM;
+  int base = 0;
+  if (lane == 0) {
+    depth[ray] = dsum / dn;                                                         // :615
+    acc_ws[ray] = acc;
+    ncomp[ray] = nsh;
+    if (nit) base = atomicAdd(&counters[0], nit);
+  }
+  base = __shfl(base, 0, 64);
+  if (lane < nit) items[base + lane] = make_int2(ray, lane * ITEM);
+}
+
+// --------------------------------------------------------------------------- shade
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// appearance products for this lane's 6 channels of each plane (tensoRF.py:153-195):
+// lane (s, g) of a tile owns channels 6g..6g+5 of plane p -> K-slot g of MFMA k-step (p, j).
+__device__ __forceinline__ void gather_app6(const DField& f, const float u[3], int g, float X[3][6]) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    const float* pl = f.aplane[p] + 6 * g;
+    const float* q00 = pl + ((size_t)y0 * f.pw[p] + x0) * LRF_CA;
+    const float* q10 = pl + ((size_t)y0 * f.pw[p] + x1) * LRF_CA;
+    const float* q01 = pl + ((size_t)y1 * f.pw[p] + x0) * LRF_CA;
+    const float* q11 = pl + ((size_t)y1 * f.pw[p] + x1) * LRF_CA;
+    const float* r0 = f.aline[p] + (size_t)l0 * LRF_CA + 6 * g;
+    const float* r1 = f.aline[p] + (size_t)l1 * LRF_CA + 6 * g;
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
+    const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
+    const float wl0 = 1.0f - tl, wl1 = tl;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+      const float2 a = ld2(q00 + 2 * h), b = ld2(q10 + 2 * h), c = ld2(q01 + 2 * h), d = ld2(q11 + 2 * h);
+      const float2 e = ld2(r0 + 2 * h), q = ld2(r1 + 2 * h);
+      X[p][2 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
+      X[p][2 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_shade(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int2* __restrict__ items, int* __restrict__ counters,
+    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
+    float* __restrict__ part, int pmax) {
+  __shared__ __attribute__((aligned(16))) float img[IMG_FLOATS];
+  {
+    const float4* src = reinterpret_cast<const float4*>(f.mlp);
+    float4* dst = reinterpret_cast<float4*>(img);
+    for (int i = threadIdx.x; i < IMG_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  const int n_items = counters[0];
+
+  for (;;) {
+    int it = 0;
+    if (lane == 0) it = atomicAdd(&counters[1], 1);
+    it = __builtin_amdgcn_readfirstlane(it);
+    if (it >= n_items) break;
+    const int2 d = items[it];
+    const int ray = __builtin_amdgcn_readfirstlane(d.x);
+    const int j0 = __builtin_amdgcn_readfirstlane(d.y);
+    const int cnt = min(ITEM, ncomp[ray] - j0);
+
+    const float* rp = rays + (size_t)ray * 6;
+    const float o[3] = {rp[0], rp[1], rp[2]};
+    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+    // view-direction part of mlp_view.0 + bias: constant per ray (tensorBase.py:131-132;
+    // viewdirs detached :628)
+    float vb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 wv = *reinterpret_cast<const float4*>(&img[IMG_W3V + 4 * c]);
+      vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
+    }
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+
+    for (int tile = 0; tile < ITEM_TILES; ++tile) {
+      if (tile * 16 >= cnt) break;
+      const int jj = tile * 16 + s;
+      const bool valid = jj < cnt;
+      const size_t ci = (size_t)ray * S + j0 + (valid ? jj : 0);
+      const int k = cidx[ci];
+      const float w = valid ? cw[ci] : 0.0f;
+      float x[3], u[3];
+      sample_point(f, o, dh, z[k], x, u);
+      float X[3][6];
+      gather_app6(f, u, g, X);
+
+      // basis: feat = basis_mat.weight @ (plane*line)            (tensoRF.py:196)
+      f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1) {
+          const float* ap = &img[IMG_BAS + ((t1 * 3 + p) * 64 + lane) * 8];
+          const float4 a0 = *reinterpret_cast<const float4*>(ap);
+          const float2 a1 = *reinterpret_cast<const float2*>(ap + 4);
+          fe[t1] = mfma4(a0.x, X[p][0], fe[t1]);
+          fe[t1] = mfma4(a0.y, X[p][1], fe[t1]);
+          fe[t1] = mfma4(a0.z, X[p][2], fe[t1]);
+          fe[t1] = mfma4(a0.w, X[p][3], fe[t1]);
+          fe[t1] = mfma4(a1.x, X[p][4], fe[t1]);
+          fe[t1] = mfma4(a1.y, X[p][5], fe[t1]);
+        }
+      }
+      // layer 1: relu(W1 feat + b1)                               (tensorBase.py:129-130)
+      f32x4 h1[8];
+#pragma unroll
+      for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&img[IMG_B1 + 16 * t1 + 4 * g]);
+#pragma unroll
+      for (int t0 = 0; t0 < 2; ++t0) {
+#pragma unroll
+        for (int t1 = 0; t1 < 8; ++t1) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMG_W1 + ((t1 * 2 + t0) * 64 + lane) * 4]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h1[t1] = mfma4(a[r], fe[t0][r], h1[t1]);
+        }
+      }
+#pragma unroll
+      for (int t1 = 0; t1 < 8; ++t1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
+      // layer 2: relu(W2 h1 + b2)
+      f32x4 h2[8];
+#pragma unroll
+      for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&img[IMG_B2 + 16 * t1 + 4 * g]);
+#pragma unroll
+      for (int t0 = 0; t0 < 8; ++t0) {
+#pragma unroll
+        for (int t1 = 0; t1 < 8; ++t1) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMG_W2 + ((t1 * 8 + t0) * 64 + lane) * 4]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[t1] = mfma4(a[r], h1[t0][r], h2[t1]);
+        }
+      }
+      // head: sigmoid(W3 [h2 ; dhat] + b3) on the VALU            (tensorBase.py:131-133)
+      float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+      for (int t1 = 0; t1 < 8; ++t1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = fmaxf(h2[t1][r], 0.0f);
+          const float4 wv = *reinterpret_cast<const float4*>(&img[IMG_W3H + (g * 32 + t1 * 4 + r) * 4]);
+          o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
+        }
+      o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+      o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+      float cr = w / (1.0f + expf(-(o0 + vb[0])));                 // :133, :632
+      float cg = w / (1.0f + expf(-(o1 + vb[1])));
+      float cb = w / (1.0f + expf(-(o2 + vb[2])));
+#pragma unroll
+      for (int dd = 1; dd < 16; dd <<= 1) {
+        cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
+      }
+      acc_r += cr; acc_g += cg; acc_b += cb;
+    }
+    if (lane == 0) {
+      float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
+      pp[0] = acc_r; pp[1] = acc_g; pp[2] = acc_b;
+    }
+  }
+}
+
+// Debug engine (LRF_FLAG_MLP_VALU): same work list, one lane per compact sample,
+// natural-layout weights from global memory, plain loops.  Slow by design; exists so a
+// parity failure can be bisected between the gather/compositing and the MFMA chain.
+__global__ __launch_bounds__(64) void k_shade_valu(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int2* __restrict__ items, const int* __restrict__ counters,
+    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
+    float* __restrict__ part, int pmax) {
+  const int it = blockIdx.x;
+  if (it >= counters[0]) return;
+  const int lane = threadIdx.x;
+  const int2 d = items[it];
+  const int ray = d.x, j0 = d.y;
+  const int cnt = min(ITEM, ncomp[ray] - j0);
+  const float* rp = rays + (size_t)ray * 6;
+  const float o[3] = {rp[0], rp[1], rp[2]};
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+  const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+  float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+  if (lane < cnt) {
+    const size_t ci = (size_t)ray * S + j0 + lane;
+    const int k = cidx[ci];
+    const float w = cw[ci];
+    float x[3], u[3];
+    sample_point(f, o, dh, z[k], x, u);
+    float X[72];
+    for (int p = 0; p < 3; ++p) {
+      int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+      tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+      tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+      tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+      const float* pl = f.aplane[p];
+      for (int c = 0; c < LRF_CA; ++c) {
+        const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * (1.0f - ty))
+                      + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CA + c] * (tx * (1.0f - ty))
+                      + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * ty)
+                      + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CA + c] * (tx * ty);
+        const float l = f.aline[p][(size_t)l0 * LRF_CA + c] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CA + c] * tl;
+        X[p * LRF_CA + c] = v * l;
+      }
+    }
+    float fe[LRF_APP_DIM];
+    for (int i = 0; i < LRF_APP_DIM; ++i) {
+      float a = 0.0f;
+      for (int c = 0; c < 72; ++c) a += f.basis[i * 72 + c] * X[c];
+      fe[i] = a;
+    }
+    float h1[LRF_FEATC], h2[LRF_FEATC];
+    for (int i = 0; i < LRF_FEATC; ++i) {
+      float a = f.b1[i];
+      for (int c = 0; c < LRF_APP_DIM; ++c) a += f.w1[i * LRF_APP_DIM + c] * fe[c];
+      h1[i] = fmaxf(a, 0.0f);
+    }
+    for (int i = 0; i < LRF_FEATC; ++i) {
+      float a = f.b2[i];
+      for (int c = 0; c < LRF_FEATC; ++c) a += f.w2[i * LRF_FEATC + c] * h1[c];
+      h2[i] = fmaxf(a, 0.0f);
+    }
+    float oo[3];
+    for (int i = 0; i < 3; ++i) {
+      float a = f.b3[i];
+      for (int c = 0; c < LRF_FEATC; ++c) a += f.w3[i * (LRF_FEATC + 3) + c] * h2[c];
+      for (int c = 0; c < 3; ++c) a += f.w3[i * (LRF_FEATC + 3) + LRF_FEATC + c] * dh[c];
+      oo[i] = w / (1.0f + expf(-a));
+    }
+    cr = oo[0]; cg = oo[1]; cb = oo[2];
+  }
+  cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb);
+  if (lane == 0) {
+    float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
+    pp[0] = cr; pp[1] = cg; pp[2] = cb;
+  }
+}
+
+// rgb_map = sum_k w_k rgb_k (+ 1 - acc)                        (tensorBase.py:632-634)
+__global__ void k_finalize(int R, int pmax, uint32_t flags, const int* __restrict__ ncomp,
+                           const float* __restrict__ acc, const float* __restrict__ part,
+                           float* __restrict__ rgb, float* __restrict__ acc_out) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= R) return;
+  const int nit = (ncomp[ray] + ITEM - 1) / ITEM;
+  float r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int i = 0; i < nit; ++i) {
+    const float* pp = part + ((size_t)ray * pmax + i) * 3;
+    r += pp[0]; g += pp[1]; b += pp[2];
+  }
+  if (flags & LRF_FLAG_WHITE_BG) {
+    const float bg = 1.0f - acc[ray];
+    r += bg; g += bg; b += bg;
+  }
+  rgb[(size_t)ray * 3 + 0] = r; rgb[(size_t)ray * 3 + 1] = g; rgb[(size_t)ray * 3 + 2] = b;
+  if (acc_out) acc_out[ray] = acc[ray];
+}
+
+// ----------------------------------------------------------------- stand-alone pieces
+__global__ void k_density_feature(DField f, const float* __restrict__ u, int P, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float uu[3] = {u[(size_t)i * 3], u[(size_t)i * 3 + 1], u[(size_t)i * 3 + 2]};
+  out[i] = density_feature(f, uu);
+}
+
+__global__ void k_app_feature(DField f, const float* __restrict__ u, int P, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float uu[3] = {u[(size_t)i * 3], u[(size_t)i * 3 + 1], u[(size_t)i * 3 + 2]};
+  float acc[LRF_APP_DIM];
+  for (int a = 0; a < LRF_APP_DIM; ++a) acc[a] = 0.0f;
+  for (int p = 0; p < 3; ++p) {
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(uu[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(uu[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(uu[VEC[p]],  f.ll[p], l0, l1, tl);
+    const float* pl = f.aplane[p];
+    for (int c = 0; c < LRF_CA; ++c) {
+      const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * (1.0f - ty))
+                    + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CA + c] * (tx * (1.0f - ty))
+                    + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * ty)
+                    + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CA + c] * (tx * ty);
+      const float l = f.aline[p][(size_t)l0 * LRF_CA + c] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CA + c] * tl;
+      const float xv = v * l;
+      for (int a = 0; a < LRF_APP_DIM; ++a) acc[a] += f.basis[a * 72 + p * LRF_CA + c] * xv;
+    }
+  }
+  for (int a = 0; a < LRF_APP_DIM; ++a) out[(size_t)i * LRF_APP_DIM + a] = acc[a];
+}
+
+// tensorBase.py:396-417
+__global__ void k_sample_ray_aabb(const float* __restrict__ rays, float lo0, float lo1, float lo2,
+                                  float hi0, float hi1, float hi2, float step, float near_, float far_,
+                                  const float* __restrict__ jitter, int R, int N,
+                                  float* __restrict__ pts, float* __restrict__ tt, uint8_t* __restrict__ inside) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * N) return;
+  const int ray = (int)(i / N), k = (int)(i % N);
+  const float* rp = rays + (size_t)ray * 6;
+  const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+  float tmin = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float v = rp[3 + a] == 0.0f ? 1e-6f : rp[3 + a];
+    const float ra = (hi[a] - rp[a]) / v, rb = (lo[a] - rp[a]) / v;
+    tmin = fmaxf(tmin, fminf(ra, rb));
+  }
+  tmin = fminf(fmaxf(tmin, near_), far_);
+  float rng = (float)k;
+  if (jitter) rng += jitter[ray];
+  const float t = tmin + step * rng;
+  bool in = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float pv = rp[a] + rp[3 + a] * t;
+    pts[i * 3 + a] = pv;
+    in = in && !(lo[a] > pv) && !(pv > hi[a]);
+  }
+  tt[i] = t;
+  inside[i] = in ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------- host side
+static DField make_dfield(const LrfField* f) {
+  DField d;
+  const Layout L = make_layout(f->grid);
+  const float* base = reinterpret_cast<const float*>(f->cache);
+  for (int p = 0; p < 3; ++p) {
+    d.dplane[p] = base + L.dplane[p]; d.dline[p] = base + L.dline[p];
+    d.aplane[p] = base + L.aplane[p]; d.aline[p] = base + L.aline[p];
+    d.pw[p] = L.pw[p]; d.ph[p] = L.ph[p]; d.ll[p] = L.ll[p];
+  }
+  d.mlp = base + L.mlp;
+  d.alpha_vol = f->alpha_vol;
+  d.ax = f->alpha_dim[0]; d.ay = f->alpha_dim[1]; d.az = f->alpha_dim[2];
+  for (int a = 0; a < 3; ++a) {
+    d.lo[a] = f->aabb[a];
+    d.inv[a] = 2.0f / (f->aabb[3 + a] - f->aabb[a]);                      // tensorBase.py:321
+    d.m_lo[a] = f->alpha_aabb[a];
+    d.m_inv[a] = 1.0f / (f->alpha_aabb[3 + a] - f->alpha_aabb[a]) * 2.0f;  // tensorBase.py:44
+  }
+  d.density_shift = f->density_shift; d.distance_scale = f->distance_scale; d.weight_thres = f->weight_thres;
+  d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
+  return d;
+}
+
+struct Workspace {
+  int* counters; int* ncomp; float* acc; uint16_t* cidx; float* cw; int2* items; float* part;
+  int pmax; size_t bytes;
+};
+static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
+static Workspace carve(void* ws, int R, int S) {
+  Workspace w;
+  char* p = reinterpret_cast<char*>(ws);
+  size_t off = 0;
+  w.pmax = (S + ITEM - 1) / ITEM;
+  w.counters = reinterpret_cast<int*>(p + off);       off += 256;
+  w.ncomp    = reinterpret_cast<int*>(p + off);       off += up256((size_t)R * 4);
+  w.acc      = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 4);
+  w.cidx     = reinterpret_cast<uint16_t*>(p + off);  off += up256((size_t)R * S * 2);
+  w.cw       = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
+  w.items    = reinterpret_cast<int2*>(p + off);      off += up256((size_t)R * w.pmax * 8);
+  w.part     = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
+  w.bytes = off;
+  return w;
+}
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+}  // namespace lrf
+
+using namespace lrf;
+
+extern "C" {
+
+int lrf_abi_version(void) { return LRF_ABI_VERSION; }
+const char* lrf_last_error(void) { return g_err; }
+
+size_t lrf_cache_bytes(const int32_t grid[3]) { return make_layout(grid).total * sizeof(float); }
+
+int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
+  if (!p || !cache) return set_err("lrf_pack_field: null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const Layout L = make_layout(p->grid);
+  float* base = reinterpret_cast<float*>(cache);
+  for (int q = 0; q < 3; ++q) {
+    dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
+    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->density_plane[q], base + L.dplane[q], LRF_CD, L.ph[q], L.pw[q]);
+    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->app_plane[q], base + L.aplane[q], LRF_CA, L.ph[q], L.pw[q]);
+    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, p->density_line[q], base + L.dline[q], LRF_CD, L.ll[q]);
+    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, p->app_line[q], base + L.aline[q], LRF_CA, L.ll[q]);
+  }
+  hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+size_t lrf_workspace_bytes(int32_t R, int32_t S) {
+  return carve(nullptr, R, S).bytes;
+}
+
+static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                           uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                           float* weight_out, float* acc_out, void* workspace, hipStream_t st,
+                           hipEvent_t* ev /* 4 events or null */) {
+  if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
+  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
+  const DField d = make_dfield(f);
+  const Workspace w = carve(workspace, R, S);
+  LRF_HIP(hipMemsetAsync(w.counters, 0, 256, st));
+  if (ev) LRF_HIP(hipEventRecord(ev[0], st));
+  hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
+                     d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out,
+                     w.ncomp, w.cidx, w.cw, w.items, w.counters);
+  if (ev) LRF_HIP(hipEventRecord(ev[1], st));
+  if (flags & LRF_FLAG_MLP_VALU) {
+    hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st,
+                       d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+  } else {
+    const int wgs = device_cus();
+    hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(1024), 0, st,
+                       d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+  }
+  if (ev) LRF_HIP(hipEventRecord(ev[2], st));
+  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
+                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, acc_out);
+  if (ev) LRF_HIP(hipEventRecord(ev[3], st));
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+int lrf_render_fwd(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                   uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                   float* weight_out, float* acc_out, void* workspace, void* stream) {
+  return render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out,
+                         workspace, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                           uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                           void* workspace, void* stream, float* ms_out, int32_t* n_shaded_out) {
+  if (!ms_out) return set_err("lrf_render_fwd_profile: null ms_out");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; ++i) LRF_HIP(hipEventCreate(&ev[i]));
+  int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, nullptr, nullptr, workspace, st, ev);
+  if (rc == 0) {
+    hipError_t e = hipEventSynchronize(ev[3]);
+    if (e != hipSuccess) rc = set_err("hipEventSynchronize", e);
+  }
+  if (rc == 0) {
+    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+    (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
+    if (n_shaded_out) {
+      // shaded-sample count of this batch = sum of ncomp (host copy; measurement only)
+      const Workspace w = carve(workspace, R, S);
+      int* h = (int*)malloc((size_t)R * sizeof(int));
+      if (h && hipMemcpy(h, w.ncomp, (size_t)R * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+        long long tot = 0; for (int i = 0; i < R; ++i) tot += h[i];
+        *n_shaded_out = (int32_t)tot;
+      }
+      free(h);
+    }
+  }
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+  return rc;
+}
+
+int lrf_render_bwd(const LrfField*, const LrfParams*, const float*, const float*, int32_t, int32_t, uint32_t,
+                   const float*, const float*, const LrfGrads*, float*, void*, void*) {
+  return set_err("lrf_render_bwd: not implemented in this build");
+}
+
+int lrf_density_feature(const LrfField* f, const float* u, int32_t P, float* out, void* stream) {
+  if (!f || !f->cache || !u || !out) return set_err("lrf_density_feature: null argument");
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_density_feature, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     make_dfield(f), u, P, out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+int lrf_app_feature(const LrfField* f, const float* u, int32_t P, float* out, void* stream) {
+  if (!f || !f->cache || !u || !out || !f->basis) return set_err("lrf_app_feature: null argument");
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(k_app_feature, dim3((P + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
+                     make_dfield(f), u, P, out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size, float near_, float far_,
+                        const float* jitter, int32_t R, int32_t N, float* pts, float* t, uint8_t* inside,
+                        void* stream) {
+  if (!rays || !aabb || !pts || !t || !inside) return set_err("lrf_sample_ray_aabb: null argument");
+  const size_t n = (size_t)R * N;
+  if (!n) return 0;
+  hipLaunchKernelGGL(k_sample_ray_aabb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     rays, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], step_size, near_, far_,
+                     jitter, R, N, pts, t, inside);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

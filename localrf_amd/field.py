@@ -1,0 +1,542 @@
+"""TensorVMSplit -- one VM-decomposed radiance field, MI355X-native.
+
+Drop-in for the reference's `models.tensoRF.TensorVMSplit` (+ `models.tensorBase.TensorBase`,
+`AlphaGridMask`, `MLPRender_Fea_late_view`): same constructor arguments and defaults, same
+parameter names / shapes / creation order (so `torch.manual_seed(s)` yields the same field
+and reference checkpoints load with `load_state_dict`), same `forward` signature and
+return tuple.  Behind `forward` the work of tensorBase.py:567-636 + tensoRF.py:112-196 is
+done by hand-written HIP kernels (csrc/lrf_render.hip, csrc/lrf_backward.hip) called
+through the C ABI in include/lrf.h.  There is no PyTorch/CPU fallback for that path: a
+missing library or a non-GPU tensor raises.
+
+Cited lines are relative to /root/reference/localTensoRF.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]     # tensorBase.py:274
+VEC_MODE = [2, 1, 0]                    # tensorBase.py:275
+
+
+class AlphaGridMask(torch.nn.Module):
+    """Binary occupancy volume used to skip empty samples (tensorBase.py:38-62).  The
+    lookup on the render path is fused into the march kernel; `sample_alpha` here serves
+    the mask-rebuild row."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = torch.nn.Parameter(aabb.to(device), requires_grad=False)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = torch.nn.Parameter(1.0 / self.aabbSize * 2, requires_grad=False)
+        self.alpha_volume = torch.nn.Parameter(
+            alpha_volume.view(1, 1, *alpha_volume.shape[-3:]), requires_grad=False)
+        self.gridSize = torch.LongTensor(
+            [alpha_volume.shape[-1], alpha_volume.shape[-2], alpha_volume.shape[-3]]).to(device)
+
+    def normalize_coord(self, xyz):
+        return (xyz - self.aabb[0]) * self.invgridSize - 1
+
+    def sample_alpha(self, xyz):
+        g = self.normalize_coord(xyz).view(1, -1, 1, 1, 3)
+        return F.grid_sample(self.alpha_volume, g, align_corners=True).view(-1)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return super().to(device)
+
+
+class MLPRender_Fea_late_view(torch.nn.Module):
+    """Parameter container of the late-view colour network (tensorBase.py:97-113):
+    27 -> 128 -> 128 (+3 view) -> 3.  Its arithmetic runs inside k_shade as an MFMA chain."""
+
+    def __init__(self, inChanel, viewpe=0, feape=0, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * feape * inChanel + inChanel
+        self.in_view = 2 * viewpe * 3 + 3
+        self.viewpe, self.feape = viewpe, feape
+        l1 = torch.nn.Linear(self.in_mlpC, featureC)
+        l2 = torch.nn.Linear(featureC, featureC)
+        l3 = torch.nn.Linear(featureC + self.in_view, 3)
+        self.mlp = torch.nn.Sequential(l1, torch.nn.ReLU(inplace=True), l2, torch.nn.ReLU(inplace=True))
+        self.mlp_view = torch.nn.Sequential(l3)
+        torch.nn.init.constant_(self.mlp_view[-1].bias, 0)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("MLPRender_Fea_late_view is evaluated inside the fused HIP render "
+                           "kernel (lrf_render_fwd); call TensorVMSplit.forward")
+
+
+class _RenderFn(torch.autograd.Function):
+    """Seam between autograd and the C ABI: lrf_render_fwd / lrf_render_bwd."""
+
+    @staticmethod
+    def forward(ctx, field, rays, z, flags, floater, *params):
+        rgb, depth = field._native_forward(rays, z, flags, floater)
+        ctx.field, ctx.flags = field, flags
+        ctx.save_for_backward(rays, z)
+        return rgb, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth):
+        rays, z = ctx.saved_tensors
+        g_rays, g_params = ctx.field._native_backward(rays, z, ctx.flags, g_rgb, g_depth)
+        return (None, g_rays, None, None, None) + tuple(g_params)
+
+
+class TensorVMSplit(torch.nn.Module):
+    # constructor signature and defaults: tensorBase.py:236-257, tensoRF.py:10-12
+    def __init__(self, device, aabb, gridSize, density_n_comp=8, appearance_n_comp=24, app_dim=27,
+                 shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10,
+                 alphaMask_thres=0.001, distance_scale=25, rayMarch_weight_thres=0.001,
+                 pos_pe=6, view_pe=6, fea_pe=6, featureC=128, step_ratio=2.0,
+                 fea2denseAct="softplus"):
+        super().__init__()
+        if isinstance(density_n_comp, int):
+            density_n_comp = [density_n_comp] * 3
+        if isinstance(appearance_n_comp, int):
+            appearance_n_comp = [appearance_n_comp] * 3
+        self.density_n_comp = list(density_n_comp)
+        self.app_n_comp = list(appearance_n_comp)
+        self.app_dim = app_dim
+        self.aabb = torch.nn.Parameter(aabb, requires_grad=False)
+        self.alphaMask = alphaMask
+        self.device = device
+        self.density_shift = density_shift
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.fea2denseAct = fea2denseAct
+        self.near_far = list(near_far)
+        self.step_ratio = step_ratio
+        self.matMode, self.vecMode = MAT_MODE, VEC_MODE
+        self.comp_w = [1, 1, 1]
+        self._check_supported(shadingMode, pos_pe, view_pe, fea_pe, featureC)
+        self.update_stepSize(list(gridSize))
+        self.init_svd_volume(list(gridSize), device)
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = (
+            shadingMode, pos_pe, view_pe, fea_pe, featureC)
+        self.renderModule = MLPRender_Fea_late_view(app_dim, view_pe, fea_pe, featureC).to(device)
+        # native-side state (derived; never stored in checkpoints)
+        self._cache = None
+        self._cache_key = None
+        self._ws = None
+        self.mlp_engine = "mfma"        # "mfma" | "valu" (debug engine, LRF_FLAG_MLP_VALU)
+        self.z_override = None          # tests: inject a recorded z schedule
+
+    # ------------------------------------------------------------------ construction
+    def _check_supported(self, shadingMode, pos_pe, view_pe, fea_pe, featureC):
+        """This build specialises the kernels to the configuration train.py runs
+        (opt.py:117-119,148-157).  Anything else fails loudly instead of falling back."""
+        bad = []
+        if shadingMode != "MLP_Fea_late_view":
+            bad.append(f"shadingMode={shadingMode!r} (only 'MLP_Fea_late_view' is live in the "
+                       "reference: tensorBase.py:627-629 passes 4 arguments)")
+        if self.density_n_comp != [8, 8, 8] or self.app_n_comp != [24, 24, 24]:
+            bad.append(f"n_comp {self.density_n_comp}/{self.app_n_comp} (built for [8,8,8]/[24,24,24])")
+        if self.app_dim != 27 or featureC != 128:
+            bad.append(f"app_dim={self.app_dim}, featureC={featureC} (built for 27/128)")
+        if view_pe != 0 or fea_pe != 0:
+            bad.append(f"view_pe={view_pe}, fea_pe={fea_pe} (built for 0/0, the opt.py defaults)")
+        if self.fea2denseAct not in ("softplus", "relu"):
+            bad.append(f"fea2denseAct={self.fea2denseAct!r}")
+        if bad:
+            raise NotImplementedError("localrf_amd.TensorVMSplit: unsupported " + "; ".join(bad))
+
+    def update_stepSize(self, gridSize):
+        """tensorBase.py:317-330 (without the prints)."""
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = torch.nn.Parameter(2.0 / self.aabbSize, requires_grad=False)
+        self.gridSize = torch.LongTensor(gridSize).to(self.device)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+
+    def init_svd_volume(self, res, device):
+        """tensoRF.py:18-50: 0.1*randn planes [1,C,g[m1],g[m0]] and lines [1,C,g[v],1],
+        drawn on the CPU generator in the reference's order, then the 72->27 basis."""
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, res, 0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, res, 0.1, device)
+        self.basis_mat = torch.nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        planes, lines = [], []
+        for i in range(3):
+            m0, m1 = self.matMode[i]
+            planes.append(torch.nn.Parameter(
+                scale * torch.randn((1, n_component[i], gridSize[m1], gridSize[m0]))))
+            lines.append(torch.nn.Parameter(
+                scale * torch.randn((1, n_component[i], gridSize[self.vecMode[i]], 1))))
+        return torch.nn.ParameterList(planes).to(device), torch.nn.ParameterList(lines).to(device)
+
+    # ------------------------------------------------------------------ bookkeeping
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        """tensoRF.py:52-64 (group order is read by index at train.py:480,485)."""
+        return [
+            {"params": self.density_line, "lr": lr_init_spatialxyz},
+            {"params": self.density_plane, "lr": lr_init_spatialxyz},
+            {"params": self.app_line, "lr": lr_init_spatialxyz},
+            {"params": self.app_plane, "lr": lr_init_spatialxyz},
+            {"params": self.basis_mat.parameters(), "lr": lr_init_network},
+            {"params": self.renderModule.parameters(), "lr": lr_init_network},
+        ]
+
+    def get_kwargs(self):
+        """tensorBase.py:350-369."""
+        return {
+            "aabb": self.aabb, "gridSize": self.gridSize.tolist(),
+            "density_n_comp": self.density_n_comp, "appearance_n_comp": self.app_n_comp,
+            "app_dim": self.app_dim, "density_shift": self.density_shift,
+            "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
+            "rayMarch_weight_thres": self.rayMarch_weight_thres,
+            "fea2denseAct": self.fea2denseAct, "near_far": self.near_far,
+            "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
+            "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe,
+            "featureC": self.featureC,
+        }
+
+    def to(self, device):
+        """tensorBase.py:560-565."""
+        self.device = torch.device(device)
+        self.stepSize = self.stepSize.to(device)
+        self.gridSize = self.gridSize.to(device)
+        if self.alphaMask is not None:
+            self.alphaMask = self.alphaMask.to(device)
+        self._cache = self._cache_key = self._ws = None
+        return super().to(device)
+
+    def normalize_coord(self, xyz):
+        """tensorBase.py:342-345."""
+        return (xyz - self.aabb[0]) * self.invaabbSize - 1
+
+    # ------------------------------------------------------------------ native plumbing
+    def _param_list(self):
+        rm = self.renderModule
+        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane)
+                + list(self.app_line)
+                + [self.basis_mat.weight, rm.mlp[0].weight, rm.mlp[0].bias, rm.mlp[2].weight,
+                   rm.mlp[2].bias, rm.mlp_view[0].weight, rm.mlp_view[0].bias])
+
+    def _require_gpu(self, t):
+        if not t.is_cuda:
+            raise N.NativeError(
+                "localrf_amd: the render path runs only on an AMD GPU (HIP kernels); got a "
+                f"{t.device} tensor. There is no CPU fallback.")
+
+    def _c_params(self):
+        ps = [p.detach() for p in self._param_list()]
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise N.NativeError("localrf_amd: parameters must be contiguous fp32")
+        cp = N.LrfParams()
+        for i in range(3):
+            cp.density_plane[i] = ps[i].data_ptr()
+            cp.density_line[i] = ps[3 + i].data_ptr()
+            cp.app_plane[i] = ps[6 + i].data_ptr()
+            cp.app_line[i] = ps[9 + i].data_ptr()
+        (cp.basis, cp.w1, cp.b1, cp.w2, cp.b2, cp.w3, cp.b3) = [p.data_ptr() for p in ps[12:]]
+        g = [int(v) for v in self.gridSize.tolist()]
+        cp.grid[:] = g
+        return cp, ps
+
+    def _ensure_cache(self):
+        """(Re)build the channel-last / fragment-ordered layout cache when any parameter
+        changed (optimizer step, upsample tensoRF.py:224-233, load_state_dict, .to())."""
+        lib = N.lib()
+        ps = self._param_list()
+        key = tuple((p.data_ptr(), p._version) for p in ps) + tuple(self.gridSize.tolist())
+        if self._cache is not None and key == self._cache_key:
+            return
+        cp, keep = self._c_params()
+        nbytes = lib.lrf_cache_bytes(cp.grid)
+        dev = ps[0].device
+        if self._cache is None or self._cache.numel() * 4 != nbytes or self._cache.device != dev:
+            self._cache = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_pack_field(C.byref(cp), self._cache.data_ptr(), st), "lrf_pack_field")
+        self._cache_key = key
+
+    def _c_field(self):
+        f = N.LrfField()
+        f.cache = self._cache.data_ptr()
+        aabb = [float(v) for v in self.aabb.detach().reshape(-1).tolist()]
+        f.aabb[:] = aabb
+        f.grid[:] = [int(v) for v in self.gridSize.tolist()]
+        if self.alphaMask is not None:
+            vol = self.alphaMask.alpha_volume.detach()
+            f.alpha_vol = vol.data_ptr()
+            f.alpha_dim[:] = [vol.shape[-1], vol.shape[-2], vol.shape[-3]]
+            f.alpha_aabb[:] = [float(v) for v in self.alphaMask.aabb.detach().reshape(-1).tolist()]
+        else:
+            f.alpha_vol = None
+            f.alpha_dim[:] = [0, 0, 0]
+            f.alpha_aabb[:] = aabb
+        f.density_shift = float(self.density_shift)
+        f.distance_scale = float(self.distance_scale)
+        f.weight_thres = float(self.rayMarch_weight_thres)
+        ps = self._param_list()[12:]
+        (f.basis, f.w1, f.b1, f.w2, f.b2, f.w3, f.b3) = [p.data_ptr() for p in ps]
+        return f
+
+    def _workspace(self, R, S, dev):
+        nbytes = N.lib().lrf_workspace_bytes(R, S)
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def _flags(self, white_bg):
+        fl = 0
+        if white_bg:
+            fl |= N.LRF_FLAG_WHITE_BG
+        if self.fea2denseAct == "relu":
+            fl |= N.LRF_FLAG_RELU_DENS
+        if self.mlp_engine == "valu":
+            fl |= N.LRF_FLAG_MLP_VALU
+        return fl
+
+    def _native_forward(self, rays, z, flags, floater, want_weights=False):
+        self._require_gpu(rays)
+        lib = N.lib()
+        self._ensure_cache()
+        rays = rays.detach().contiguous().float()
+        z = z.detach().contiguous().float().view(-1)
+        R, S = rays.shape[0], z.shape[0]
+        dev = rays.device
+        rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        w_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_weights else None
+        acc = torch.empty(R, dtype=torch.float32, device=dev) if want_weights else None
+        if R == 0:
+            return (rgb, depth, w_out, acc) if want_weights else (rgb, depth)
+        ws = self._workspace(R, S, dev)
+        f = self._c_field()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_render_fwd(C.byref(f), N.ptr(rays), N.ptr(z), R, S, flags, float(floater),
+                                   N.ptr(rgb), N.ptr(depth), N.ptr(w_out), N.ptr(acc),
+                                   ws.data_ptr(), st), "lrf_render_fwd")
+        return (rgb, depth, w_out, acc) if want_weights else (rgb, depth)
+
+    def _native_backward(self, rays, z, flags, g_rgb, g_depth):
+        lib = N.lib()
+        self._ensure_cache()
+        rays = rays.detach().contiguous().float()
+        z = z.detach().contiguous().float().view(-1)
+        R, S = rays.shape[0], z.shape[0]
+        dev = rays.device
+        cp, keep = self._c_params()
+        grads = [torch.zeros_like(p) for p in keep]
+        g_rays = torch.zeros(R, 6, dtype=torch.float32, device=dev)
+        if R == 0:
+            return g_rays, grads
+        cg = N.LrfGrads()
+        for i in range(3):
+            cg.density_plane[i] = grads[i].data_ptr()
+            cg.density_line[i] = grads[3 + i].data_ptr()
+            cg.app_plane[i] = grads[6 + i].data_ptr()
+            cg.app_line[i] = grads[9 + i].data_ptr()
+        (cg.basis, cg.w1, cg.b1, cg.w2, cg.b2, cg.w3, cg.b3) = [g.data_ptr() for g in grads[12:]]
+        ws = self._workspace(R, S, dev)
+        f = self._c_field()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_render_bwd(C.byref(f), C.byref(cp), N.ptr(rays), N.ptr(z), R, S, flags,
+                                   N.ptr(g_rgb.contiguous().float()), N.ptr(g_depth.contiguous().float()),
+                                   C.byref(cg), N.ptr(g_rays), ws.data_ptr(), st), "lrf_render_bwd")
+        return g_rays, grads
+
+    # ------------------------------------------------------------------ sampling
+    def z_schedule(self, is_train, N_samples, device):
+        """Ray-independent sample distances of sample_ray_contracted (tensorBase.py:419-437):
+        half linear in [0,1), half inverse-depth out to 1e3, +0.1; two independent jitters in
+        train mode drawn with the reference's RNG calls (rand_like on the device generator)."""
+        if self.z_override is not None:
+            return self.z_override.to(device).view(-1)
+        n = N_samples if N_samples > 0 else self.nSamples
+        h = n // 6
+        t = torch.linspace(0.0, h - 1, h, device=device)[None] / h
+        a = t.clone()
+        if is_train:
+            a = a + torch.rand_like(t) / h
+            t = t + torch.rand_like(t) / h
+        near, far = 1.0, 1e3
+        b = 1.0 / (1.0 / near * (1.0 - t) + 1.0 / far * t)
+        return (torch.cat([a, b], dim=1) + 1e-1).view(-1)
+
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        """AABB march (tensorBase.py:396-417), via lrf_sample_ray_aabb."""
+        self._require_gpu(rays_o)
+        lib = N.lib()
+        n = N_samples if N_samples > 0 else self.nSamples
+        rays = torch.cat([rays_o, rays_d], -1).contiguous().float()
+        R, dev = rays.shape[0], rays.device
+        jit = torch.rand(R, 1, device=dev)[:, 0].contiguous() if is_train else None
+        pts = torch.empty(R, n, 3, device=dev)
+        t = torch.empty(R, n, device=dev)
+        inside = torch.empty(R, n, dtype=torch.uint8, device=dev)
+        aabb = (C.c_float * 6)(*[float(v) for v in self.aabb.detach().reshape(-1).tolist()])
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_sample_ray_aabb(N.ptr(rays), aabb, float(self.stepSize), float(self.near_far[0]),
+                                        float(self.near_far[1]), N.ptr(jit), R, n, N.ptr(pts), N.ptr(t),
+                                        inside.data_ptr(), st), "lrf_sample_ray_aabb")
+        return pts, t, inside.bool()
+
+    # ------------------------------------------------------------------ features
+    def compute_densityfeature(self, xyz_sampled):
+        """tensoRF.py:112-151 on normalised coordinates [P,3] (no autograd; the training
+        gradient flows through forward())."""
+        self._require_gpu(xyz_sampled)
+        self._ensure_cache()
+        u = xyz_sampled.detach().reshape(-1, 3).contiguous().float()
+        out = torch.empty(u.shape[0], device=u.device)
+        f = self._c_field()
+        st = torch.cuda.current_stream(u.device).cuda_stream
+        N.check(N.lib().lrf_density_feature(C.byref(f), N.ptr(u), u.shape[0], N.ptr(out), st),
+                "lrf_density_feature")
+        return out
+
+    def compute_appfeature(self, xyz_sampled):
+        """tensoRF.py:153-196 on normalised coordinates [P,3] -> [P,27]."""
+        self._require_gpu(xyz_sampled)
+        self._ensure_cache()
+        u = xyz_sampled.detach().reshape(-1, 3).contiguous().float()
+        out = torch.empty(u.shape[0], self.app_dim, device=u.device)
+        f = self._c_field()
+        st = torch.cuda.current_stream(u.device).cuda_stream
+        N.check(N.lib().lrf_app_feature(C.byref(f), N.ptr(u), u.shape[0], N.ptr(out), st),
+                "lrf_app_feature")
+        return out
+
+    def feature2density(self, density_features):
+        """tensorBase.py:495-499."""
+        if self.fea2denseAct == "softplus":
+            return F.softplus(density_features + self.density_shift)
+        return F.relu(density_features)
+
+    # ------------------------------------------------------------------ the hot path
+    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, refine=True,
+                floater_thresh=0):
+        """tensorBase.py:567-636.  rays_chunk [R,6] -> (rgb_map [R,3], depth_map [R]).
+        `refine` only matters when fea_pe > 0 (tensorBase.py:117-126); this build has fea_pe=0."""
+        self._require_gpu(rays_chunk)
+        z = self.z_schedule(is_train, N_samples, rays_chunk.device)
+        use_white = bool(white_bg) or bool(is_train and torch.rand((1,)) < 0.5)   # :633
+        flags = self._flags(use_white)
+        needs_grad = torch.is_grad_enabled() and (
+            rays_chunk.requires_grad or any(p.requires_grad for p in self._param_list()))
+        if needs_grad:
+            if floater_thresh > 0:
+                raise N.NativeError("floater_thresh > 0 is an eval-only filter (train.py:107,139)")
+            return _RenderFn.apply(self, rays_chunk, z, flags, 0.0, *self._param_list())
+        return self._native_forward(rays_chunk, z, flags, float(floater_thresh))
+
+    def render_weights(self, rays_chunk, N_samples=-1, floater_thresh=0, white_bg=True):
+        """Debug/test hook: forward plus the per-sample weights and acc map."""
+        z = self.z_schedule(False, N_samples, rays_chunk.device)
+        return self._native_forward(rays_chunk, z, self._flags(white_bg), float(floater_thresh),
+                                    want_weights=True) + (z,)
+
+    # ------------------------------------------------------------------ "next" rows
+    # Regularisers, upsample and alpha-mask rebuild sit either side of the hot path; they are
+    # host-side torch code for now, same arithmetic as the reference.
+    def vectorDiffs(self, vector_comps):
+        """tensoRF.py:66-78."""
+        total = 0
+        for v in vector_comps:
+            n_comp, n_size = v.shape[1:-1]
+            m = v.view(n_comp, n_size)
+            dotp = m @ m.transpose(-1, -2)
+            off = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
+            total = total + torch.mean(torch.abs(off))
+        return total
+
+    def vector_comp_diffs(self):
+        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
+
+    def density_L1(self):
+        """tensoRF.py:83-92."""
+        n = int(torch.prod(self.gridSize))
+        feat = torch.zeros((n,), device=self.gridSize.device)
+        for i in range(3):
+            pl = self.density_plane[i].view(-1, int(torch.prod(self.gridSize[self.matMode[i]])))
+            ln = self.density_line[i].view(-1, int(self.gridSize[self.vecMode[i]]))
+            feat = feat + torch.bmm(pl[..., None], ln[:, None]).view(-1, n).sum(0)
+        return torch.sqrt(self.feature2density(feat).clamp(1e-5)).mean()
+
+    def TV_loss_density(self, reg):
+        """tensoRF.py:94-101."""
+        total = 0
+        for i in range(3):
+            total = total + reg(self.density_plane[i].transpose(0, 1)) * 1e-2 \
+                + reg(self.density_line[i].transpose(0, 1)) * 1e-3
+        return total
+
+    def TV_loss_app(self, reg):
+        """tensoRF.py:103-110."""
+        total = 0
+        for i in range(3):
+            total = total + reg(self.app_plane[i].transpose(0, 1)) * 1e-2 \
+                + reg(self.app_line[i].transpose(0, 1)) * 1e-3
+        return total
+
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        """tensoRF.py:198-221: bilinear, align_corners=True; new Parameter objects."""
+        for i in range(3):
+            m0, m1 = self.matMode[i]
+            plane_coef[i] = torch.nn.Parameter(F.interpolate(
+                plane_coef[i].data, size=(res_target[m1], res_target[m0]), mode="bilinear",
+                align_corners=True))
+            line_coef[i] = torch.nn.Parameter(F.interpolate(
+                line_coef[i].data, size=(res_target[self.vecMode[i]], 1), mode="bilinear",
+                align_corners=True))
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """tensoRF.py:223-233.  The layout cache is keyed on parameter identity, so the new
+        Parameters invalidate it automatically."""
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(
+            self.density_plane, self.density_line, res_target)
+        self.update_stepSize(list(res_target))
+
+    @torch.no_grad()
+    def compute_alpha(self, xyz_locs, length=1):
+        """tensorBase.py:538-558, density features from the HIP gather kernel."""
+        if self.alphaMask is not None:
+            mask = self.alphaMask.sample_alpha(xyz_locs) > 0
+        else:
+            mask = torch.ones_like(xyz_locs[:, 0], dtype=bool)
+        sigma = torch.zeros(xyz_locs.shape[:-1], device=xyz_locs.device)
+        if mask.any():
+            feat = self.compute_densityfeature(self.normalize_coord(xyz_locs[mask]))
+            sigma[mask] = self.feature2density(feat)
+        return 1 - torch.exp(-sigma * length).view(xyz_locs.shape[:-1])
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):
+        """tensorBase.py:501-516, evaluated on the field's device."""
+        gridSize = self.gridSize if gridSize is None else gridSize
+        dev = self.aabb.device
+        lin = [torch.linspace(0, 1, int(g), device=dev) for g in gridSize]
+        dense = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)
+        dense = self.aabb[0] * (1 - dense) + self.aabb[1] * dense
+        alpha = torch.zeros_like(dense[..., 0])
+        for i in range(int(gridSize[0])):
+            alpha[i] = self.compute_alpha(dense[i].view(-1, 3), self.stepSize).view(
+                int(gridSize[1]), int(gridSize[2]))
+        return alpha
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):
+        """tensorBase.py:518-536 without the round trip through host memory."""
+        gridSize = tuple(int(g) for g in gridSize)
+        alpha = self.getDenseAlpha(gridSize)
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(gridSize[::-1])
+        alpha = (alpha >= self.alphaMask_thres).float()
+        self.alphaMask = AlphaGridMask(self.aabb.device, self.aabb.detach(), alpha)

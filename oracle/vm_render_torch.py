@@ -1,0 +1,120 @@
+"""CPU ORACLE, torch flavour (test infrastructure, NOT product code).
+
+A functional restatement of the reference's PyTorch path using the same ATen operators
+the reference calls (F.grid_sample, cumprod, softplus, boolean-mask compaction), so that
+timing it reproduces what the reference costs on this machine's host cores (bench.py's
+`cpu_baseline`, kind "port") and, moved to the GPU, what the stock PyTorch-ROCm path
+costs (the denominator of BASELINE.json's >=10x target).  localrf_amd/ never imports it.
+
+Parity status: PINNED against tests/golden/*.npz (recorded from the real reference) by
+tests/test_oracle_golden.py::test_torch_port_matches_reference.
+
+`fld` is a dict of torch tensors with the reference's state-dict names (see
+oracle/vm_render_np.py).  Cited lines: /root/reference/localTensoRF.
+"""
+import torch
+import torch.nn.functional as F
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))
+VEC_MODE = (2, 1, 0)
+
+
+def z_schedule(n_samples_arg, device="cpu", jitter=None):
+    """models/tensorBase.py:419-437."""
+    h = int(n_samples_arg) // 6
+    t = torch.linspace(0.0, h - 1, h, device=device)[None] / h
+    a = t.clone()
+    if jitter is not None:
+        a = a + jitter[0].to(device)[None] / h
+        t = t + jitter[1].to(device)[None] / h
+    b = 1.0 / ((1.0 - t) + t / 1e3)
+    return torch.cat([a, b], 1) + 0.1
+
+
+def _vm_lookup(planes, lines, u):
+    """grid_sample of 3 planes and 3 lines at normalised points u [P,3]
+    (models/tensoRF.py:115-146 / 156-191).  Returns lists of [C,P] tensors."""
+    P = u.shape[0]
+    outs_p, outs_l = [], []
+    for p in range(3):
+        gp = u[:, list(MAT_MODE[p])].view(1, P, 1, 2)
+        gl = torch.stack([torch.zeros_like(u[:, 0]), u[:, VEC_MODE[p]]], -1).view(1, P, 1, 2)
+        outs_p.append(F.grid_sample(planes[p], gp, align_corners=True, padding_mode="border").view(-1, P))
+        outs_l.append(F.grid_sample(lines[p], gl, align_corners=True, padding_mode="border").view(-1, P))
+    return outs_p, outs_l
+
+
+def density_feature(fld, u):
+    """models/tensoRF.py:112-151."""
+    pp, ll = _vm_lookup([fld[f"density_plane.{i}"] for i in range(3)],
+                        [fld[f"density_line.{i}"] for i in range(3)], u)
+    out = torch.zeros(u.shape[0], device=u.device)
+    for a, b in zip(pp, ll):
+        out = out + (a * b).sum(0)
+    return out
+
+
+def app_feature(fld, u):
+    """models/tensoRF.py:153-196."""
+    pp, ll = _vm_lookup([fld[f"app_plane.{i}"] for i in range(3)],
+                        [fld[f"app_line.{i}"] for i in range(3)], u)
+    x = (torch.cat(pp) * torch.cat(ll)).T
+    return F.linear(x, fld["basis_mat.weight"])
+
+
+def late_view_mlp(fld, feat, viewdirs):
+    """models/tensorBase.py:115-135 with fea_pe = view_pe = 0."""
+    h = F.relu(F.linear(feat, fld["renderModule.mlp.0.weight"], fld["renderModule.mlp.0.bias"]))
+    h = F.relu(F.linear(h, fld["renderModule.mlp.2.weight"], fld["renderModule.mlp.2.bias"]))
+    o = F.linear(torch.cat([h, viewdirs], -1), fld["renderModule.mlp_view.0.weight"],
+                 fld["renderModule.mlp_view.0.bias"])
+    return torch.sigmoid(o)
+
+
+def alpha2weights(alpha):
+    """models/tensorBase.py:23-32."""
+    alpha[:, -1] = 1
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)
+    return alpha * T[:, :-1]
+
+
+def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, density_shift=-5.0,
+                 distance_scale=25.0, weight_thres=1e-3):
+    """models/tensorBase.py:567-636 (softplus density, late-view shading).  z: [1,S]."""
+    o, d = rays[:, :3], rays[:, 3:6]
+    n = torch.norm(d, dim=-1, keepdim=True)
+    dh = d / n
+    x = o[:, None, :] + dh[:, None, :] * z[..., None]
+    m = x.abs().amax(dim=-1, keepdim=True).clamp(min=1e-6)              # utils/ray_utils.py:9-12
+    x = torch.where(m <= 1, x, ((2 * m - 1) / (m ** 2)) * x)
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
+    valid = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
+    aabb = fld["aabb"]
+    if fld.get("alphaMask.alpha_volume") is not None:
+        maabb = fld.get("alphaMask.aabb", aabb)
+        pm = (x.reshape(-1, 3) - maabb[0]) * (1.0 / (maabb[1] - maabb[0]) * 2) - 1
+        a = F.grid_sample(fld["alphaMask.alpha_volume"], pm.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
+        valid &= (a > 0).view(valid.shape)
+    valid[:, -1] = False
+    u = (x - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1
+    sigma = torch.zeros(x.shape[:2], device=x.device)
+    if valid.any():
+        sigma[valid] = F.softplus(density_feature(fld, u[valid]) + density_shift)
+    alpha = 1.0 - torch.exp(-sigma * dists * distance_scale)
+    w = alpha2weights(alpha)
+    acc = w.sum(-1)
+    depth = (w * z).sum(-1) / n[:, 0]
+    if floater_thresh > 0:
+        k = torch.arange(alpha.shape[1], device=x.device)[None]
+        idx = (w * k).sum(-1, keepdim=True)
+        alpha[k < idx * floater_thresh] = 0
+        w = alpha2weights(alpha)
+    shade = w > weight_thres
+    rgb = torch.zeros(x.shape[:2] + (3,), device=x.device)
+    if shade.any():
+        vd = dh[:, None, :].expand(x.shape)[shade]
+        rgb[shade] = late_view_mlp(fld, app_feature(fld, u[shade]), vd)
+    rgb_map = (w[..., None] * rgb).sum(-2)
+    if white_bg:
+        rgb_map = rgb_map + (1.0 - acc[:, None])
+    return rgb_map, depth
