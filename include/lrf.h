@@ -34,6 +34,8 @@ extern "C" {
 #define LRF_FLAG_WHITE_BG   1u   /* tensorBase.py:633-634 */
 #define LRF_FLAG_RELU_DENS  2u   /* fea2denseAct == "relu" (tensorBase.py:498-499) */
 #define LRF_FLAG_MLP_VALU   4u   /* debug engine: colour MLP on the vector ALU, natural-layout weights */
+#define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
+                                    split-bf16 (hi+lo, 3-term) MFMA chain */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
  * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblrf_hip.so")
 LRF_FLAG_WHITE_BG = 1
 LRF_FLAG_RELU_DENS = 2
 LRF_FLAG_MLP_VALU = 4
+LRF_FLAG_MLP_F32 = 8
 
 _f = C.c_void_p  # device float*
 

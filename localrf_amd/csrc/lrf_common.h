@@ -26,8 +26,21 @@ constexpr int IMG_B2   = IMG_B1 + 128;               // [128]
 constexpr int IMG_W3V  = IMG_B2 + 128;               // [o4][4] = (wx,wy,wz,bias) per colour
 constexpr int IMG_FLOATS = IMG_W3V + 16;             // 24336 floats = 97,344 B
 
+// Split-bf16 MLP image (16-byte units, then a float tail).  Every weight w is stored as
+// hi = bf16(w), lo = bf16(w - hi); a fragment is [part hi/lo][lane64][8 bf16] and feeds the
+// A operand of v_mfma_f32_16x16x32_bf16.  K-slot (g = lane>>4, j) of k-step ks maps to input
+// feature: basis q=8ks+j -> (p=q/6, c=6g+q%6); layers 1/2: tile 2ks+(j>>2), feature
+// 16*tile+4g+(j&3) -- i.e. exactly the D registers the lane already holds.
+constexpr int IMGB_BAS = 0;                        // frags [t'2][ks3]
+constexpr int IMGB_W1  = IMGB_BAS + 2 * 3 * 128;   // frags [t'8][ks1]
+constexpr int IMGB_W2  = IMGB_W1 + 8 * 1 * 128;    // frags [t'8][ks4]
+constexpr int IMGB_TAIL = IMGB_W2 + 8 * 4 * 128;   // uint4 index of the float tail
+constexpr int TAIL_W3H = 0;                        // floats, same content as IMG_W3H..IMG_W3V+16
+constexpr int TAIL_B1 = 512, TAIL_B2 = 640, TAIL_W3V = 768, TAIL_FLOATS = 784;
+constexpr int IMGB_U4 = IMGB_TAIL + TAIL_FLOATS / 4;   // 6084 uint4 = 97,344 B
+
 struct Layout {
-  size_t dplane[3], dline[3], aplane[3], aline[3], mlp, total;   // float offsets
+  size_t dplane[3], dline[3], aplane[3], aline[3], mlp, mlpb, total;   // float offsets
   int pw[3], ph[3], ll[3];
 };
 
@@ -44,6 +57,7 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
   for (int p = 0; p < 3; ++p) { L.aplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CA); }
   for (int p = 0; p < 3; ++p) { L.aline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CA); }
   L.mlp = off; off = align64(off + IMG_FLOATS);
+  L.mlpb = off; off = align64(off + (size_t)IMGB_U4 * 4);
   L.total = off;
   return L;
 }
@@ -53,6 +67,7 @@ struct DField {
   const float* dplane[3]; const float* dline[3];
   const float* aplane[3]; const float* aline[3];
   const float* mlp;
+  const uint4* mlpb;
   int pw[3], ph[3], ll[3];
   const float* alpha_vol; int ax, ay, az;
   float m_lo[3], m_inv[3];     // alpha-mask aabb: lo and 2/size   (tensorBase.py:57-58)

@@ -26,8 +26,7 @@
 
 namespace lrf {
 
-constexpr int ITEM = 32;          // compact samples per shade work item (2 MFMA tiles)
-constexpr int ITEM_TILES = ITEM / 16;
+constexpr int ITEM = 16;          // compact samples per shade work item = one 16-column MFMA tile
 
 thread_local char g_err[512] = "";
 static int set_err(const char* msg, hipError_t e = hipSuccess) {
@@ -92,6 +91,62 @@ __global__ void k_pack_mlp(LrfParams p, float* __restrict__ img) {
     if (o < 3) v = (c < 3) ? p.w3[o * (LRF_FEATC + 3) + LRF_FEATC + c] : p.b3[o];
   }
   img[idx] = v;
+}
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+  return __builtin_bit_cast(unsigned short, (__bf16)v);       // round-to-nearest-even
+}
+__device__ __forceinline__ float bf16_val(unsigned short b) {
+  return __uint_as_float(((unsigned)b) << 16);
+}
+
+// colour network -> split-bf16 fragment image (lrf_common.h IMGB_*).  One thread per
+// 32-bit word (two bf16) of the fragment area, then the fp32 tail.
+__global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= IMGB_U4 * 4) return;
+  if (idx >= IMGB_TAIL * 4) {                                  // fp32 tail
+    const int e = idx - IMGB_TAIL * 4;
+    float v = 0.0f;
+    if (e < TAIL_B1) {
+      const int o = e & 3, fidx = (e >> 2) & 31, g = e >> 7;
+      const int feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3);
+      if (o < 3) v = p.w3[o * (LRF_FEATC + 3) + feat];
+    } else if (e < TAIL_B2) v = p.b1[e - TAIL_B1];
+    else if (e < TAIL_W3V) v = p.b2[e - TAIL_B2];
+    else {
+      const int o = (e - TAIL_W3V) >> 2, c = (e - TAIL_W3V) & 3;
+      if (o < 3) v = (c < 3) ? p.w3[o * (LRF_FEATC + 3) + LRF_FEATC + c] : p.b3[o];
+    }
+    img[idx] = __float_as_uint(v);
+    return;
+  }
+  // word -> (frag, part, lane, j pair)
+  const int u4 = idx >> 2, wj = idx & 3;
+  const int lane = u4 & 63, part = (u4 >> 6) & 1, frag = u4 >> 7;
+  const int i = lane & 15, g = lane >> 4;
+  unsigned short out[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = 2 * wj + h;
+    float v = 0.0f;
+    if (frag < 6) {                                            // basis: frag = t'*3 + ks
+      const int t1 = frag / 3, ks = frag % 3;
+      const int q = 8 * ks + j, row = 16 * t1 + i;
+      if (q < 18 && row < LRF_APP_DIM) v = p.basis[row * 72 + (q / 6) * LRF_CA + 6 * g + (q % 6)];
+    } else if (frag < 14) {                                    // layer 1: frag-6 = t'
+      const int t1 = frag - 6;
+      const int col = 16 * (j >> 2) + 4 * g + (j & 3);
+      if (col < LRF_APP_DIM) v = p.w1[(16 * t1 + i) * LRF_APP_DIM + col];
+    } else {                                                   // layer 2: frag-14 = t'*4 + ks
+      const int t1 = (frag - 14) >> 2, ks = (frag - 14) & 3;
+      const int col = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);
+      v = p.w2[(16 * t1 + i) * LRF_FEATC + col];
+    }
+    const unsigned short hi = bf16_bits(v);
+    out[h] = part ? bf16_bits(v - bf16_val(hi)) : hi;
+  }
+  img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
 }
 
 // --------------------------------------------------------------------------- march
@@ -227,6 +282,13 @@ __device__ __forceinline__ void gather_app6(const DField& f, const float u[3], i
   }
 }
 
+// next work item for this wave (wave-uniform)
+__device__ __forceinline__ int pull_item(int* counters, int lane) {
+  int v = 0;
+  if (lane == 0) v = atomicAdd(&counters[1], 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 __global__ __launch_bounds__(1024) void k_shade(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int2* __restrict__ items, int* __restrict__ counters,
@@ -242,11 +304,9 @@ __global__ __launch_bounds__(1024) void k_shade(
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
   const int n_items = counters[0];
 
-  for (;;) {
-    int it = 0;
-    if (lane == 0) it = atomicAdd(&counters[1], 1);
-    it = __builtin_amdgcn_readfirstlane(it);
-    if (it >= n_items) break;
+  int it = pull_item(counters, lane);
+  while (it < n_items) {
+    asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
     const int2 d = items[it];
     const int ray = __builtin_amdgcn_readfirstlane(d.x);
     const int j0 = __builtin_amdgcn_readfirstlane(d.y);
@@ -264,13 +324,9 @@ __global__ __launch_bounds__(1024) void k_shade(
       const float4 wv = *reinterpret_cast<const float4*>(&img[IMG_W3V + 4 * c]);
       vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
     }
-    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
-
-    for (int tile = 0; tile < ITEM_TILES; ++tile) {
-      if (tile * 16 >= cnt) break;
-      const int jj = tile * 16 + s;
-      const bool valid = jj < cnt;
-      const size_t ci = (size_t)ray * S + j0 + (valid ? jj : 0);
+    {
+      const bool valid = s < cnt;
+      const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
       const int k = cidx[ci];
       const float w = valid ? cw[ci] : 0.0f;
       float x[3], u[3];
@@ -344,12 +400,150 @@ __global__ __launch_bounds__(1024) void k_shade(
       for (int dd = 1; dd < 16; dd <<= 1) {
         cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
       }
-      acc_r += cr; acc_g += cg; acc_b += cb;
+      if (lane == 0) {
+        float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
+        pp[0] = cr; pp[1] = cg; pp[2] = cb;
+      }
+    }
+    it = pull_item(counters, lane);
+  }
+}
+
+// ------------------------------------------------------------------ shade, split-bf16 engine
+// Same structure as k_shade, but every GEMM runs on v_mfma_f32_16x16x32_bf16 with both
+// operands split into hi + lo bf16 (x ~ hi + lo to 2^-16): acc += Ah*Bh + Ah*Bl + Al*Bh,
+// fp32 accumulate.  3 bf16 MFMAs (K=32 each) replace 8 fp32 MFMAs (K=4 each): ~5x fewer
+// matrix-pipe cycles at ~1e-5 relative error per product -- inside the 1e-4 parity budget
+// (measured in tests/test_gpu_parity.py).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float v[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 lds_frag(const uint4* img, int frag, int part, int lane) {
+  return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
+}
+// acc[t1] += A(frag0 + t1*stride) x B for t1 in [0, NT), three-term split product
+template <int NT>
+__device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int stride, int lane,
+                                          bf16x8 bh, bf16x8 bl, f32x4* acc) {
+#pragma unroll
+  for (int t1 = 0; t1 < NT; ++t1) {
+    const bf16x8 ah = lds_frag(img, frag0 + t1 * stride, 0, lane);
+    const bf16x8 al = lds_frag(img, frag0 + t1 * stride, 1, lane);
+    acc[t1] = mfma_bf16(al, bh, acc[t1]);
+    acc[t1] = mfma_bf16(ah, bl, acc[t1]);
+    acc[t1] = mfma_bf16(ah, bh, acc[t1]);
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_shade_bf16(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int2* __restrict__ items, int* __restrict__ counters,
+    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
+    float* __restrict__ part, int pmax) {
+  __shared__ uint4 img[IMGB_U4];
+  for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
+  __syncthreads();
+  const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  const int n_items = counters[0];
+
+  int it = pull_item(counters, lane);
+  while (it < n_items) {
+    asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop
+    const int2 d = items[it];
+    const int ray = __builtin_amdgcn_readfirstlane(d.x);
+    const int j0 = __builtin_amdgcn_readfirstlane(d.y);
+    const int cnt = min(ITEM, ncomp[ray] - j0);
+
+    const float* rp = rays + (size_t)ray * 6;
+    const float o[3] = {rp[0], rp[1], rp[2]};
+    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+    float vb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
+      vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
+    }
+    const bool valid = s < cnt;
+    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
+    const int k = cidx[ci];
+    const float w = valid ? cw[ci] : 0.0f;
+    float x[3], u[3];
+    sample_point(f, o, dh, z[k], x, u);
+    float X[3][6];
+    gather_app6(f, u, g, X);
+
+    // basis 72 -> 27 (tensoRF.py:196): 3 k-steps of 8 K-slots per lane group
+    f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    {
+      float v[24];
+#pragma unroll
+      for (int q = 0; q < 24; ++q) v[q] = q < 18 ? X[q / 6][q % 6] : 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        bf16x8 bh, bl;
+        split8(&v[8 * ks], bh, bl);
+        gemm_step<2>(img, IMGB_BAS / 128 + ks, 3, lane, bh, bl, fe);
+      }
+    }
+    // layer 1 (tensorBase.py:129-130): one k-step, the two feat tiles are its 8 K-slots
+    f32x4 h1[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * t1 + 4 * g]);
+    {
+      const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
+    }
+    // layer 2: 4 k-steps, k-step ks consumes relu(h1) tiles 2ks and 2ks+1
+    f32x4 h2[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[2 * ks + (j >> 2)][j & 3], 0.0f);
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
+    }
+    // head on the VALU in fp32 (tensorBase.py:131-133)
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = fmaxf(h2[t1][r], 0.0f);
+        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + (g * 32 + t1 * 4 + r) * 4]);
+        o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
+      }
+    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+    float cr = w / (1.0f + expf(-(o0 + vb[0])));
+    float cg = w / (1.0f + expf(-(o1 + vb[1])));
+    float cb = w / (1.0f + expf(-(o2 + vb[2])));
+#pragma unroll
+    for (int dd = 1; dd < 16; dd <<= 1) {
+      cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
     }
     if (lane == 0) {
       float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
-      pp[0] = acc_r; pp[1] = acc_g; pp[2] = acc_b;
+      pp[0] = cr; pp[1] = cg; pp[2] = cb;
     }
+    it = pull_item(counters, lane);
   }
 }
 
@@ -523,6 +717,7 @@ static DField make_dfield(const LrfField* f) {
     d.pw[p] = L.pw[p]; d.ph[p] = L.ph[p]; d.ll[p] = L.ll[p];
   }
   d.mlp = base + L.mlp;
+  d.mlpb = reinterpret_cast<const uint4*>(base + L.mlpb);
   d.alpha_vol = f->alpha_vol;
   d.ax = f->alpha_dim[0]; d.ay = f->alpha_dim[1]; d.az = f->alpha_dim[2];
   for (int a = 0; a < 3; ++a) {
@@ -592,6 +787,8 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
     hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, p->app_line[q], base + L.aline[q], LRF_CA, L.ll[q]);
   }
   hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
+  hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p,
+                     reinterpret_cast<uint32_t*>(base + L.mlpb));
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -617,9 +814,11 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   if (flags & LRF_FLAG_MLP_VALU) {
     hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st,
                        d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+  } else if (flags & LRF_FLAG_MLP_F32) {
+    hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st,
+                       d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   } else {
-    const int wgs = device_cus();
-    hipLaunchKernelGGL(k_shade, dim3(wgs), dim3(1024), 0, st,
+    hipLaunchKernelGGL(k_shade_bf16, dim3(device_cus()), dim3(1024), 0, st,
                        d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   }
   if (ev) LRF_HIP(hipEventRecord(ev[2], st));

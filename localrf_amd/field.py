@@ -125,7 +125,9 @@ class TensorVMSplit(torch.nn.Module):
         self._cache = None
         self._cache_key = None
         self._ws = None
-        self.mlp_engine = "mfma"        # "mfma" | "valu" (debug engine, LRF_FLAG_MLP_VALU)
+        # colour-MLP engine: "bf16x3" split-bf16 MFMA chain (default) | "f32" exact fp32 MFMA
+        # chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
+        self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
 
     # ------------------------------------------------------------------ construction
@@ -156,6 +158,10 @@ class TensorVMSplit(torch.nn.Module):
         self.stepSize = torch.mean(self.units) * self.step_ratio
         self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
         self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        # host copies, so the render call never synchronises to read them back
+        self._grid_host = [int(g) for g in gridSize]
+        self._aabb_host = [float(v) for v in self.aabb.detach().reshape(-1).tolist()]
+        self._z_cache = {}
 
     def init_svd_volume(self, res, device):
         """tensoRF.py:18-50: 0.1*randn planes [1,C,g[m1],g[m0]] and lines [1,C,g[v],1],
@@ -208,6 +214,8 @@ class TensorVMSplit(torch.nn.Module):
         if self.alphaMask is not None:
             self.alphaMask = self.alphaMask.to(device)
         self._cache = self._cache_key = self._ws = None
+        self._cfield_key = None
+        self._z_cache = {}
         return super().to(device)
 
     def normalize_coord(self, xyz):
@@ -240,8 +248,7 @@ class TensorVMSplit(torch.nn.Module):
             cp.app_plane[i] = ps[6 + i].data_ptr()
             cp.app_line[i] = ps[9 + i].data_ptr()
         (cp.basis, cp.w1, cp.b1, cp.w2, cp.b2, cp.w3, cp.b3) = [p.data_ptr() for p in ps[12:]]
-        g = [int(v) for v in self.gridSize.tolist()]
-        cp.grid[:] = g
+        cp.grid[:] = self._grid_host
         return cp, ps
 
     def _ensure_cache(self):
@@ -249,7 +256,7 @@ class TensorVMSplit(torch.nn.Module):
         changed (optimizer step, upsample tensoRF.py:224-233, load_state_dict, .to())."""
         lib = N.lib()
         ps = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in ps) + tuple(self.gridSize.tolist())
+        key = tuple((p.data_ptr(), p._version) for p in ps) + tuple(self._grid_host)
         if self._cache is not None and key == self._cache_key:
             return
         cp, keep = self._c_params()
@@ -262,25 +269,32 @@ class TensorVMSplit(torch.nn.Module):
         self._cache_key = key
 
     def _c_field(self):
+        """LrfField struct for the current cache / alpha mask (rebuilt only when they change)."""
+        mask = self.alphaMask
+        key = (self._cache.data_ptr(), self._cache_key, id(mask),
+               None if mask is None else mask.alpha_volume.data_ptr(),
+               float(self.density_shift), float(self.distance_scale), float(self.rayMarch_weight_thres))
+        if getattr(self, "_cfield_key", None) == key:
+            return self._cfield
         f = N.LrfField()
         f.cache = self._cache.data_ptr()
-        aabb = [float(v) for v in self.aabb.detach().reshape(-1).tolist()]
-        f.aabb[:] = aabb
-        f.grid[:] = [int(v) for v in self.gridSize.tolist()]
-        if self.alphaMask is not None:
-            vol = self.alphaMask.alpha_volume.detach()
+        f.aabb[:] = self._aabb_host
+        f.grid[:] = self._grid_host
+        if mask is not None:
+            vol = mask.alpha_volume.detach()
             f.alpha_vol = vol.data_ptr()
             f.alpha_dim[:] = [vol.shape[-1], vol.shape[-2], vol.shape[-3]]
-            f.alpha_aabb[:] = [float(v) for v in self.alphaMask.aabb.detach().reshape(-1).tolist()]
+            f.alpha_aabb[:] = [float(v) for v in mask.aabb.detach().reshape(-1).tolist()]
         else:
             f.alpha_vol = None
             f.alpha_dim[:] = [0, 0, 0]
-            f.alpha_aabb[:] = aabb
+            f.alpha_aabb[:] = self._aabb_host
         f.density_shift = float(self.density_shift)
         f.distance_scale = float(self.distance_scale)
         f.weight_thres = float(self.rayMarch_weight_thres)
         ps = self._param_list()[12:]
         (f.basis, f.w1, f.b1, f.w2, f.b2, f.w3, f.b3) = [p.data_ptr() for p in ps]
+        self._cfield, self._cfield_key = f, key
         return f
 
     def _workspace(self, R, S, dev):
@@ -297,6 +311,10 @@ class TensorVMSplit(torch.nn.Module):
             fl |= N.LRF_FLAG_RELU_DENS
         if self.mlp_engine == "valu":
             fl |= N.LRF_FLAG_MLP_VALU
+        elif self.mlp_engine == "f32":
+            fl |= N.LRF_FLAG_MLP_F32
+        elif self.mlp_engine != "bf16x3":
+            raise ValueError(f"unknown mlp_engine {self.mlp_engine!r}")
         return fl
 
     def _native_forward(self, rays, z, flags, floater, want_weights=False):
@@ -357,6 +375,10 @@ class TensorVMSplit(torch.nn.Module):
             return self.z_override.to(device).view(-1)
         n = N_samples if N_samples > 0 else self.nSamples
         h = n // 6
+        if not is_train:                    # deterministic: build once per (count, device)
+            zc = self._z_cache.get((h, str(device)))
+            if zc is not None:
+                return zc
         t = torch.linspace(0.0, h - 1, h, device=device)[None] / h
         a = t.clone()
         if is_train:
@@ -364,7 +386,10 @@ class TensorVMSplit(torch.nn.Module):
             t = t + torch.rand_like(t) / h
         near, far = 1.0, 1e3
         b = 1.0 / (1.0 / near * (1.0 - t) + 1.0 / far * t)
-        return (torch.cat([a, b], dim=1) + 1e-1).view(-1)
+        z = (torch.cat([a, b], dim=1) + 1e-1).view(-1).contiguous()
+        if not is_train:
+            self._z_cache[(h, str(device))] = z
+        return z
 
     def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):
         """AABB march (tensorBase.py:396-417), via lrf_sample_ray_aabb."""
@@ -377,7 +402,7 @@ class TensorVMSplit(torch.nn.Module):
         pts = torch.empty(R, n, 3, device=dev)
         t = torch.empty(R, n, device=dev)
         inside = torch.empty(R, n, dtype=torch.uint8, device=dev)
-        aabb = (C.c_float * 6)(*[float(v) for v in self.aabb.detach().reshape(-1).tolist()])
+        aabb = (C.c_float * 6)(*self._aabb_host)
         st = torch.cuda.current_stream(dev).cuda_stream
         N.check(lib.lrf_sample_ray_aabb(N.ptr(rays), aabb, float(self.stepSize), float(self.near_far[0]),
                                         float(self.near_far[1]), N.ptr(jit), R, n, N.ptr(pts), N.ptr(t),

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One GPU visit: parity tests, bench line, rocprofv3 kernel-trace stats.  Outputs -> gpurun_out/.
+# usage: scripts/gpu_round.sh <tag> [pytest|bench|prof ...]
+TAG=${1:-r01}; shift
+WHAT=${@:-pytest bench prof}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for w in $WHAT; do
+  case $w in
+    pytest)
+      timeout 420 python -u -m pytest tests -m gpu -q --timeout 120 -p no:cacheprovider > gpurun_out/pytest_$TAG.log 2>&1
+      echo "pytest rc=$?" >> gpurun_out/pytest_$TAG.log; tail -25 gpurun_out/pytest_$TAG.log ;;
+    bench)
+      timeout 300 python -u bench.py --steps 200 --warmup 20 > gpurun_out/bench_$TAG.log 2>&1
+      echo "bench rc=$?" >> gpurun_out/bench_$TAG.log; tail -3 gpurun_out/bench_$TAG.log ;;
+    prof)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o bench -- \
+         python -u $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-baselines > $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG.log 2>&1)
+      echo "prof rc=$?" >> gpurun_out/prof_$TAG.log
+      find gpurun_out/prof_$TAG -name "*stats*" | head; f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
+      [ -n "$f" ] && head -12 "$f" ;;
+  esac
+done

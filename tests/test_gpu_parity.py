@@ -34,7 +34,7 @@ def _check_rays(got, ref, tol=TOL, max_outliers=0, outlier_abs=2e-3):
         assert np.abs(got - ref).max() < outlier_abs
 
 
-@pytest.mark.parametrize("engine", ["mfma", "valu"])
+@pytest.mark.parametrize("engine", ["bf16x3", "f32", "valu"])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_field_forward_vs_reference_golden(built_lib, name, engine):
     g = load_golden(name)
@@ -193,12 +193,15 @@ def test_full_size_properties(big):
     assert torch.allclose(rgb, rgb_nobg + (1 - acc)[:, None], atol=1e-6)
     assert torch.allclose(depth * rays[:, 3:].norm(dim=-1), (w * z[None]).sum(-1), rtol=1e-5, atol=1e-5)
     assert rgb.min() >= 0 and rgb.max() <= 1.0 + 1e-5
-    # engines agree (MFMA chain vs plain VALU loops on natural-layout weights)
-    f.mlp_engine = "valu"
-    with torch.no_grad():
-        rgb_v, _ = f(rays[:512], white_bg=True, is_train=False, N_samples=1536)
-    f.mlp_engine = "mfma"
-    assert rel_err(_np(rgb[:512]), _np(rgb_v)) < 2e-5
+    # engines agree: split-bf16 MFMA chain (default) vs exact-fp32 MFMA chain vs plain VALU
+    # loops on natural-layout weights
+    outs = {}
+    for eng in ("valu", "f32", "bf16x3"):
+        f.mlp_engine = eng
+        with torch.no_grad():
+            outs[eng], _ = f(rays[:512], white_bg=True, is_train=False, N_samples=1536)
+    assert rel_err(_np(outs["f32"]), _np(outs["valu"])) < 5e-6
+    assert rel_err(_np(outs["bf16x3"]), _np(outs["valu"])) < 3e-5
 
 
 def test_layout_cache_tracks_parameter_updates(built_lib):

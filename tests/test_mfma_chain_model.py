@@ -1,0 +1,235 @@
+"""Lane-level model of k_shade's register-resident MFMA chain (csrc/lrf_render.hip).
+
+Re-states, in numpy, (a) the fragment-ordered MLP image written by k_pack_mlp and (b) the
+v_mfma_f32_16x16x4_f32 lane maps (A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+D[row=4*(l>>4)+r][col=l&15]) and runs the chain exactly as the kernel indexes it.  It proves
+the K-permutation trick (layer n's D registers are layer n+1's B operands with no lane
+movement) against a plain matmul MLP.  CPU-only: guards the layout before GPU time is spent."""
+import numpy as np
+
+IMG_BAS = 0
+IMG_W1 = IMG_BAS + 2 * 3 * 64 * 8
+IMG_W2 = IMG_W1 + 8 * 2 * 64 * 4
+IMG_W3H = IMG_W2 + 8 * 8 * 64 * 4
+IMG_B1 = IMG_W3H + 4 * 32 * 4
+IMG_B2 = IMG_B1 + 128
+IMG_W3V = IMG_B2 + 128
+IMG_FLOATS = IMG_W3V + 16
+
+
+def pack_image(basis, w1, b1, w2, b2, w3, b3):
+    img = np.zeros(IMG_FLOATS, np.float64)
+    for idx in range(IMG_FLOATS):
+        v = 0.0
+        if idx < IMG_W1:
+            e = idx - IMG_BAS
+            j, lane, tp = e & 7, (e >> 3) & 63, e >> 9
+            t1, pl = tp // 3, tp % 3
+            row, col = 16 * t1 + (lane & 15), pl * 24 + 6 * (lane >> 4) + j
+            if row < 27 and j < 6:
+                v = basis[row, col]
+        elif idx < IMG_W2:
+            e = idx - IMG_W1
+            r, lane, tt = e & 3, (e >> 2) & 63, e >> 8
+            t1, t0 = tt >> 1, tt & 1
+            row, col = 16 * t1 + (lane & 15), 16 * t0 + 4 * (lane >> 4) + r
+            if col < 27:
+                v = w1[row, col]
+        elif idx < IMG_W3H:
+            e = idx - IMG_W2
+            r, lane, tt = e & 3, (e >> 2) & 63, e >> 8
+            t1, t0 = tt >> 3, tt & 7
+            v = w2[16 * t1 + (lane & 15), 16 * t0 + 4 * (lane >> 4) + r]
+        elif idx < IMG_B1:
+            e = idx - IMG_W3H
+            o, fidx, g = e & 3, (e >> 2) & 31, e >> 7
+            feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3)
+            if o < 3:
+                v = w3[o, feat]
+        elif idx < IMG_B2:
+            v = b1[idx - IMG_B1]
+        elif idx < IMG_W3V:
+            v = b2[idx - IMG_B2]
+        else:
+            e = idx - IMG_W3V
+            o, c = e >> 2, e & 3
+            if o < 3:
+                v = w3[o, 128 + c] if c < 3 else b3[o]
+        img[idx] = v
+    return img
+
+
+def mfma(a, b, c):
+    """a[64], b[64] per-lane scalars; c[64,4] accumulators -> D."""
+    A = np.zeros((16, 4)); B = np.zeros((4, 16))
+    for l in range(64):
+        A[l & 15, l >> 4] = a[l]
+        B[l >> 4, l & 15] = b[l]
+    D = A @ B
+    out = c.copy()
+    for l in range(64):
+        for r in range(4):
+            out[l, r] += D[4 * (l >> 4) + r, l & 15]
+    return out
+
+
+def chain(img, X, dh):
+    """X[16,72] appearance products of the tile's 16 samples; dh[3] unit view direction.
+    Returns rgb [16,3] following k_shade's indexing."""
+    lanes = np.arange(64)
+    s, g = lanes & 15, lanes >> 4
+    Xl = np.zeros((64, 3, 6))
+    for l in range(64):
+        for p in range(3):
+            Xl[l, p] = X[s[l], p * 24 + 6 * g[l]: p * 24 + 6 * g[l] + 6]
+    fe = [np.zeros((64, 4)) for _ in range(2)]
+    for p in range(3):
+        for t1 in range(2):
+            for j in range(6):
+                a = np.array([img[IMG_BAS + ((t1 * 3 + p) * 64 + l) * 8 + j] for l in range(64)])
+                fe[t1] = mfma(a, Xl[:, p, j], fe[t1])
+    h1 = [np.stack([img[IMG_B1 + 16 * t1 + 4 * g + r] for r in range(4)], -1) for t1 in range(8)]
+    for t0 in range(2):
+        for t1 in range(8):
+            for r in range(4):
+                a = np.array([img[IMG_W1 + ((t1 * 2 + t0) * 64 + l) * 4 + r] for l in range(64)])
+                h1[t1] = mfma(a, fe[t0][:, r], h1[t1])
+    h1 = [np.maximum(h, 0) for h in h1]
+    h2 = [np.stack([img[IMG_B2 + 16 * t1 + 4 * g + r] for r in range(4)], -1) for t1 in range(8)]
+    for t0 in range(8):
+        for t1 in range(8):
+            for r in range(4):
+                a = np.array([img[IMG_W2 + ((t1 * 8 + t0) * 64 + l) * 4 + r] for l in range(64)])
+                h2[t1] = mfma(a, h1[t0][:, r], h2[t1])
+    o = np.zeros((64, 3))
+    for t1 in range(8):
+        for r in range(4):
+            hv = np.maximum(h2[t1][:, r], 0)
+            for l in range(64):
+                base = IMG_W3H + (g[l] * 32 + t1 * 4 + r) * 4
+                o[l] += hv[l] * img[base: base + 3]
+    # cross-group reduce (xor 16, xor 32): lanes with equal s sum over g
+    tot = np.zeros((16, 3))
+    for l in range(64):
+        tot[s[l]] += o[l]
+    vb = np.array([img[IMG_W3V + 4 * c + 3] + img[IMG_W3V + 4 * c: IMG_W3V + 4 * c + 3] @ dh for c in range(3)])
+    return 1.0 / (1.0 + np.exp(-(tot + vb)))
+
+
+def test_chain_equals_plain_mlp():
+    rng = np.random.default_rng(0)
+    basis = rng.normal(size=(27, 72)) * 0.3
+    w1 = rng.normal(size=(128, 27)) * 0.3
+    b1 = rng.normal(size=128) * 0.3
+    w2 = rng.normal(size=(128, 128)) * 0.1     # asymmetric: catches row/col swaps
+    b2 = rng.normal(size=128) * 0.3
+    w3 = rng.normal(size=(3, 131)) * 0.2
+    b3 = rng.normal(size=3)
+    X = rng.normal(size=(16, 72))
+    dh = rng.normal(size=3)
+    dh /= np.linalg.norm(dh)
+    img = pack_image(basis, w1, b1, w2, b2, w3, b3)
+    got = chain(img, X, dh)
+    feat = X @ basis.T
+    h = np.maximum(feat @ w1.T + b1, 0)
+    h = np.maximum(h @ w2.T + b2, 0)
+    ref = 1.0 / (1.0 + np.exp(-(np.concatenate([h, np.tile(dh, (16, 1))], -1) @ w3.T + b3)))
+    assert np.abs(got - ref).max() < 1e-12
+
+
+# ------------------------------------------------------------------ split-bf16 engine model
+def to_bf16(x):
+    """round-to-nearest-even fp32 -> bf16 (returned as fp32 values)."""
+    b = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def frag_weight(frag, lane, j, basis, w1, w2):
+    """k_pack_mlp_bf16's (frag, lane, j) -> weight value."""
+    i, g = lane & 15, lane >> 4
+    if frag < 6:
+        t1, ks = frag // 3, frag % 3
+        q, row = 8 * ks + j, 16 * t1 + i
+        return basis[row, (q // 6) * 24 + 6 * g + (q % 6)] if (q < 18 and row < 27) else 0.0
+    if frag < 14:
+        col = 16 * (j >> 2) + 4 * g + (j & 3)
+        return w1[16 * (frag - 6) + i, col] if col < 27 else 0.0
+    t1, ks = (frag - 14) >> 2, (frag - 14) & 3
+    return w2[16 * t1 + i, 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3)]
+
+
+def mfma32(A_l, B_l, c, split):
+    """v_mfma_f32_16x16x32_bf16 lane maps: A[i=l&15][k=8*(l>>4)+j], B[k=8*(l>>4)+j][n=l&15].
+    A_l, B_l: [64,8] per-lane values.  split=True applies the 3-term hi/lo product."""
+    A = np.zeros((16, 32)); B = np.zeros((32, 16))
+    for l in range(64):
+        A[l & 15, 8 * (l >> 4): 8 * (l >> 4) + 8] = A_l[l]
+        B[8 * (l >> 4): 8 * (l >> 4) + 8, l & 15] = B_l[l]
+    if split:
+        Ah, Bh = to_bf16(A), to_bf16(B)
+        Al, Bl = to_bf16(A - Ah), to_bf16(B - Bh)
+        D = Al @ Bh + Ah @ Bl + Ah @ Bh
+    else:
+        D = A @ B
+    out = c.copy()
+    for l in range(64):
+        for r in range(4):
+            out[l, r] += D[4 * (l >> 4) + r, l & 15]
+    return out
+
+
+def chain_bf16(params, X, dh, split):
+    basis, w1, b1, w2, b2, w3, b3 = params
+    lanes = np.arange(64)
+    s, g = lanes & 15, lanes >> 4
+
+    def A_of(frag):
+        return np.array([[frag_weight(frag, l, j, basis, w1, w2) for j in range(8)] for l in range(64)])
+    v = np.zeros((64, 24))
+    for l in range(64):
+        for q in range(18):
+            v[l, q] = X[s[l], (q // 6) * 24 + 6 * g[l] + q % 6]
+    fe = [np.zeros((64, 4)) for _ in range(2)]
+    for ks in range(3):
+        for t1 in range(2):
+            fe[t1] = mfma32(A_of(t1 * 3 + ks), v[:, 8 * ks: 8 * ks + 8], fe[t1], split)
+    h1 = [np.stack([b1[16 * t1 + 4 * g + r] for r in range(4)], -1) for t1 in range(8)]
+    Bv = np.concatenate([fe[0], fe[1]], -1)
+    for t1 in range(8):
+        h1[t1] = mfma32(A_of(6 + t1), Bv, h1[t1], split)
+    h2 = [np.stack([b2[16 * t1 + 4 * g + r] for r in range(4)], -1) for t1 in range(8)]
+    for ks in range(4):
+        Bv = np.maximum(np.concatenate([h1[2 * ks], h1[2 * ks + 1]], -1), 0)
+        for t1 in range(8):
+            h2[t1] = mfma32(A_of(14 + t1 * 4 + ks), Bv, h2[t1], split)
+    tot = np.zeros((16, 3))
+    for l in range(64):
+        for t1 in range(8):
+            for r in range(4):
+                tot[s[l]] += max(h2[t1][l, r], 0) * w3[:, 16 * t1 + 4 * g[l] + r]
+    return 1.0 / (1.0 + np.exp(-(tot + w3[:, 128:131] @ dh + b3)))
+
+
+def _torch_like_params(rng):
+    k = lambda n: 1.0 / np.sqrt(n)        # nn.Linear default init range
+    return (rng.uniform(-k(72), k(72), (27, 72)), rng.uniform(-k(27), k(27), (128, 27)),
+            rng.uniform(-k(27), k(27), 128), rng.uniform(-k(128), k(128), (128, 128)),
+            rng.uniform(-k(128), k(128), 128), rng.uniform(-k(131), k(131), (3, 131)), np.zeros(3))
+
+
+def test_bf16_fragment_mapping_and_split_accuracy():
+    rng = np.random.default_rng(1)
+    params = _torch_like_params(rng)
+    basis, w1, b1, w2, b2, w3, b3 = params
+    X = rng.normal(size=(16, 72)) * 0.02        # plane*line products of 0.1*randn grids
+    dh = rng.normal(size=3)
+    dh /= np.linalg.norm(dh)
+    feat = X @ basis.T
+    h = np.maximum(feat @ w1.T + b1, 0)
+    h = np.maximum(h @ w2.T + b2, 0)
+    ref = 1.0 / (1.0 + np.exp(-(np.concatenate([h, np.tile(dh, (16, 1))], -1) @ w3.T + b3)))
+    exact = chain_bf16(params, X, dh, split=False)
+    assert np.abs(exact - ref).max() < 1e-12                 # K-slot mapping is right
+    split = chain_bf16(params, X, dh, split=True)
+    assert np.abs(split - ref).max() < 2e-5                  # 3-term split-bf16 error budget
