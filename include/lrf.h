@@ -85,6 +85,9 @@ typedef struct LrfGrads {
 } LrfGrads;
 
 int         lrf_abi_version(void);
+/* Debug: when set (device buffer of R*S*64 floats), the split-bf16 shade kernel stores 16
+ * intermediate values per (compact sample, lane group); NULL (default) disables it. */
+void        lrf_debug_set_dump(float* buf);
 const char* lrf_last_error(void);
 
 /* Bytes of the layout cache for a grid (x,y,z). */

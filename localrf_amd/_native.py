@@ -40,6 +40,7 @@ class LrfGrads(C.Structure):
 SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
     "lrf_last_error": (C.c_char_p, []),
+    "lrf_debug_set_dump": (None, [C.c_void_p]),
     "lrf_cache_bytes": (C.c_size_t, [C.POINTER(C.c_int32)]),
     "lrf_pack_field": (C.c_int, [C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),
     "lrf_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -75,6 +75,7 @@ struct DField {
   float density_shift, distance_scale, weight_thres;
   const float* basis; const float* w1; const float* b1; const float* w2; const float* b2;
   const float* w3; const float* b3;
+  float* dump;                 // debug: per-sample stage values (lrf_debug_set_dump), else null
 };
 
 // ------------------------------------------------------------------ geometry

@@ -8,8 +8,9 @@
 //              samples that pass weight > thres into per-ray lists + a global work-item
 //              list (ITEM compact samples per item).
 //   k_shade    persistent, one 1024-thread workgroup per CU, the colour network's weights
-//              resident in LDS in MFMA-fragment order.  Each wave pulls items from a device
-//              queue; per 16-sample tile it gathers the 72 appearance products straight
+//              resident in LDS in MFMA-fragment order.  Tiles (16 compact samples of one ray)
+//              are split statically and contiguously over the waves via a prefix sum of the
+//              per-ray tile counts (k_scan_tiles); per 16-sample tile it gathers the 72 appearance products straight
 //              into the B-operand layout of v_mfma_f32_16x16x4_f32 and runs
 //              basis(72->27) -> 128 -> 128 as a register-resident MFMA chain (the D layout
 //              of one layer IS the B layout of the next after a K permutation folded into
@@ -156,8 +157,7 @@ __global__ __launch_bounds__(256) void k_march(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
     uint32_t flags, float floater,
     float* __restrict__ depth, float* __restrict__ acc_ws, float* __restrict__ w_all,
-    int* __restrict__ ncomp, uint16_t* __restrict__ cidx, float* __restrict__ cw,
-    int2* __restrict__ items, int* __restrict__ counters) {
+    int* __restrict__ ncomp, uint16_t* __restrict__ cidx, float* __restrict__ cw) {
   extern __shared__ float s_alpha_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
@@ -234,16 +234,42 @@ __global__ __launch_bounds__(256) void k_march(
       kbar = wave_sum(a_k);
     }
   }
-  const int nit = (nsh + ITEM - 1) / ITEM;
-  int base = 0;
   if (lane == 0) {
     depth[ray] = dsum / dn;                                                         // :615
     acc_ws[ray] = acc;
     ncomp[ray] = nsh;
-    if (nit) base = atomicAdd(&counters[0], nit);
   }
-  base = __shfl(base, 0, 64);
-  if (lane < nit) items[base + lane] = make_int2(ray, lane * ITEM);
+}
+
+// Exclusive prefix sum of per-ray tile counts: toff[r] = sum_{q<r} ceil(ncomp[q]/16),
+// toff[R] = total.  One 1024-thread block; replaces a device-wide atomic work queue (one
+// atomic word saturates at ~88 dequeues/us on this chip -- 52K pulls cost 0.59 ms).
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ ncomp, int R, int* __restrict__ toff) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < R; base += 1024) {
+    const int r = base + tid;
+    const int v = r < R ? (ncomp[r] + ITEM - 1) / ITEM : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wave; ++q) woff += s_wave[q];
+    const int carry = s_carry;
+    if (r < R) toff[r] = carry + woff + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if (tid == 0) toff[R] = s_carry;
 }
 
 // --------------------------------------------------------------------------- shade
@@ -282,16 +308,37 @@ __device__ __forceinline__ void gather_app6(const DField& f, const float u[3], i
   }
 }
 
-// next work item for this wave (wave-uniform)
-__device__ __forceinline__ int pull_item(int* counters, int lane) {
-  int v = 0;
-  if (lane == 0) v = atomicAdd(&counters[1], 1);
-  return __builtin_amdgcn_readfirstlane(v);
+// Static, contiguous split of the T = toff[R] tiles over all waves of the grid (tiles cost
+// the same, so this is balanced to one tile; consecutive tiles of a wave belong to the same
+// ray -> L1/L2 locality; no atomics).  TileWalk yields (ray, j0) for tiles [t, t_end).
+struct TileWalk {
+  int t, t_end, ray, next_off;
+};
+__device__ __forceinline__ TileWalk tile_walk_begin(const int* __restrict__ toff, int R) {
+  TileWalk tw;
+  const int T = toff[R];
+  const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  tw.t = __builtin_amdgcn_readfirstlane((int)(wid * T / waves));
+  tw.t_end = __builtin_amdgcn_readfirstlane((int)((wid + 1) * T / waves));
+  // largest ray with toff[ray] <= t
+  int lo = 0, hi = R;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (toff[mid] <= tw.t) lo = mid; else hi = mid;
+  }
+  tw.ray = lo;
+  tw.next_off = toff[lo + 1];
+  return tw;
+}
+// advance to the ray owning tile tw.t (skips rays without shaded samples)
+__device__ __forceinline__ void tile_walk_seek(TileWalk& tw, const int* __restrict__ toff) {
+  while (tw.next_off <= tw.t) { ++tw.ray; tw.next_off = toff[tw.ray + 1]; }
 }
 
 __global__ __launch_bounds__(1024) void k_shade(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int2* __restrict__ items, int* __restrict__ counters,
+    const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     float* __restrict__ part, int pmax) {
   __shared__ __attribute__((aligned(16))) float img[IMG_FLOATS];
@@ -302,14 +349,12 @@ __global__ __launch_bounds__(1024) void k_shade(
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
-  const int n_items = counters[0];
-
-  int it = pull_item(counters, lane);
-  while (it < n_items) {
+  TileWalk tw = tile_walk_begin(toff, R);
+  for (; tw.t < tw.t_end; ++tw.t) {
     asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
-    const int2 d = items[it];
-    const int ray = __builtin_amdgcn_readfirstlane(d.x);
-    const int j0 = __builtin_amdgcn_readfirstlane(d.y);
+    tile_walk_seek(tw, toff);
+    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
+    const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
     const int cnt = min(ITEM, ncomp[ray] - j0);
 
     const float* rp = rays + (size_t)ray * 6;
@@ -405,7 +450,6 @@ __global__ __launch_bounds__(1024) void k_shade(
         pp[0] = cr; pp[1] = cg; pp[2] = cb;
       }
     }
-    it = pull_item(counters, lane);
   }
 }
 
@@ -420,13 +464,49 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8(const float v[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
+    const __bf16 h = (__bf16)v[j];             // v_cvt_pk_bf16_f32, round-to-nearest-even
     hi[j] = h;
     lo[j] = (__bf16)(v[j] - (float)h);
   }
+  // VALU -> MFMA pad (see settle() below for the measurements): all eight operand registers
+  // pass through one asm statement, so every conversion has retired 16 wait states before
+  // the first MFMA that reads them and none is interleaved with the MFMA burst.
+  {
+    uint4 H = __builtin_bit_cast(uint4, hi), L = __builtin_bit_cast(uint4, lo);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(H.x), "+v"(H.y), "+v"(H.z), "+v"(H.w),
+                                          "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w));
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
+  }
 }
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+// Explicit wait states on both sides of every v_mfma_f32_16x16x32_bf16 burst.
+// Measured on MI355X (scripts/gpu_diag.py stage_nondet, 4096 rays x 512 samples, 39 repeats):
+//   compiler-scheduled (hipcc ROCm 7.2 hazard padding only)      7-15 rays differ per run
+//   + 16 nops VALU->MFMA only                                    ~100-130 rays differ per run
+//   + 24 nops MFMA->VALU only                                    still differs
+//   + both                                                       0 rays differ
+// The differences are single tiles off by 1e-5-scale amounts (a lo-term product computed
+// from a not-yet-written / already-overwritten operand), i.e. the VALU<->XDL hazards of this
+// new gfx950 opcode are handled by hand around the asm MFMAs (see mfma_bf16_acc).  The f32
+// engine (v_mfma_f32_16x16x4_f32, compiler-scheduled) never showed any of this.
+template <int NT>
+__device__ __forceinline__ void settle(f32x4* acc) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[t]));
+}
+// acc += A x B on v_mfma_f32_16x16x32_bf16, ALWAYS accumulating in place (vDst == SrcC).
+// Written as inline asm with a tied "+v" accumulator because hipcc (ROCm 7.2) is free to give
+// the builtin a destination different from its SrcC, and it under-pads the resulting
+// "XDL write -> XDL read SrcC, different vDst" hazard for this gfx950 opcode: the second MFMA
+// of a chain then sometimes read a half-written accumulator (seen as basis-layer outputs
+// 25 % off in ~600 of 48K tiles, different tiles every run; scripts/gpu_diag.py stage_dump).
+// In-place accumulation is the case the hardware interlocks back to back.  Hazards the
+// compiler no longer sees because of the asm are padded by hand: operands are final 16
+// wait states before (split8), results are read 24 wait states after (settle).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_bf16_acc(bf16x8 a, bf16x8 b, f32x4& acc) {
+  const i32x4 ai = __builtin_bit_cast(i32x4, a), bi = __builtin_bit_cast(i32x4, b);
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ai), "v"(bi));
 }
 __device__ __forceinline__ bf16x8 lds_frag(const uint4* img, int frag, int part, int lane) {
   return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
@@ -439,15 +519,15 @@ __device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int strid
   for (int t1 = 0; t1 < NT; ++t1) {
     const bf16x8 ah = lds_frag(img, frag0 + t1 * stride, 0, lane);
     const bf16x8 al = lds_frag(img, frag0 + t1 * stride, 1, lane);
-    acc[t1] = mfma_bf16(al, bh, acc[t1]);
-    acc[t1] = mfma_bf16(ah, bl, acc[t1]);
-    acc[t1] = mfma_bf16(ah, bh, acc[t1]);
+    mfma_bf16_acc(al, bh, acc[t1]);
+    mfma_bf16_acc(ah, bl, acc[t1]);
+    mfma_bf16_acc(ah, bh, acc[t1]);
   }
 }
 
 __global__ __launch_bounds__(1024) void k_shade_bf16(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int2* __restrict__ items, int* __restrict__ counters,
+    const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     float* __restrict__ part, int pmax) {
   __shared__ uint4 img[IMGB_U4];
@@ -455,14 +535,12 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
   __syncthreads();
   const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
-  const int n_items = counters[0];
-
-  int it = pull_item(counters, lane);
-  while (it < n_items) {
-    asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop
-    const int2 d = items[it];
-    const int ray = __builtin_amdgcn_readfirstlane(d.x);
-    const int j0 = __builtin_amdgcn_readfirstlane(d.y);
+  TileWalk tw = tile_walk_begin(toff, R);
+  for (; tw.t < tw.t_end; ++tw.t) {
+    asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
+    tile_walk_seek(tw, toff);
+    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
+    const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
     const int cnt = min(ITEM, ncomp[ray] - j0);
 
     const float* rp = rays + (size_t)ray * 6;
@@ -484,8 +562,10 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
     float X[3][6];
     gather_app6(f, u, g, X);
 
-    // basis 72 -> 27 (tensoRF.py:196): 3 k-steps of 8 K-slots per lane group
+    // basis 72 -> 27 (tensoRF.py:196): 3 k-steps of 8 K-slots per lane group.  fe is zeroed
+    // (VALU writes) before split8's 16-state pad, so the asm MFMAs read a settled SrcC.
     f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
     {
       float v[24];
 #pragma unroll
@@ -496,6 +576,7 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
         split8(&v[8 * ks], bh, bl);
         gemm_step<2>(img, IMGB_BAS / 128 + ks, 3, lane, bh, bl, fe);
       }
+      settle<2>(fe);
     }
     // layer 1 (tensorBase.py:129-130): one k-step, the two feat tiles are its 8 K-slots
     f32x4 h1[8];
@@ -506,6 +587,7 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
       bf16x8 bh, bl;
       split8(v, bh, bl);
       gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
+      settle<8>(h1);
     }
     // layer 2: 4 k-steps, k-step ks consumes relu(h1) tiles 2ks and 2ks+1
     f32x4 h2[8];
@@ -520,6 +602,7 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
       split8(v, bh, bl);
       gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
     }
+    settle<8>(h2);
     // head on the VALU in fp32 (tensorBase.py:131-133)
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -532,6 +615,14 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
       }
     o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+    if (f.dump && valid) {
+      float* dp = f.dump + (((size_t)ray * S + j0 + s) * 4 + g) * 16;
+      dp[0] = X[0][0]; dp[1] = X[1][3]; dp[2] = X[2][5];
+      dp[3] = fe[0][0]; dp[4] = fe[0][3]; dp[5] = fe[1][2];
+      dp[6] = h1[0][0]; dp[7] = h1[3][1]; dp[8] = h1[7][3];
+      dp[9] = h2[0][0]; dp[10] = h2[4][2]; dp[11] = h2[7][3];
+      dp[12] = o0; dp[13] = o1; dp[14] = o2; dp[15] = w;
+    }
     float cr = w / (1.0f + expf(-(o0 + vb[0])));
     float cg = w / (1.0f + expf(-(o1 + vb[1])));
     float cb = w / (1.0f + expf(-(o2 + vb[2])));
@@ -543,7 +634,6 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
       float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
       pp[0] = cr; pp[1] = cg; pp[2] = cb;
     }
-    it = pull_item(counters, lane);
   }
 }
 
@@ -552,15 +642,12 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
 // parity failure can be bisected between the gather/compositing and the MFMA chain.
 __global__ __launch_bounds__(64) void k_shade_valu(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int2* __restrict__ items, const int* __restrict__ counters,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     float* __restrict__ part, int pmax) {
-  const int it = blockIdx.x;
-  if (it >= counters[0]) return;
+  const int ray = blockIdx.x / pmax, j0 = (blockIdx.x % pmax) * ITEM;
   const int lane = threadIdx.x;
-  const int2 d = items[it];
-  const int ray = d.x, j0 = d.y;
   const int cnt = min(ITEM, ncomp[ray] - j0);
+  if (cnt <= 0) return;
   const float* rp = rays + (size_t)ray * 6;
   const float o[3] = {rp[0], rp[1], rp[2]};
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
@@ -727,12 +814,13 @@ static DField make_dfield(const LrfField* f) {
     d.m_inv[a] = 1.0f / (f->alpha_aabb[3 + a] - f->alpha_aabb[a]) * 2.0f;  // tensorBase.py:44
   }
   d.density_shift = f->density_shift; d.distance_scale = f->distance_scale; d.weight_thres = f->weight_thres;
+  d.dump = nullptr;
   d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
   return d;
 }
 
 struct Workspace {
-  int* counters; int* ncomp; float* acc; uint16_t* cidx; float* cw; int2* items; float* part;
+  int* toff; int* ncomp; float* acc; uint16_t* cidx; float* cw; float* part;
   int pmax; size_t bytes;
 };
 static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -741,16 +829,17 @@ static Workspace carve(void* ws, int R, int S) {
   char* p = reinterpret_cast<char*>(ws);
   size_t off = 0;
   w.pmax = (S + ITEM - 1) / ITEM;
-  w.counters = reinterpret_cast<int*>(p + off);       off += 256;
-  w.ncomp    = reinterpret_cast<int*>(p + off);       off += up256((size_t)R * 4);
-  w.acc      = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 4);
-  w.cidx     = reinterpret_cast<uint16_t*>(p + off);  off += up256((size_t)R * S * 2);
-  w.cw       = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
-  w.items    = reinterpret_cast<int2*>(p + off);      off += up256((size_t)R * w.pmax * 8);
-  w.part     = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
+  w.toff  = reinterpret_cast<int*>(p + off);       off += up256((size_t)(R + 1) * 4);
+  w.ncomp = reinterpret_cast<int*>(p + off);       off += up256((size_t)R * 4);
+  w.acc   = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 4);
+  w.cidx  = reinterpret_cast<uint16_t*>(p + off);  off += up256((size_t)R * S * 2);
+  w.cw    = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
+  w.part  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
   w.bytes = off;
   return w;
 }
+
+static float* g_dump = nullptr;
 
 static int device_cus() {
   static int cus = 0;
@@ -770,6 +859,7 @@ using namespace lrf;
 extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
+void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 const char* lrf_last_error(void) { return g_err; }
 
 size_t lrf_cache_bytes(const int32_t grid[3]) { return make_layout(grid).total * sizeof(float); }
@@ -803,23 +893,25 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
                            hipEvent_t* ev /* 4 events or null */) {
   if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
   if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
-  const DField d = make_dfield(f);
+  DField d = make_dfield(f);
+  d.dump = g_dump;
   const Workspace w = carve(workspace, R, S);
-  LRF_HIP(hipMemsetAsync(w.counters, 0, 256, st));
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
                      d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out,
-                     w.ncomp, w.cidx, w.cw, w.items, w.counters);
+                     w.ncomp, w.cidx, w.cw);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (flags & LRF_FLAG_MLP_VALU) {
     hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st,
-                       d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
-  } else if (flags & LRF_FLAG_MLP_F32) {
-    hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st,
-                       d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+                       d, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   } else {
-    hipLaunchKernelGGL(k_shade_bf16, dim3(device_cus()), dim3(1024), 0, st,
-                       d, rays, z, S, w.items, w.counters, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+    if (flags & LRF_FLAG_MLP_F32)
+      hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st,
+                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+    else
+      hipLaunchKernelGGL(k_shade_bf16, dim3(device_cus()), dim3(1024), 0, st,
+                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   }
   if (ev) LRF_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,

@@ -103,7 +103,78 @@ def stage_render_big():
     log("config2 forward ms", round(dt * 1e3, 3), "rays/s", round(4096 / dt))
 
 
-STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120)]
+def stage_chunk():
+    import torch
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).to("cuda:0")
+    for eng in ("bf16x3", "f32", "valu"):
+        f.mlp_engine = eng
+        with torch.no_grad():
+            rgb, depth = f(rays, N_samples=1536)
+            rgb2, depth2 = f(rays, N_samples=1536)
+            ra, da = f(rays[:1000], N_samples=1536)
+            rb, db = f(rays[1000:], N_samples=1536)
+        rc, dc = torch.cat([ra, rb]), torch.cat([da, db])
+        bad = ((rc - rgb).abs().amax(-1) > 0).nonzero()[:, 0]
+        log(eng, "repeat equal", torch.equal(rgb, rgb2), "depth chunk equal", torch.equal(dc, depth),
+            "rgb chunk max diff", float((rc - rgb).abs().max()), "n rays differ", int(bad.numel()),
+            "first", bad[:8].tolist())
+
+
+def stage_nondet():
+    """Run the split-bf16 engine repeatedly on identical inputs and count tiles whose partial
+    sums differ between runs (must be 0).  LRF_BF16_VARIANT selects the experiment build."""
+    import torch
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).to("cuda:0")
+    f.mlp_engine = os.environ.get("DIAG_ENGINE", "bf16x3")
+    outs = []
+    with torch.no_grad():
+        for i in range(40):
+            rgb, _ = f(rays, N_samples=1536)
+            outs.append(rgb.clone())
+        torch.cuda.synchronize()
+        t = time.time()
+        for i in range(50):
+            f(rays, N_samples=1536)
+        torch.cuda.synchronize()
+        dt = (time.time() - t) / 50
+    nd = [int(((o - outs[0]).abs().amax(-1) > 0).sum()) for o in outs[1:]]
+    log("variant", os.environ.get("LRF_BF16_VARIANT", "0"), "engine", f.mlp_engine, "rays differing per run", nd,
+        "max abs diff", max(float((o - outs[0]).abs().max()) for o in outs[1:]), "ms/step", round(dt * 1e3, 4))
+
+
+def stage_dump():
+    """Find the first stage of the split-bf16 chain whose values differ between two runs."""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).to("cuda:0")
+    R, S = 4096, 512
+    names = ["X00", "X13", "X25", "fe00", "fe03", "fe12", "h1_00", "h1_31", "h1_73", "h2_00", "h2_42", "h2_73",
+             "o0", "o1", "o2", "w"]
+    bufs = []
+    with torch.no_grad():
+        for i in range(4):
+            buf = torch.zeros(R * S * 64, device="cuda:0")
+            N.lib().lrf_debug_set_dump(buf.data_ptr())
+            f(rays, N_samples=1536)
+            torch.cuda.synchronize()
+            bufs.append(buf.view(R, S, 4, 16))
+        N.lib().lrf_debug_set_dump(None)
+    for i in range(1, 4):
+        d = (bufs[i] != bufs[0])
+        log("run", i, "differing entries per stage value:", {n: int(d[..., k].sum()) for k, n in enumerate(names)})
+        idx = d.any(-1).nonzero()[:6]
+        for ray, j, g in idx.tolist():
+            a, b = bufs[0][ray, j, g].tolist(), bufs[i][ray, j, g].tolist()
+            log("  ray", ray, "j", j, "g", g, [(n, x, y) for n, x, y in zip(names, a, b) if x != y])
+
+
+STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

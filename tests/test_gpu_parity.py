@@ -204,6 +204,20 @@ def test_full_size_properties(big):
     assert rel_err(_np(outs["bf16x3"]), _np(outs["valu"])) < 3e-5
 
 
+@pytest.mark.parametrize("engine", ["bf16x3", "f32"])
+def test_repeat_runs_are_bitwise_identical(big, engine):
+    """Guards the MFMA->VALU hazard padding in k_shade_bf16 (see settle() in lrf_render.hip):
+    40 renders of the same 4096x512 batch must agree bit for bit."""
+    f, rays = big
+    f.mlp_engine = engine
+    with torch.no_grad():
+        first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+        for _ in range(40):
+            again, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            assert torch.equal(first, again)
+    f.mlp_engine = "bf16x3"
+
+
 def test_layout_cache_tracks_parameter_updates(built_lib):
     f = quiet(make_field, [24, 24, 24], "cpu", seed=2).to(DEV)
     rays = make_rays(64, 3).to(DEV)
