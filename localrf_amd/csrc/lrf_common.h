@@ -29,7 +29,7 @@ constexpr int IMG_FLOATS = IMG_W3V + 16;             // 24336 floats = 97,344 B
 // Split-bf16 MLP image (16-byte units, then a float tail).  Every weight w is stored as
 // hi = bf16(w), lo = bf16(w - hi); a fragment is [part hi/lo][lane64][8 bf16] and feeds the
 // A operand of v_mfma_f32_16x16x32_bf16.  K-slot (g = lane>>4, j) of k-step ks maps to input
-// feature: basis q=8ks+j -> (p=q/6, c=6g+q%6); layers 1/2: tile 2ks+(j>>2), feature
+// feature: basis k-step p (a plane): j<6 -> channel 6g+j, j>=6 -> zero; layers 1/2: tile 2ks+(j>>2), feature
 // 16*tile+4g+(j&3) -- i.e. exactly the D registers the lane already holds.
 constexpr int IMGB_BAS = 0;                        // frags [t'2][ks3]
 constexpr int IMGB_W1  = IMGB_BAS + 2 * 3 * 128;   // frags [t'8][ks1]

@@ -132,9 +132,8 @@ __global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
     const int j = 2 * wj + h;
     float v = 0.0f;
     if (frag < 6) {                                            // basis: frag = t'*3 + ks
-      const int t1 = frag / 3, ks = frag % 3;
-      const int q = 8 * ks + j, row = 16 * t1 + i;
-      if (q < 18 && row < LRF_APP_DIM) v = p.basis[row * 72 + (q / 6) * LRF_CA + 6 * g + (q % 6)];
+      const int t1 = frag / 3, pl = frag % 3, row = 16 * t1 + i;
+      if (j < 6 && row < LRF_APP_DIM) v = p.basis[row * 72 + pl * LRF_CA + 6 * g + j];
     } else if (frag < 14) {                                    // layer 1: frag-6 = t'
       const int t1 = frag - 6;
       const int col = 16 * (j >> 2) + 4 * g + (j & 3);
@@ -281,31 +280,34 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 // appearance products for this lane's 6 channels of each plane (tensoRF.py:153-195):
 // lane (s, g) of a tile owns channels 6g..6g+5 of plane p -> K-slot g of MFMA k-step (p, j).
-__device__ __forceinline__ void gather_app6(const DField& f, const float u[3], int g, float X[3][6]) {
+template <int p>
+__device__ __forceinline__ void gather_app6_plane(const DField& f, const float u[3], int g, float X[6]) {
+  int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+  tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+  tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+  tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+  const float* pl = f.aplane[p] + 6 * g;
+  const float* q00 = pl + ((size_t)y0 * f.pw[p] + x0) * LRF_CA;
+  const float* q10 = pl + ((size_t)y0 * f.pw[p] + x1) * LRF_CA;
+  const float* q01 = pl + ((size_t)y1 * f.pw[p] + x0) * LRF_CA;
+  const float* q11 = pl + ((size_t)y1 * f.pw[p] + x1) * LRF_CA;
+  const float* r0 = f.aline[p] + (size_t)l0 * LRF_CA + 6 * g;
+  const float* r1 = f.aline[p] + (size_t)l1 * LRF_CA + 6 * g;
+  const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
+  const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
+  const float wl0 = 1.0f - tl, wl1 = tl;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-    const float* pl = f.aplane[p] + 6 * g;
-    const float* q00 = pl + ((size_t)y0 * f.pw[p] + x0) * LRF_CA;
-    const float* q10 = pl + ((size_t)y0 * f.pw[p] + x1) * LRF_CA;
-    const float* q01 = pl + ((size_t)y1 * f.pw[p] + x0) * LRF_CA;
-    const float* q11 = pl + ((size_t)y1 * f.pw[p] + x1) * LRF_CA;
-    const float* r0 = f.aline[p] + (size_t)l0 * LRF_CA + 6 * g;
-    const float* r1 = f.aline[p] + (size_t)l1 * LRF_CA + 6 * g;
-    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
-    const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
-    const float wl0 = 1.0f - tl, wl1 = tl;
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-      const float2 a = ld2(q00 + 2 * h), b = ld2(q10 + 2 * h), c = ld2(q01 + 2 * h), d = ld2(q11 + 2 * h);
-      const float2 e = ld2(r0 + 2 * h), q = ld2(r1 + 2 * h);
-      X[p][2 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
-      X[p][2 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
-    }
+  for (int h = 0; h < 3; ++h) {
+    const float2 a = ld2(q00 + 2 * h), b = ld2(q10 + 2 * h), c = ld2(q01 + 2 * h), d = ld2(q11 + 2 * h);
+    const float2 e = ld2(r0 + 2 * h), q = ld2(r1 + 2 * h);
+    X[2 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
+    X[2 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
   }
+}
+__device__ __forceinline__ void gather_app6(const DField& f, const float u[3], int g, float X[3][6]) {
+  gather_app6_plane<0>(f, u, g, X[0]);
+  gather_app6_plane<1>(f, u, g, X[1]);
+  gather_app6_plane<2>(f, u, g, X[2]);
 }
 
 // Static, contiguous split of the T = toff[R] tiles over all waves of the grid (tiles cost
@@ -559,23 +561,29 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
     const float w = valid ? cw[ci] : 0.0f;
     float x[3], u[3];
     sample_point(f, o, dh, z[k], x, u);
-    float X[3][6];
-    gather_app6(f, u, g, X);
-
-    // basis 72 -> 27 (tensoRF.py:196): 3 k-steps of 8 K-slots per lane group.  fe is zeroed
-    // (VALU writes) before split8's 16-state pad, so the asm MFMAs read a settled SrcC.
+    // basis 72 -> 27 (tensoRF.py:196): one k-step per plane -- K-slots j<6 of lane group g are
+    // the plane's channels 6g..6g+5, slots 6,7 are zero -- so each plane's gather feeds its
+    // MFMAs directly and only six products are live at a time.  fe is zeroed (VALU writes)
+    // before split8's 16-state pad, so the asm MFMAs read a settled SrcC.
     f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
+    float xdbg[3] = {0.0f, 0.0f, 0.0f};
     {
-      float v[24];
-#pragma unroll
-      for (int q = 0; q < 24; ++q) v[q] = q < 18 ? X[q / 6][q % 6] : 0.0f;
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        bf16x8 bh, bl;
-        split8(&v[8 * ks], bh, bl);
-        gemm_step<2>(img, IMGB_BAS / 128 + ks, 3, lane, bh, bl, fe);
-      }
+      float v[8];
+      v[6] = 0.0f; v[7] = 0.0f;
+      bf16x8 bh, bl;
+      gather_app6_plane<0>(f, u, g, v);
+      xdbg[0] = v[0];
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
+      gather_app6_plane<1>(f, u, g, v);
+      xdbg[1] = v[3];
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
+      gather_app6_plane<2>(f, u, g, v);
+      xdbg[2] = v[5];
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
     }
     // layer 1 (tensorBase.py:129-130): one k-step, the two feat tiles are its 8 K-slots
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
     if (f.dump && valid) {
       float* dp = f.dump + (((size_t)ray * S + j0 + s) * 4 + g) * 16;
-      dp[0] = X[0][0]; dp[1] = X[1][3]; dp[2] = X[2][5];
+      dp[0] = xdbg[0]; dp[1] = xdbg[1]; dp[2] = xdbg[2];
       dp[3] = fe[0][0]; dp[4] = fe[0][3]; dp[5] = fe[1][2];
       dp[6] = h1[0][0]; dp[7] = h1[3][1]; dp[8] = h1[7][3];
       dp[9] = h2[0][0]; dp[10] = h2[4][2]; dp[11] = h2[7][3];

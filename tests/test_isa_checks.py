@@ -4,7 +4,10 @@
    emits that overlap when a source dies at the instruction; on MI355X it produced rare,
    run-to-run different 1e-5-scale errors in the split-bf16 colour chain (see keep_live() in
    csrc/lrf_render.hip).  The kernel keeps sources live to forbid it; this test pins that.
-2. The hot kernels must not spill to scratch.
+2. The bf16 MFMAs must accumulate in place (vDst == SrcC): the compiler under-pads the
+   "different vDst" dependent-MFMA hazard for this opcode (see mfma_bf16_acc()).
+3. k_march must not spill; k_shade_bf16 (capped at 128 VGPRs by its 1024-thread workgroup)
+   may park a few loop-invariant lane constants in scratch, bounded here.
 """
 import os
 import re
@@ -44,9 +47,17 @@ def test_bf16_mfma_destination_never_overlaps_sources(asm):
     assert n >= 138           # 18 (basis) + 24 (layer 1) + 96 (layer 2) per tile
 
 
-def test_hot_kernels_do_not_spill(asm):
-    for kern in ("k_marchE", "k_shade_bf16E"):
+def test_bf16_mfma_accumulates_in_place(asm):
+    pat = re.compile(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], (v\[\d+:\d+\]|0)")
+    ms = list(pat.finditer(asm))
+    assert len(ms) >= 138
+    for m in ms:
+        assert m[1] == m[2], m[0]
+
+
+def test_scratch_use_is_bounded(asm):
+    for kern, limit in (("k_marchE", 0), ("k_shade_bf16E", 128)):
         m = re.search(r"\.amdhsa_kernel _ZN3lrf\d+%s.*?\.end_amdhsa_kernel" % kern, asm, re.S)
         assert m, kern
         priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m[0])
-        assert priv and int(priv[1]) == 0, (kern, priv and priv[1])
+        assert priv and int(priv[1]) <= limit, (kern, priv and priv[1])

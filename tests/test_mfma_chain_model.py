@@ -149,9 +149,9 @@ def frag_weight(frag, lane, j, basis, w1, w2):
     """k_pack_mlp_bf16's (frag, lane, j) -> weight value."""
     i, g = lane & 15, lane >> 4
     if frag < 6:
-        t1, ks = frag // 3, frag % 3
-        q, row = 8 * ks + j, 16 * t1 + i
-        return basis[row, (q // 6) * 24 + 6 * g + (q % 6)] if (q < 18 and row < 27) else 0.0
+        t1, pl = frag // 3, frag % 3
+        row = 16 * t1 + i
+        return basis[row, pl * 24 + 6 * g + j] if (j < 6 and row < 27) else 0.0
     if frag < 14:
         col = 16 * (j >> 2) + 4 * g + (j & 3)
         return w1[16 * (frag - 6) + i, col] if col < 27 else 0.0
@@ -188,8 +188,8 @@ def chain_bf16(params, X, dh, split):
         return np.array([[frag_weight(frag, l, j, basis, w1, w2) for j in range(8)] for l in range(64)])
     v = np.zeros((64, 24))
     for l in range(64):
-        for q in range(18):
-            v[l, q] = X[s[l], (q // 6) * 24 + 6 * g[l] + q % 6]
+        for pl in range(3):
+            v[l, 8 * pl: 8 * pl + 6] = X[s[l], pl * 24 + 6 * g[l]: pl * 24 + 6 * g[l] + 6]
     fe = [np.zeros((64, 4)) for _ in range(2)]
     for ks in range(3):
         for t1 in range(2):
