@@ -117,10 +117,13 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            float* rgb, float* depth, void* workspace, void* stream,
                            float* ms_out, int32_t* n_shaded_out);
 
+/* Bytes of scratch lrf_render_bwd needs (worst case: every sample shaded). */
+size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]);
+
 /* Backward of lrf_render_fwd (replaces autograd through tensorBase.py:567-636,
  * tensoRF.py:112-196): recomputes the forward, scatters parameter gradients into `g`
- * (reference layout) and writes d(loss)/d(rays) [R,6]. floater_thresh must be 0
- * (the filter is eval-only, train.py:107,139). */
+ * (reference layout, +=) and writes d(loss)/d(rays) [R,6]. The floater filter is eval-only
+ * (train.py:107,139) and not differentiated. `workspace`: lrf_workspace_bytes_bwd bytes. */
 int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, const float* z,
                    int32_t R, int32_t S, uint32_t flags,
                    const float* g_rgb, const float* g_depth,

@@ -1,0 +1,734 @@
+// lrf_backward.inl -- backward of the render path for gfx950 (included by lrf_render.hip).
+//
+// lrf_render_bwd replaces autograd through tensorBase.py:567-636 + tensoRF.py:112-196
+// (paths relative to /root/reference/localTensoRF).  Nothing from the forward call is kept:
+// the forward is recomputed (it costs ~0.2 ms) and the backward runs as
+//
+//   k_march (+feat)      density features of every sample, compaction lists (as in forward)
+//   k_scan_tiles         tile offsets
+//   k_bwd_shade_fwd      split-bf16 colour chain again, now saving per shaded sample: rgb and
+//                        the activation row ACT = [X | feat,1 | relu(h1),1 | relu(h2), dhat,1]
+//   k_bwd_shade_dgrad    per tile: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX as an
+//                        exact-fp32 MFMA chain on TRANSPOSED weight fragments (same register-
+//                        resident trick as the forward: D layout of one layer = B operand of
+//                        the next), gradient row GRD = [go | dfeat | dz1 | dz2]; appearance
+//                        plane/line gradients by fp32 hardware atomics into a channel-last
+//                        gradient image; d/d(position) -> per-tile ray-gradient partials
+//   k_wgrad<MT,NT> x4    weight gradients as tall-skinny GEMMs C = A^T B over the saved rows
+//                        (K = shaded samples) on v_mfma_f32_16x16x4_f32, per-chunk partials
+//   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts
+//   k_bwd_ray            one wavefront per ray: weights, d(loss)/d(w), suffix sums ->
+//                        d/d(alpha) -> d/d(density feature); density plane/line gradients by
+//                        atomics; position gradients through the contraction to (o, d)
+//   k_unpack_grad        channel-last gradient image -> += the reference's [1,C,H,W] grads
+#pragma once
+
+namespace lrf {
+
+// ---- saved rows (floats) -------------------------------------------------------------
+constexpr int ACT_X = 0, ACT_FEAT = 80, ACT_H1 = 112, ACT_H2 = 256, ACT_LD = 400;
+constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DZ1 = 48, GRD_DZ2 = 176, GRD_LD = 304;
+// transposed fp32 fragment image for the dgrad chain
+constexpr int IMT_W2T = 0;                          // [t'8][t8][lane64][4]  W2[16t+4g+r][16t'+i]
+constexpr int IMT_W1T = IMT_W2T + 8 * 8 * 256;      // [t'2][t8][lane64][4]  W1[16t+4g+r][16t'+i]
+constexpr int IMT_BT  = IMT_W1T + 2 * 8 * 256;      // [t'5][t2][lane64][4]  basis[16t+4g+r][phi(i>>2, 4t'+(i&3))]
+constexpr int IMT_W3H = IMT_BT + 5 * 2 * 256;       // [g4][f32][4]          as IMG_W3H
+constexpr int IMT_FLOATS = IMT_W3H + 512;           // 23552 floats = 94,208 B
+// weight-gradient partial block per K-chunk (floats)
+constexpr int WP_W2 = 0;                            // [128][144]  dz2^T [h1r | 1]
+constexpr int WP_W1 = WP_W2 + 128 * 144;            // [128][32]   dz1^T [feat | 1]
+constexpr int WP_BAS = WP_W1 + 128 * 32;            // [32][80]    dfeat^T X
+constexpr int WP_W3 = WP_BAS + 32 * 80;             // [16][144]   go^T [h2r | dhat | 1]
+constexpr int WP_FLOATS = WP_W3 + 16 * 144;
+constexpr int WGRAD_CH = 2048;                      // rows per K-chunk
+
+__global__ void k_pack_mlp_t(LrfParams p, float* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= IMT_FLOATS) return;
+  float v = 0.0f;
+  if (idx < IMT_W1T) {
+    const int e = idx - IMT_W2T, r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
+    const int t1 = tt >> 3, t0 = tt & 7;
+    v = p.w2[(16 * t0 + 4 * (lane >> 4) + r) * LRF_FEATC + 16 * t1 + (lane & 15)];
+  } else if (idx < IMT_BT) {
+    const int e = idx - IMT_W1T, r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
+    const int t1 = tt >> 3, t0 = tt & 7;
+    const int col = 16 * t1 + (lane & 15);
+    if (col < LRF_APP_DIM) v = p.w1[(16 * t0 + 4 * (lane >> 4) + r) * LRF_APP_DIM + col];
+  } else if (idx < IMT_W3H) {
+    const int e = idx - IMT_BT, r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
+    const int t1 = tt >> 1, t0 = tt & 1;
+    const int i = lane & 15, row = 16 * t0 + 4 * (lane >> 4) + r;    // basis row (feat index)
+    const int q = 4 * t1 + (i & 3), gp = i >> 2;                     // output slot q of lane group gp
+    if (row < LRF_APP_DIM && q < 18) v = p.basis[row * 72 + (q / 6) * LRF_CA + 6 * gp + (q % 6)];
+  } else {
+    const int e = idx - IMT_W3H, o = e & 3, fidx = (e >> 2) & 31, g = e >> 7;
+    const int feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3);
+    if (o < 3) v = p.w3[o * (LRF_FEATC + 3) + feat];
+  }
+  img[idx] = v;
+}
+
+// tap1d + d(ix)/d(u): (size-1)/2 inside, 0 where ATen's clip_coordinates_set_grad zeroes it
+__device__ __forceinline__ void tap1d_g(float u, int size, int& i0, int& i1, float& t, float& gmul) {
+  const float raw = ((u + 1.0f) * 0.5f) * (float)(size - 1);
+  const float hi = (float)(size - 1);
+  gmul = (raw <= 0.0f || raw >= hi) ? 0.0f : 0.5f * hi;
+  const float ix = fminf(fmaxf(raw, 0.0f), hi);
+  const float f0 = floorf(ix);
+  t = ix - f0;
+  i0 = (int)f0;
+  i1 = min(i0 + 1, size - 1);
+}
+
+// backward of contract3 (utils/ray_utils.py:9-12): xr = uncontracted position, g = grad wrt
+// the contracted position (in/out: becomes grad wrt xr)
+__device__ __forceinline__ void contract3_bwd(const float xr[3], float g[3]) {
+  const float a0 = fabsf(xr[0]), a1 = fabsf(xr[1]), a2 = fabsf(xr[2]);
+  const float m = fmaxf(fmaxf(fmaxf(a0, a1), a2), 1e-6f);
+  if (m > 1.0f) {
+    const float s = (2.0f * m - 1.0f) / (m * m);
+    const float sp = (2.0f - 2.0f * m) / (m * m * m);
+    const float dot = xr[0] * g[0] + xr[1] * g[1] + xr[2] * g[2];
+    const int am = (a0 >= a1 && a0 >= a2) ? 0 : (a1 >= a2 ? 1 : 2);
+    g[0] *= s; g[1] *= s; g[2] *= s;
+    g[am] += (xr[am] >= 0.0f ? 1.0f : -1.0f) * sp * dot;
+  }
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---------------------------------------------------------------- colour chain, saving rows
+// Same arithmetic as k_shade_bf16; additionally writes rgb per shaded sample and the ACT row.
+__global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff, int R,
+    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    float* __restrict__ crgb, float* __restrict__ act) {
+  __shared__ uint4 img[IMGB_U4];
+  for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
+  __syncthreads();
+  const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  TileWalk tw = tile_walk_begin(toff, R);
+  for (; tw.t < tw.t_end; ++tw.t) {
+    asm volatile("" ::: "memory");
+    tile_walk_seek(tw, toff);
+    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
+    const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
+    const int cnt = min(ITEM, ncomp[ray] - j0);
+    const float* rp = rays + (size_t)ray * 6;
+    const float o[3] = {rp[0], rp[1], rp[2]};
+    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+    float vb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
+      vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
+    }
+    const bool valid = s < cnt;
+    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
+    const int k = cidx[ci];
+    float x[3], u[3];
+    sample_point(f, o, dh, z[k], x, u);
+    float* arow = act + ((size_t)tw.t * 16 + s) * ACT_LD;
+
+    f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
+    {
+      float v[8];
+      v[6] = 0.0f; v[7] = 0.0f;
+      bf16x8 bh, bl;
+      gather_app6_plane<0>(f, u, g, v);
+#pragma unroll
+      for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 0 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
+      gather_app6_plane<1>(f, u, g, v);
+#pragma unroll
+      for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 1 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
+      gather_app6_plane<2>(f, u, g, v);
+#pragma unroll
+      for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 2 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
+      settle<2>(fe);
+    }
+    // feat (27) | 1 | 0 0 0 0 ; pad columns 72..79 of the X block
+    {
+      float4 a = make_float4(fe[0][0], fe[0][1], fe[0][2], fe[0][3]);
+      float4 b = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
+      if (g == 2) b.w = 1.0f;                        // column 27 = bias column of the dW1 GEMM
+      if (g == 3) b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(arow + ACT_FEAT + 4 * g) = a;
+      *reinterpret_cast<float4*>(arow + ACT_FEAT + 16 + 4 * g) = b;
+      if (g < 2) *reinterpret_cast<float4*>(arow + 72 + 4 * g) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    f32x4 h1[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * t1 + 4 * g]);
+    {
+      const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
+      settle<8>(h1);
+    }
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
+      *reinterpret_cast<f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g) = h1[t1];
+    }
+    *reinterpret_cast<float4*>(arow + ACT_H1 + 128 + 4 * g) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+    f32x4 h2[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h1[2 * ks + (j >> 2)][j & 3];
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
+    }
+    settle<8>(h2);
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h2[t1][r] = fmaxf(h2[t1][r], 0.0f);
+        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + (g * 32 + t1 * 4 + r) * 4]);
+        o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
+      }
+      *reinterpret_cast<f32x4*>(arow + ACT_H2 + 16 * t1 + 4 * g) = h2[t1];
+    }
+    *reinterpret_cast<float4*>(arow + ACT_H2 + 128 + 4 * g) =
+        g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+    if (valid && g == 0) {
+      float* cp = crgb + ((size_t)ray * S + j0 + s) * 3;
+      cp[0] = 1.0f / (1.0f + expf(-(o0 + vb[0])));
+      cp[1] = 1.0f / (1.0f + expf(-(o1 + vb[1])));
+      cp[2] = 1.0f / (1.0f + expf(-(o2 + vb[2])));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- colour chain, data gradient
+__global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
+    DField f, const float* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff, int R,
+    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
+    const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
+    float* __restrict__ grd, float* __restrict__ gcache, Layout L, float* __restrict__ rpart, int pmax) {
+  __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
+  {
+    const float4* src = reinterpret_cast<const float4*>(imt);
+    float4* dst = reinterpret_cast<float4*>(img);
+    for (int i = threadIdx.x; i < IMT_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  TileWalk tw = tile_walk_begin(toff, R);
+  for (; tw.t < tw.t_end; ++tw.t) {
+    asm volatile("" ::: "memory");
+    tile_walk_seek(tw, toff);
+    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
+    const int tile = tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM);
+    const int j0 = tile * ITEM;
+    const int cnt = min(ITEM, ncomp[ray] - j0);
+    const float* rp = rays + (size_t)ray * 6;
+    const float o[3] = {rp[0], rp[1], rp[2]};
+    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+    const bool valid = s < cnt;
+    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
+    const int k = cidx[ci];
+    const float zk = z[k];
+    const size_t row = (size_t)tw.t * 16 + s;
+    const float* arow = act + row * ACT_LD;
+    float* grow = grd + row * GRD_LD;
+
+    // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k  (tensorBase.py:632-633)
+    float go[3] = {0.0f, 0.0f, 0.0f};
+    if (valid) {
+      const float w = cw[ci];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float r = crgb[ci * 3 + c];
+        go[c] = g_rgb[(size_t)ray * 3 + c] * w * r * (1.0f - r);
+      }
+    }
+    *reinterpret_cast<float4*>(grow + GRD_GO + 4 * g) =
+        g == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    // dz2 = (W3[:, :128]^T go) * [h2 > 0]
+    f32x4 dz[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) {
+      const f32x4 h2 = *reinterpret_cast<const f32x4*>(arow + ACT_H2 + 16 * t1 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 wv = *reinterpret_cast<const float4*>(&img[IMT_W3H + (g * 32 + t1 * 4 + r) * 4]);
+        const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
+        dz[t1][r] = h2[r] > 0.0f ? d : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];
+    }
+    // dz1 = (W2^T dz2) * [h1 > 0]      (exact fp32 MFMA, transposed fragments)
+    f32x4 d1[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) d1[t1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t0 = 0; t0 < 8; ++t0) {
+#pragma unroll
+      for (int t1 = 0; t1 < 8; ++t1) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W2T + ((t1 * 8 + t0) * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[t1] = mfma4(a[r], dz[t0][r], d1[t1]);
+      }
+    }
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) {
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d1[t1][r] = h1[r] > 0.0f ? d1[t1][r] : 0.0f;
+      *reinterpret_cast<f32x4*>(grow + GRD_DZ1 + 16 * t1 + 4 * g) = d1[t1];
+    }
+    // dfeat = W1^T dz1
+    f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int t0 = 0; t0 < 8; ++t0) {
+#pragma unroll
+      for (int t1 = 0; t1 < 2; ++t1) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W1T + ((t1 * 8 + t0) * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) df[t1] = mfma4(a[r], d1[t0][r], df[t1]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(grow + GRD_DFEAT + 4 * g) = df[0];
+    *reinterpret_cast<f32x4*>(grow + GRD_DFEAT + 16 + 4 * g) = df[1];
+    // dX = basis^T dfeat, delivered in the gather layout: slot q = 4t'+r of lane (s,g) is
+    // channel (p = q/6, 6g + q%6)
+    f32x4 dxs[5];
+#pragma unroll
+    for (int t1 = 0; t1 < 5; ++t1) dxs[t1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t0 = 0; t0 < 2; ++t0) {
+#pragma unroll
+      for (int t1 = 0; t1 < 5; ++t1) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_BT + ((t1 * 2 + t0) * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dxs[t1] = mfma4(a[r], df[t0][r], dxs[t1]);
+      }
+    }
+    float dX[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) dX[q] = dxs[q >> 2][q & 3];
+
+    // scatter into the appearance planes/lines and collect d/d(position)
+    float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
+    float xc[3] = {xr[0], xr[1], xr[2]};
+    contract3(xc[0], xc[1], xc[2]);
+    float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - f.lo[a]) * f.inv[a] - 1.0f;
+    if (valid) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        int x0, x1, y0, y1, l0, l1; float tx, ty, tl, gx, gy, gl;
+        tap1d_g(u[MAT0[p]], f.pw[p], x0, x1, tx, gx);
+        tap1d_g(u[MAT1[p]], f.ph[p], y0, y1, ty, gy);
+        tap1d_g(u[VEC[p]],  f.ll[p], l0, l1, tl, gl);
+        const size_t i00 = ((size_t)y0 * f.pw[p] + x0) * LRF_CA + 6 * g, i10 = ((size_t)y0 * f.pw[p] + x1) * LRF_CA + 6 * g;
+        const size_t i01 = ((size_t)y1 * f.pw[p] + x0) * LRF_CA + 6 * g, i11 = ((size_t)y1 * f.pw[p] + x1) * LRF_CA + 6 * g;
+        const size_t j0l = (size_t)l0 * LRF_CA + 6 * g, j1l = (size_t)l1 * LRF_CA + 6 * g;
+        const float* pl = f.aplane[p];
+        const float* ln = f.aline[p];
+        float* gpl = gcache + L.aplane[p];
+        float* gln = gcache + L.aline[p];
+        const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+        float gix = 0.0f, giy = 0.0f, gil = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const float v00 = pl[i00 + c], v10 = pl[i10 + c], v01 = pl[i01 + c], v11 = pl[i11 + c];
+          const float e0 = ln[j0l + c], e1 = ln[j1l + c];
+          const float P = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
+          const float Lv = e0 * (1.0f - tl) + e1 * tl;
+          const float d = dX[p * 6 + c];
+          const float dP = d * Lv, dL = d * P;
+          atomic_add_f32(gpl + i00 + c, dP * w00); atomic_add_f32(gpl + i10 + c, dP * w10);
+          atomic_add_f32(gpl + i01 + c, dP * w01); atomic_add_f32(gpl + i11 + c, dP * w11);
+          atomic_add_f32(gln + j0l + c, dL * (1.0f - tl)); atomic_add_f32(gln + j1l + c, dL * tl);
+          gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
+          giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
+          gil += dL * (e1 - e0);
+        }
+        gu[MAT0[p]] += gix * gx; gu[MAT1[p]] += giy * gy; gu[VEC[p]] += gil * gl;
+      }
+    }
+    // sum the four channel groups of a sample, go back through normalise + contraction
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      gu[a] += __shfl_xor(gu[a], 16, 64);
+      gu[a] += __shfl_xor(gu[a], 32, 64);
+    }
+    float gx3[3] = {gu[0] * f.inv[0], gu[1] * f.inv[1], gu[2] * f.inv[2]};
+    contract3_bwd(xr, gx3);
+    float pr[6] = {gx3[0], gx3[1], gx3[2], gx3[0] * zk, gx3[1] * zk, gx3[2] * zk};
+    if (!valid) { pr[0] = pr[1] = pr[2] = pr[3] = pr[4] = pr[5] = 0.0f; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int dd = 1; dd < 16; dd <<= 1) pr[q] += __shfl_xor(pr[q], dd, 64);
+    if (lane == 0) {
+      float* rpp = rpart + ((size_t)ray * pmax + tile) * 8;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rpp[q] = pr[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight gradients
+// C[M x N] partial = A[rows, M]^T  B[rows, N] over one K-chunk of saved rows.
+// 4 waves; wave w owns M-tiles w, w+4, ...; every wave sweeps all NT N-tiles.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                               const int* __restrict__ toff, int R, float* __restrict__ wpart, int wp_off) {
+  const int rows = toff[R] * 16;
+  const int r0 = blockIdx.x * WGRAD_CH;
+  if (r0 >= rows) return;
+  const int r1 = min(r0 + WGRAD_CH, rows);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  constexpr int MW = (MT + 3) / 4;
+  f32x4 acc[MW][NT];
+#pragma unroll
+  for (int m = 0; m < MW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  for (int r = r0; r < r1; r += 4) {
+    const int row = r + g;
+    const bool ok = row < r1;
+    const float* ap = A + (size_t)row * lda + i;
+    const float* bp = B + (size_t)row * ldb + i;
+    float a[MW], b[NT];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) a[m] = (ok && wave + 4 * m < MT) ? ap[16 * (wave + 4 * m)] : 0.0f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b[n] = ok ? bp[16 * n] : 0.0f;
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], b[n], acc[m][n]);
+  }
+  float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    const int mt = wave + 4 * m;
+    if (mt < MT) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * (NT * 16) + 16 * n + i] = acc[m][n][r];
+    }
+  }
+}
+
+// dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in order)
+__global__ void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
+                               int off, int ld, int n_off, int m_count, int n_count,
+                               float* __restrict__ dst, int dst_ld) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m_count * n_count) return;
+  const int m = idx / n_count, n = idx % n_count;
+  const int nch = (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
+  float acc = 0.0f;
+  for (int c = 0; c < nch; ++c) acc += wpart[(size_t)c * WP_FLOATS + off + m * ld + n_off + n];
+  dst[m * dst_ld + n] += acc;
+}
+
+// ---------------------------------------------------------------- per-ray backward
+// tensorBase.py:584-615,632-634 backwards: d(loss)/d(w) -> d/d(alpha) -> d/d(sigma feature),
+// density plane/line gradients, d/d(rays).
+__global__ __launch_bounds__(256) void k_bwd_ray(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S, uint32_t flags,
+    const float* __restrict__ feat, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    const float* __restrict__ crgb, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+    float* __restrict__ gcache, Layout L, const float* __restrict__ rpart, int pmax,
+    float* __restrict__ g_rays) {
+  extern __shared__ float s_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + wave;
+  if (ray >= R) return;
+  float* s_alpha = s_all + (size_t)wave * 4 * S;
+  float* s_w = s_alpha + S;
+  float* s_gw = s_w + S;
+  int* s_idx = reinterpret_cast<int*>(s_gw + S);
+  const float* rp = rays + (size_t)ray * 6;
+  const float o[3] = {rp[0], rp[1], rp[2]};
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+  const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+  const bool relu = flags & LRF_FLAG_RELU_DENS;
+  const float white = (flags & LRF_FLAG_WHITE_BG) ? 1.0f : 0.0f;
+  const float gr[3] = {g_rgb[(size_t)ray * 3], g_rgb[(size_t)ray * 3 + 1], g_rgb[(size_t)ray * 3 + 2]};
+  const float gsum = (gr[0] + gr[1] + gr[2]) * white;
+  const float gd = g_depth[ray];
+  const int nchunk = (S + 63) >> 6;
+  const int nsh = ncomp[ray];
+
+  for (int k = lane; k < S; k += 64) s_idx[k] = -1;
+  for (int j = lane; j < nsh; j += 64) s_idx[cidx[(size_t)ray * S + j]] = j;
+  // alpha per sample (same arithmetic as k_march)
+  for (int k = lane; k < S; k += 64) {
+    float alpha = 0.0f;
+    const float fk = feat[(size_t)ray * S + k];
+    if (k < S - 1 && fk > -INFINITY) {
+      const float sigma = feature2density(fk, f.density_shift, relu);
+      alpha = 1.0f - expf(-sigma * (z[k + 1] - z[k]) * f.distance_scale);
+    }
+    if (k == S - 1) alpha = 1.0f;
+    s_alpha[k] = alpha;
+  }
+  // weights and d(loss)/d(w_k);  total = sum_k gw_k w_k
+  float carry = 1.0f, tot = 0.0f, dsum = 0.0f;
+  for (int c = 0; c < nchunk; ++c) {
+    const int k = (c << 6) + lane;
+    const float alpha = k < S ? s_alpha[k] : 0.0f;
+    const float v = k < S ? (1.0f - alpha + 1e-10f) : 1.0f;
+    float excl, total;
+    wave_scan_prod(v, lane, excl, total);
+    const float T = carry * excl;
+    carry *= total;
+    const float w = alpha * T;
+    if (k < S) {
+      float gw = gd * z[k] / dn - gsum;
+      const int j = s_idx[k];
+      if (j >= 0) {
+        const float* cp = crgb + ((size_t)ray * S + j) * 3;
+        gw += gr[0] * cp[0] + gr[1] * cp[1] + gr[2] * cp[2];
+      }
+      s_w[k] = w;
+      s_gw[k] = gw;
+      tot += gw * w;
+      dsum += w * z[k];
+    }
+  }
+  tot = wave_sum(tot);
+  dsum = wave_sum(dsum);
+  // d/d(alpha_k) = gw_k T_k - (sum_{j>k} gw_j w_j) / (1 - alpha_k + 1e-10)   (alpha2weights,
+  // tensorBase.py:23-32), then alpha -> sigma -> feature (:610, :495-499).  T_k comes from a
+  // second product scan, the suffix sum from a running inclusive sum of gw*w.
+  float go3[3] = {0.0f, 0.0f, 0.0f}, gdh[3] = {0.0f, 0.0f, 0.0f};
+  float run = 0.0f;
+  carry = 1.0f;
+  for (int c = 0; c < nchunk; ++c) {
+    const int k = (c << 6) + lane;
+    const float alpha = k < S ? s_alpha[k] : 0.0f;
+    const float vk = k < S ? (1.0f - alpha + 1e-10f) : 1.0f;
+    float excl, total;
+    wave_scan_prod(vk, lane, excl, total);
+    const float Tk = carry * excl;
+    carry *= total;
+    const float gww = k < S ? s_gw[k] * s_w[k] : 0.0f;
+    float incl = gww;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    const float chunk_total = __shfl(incl, 63, 64);
+    float gf = 0.0f;
+    if (k < S - 1) {
+      const float fk = feat[(size_t)ray * S + k];
+      if (fk > -INFINITY) {
+        const float suffix = tot - (run + incl);
+        const float dalpha = s_gw[k] * Tk - suffix / vk;
+        const float y = fk + f.density_shift;
+        const float dsig_df = relu ? (fk > 0.0f ? 1.0f : 0.0f) : (y > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-y)));
+        gf = dalpha * (z[k + 1] - z[k]) * f.distance_scale * (1.0f - alpha) * dsig_df;
+      }
+    }
+    run += chunk_total;
+    if (k < S) s_alpha[k] = gf;            // alpha of sample k is not needed any more
+  }
+  // density scatter + position gradient
+  for (int k = lane; k < S - 1; k += 64) {
+    const float gf = s_alpha[k];
+    if (gf == 0.0f) continue;
+    const float zk = z[k];
+    float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
+    float xc[3] = {xr[0], xr[1], xr[2]};
+    contract3(xc[0], xc[1], xc[2]);
+    float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - f.lo[a]) * f.inv[a] - 1.0f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      int x0, x1, y0, y1, l0, l1; float tx, ty, tl, gx, gy, gl;
+      tap1d_g(u[MAT0[p]], f.pw[p], x0, x1, tx, gx);
+      tap1d_g(u[MAT1[p]], f.ph[p], y0, y1, ty, gy);
+      tap1d_g(u[VEC[p]],  f.ll[p], l0, l1, tl, gl);
+      const size_t i00 = ((size_t)y0 * f.pw[p] + x0) * LRF_CD, i10 = ((size_t)y0 * f.pw[p] + x1) * LRF_CD;
+      const size_t i01 = ((size_t)y1 * f.pw[p] + x0) * LRF_CD, i11 = ((size_t)y1 * f.pw[p] + x1) * LRF_CD;
+      const size_t j0l = (size_t)l0 * LRF_CD, j1l = (size_t)l1 * LRF_CD;
+      const float* pl = f.dplane[p];
+      const float* ln = f.dline[p];
+      float* gpl = gcache + L.dplane[p];
+      float* gln = gcache + L.dline[p];
+      const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+      float gix = 0.0f, giy = 0.0f, gil = 0.0f;
+#pragma unroll
+      for (int c = 0; c < LRF_CD; ++c) {
+        const float v00 = pl[i00 + c], v10 = pl[i10 + c], v01 = pl[i01 + c], v11 = pl[i11 + c];
+        const float e0 = ln[j0l + c], e1 = ln[j1l + c];
+        const float P = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
+        const float Lv = e0 * (1.0f - tl) + e1 * tl;
+        const float dP = gf * Lv, dL = gf * P;
+        atomic_add_f32(gpl + i00 + c, dP * w00); atomic_add_f32(gpl + i10 + c, dP * w10);
+        atomic_add_f32(gpl + i01 + c, dP * w01); atomic_add_f32(gpl + i11 + c, dP * w11);
+        atomic_add_f32(gln + j0l + c, dL * (1.0f - tl)); atomic_add_f32(gln + j1l + c, dL * tl);
+        gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
+        giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
+        gil += dL * (e1 - e0);
+      }
+      gu[MAT0[p]] += gix * gx; gu[MAT1[p]] += giy * gy; gu[VEC[p]] += gil * gl;
+    }
+    float gx3[3] = {gu[0] * f.inv[0], gu[1] * f.inv[1], gu[2] * f.inv[2]};
+    contract3_bwd(xr, gx3);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { go3[a] += gx3[a]; gdh[a] += gx3[a] * zk; }
+  }
+  // appearance partials of this ray's tiles (written by k_bwd_shade_dgrad)
+  const int nt = (nsh + ITEM - 1) / ITEM;
+  for (int t = lane; t < nt; t += 64) {
+    const float* rpp = rpart + ((size_t)ray * pmax + t) * 8;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { go3[a] += rpp[a]; gdh[a] += rpp[3 + a]; }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { go3[a] = wave_sum(go3[a]); gdh[a] = wave_sum(gdh[a]); }
+  if (lane == 0) {
+    // dhat = d / n (tensorBase.py:578-580); depth = sum(w z) / n (:615)
+    const float dot = dh[0] * gdh[0] + dh[1] * gdh[1] + dh[2] * gdh[2];
+    const float depth = dsum / dn;
+    float* gp = g_rays + (size_t)ray * 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      gp[a] = go3[a];
+      gp[3 + a] = (gdh[a] - dh[a] * dot) / dn - gd * depth / dn * dh[a];
+    }
+  }
+}
+
+// channel-last gradient image -> += reference layout [C,H,W]
+__global__ void k_unpack_plane_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= W) return;
+  for (int c = 0; c < C; ++c) dst[((size_t)c * H + y) * W + x] += src[((size_t)y * W + x) * C + c];
+}
+__global__ void k_unpack_line_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int Lh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * Lh) return;
+  const int l = i / C, c = i % C;
+  dst[(size_t)c * Lh + l] += src[i];
+}
+
+struct BwdWorkspace {
+  Workspace fw;
+  float* feat; float* crgb; float* gcache; float* imt; float* act; float* grd; float* rpart; float* wpart;
+  float* depth; float* rgb;
+  size_t gcache_floats, bytes;
+};
+static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
+  BwdWorkspace b;
+  b.fw = carve(ws, R, S);
+  char* p = reinterpret_cast<char*>(ws);
+  size_t off = b.fw.bytes;
+  const Layout L = make_layout(grid);
+  const size_t rows = (size_t)R * b.fw.pmax * 16;
+  const size_t nch = (rows + WGRAD_CH - 1) / WGRAD_CH;
+  b.gcache_floats = L.mlp;
+  auto take = [&](size_t nfloat) { float* q = reinterpret_cast<float*>(p + off); off += up256(nfloat * 4); return q; };
+  b.feat = take((size_t)R * S);
+  b.crgb = take((size_t)R * S * 3);
+  b.gcache = take(L.mlp);
+  b.imt = take(IMT_FLOATS);
+  b.act = take(rows * ACT_LD);
+  b.grd = take(rows * GRD_LD);
+  b.rpart = take((size_t)R * b.fw.pmax * 8);
+  b.wpart = take(nch * WP_FLOATS);
+  b.depth = take(R);
+  b.rgb = take((size_t)R * 3);
+  b.bytes = off;
+  return b;
+}
+
+}  // namespace lrf
+
+extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
+  return lrf::carve_bwd(nullptr, R, S, grid).bytes;
+}
+
+extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, const float* z,
+                              int32_t R, int32_t S, uint32_t flags, const float* g_rgb, const float* g_depth,
+                              const LrfGrads* g, float* g_rays, void* workspace, void* stream) {
+  using namespace lrf;
+  if (!f || !f->cache || !p || !rays || !z || !g_rgb || !g_depth || !g || !g_rays || !workspace)
+    return set_err("lrf_render_bwd: null argument");
+  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_bwd: need R > 0 and 2 <= S <= 4096");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const DField d = make_dfield(f);
+  const Layout L = make_layout(f->grid);
+  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
+  const Workspace& w = b.fw;
+  const int cus = device_cus();
+  LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
+  hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
+  hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
+                     d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, (float*)nullptr, w.ncomp, w.cidx, w.cw, b.feat);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+  hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
+                     b.crgb, b.act);
+  hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
+                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.gcache, L, b.rpart, w.pmax);
+  const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
+  hipLaunchKernelGGL((k_wgrad<8, 9>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
+                     w.toff, R, b.wpart, WP_W2);
+  hipLaunchKernelGGL((k_wgrad<8, 2>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
+                     w.toff, R, b.wpart, WP_W1);
+  hipLaunchKernelGGL((k_wgrad<2, 5>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
+                     w.toff, R, b.wpart, WP_BAS);
+  hipLaunchKernelGGL((k_wgrad<1, 9>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
+                     w.toff, R, b.wpart, WP_W3);
+  auto reduce = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld) {
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((m * n + 255) / 256), dim3(256), 0, st, b.wpart, w.toff, R,
+                       off, ld, n_off, m, n, dst, dst_ld);
+  };
+  reduce(WP_W2, 144, 0, 128, 128, g->w2, 128);
+  reduce(WP_W2, 144, 128, 128, 1, g->b2, 1);
+  reduce(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM);
+  reduce(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1);
+  reduce(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72);
+  reduce(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
+  reduce(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
+  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), st,
+                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
+                     b.gcache, L, b.rpart, w.pmax, g_rays);
+  for (int q = 0; q < 3; ++q) {
+    dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
+    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q]);
+    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q]);
+    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, b.gcache + L.dline[q], g->density_line[q], LRF_CD, L.ll[q]);
+    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, b.gcache + L.aline[q], g->app_line[q], LRF_CA, L.ll[q]);
+  }
+  LRF_HIP(hipGetLastError());
+  return 0;
+}

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void k_march(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
     uint32_t flags, float floater,
     float* __restrict__ depth, float* __restrict__ acc_ws, float* __restrict__ w_all,
-    int* __restrict__ ncomp, uint16_t* __restrict__ cidx, float* __restrict__ cw) {
+    int* __restrict__ ncomp, uint16_t* __restrict__ cidx, float* __restrict__ cw,
+    float* __restrict__ feat_out /* [R,S] density feature, -inf where not evaluated; or null */) {
   extern __shared__ float s_alpha_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void k_march(
   // pass A: alpha per sample -> LDS
   for (int c = 0; c < nchunk; ++c) {
     const int k = (c << 6) + lane;
-    float alpha = 0.0f;
+    float alpha = 0.0f, fk = -INFINITY;
     if (k < S - 1) {                               // last sample is never valid (:600)
       const float zk = z[k];
       float x[3], u[3];
@@ -181,12 +182,16 @@ __global__ __launch_bounds__(256) void k_march(
       bool valid = true;
       if (f.alpha_vol) valid = alpha_mask_sample(f, x[0], x[1], x[2]) > 0.0f;   // :593-598
       if (valid) {
-        const float sigma = feature2density(density_feature(f, u), f.density_shift, relu);  // :603-608
+        fk = density_feature(f, u);
+        const float sigma = feature2density(fk, f.density_shift, relu);            // :603-608
         const float dist = z[k + 1] - zk;                                          // :584-587
         alpha = 1.0f - expf(-sigma * dist * f.distance_scale);                     // :610
       }
     }
-    if (k < S) s_alpha[k] = alpha;
+    if (k < S) {
+      s_alpha[k] = alpha;
+      if (feat_out) feat_out[(size_t)ray * S + k] = fk;
+    }
   }
   // (each wave only touches its own LDS slice: no barrier needed, LDS ops are in order per wave)
 
@@ -862,6 +867,8 @@ static int device_cus() {
 
 }  // namespace lrf
 
+#include "lrf_backward.inl"
+
 using namespace lrf;
 
 extern "C" {
@@ -907,7 +914,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
   hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
                      d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out,
-                     w.ncomp, w.cidx, w.cw);
+                     w.ncomp, w.cidx, w.cw, (float*)nullptr);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (flags & LRF_FLAG_MLP_VALU) {
     hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st,
@@ -964,11 +971,6 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
   }
   for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
-}
-
-int lrf_render_bwd(const LrfField*, const LrfParams*, const float*, const float*, int32_t, int32_t, uint32_t,
-                   const float*, const float*, const LrfGrads*, float*, void*, void*) {
-  return set_err("lrf_render_bwd: not implemented in this build");
 }
 
 int lrf_density_feature(const LrfField* f, const float* u, int32_t P, float* out, void* stream) {

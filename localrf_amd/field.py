@@ -213,7 +213,7 @@ class TensorVMSplit(torch.nn.Module):
         self.gridSize = self.gridSize.to(device)
         if self.alphaMask is not None:
             self.alphaMask = self.alphaMask.to(device)
-        self._cache = self._cache_key = self._ws = None
+        self._cache = self._cache_key = self._ws = self._ws_bwd = None
         self._cfield_key = None
         self._z_cache = {}
         return super().to(device)
@@ -358,7 +358,11 @@ class TensorVMSplit(torch.nn.Module):
             cg.app_plane[i] = grads[6 + i].data_ptr()
             cg.app_line[i] = grads[9 + i].data_ptr()
         (cg.basis, cg.w1, cg.b1, cg.w2, cg.b2, cg.w3, cg.b3) = [g.data_ptr() for g in grads[12:]]
-        ws = self._workspace(R, S, dev)
+        nbytes = lib.lrf_workspace_bytes_bwd(R, S, cp.grid)
+        if getattr(self, "_ws_bwd", None) is None or self._ws_bwd.numel() < nbytes or self._ws_bwd.device != dev:
+            self._ws_bwd = None
+            self._ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = self._ws_bwd
         f = self._c_field()
         st = torch.cuda.current_stream(dev).cuda_stream
         N.check(lib.lrf_render_bwd(C.byref(f), C.byref(cp), N.ptr(rays), N.ptr(z), R, S, flags,

@@ -236,3 +236,53 @@ def test_layout_cache_tracks_parameter_updates(built_lib):
     fld = {k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}
     ro, _ = oracle.render_field(fld, _np(rays), oracle.z_schedule(96), True, 0.0)
     _check_rays(_np(c), ro)
+
+
+# ----------------------------------------------------------------- backward (lrf_render_bwd)
+def _grad_rel(a, b):
+    """max |a-b| relative to the largest reference magnitude of the tensor (gradients span
+    orders of magnitude inside one plane; a per-element relative error is not meaningful)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def test_backward_vs_reference_autograd_golden(built_lib):
+    """Train-mode forward with the recorded jitter, then lrf_render_bwd against the gradients
+    the reference's autograd produced (tests/golden/field_small_train_grad.npz)."""
+    g = load_golden("field_small_train_grad")
+    f = quiet(field_from_golden, g, DEV)
+    z = oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"]))
+    f.z_override = torch.from_numpy(z)
+    rays = torch.from_numpy(g["rays"]).to(DEV).requires_grad_(True)
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    _check_rays(_np(rgb), g["rgb"])
+    loss = (rgb * torch.from_numpy(g["g_rgb"]).to(DEV)).sum() + (depth * torch.from_numpy(g["g_depth"]).to(DEV)).sum()
+    loss.backward()
+    worst = {}
+    for name, p in f.named_parameters():
+        if not p.requires_grad:
+            continue
+        worst[name] = _grad_rel(_np(p.grad), g["grad." + name])
+    worst["rays"] = _grad_rel(_np(rays.grad), g["grad.rays"])
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, (bad, worst)
+
+
+def test_backward_accumulates_and_zero_grad_output(built_lib):
+    g = load_golden("field_small_train_grad")
+    f = quiet(field_from_golden, g, DEV)
+    f.z_override = torch.from_numpy(oracle.z_schedule(int(g["N_samples"])))
+    rays = torch.from_numpy(g["rays"]).to(DEV)
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    (rgb.sum() * 0.0 + depth.sum() * 0.0).backward()
+    for name, p in f.named_parameters():
+        if p.requires_grad:
+            assert float(p.grad.abs().max()) == 0.0, name
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    rgb.sum().backward()
+    g1 = {n: p.grad.clone() for n, p in f.named_parameters() if p.requires_grad}
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    rgb.sum().backward()                                   # autograd accumulates into .grad
+    for n, p in f.named_parameters():
+        if p.requires_grad:
+            assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-4, atol=1e-7), n
