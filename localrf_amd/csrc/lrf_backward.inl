@@ -27,7 +27,7 @@ namespace lrf {
 
 // ---- saved rows (floats) -------------------------------------------------------------
 constexpr int ACT_X = 0, ACT_FEAT = 80, ACT_H1 = 112, ACT_H2 = 256, ACT_LD = 400;
-constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DZ1 = 48, GRD_DZ2 = 176, GRD_LD = 304;
+constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DZ1 = 48, GRD_DZ2 = 176, GRD_DX = 304, GRD_LD = 384;
 // transposed fp32 fragment image for the dgrad chain
 constexpr int IMT_W2T = 0;                          // [t'8][t8][lane64][4]  W2[16t+4g+r][16t'+i]
 constexpr int IMT_W1T = IMT_W2T + 8 * 8 * 256;      // [t'2][t8][lane64][4]  W1[16t+4g+r][16t'+i]
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
-    float* __restrict__ grd, float* __restrict__ gcache, Layout L, float* __restrict__ rpart, int pmax) {
+    float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax) {
   __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
   {
     const float4* src = reinterpret_cast<const float4*>(imt);
@@ -332,8 +332,15 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     float dX[18];
 #pragma unroll
     for (int q = 0; q < 18; ++q) dX[q] = dxs[q >> 2][q & 3];
+    // dX row (natural channel order) + sample id for the binned plane/line scatter kernels
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq)
+#pragma unroll
+      for (int h = 0; h < 3; ++h)
+        *reinterpret_cast<float2*>(grow + GRD_DX + pq * LRF_CA + 6 * g + 2 * h) = make_float2(dX[pq * 6 + 2 * h], dX[pq * 6 + 2 * h + 1]);
+    if (g == 0) rowinfo[row] = valid ? (uint32_t)((size_t)ray * S + k) : 0xffffffffu;
 
-    // scatter into the appearance planes/lines and collect d/d(position)
+    // d/d(position) from the appearance lookups
     float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
     float xc[3] = {xr[0], xr[1], xr[2]};
     contract3(xc[0], xc[1], xc[2]);
@@ -352,21 +359,15 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         const size_t j0l = (size_t)l0 * LRF_CA + 6 * g, j1l = (size_t)l1 * LRF_CA + 6 * g;
         const float* pl = f.aplane[p];
         const float* ln = f.aline[p];
-        float* gpl = gcache + L.aplane[p];
-        float* gln = gcache + L.aline[p];
-        const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
         float gix = 0.0f, giy = 0.0f, gil = 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const float v00 = pl[i00 + c], v10 = pl[i10 + c], v01 = pl[i01 + c], v11 = pl[i11 + c];
           const float e0 = ln[j0l + c], e1 = ln[j1l + c];
-          const float P = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
+          const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
           const float Lv = e0 * (1.0f - tl) + e1 * tl;
           const float d = dX[p * 6 + c];
           const float dP = d * Lv, dL = d * P;
-          atomic_add_f32(gpl + i00 + c, dP * w00); atomic_add_f32(gpl + i10 + c, dP * w10);
-          atomic_add_f32(gpl + i01 + c, dP * w01); atomic_add_f32(gpl + i11 + c, dP * w11);
-          atomic_add_f32(gln + j0l + c, dL * (1.0f - tl)); atomic_add_f32(gln + j1l + c, dL * tl);
           gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
           giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
           gil += dL * (e1 - e0);
@@ -445,13 +446,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 __global__ void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
                                int off, int ld, int n_off, int m_count, int n_count,
                                float* __restrict__ dst, int dst_ld) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= m_count * n_count) return;
-  const int m = idx / n_count, n = idx % n_count;
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;   // 16 lanes per element
+  const bool ok = idx < m_count * n_count;
+  const int m = ok ? idx / n_count : 0, n = ok ? idx % n_count : 0;
   const int nch = (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
   float acc = 0.0f;
-  for (int c = 0; c < nch; ++c) acc += wpart[(size_t)c * WP_FLOATS + off + m * ld + n_off + n];
-  dst[m * dst_ld + n] += acc;
+  for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + off + m * ld + n_off + n];
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);          // fixed tree: deterministic
+  if (ok && sub == 0) dst[m * dst_ld + n] += acc;
 }
 
 // ---------------------------------------------------------------- per-ray backward
@@ -459,10 +462,10 @@ __global__ void k_wgrad_reduce(const float* __restrict__ wpart, const int* __res
 // density plane/line gradients, d/d(rays).
 __global__ __launch_bounds__(256) void k_bwd_ray(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S, uint32_t flags,
-    const float* __restrict__ feat, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    float* __restrict__ feat /* in: density feature; out: d(loss)/d(feature) */,
+    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
     const float* __restrict__ crgb, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
-    float* __restrict__ gcache, Layout L, const float* __restrict__ rpart, int pmax,
-    float* __restrict__ g_rays) {
+    const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays) {
   extern __shared__ float s_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
@@ -556,7 +559,10 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       }
     }
     run += chunk_total;
-    if (k < S) s_alpha[k] = gf;            // alpha of sample k is not needed any more
+    if (k < S) {
+      s_alpha[k] = gf;                     // alpha of sample k is not needed any more
+      feat[(size_t)ray * S + k] = gf;      // consumed by the binned scatter kernels
+    }
   }
   // density scatter + position gradient
   for (int k = lane; k < S - 1; k += 64) {
@@ -580,20 +586,14 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       const size_t j0l = (size_t)l0 * LRF_CD, j1l = (size_t)l1 * LRF_CD;
       const float* pl = f.dplane[p];
       const float* ln = f.dline[p];
-      float* gpl = gcache + L.dplane[p];
-      float* gln = gcache + L.dline[p];
-      const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
       float gix = 0.0f, giy = 0.0f, gil = 0.0f;
 #pragma unroll
       for (int c = 0; c < LRF_CD; ++c) {
         const float v00 = pl[i00 + c], v10 = pl[i10 + c], v01 = pl[i01 + c], v11 = pl[i11 + c];
         const float e0 = ln[j0l + c], e1 = ln[j1l + c];
-        const float P = v00 * w00 + v10 * w10 + v01 * w01 + v11 * w11;
+        const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
         const float Lv = e0 * (1.0f - tl) + e1 * tl;
         const float dP = gf * Lv, dL = gf * P;
-        atomic_add_f32(gpl + i00 + c, dP * w00); atomic_add_f32(gpl + i10 + c, dP * w10);
-        atomic_add_f32(gpl + i01 + c, dP * w01); atomic_add_f32(gpl + i11 + c, dP * w11);
-        atomic_add_f32(gln + j0l + c, dL * (1.0f - tl)); atomic_add_f32(gln + j1l + c, dL * tl);
         gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
         giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
         gil += dL * (e1 - e0);
@@ -627,6 +627,296 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   }
 }
 
+// ---------------------------------------------------------------- binned gradient scatter
+// Plane/line gradients are sums over samples that land on the same texels.  Doing them with
+// global fp32 atomics measured 40 ms per 4096x512 batch (12-20 G lane-atomics/s: every ray
+// starts near the field centre, so the same texels are hit by thousands of rays at once) --
+// no better than the stock PyTorch-ROCm grid_sample backward.  Instead samples are binned by
+// 32x32-texel plane tile (counting sort, LDS histograms), each tile's contributions are
+// accumulated in LDS (ds_add_f32) by the workgroups that own it and flushed once; lines are
+// accumulated per workgroup in LDS as well.  Global atomics remain only in the flushes.
+constexpr int BTILE = 32, BCELL = BTILE + 1;
+constexpr int BIN_CHUNK = 4096;          // entries per block in the hist/fill passes
+constexpr int BIN_MAX = 2048;            // max tiles over the three planes (640^3 -> 1200)
+constexpr int LINE_WGS = 256;            // workgroups per line
+
+struct BinGeom { int tx[3], ty[3], base[3], total; };
+__host__ __device__ inline BinGeom make_bins(const Layout& L) {
+  BinGeom b; int off = 0;
+  for (int p = 0; p < 3; ++p) {
+    b.tx[p] = (L.pw[p] + BTILE - 1) / BTILE; b.ty[p] = (L.ph[p] + BTILE - 1) / BTILE;
+    b.base[p] = off; off += b.tx[p] * b.ty[p];
+  }
+  b.total = off;
+  return b;
+}
+
+// entry i -> sample id (ray*S + k) or ~0u.  Density: every sample with a non-zero feature
+// gradient; appearance: the saved rows of the shaded samples.
+template <bool APP>
+__device__ __forceinline__ uint32_t entry_cid(uint32_t i, const float* __restrict__ gf, const uint32_t* __restrict__ rowinfo) {
+  if (APP) return rowinfo[i];
+  return gf[i] != 0.0f ? i : 0xffffffffu;
+}
+template <bool APP>
+__device__ __forceinline__ uint32_t entry_count(int R, int S, const int* __restrict__ toff) {
+  return APP ? (uint32_t)toff[R] * 16u : (uint32_t)R * (uint32_t)S;
+}
+__device__ __forceinline__ void cid_point(const DField& f, const float* __restrict__ rays, const float* __restrict__ z,
+                                          int S, uint32_t cid, float u[3]) {
+  const int ray = cid / S, k = cid % S;
+  const float* rp = rays + (size_t)ray * 6;
+  const float o[3] = {rp[0], rp[1], rp[2]};
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+  const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+  float x[3];
+  sample_point(f, o, dh, z[k], x, u);
+}
+
+// pass 1: tile id of every entry in every plane + global histogram
+template <bool APP>
+__global__ __launch_bounds__(256) void k_bin_hist(DField f, BinGeom bg, const float* __restrict__ rays, const float* __restrict__ z,
+                                                  int R, int S, const int* __restrict__ toff, const float* __restrict__ gf,
+                                                  const uint32_t* __restrict__ rowinfo, uint32_t nmax,
+                                                  uint16_t* __restrict__ tid, int* __restrict__ hist) {
+  __shared__ int s_h[BIN_MAX];
+  const uint32_t n = entry_count<APP>(R, S, toff);
+  const uint32_t b0 = blockIdx.x * (uint32_t)BIN_CHUNK;
+  if (b0 >= n) return;
+  for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
+  __syncthreads();
+  for (uint32_t i = b0 + threadIdx.x; i < min(n, b0 + BIN_CHUNK); i += 256) {
+    const uint32_t cid = entry_cid<APP>(i, gf, rowinfo);
+    if (cid == 0xffffffffu) {
+      tid[i] = 0xffff; tid[(size_t)nmax + i] = 0xffff; tid[2 * (size_t)nmax + i] = 0xffff;
+      continue;
+    }
+    float u[3];
+    cid_point(f, rays, z, S, cid, u);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      int x0, x1, y0, y1; float tx, ty;
+      tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+      tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+      const int t = (y0 / BTILE) * bg.tx[p] + x0 / BTILE;
+      tid[(size_t)p * nmax + i] = (uint16_t)t;
+      atomicAdd(&s_h[bg.base[p] + t], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bg.total; i += 256)
+    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// exclusive scan of the histogram -> list offsets; cursors start at the offsets
+__global__ __launch_bounds__(1024) void k_bin_scan(const int* __restrict__ hist, int nb, int* __restrict__ offs, int* __restrict__ cursor) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int r = base + tid;
+    const int v = r < nb ? hist[r] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wave; ++q) woff += s_wave[q];
+    const int carry = s_carry;
+    if (r < nb) { offs[r] = carry + woff + incl - v; cursor[r] = carry + woff + incl - v; }
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if (tid == 0) offs[nb] = s_carry;
+}
+
+// pass 2: entry ids into per-tile lists (block-level reservation, LDS ranks)
+__global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int R, int S, const int* __restrict__ toff, int app,
+                                                  const uint16_t* __restrict__ tid, int* __restrict__ cursor,
+                                                  uint32_t* __restrict__ list) {
+  __shared__ int s_h[BIN_MAX];
+  const uint32_t n = app ? (uint32_t)toff[R] * 16u : (uint32_t)R * (uint32_t)S;
+  const uint32_t b0 = blockIdx.x * (uint32_t)BIN_CHUNK;
+  if (b0 >= n) return;
+  for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
+  __syncthreads();
+  constexpr int PER = BIN_CHUNK / 256;
+  int rank[PER][3];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const uint32_t i = b0 + threadIdx.x + 256u * q;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      rank[q][p] = -1;
+      if (i < n) {
+        const uint16_t t = tid[(size_t)p * nmax + i];
+        if (t != 0xffff) rank[q][p] = atomicAdd(&s_h[bg.base[p] + t], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bg.total; i += 256)
+    if (s_h[i]) s_h[i] = atomicAdd(&cursor[i], s_h[i]);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const uint32_t i = b0 + threadIdx.x + 256u * q;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      if (rank[q][p] >= 0) list[s_h[bg.base[p] + tid[(size_t)p * nmax + i]] + rank[q][p]] = i;
+  }
+}
+
+// Plane gradients.  The entry lists are sorted by tile; workgroup w owns the w-th equal share
+// of the concatenated list (a few tiles hold 12 % of all samples each, so one workgroup per
+// tile is badly unbalanced), accumulates tile by tile in LDS and flushes each tile once.
+template <int C, bool APP>
+__global__ __launch_bounds__(256) void k_scatter_plane(DField f, BinGeom bg, Layout L, const float* __restrict__ rays,
+                                                       const float* __restrict__ z, int S, const int* __restrict__ offs,
+                                                       const uint32_t* __restrict__ list, const float* __restrict__ gf,
+                                                       const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
+                                                       float* __restrict__ gcache) {
+  extern __shared__ float s_acc[];                     // [BCELL*BCELL][C]
+  const long long E = offs[bg.total];
+  int a = (int)(E * blockIdx.x / gridDim.x);
+  const int b = (int)(E * (blockIdx.x + 1) / gridDim.x);
+  if (a >= b) return;
+  int lo = 0, hi = bg.total;                           // largest bin with offs[bin] <= a
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
+  int bin = lo;
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;   // 8 lanes share one entry, lane owns channels sub+8j
+  while (a < b) {
+    while (offs[bin + 1] <= a) ++bin;
+    const int seg_end = min(b, offs[bin + 1]);
+    const int p = bin >= bg.base[2] ? 2 : (bin >= bg.base[1] ? 1 : 0);
+    const int t = bin - bg.base[p];
+    const int tx0 = (t % bg.tx[p]) * BTILE, ty0 = (t / bg.tx[p]) * BTILE;
+    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += 256) s_acc[i] = 0.0f;
+    __syncthreads();
+    const float* lnp = APP ? f.aline[p] : f.dline[p];
+    for (int e = a + grp; e < seg_end; e += 32) {
+      const uint32_t i = list[e];
+      const uint32_t cid = APP ? rowinfo[i] : i;
+      float u[3];
+      cid_point(f, rays, z, S, cid, u);
+      int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+      tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+      tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+      tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+      const int c00 = ((y0 - ty0) * BCELL + (x0 - tx0)) * C, c10 = ((y0 - ty0) * BCELL + (x1 - tx0)) * C;
+      const int c01 = ((y1 - ty0) * BCELL + (x0 - tx0)) * C, c11 = ((y1 - ty0) * BCELL + (x1 - tx0)) * C;
+      const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+      const float* r0 = lnp + (size_t)l0 * C;
+      const float* r1 = lnp + (size_t)l1 * C;
+      const float gfi = APP ? 0.0f : gf[i];
+      const float* dxr = APP ? grd + (size_t)i * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
+#pragma unroll
+      for (int j = 0; j < C / 8; ++j) {
+        const int c = sub + 8 * j;
+        const float Lv = r0[c] * (1.0f - tl) + r1[c] * tl;
+        const float dP = (APP ? dxr[c] : gfi) * Lv;
+        atomicAdd(&s_acc[c00 + c], dP * w00); atomicAdd(&s_acc[c10 + c], dP * w10);
+        atomicAdd(&s_acc[c01 + c], dP * w01); atomicAdd(&s_acc[c11 + c], dP * w11);
+      }
+    }
+    __syncthreads();
+    float* gpl = gcache + (APP ? L.aplane[p] : L.dplane[p]);
+    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += 256) {
+      const float v = s_acc[i];
+      if (v == 0.0f) continue;
+      const int cell = i / C, c = i % C;
+      const int x = tx0 + cell % BCELL, y = ty0 + cell / BCELL;
+      if (x < f.pw[p] && y < f.ph[p]) atomic_add_f32(gpl + ((size_t)y * f.pw[p] + x) * C + c, v);
+    }
+    __syncthreads();
+    a = seg_end;
+  }
+}
+
+// line gradients: LINE_WGS workgroups per line, each accumulates its slice of the entries
+template <int C, bool APP>
+__global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const float* __restrict__ rays, const float* __restrict__ z,
+                                                      int R, int S, const int* __restrict__ toff, const float* __restrict__ gf,
+                                                      const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
+                                                      float* __restrict__ gcache) {
+  extern __shared__ float s_acc[];                     // [L_p][C]
+  const int p = blockIdx.x / LINE_WGS, wg = blockIdx.x % LINE_WGS;
+  const int nl = f.ll[p] * C;
+  for (int i = threadIdx.x; i < nl; i += 256) s_acc[i] = 0.0f;
+  __syncthreads();
+  const uint32_t n = entry_count<APP>(R, S, toff);
+  const uint32_t a = (uint32_t)((unsigned long long)n * wg / LINE_WGS), b = (uint32_t)((unsigned long long)n * (wg + 1) / LINE_WGS);
+  const float* plp = APP ? f.aplane[p] : f.dplane[p];
+  // 8 lanes per entry (lane `sub` owns channels sub, sub+8, ...); each 8-lane group walks a
+  // CONTIGUOUS run of entries -- consecutive samples of a ray -- and keeps the sums for the
+  // current line cell pair in registers, touching LDS only when the cell changes.
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const uint32_t len = b - a;
+  const uint32_t ga = a + (uint32_t)((unsigned long long)len * grp / 32), gb = a + (uint32_t)((unsigned long long)len * (grp + 1) / 32);
+  int cur = -1;
+  float acc0[C / 8], acc1[C / 8];
+#pragma unroll
+  for (int j = 0; j < C / 8; ++j) { acc0[j] = 0.0f; acc1[j] = 0.0f; }
+  for (uint32_t i = ga; i < gb; ++i) {
+    const uint32_t cid = entry_cid<APP>(i, gf, rowinfo);
+    if (cid == 0xffffffffu) continue;
+    float u[3];
+    cid_point(f, rays, z, S, cid, u);
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    if (l0 != cur) {
+      if (cur >= 0) {
+        const int cn = min(cur + 1, f.ll[p] - 1);
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+          atomicAdd(&s_acc[cur * C + sub + 8 * j], acc0[j]);
+          atomicAdd(&s_acc[cn * C + sub + 8 * j], acc1[j]);
+          acc0[j] = 0.0f; acc1[j] = 0.0f;
+        }
+      }
+      cur = l0;
+    }
+    const float* q00 = plp + ((size_t)y0 * f.pw[p] + x0) * C;
+    const float* q10 = plp + ((size_t)y0 * f.pw[p] + x1) * C;
+    const float* q01 = plp + ((size_t)y1 * f.pw[p] + x0) * C;
+    const float* q11 = plp + ((size_t)y1 * f.pw[p] + x1) * C;
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+    const float gfi = APP ? 0.0f : gf[i];
+    const float* dxr = APP ? grd + (size_t)i * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
+#pragma unroll
+    for (int j = 0; j < C / 8; ++j) {
+      const int c = sub + 8 * j;
+      const float P = q00[c] * w00 + q10[c] * w10 + q01[c] * w01 + q11[c] * w11;
+      const float dL = (APP ? dxr[c] : gfi) * P;
+      acc0[j] += dL * (1.0f - tl);
+      acc1[j] += dL * tl;
+    }
+  }
+  if (cur >= 0) {
+    const int cn = min(cur + 1, f.ll[p] - 1);
+#pragma unroll
+    for (int j = 0; j < C / 8; ++j) {
+      atomicAdd(&s_acc[cur * C + sub + 8 * j], acc0[j]);
+      atomicAdd(&s_acc[cn * C + sub + 8 * j], acc1[j]);
+    }
+  }
+  __syncthreads();
+  float* gln = gcache + (APP ? L.aline[p] : L.dline[p]);
+  for (int i = threadIdx.x; i < nl; i += 256) {
+    const float v = s_acc[i];
+    if (v != 0.0f) atomic_add_f32(gln + i, v);
+  }
+}
+
 // channel-last gradient image -> += reference layout [C,H,W]
 __global__ void k_unpack_plane_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,6 +935,8 @@ struct BwdWorkspace {
   Workspace fw;
   float* feat; float* crgb; float* gcache; float* imt; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
+  uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
+  uint32_t nmax;
   size_t gcache_floats, bytes;
 };
 static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
@@ -667,6 +959,13 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   b.wpart = take(nch * WP_FLOATS);
   b.depth = take(R);
   b.rgb = take((size_t)R * 3);
+  b.nmax = (uint32_t)rows;                                     // rows >= R*S
+  b.rowinfo = reinterpret_cast<uint32_t*>(take(rows));
+  b.tid = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
+  b.hist = reinterpret_cast<int*>(take(BIN_MAX));
+  b.offs = reinterpret_cast<int*>(take(BIN_MAX + 1));
+  b.cursor = reinterpret_cast<int*>(take(BIN_MAX));
+  b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.bytes = off;
   return b;
 }
@@ -698,7 +997,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
                      b.crgb, b.act);
   hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.gcache, L, b.rpart, w.pmax);
+                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax);
   const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
   hipLaunchKernelGGL((k_wgrad<8, 9>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
                      w.toff, R, b.wpart, WP_W2);
@@ -709,7 +1008,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL((k_wgrad<1, 9>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
                      w.toff, R, b.wpart, WP_W3);
   auto reduce = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld) {
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((m * n + 255) / 256), dim3(256), 0, st, b.wpart, w.toff, R,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((m * n * 16 + 255) / 256), dim3(256), 0, st, b.wpart, w.toff, R,
                        off, ld, n_off, m, n, dst, dst_ld);
   };
   reduce(WP_W2, 144, 0, 128, 128, g->w2, 128);
@@ -721,7 +1020,44 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   reduce(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
   hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), st,
                      d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
-                     b.gcache, L, b.rpart, w.pmax, g_rays);
+                     b.rpart, w.pmax, g_rays);
+  // binned scatter of the plane/line gradients: density entries (all samples), then appearance rows
+  const BinGeom bg = make_bins(L);
+  if (bg.total > BIN_MAX) return set_err("lrf_render_bwd: grid too large for the tile binning (BIN_MAX)");
+  {
+    static bool lds_attr_set = false;      // dynamic LDS above 64 KB has to be opted into once
+    if (!lds_attr_set) {
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      lds_attr_set = true;
+    }
+  }
+  const int nblk = (int)((b.nmax + BIN_CHUNK - 1) / BIN_CHUNK);
+  for (int app = 0; app < 2; ++app) {
+    LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * bg.total, st));
+    if (app) hipLaunchKernelGGL((k_bin_hist<true>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
+    else     hipLaunchKernelGGL((k_bin_hist<false>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist, bg.total, b.offs, b.cursor);
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, app, b.tid, b.cursor, b.list);
+    if (app) {
+      hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true>), dim3(cus), dim3(256), sizeof(float) * BCELL * BCELL * LRF_CA, st,
+                         d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
+      for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
+      hipLaunchKernelGGL((k_scatter_line<LRF_CA, true>), dim3(3 * LINE_WGS), dim3(256),
+                         sizeof(float) * LRF_CA * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
+                         d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
+    } else {
+      hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false>), dim3(cus * 4), dim3(256), sizeof(float) * BCELL * BCELL * LRF_CD, st,
+                         d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
+      hipLaunchKernelGGL((k_scatter_line<LRF_CD, false>), dim3(3 * LINE_WGS), dim3(256),
+                         sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
+                         d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
+    }
+  }
   for (int q = 0; q < 3; ++q) {
     dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
     hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q]);

@@ -174,7 +174,72 @@ def stage_dump():
             log("  ray", ray, "j", j, "g", g, [(n, x, y) for n, x, y in zip(names, a, b) if x != y])
 
 
-STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120)]
+def stage_bwd():
+    import numpy as np
+    import torch
+    from oracle import vm_render_np as oracle
+    from util import field_from_golden, load_golden, make_field, make_rays, quiet
+    g = load_golden("field_small_train_grad")
+    f = quiet(field_from_golden, g, "cuda:0")
+    f.z_override = torch.from_numpy(oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"])))
+    rays = torch.from_numpy(g["rays"]).cuda().requires_grad_(True)
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    ((rgb * torch.from_numpy(g["g_rgb"]).cuda()).sum() + (depth * torch.from_numpy(g["g_depth"]).cuda()).sum()).backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    errs = {n: rel(p.grad.cpu().numpy(), g["grad." + n]) for n, p in f.named_parameters() if p.requires_grad}
+    errs["rays"] = rel(rays.grad.cpu().numpy(), g["grad.rays"])
+    log("grad rel-to-max errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    # config-2 timing: forward + backward
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    gr = torch.randn(4096, 3, device="cuda")
+    gd = torch.randn(4096, device="cuda")
+    for it in range(3):
+        rgb, depth = f(rays, is_train=True, N_samples=1536)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    torch.cuda.synchronize()
+    t = time.time()
+    n = 10
+    for it in range(n):
+        for p in f.parameters():
+            p.grad = None
+        rgb, depth = f(rays, is_train=True, N_samples=1536)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / n
+    log("config2 train fwd+bwd ms", round(dt * 1e3, 3), "rays/s", round(4096 / dt))
+    log("max grad magnitudes", {n: float(p.grad.abs().max()) for n, p in list(f.named_parameters())[2:6]})
+
+
+def stage_torch_train():
+    """Stock PyTorch-ROCm (ATen op chain of the reference) forward+backward at config 2."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    fld = {k: v.detach().clone().requires_grad_(v.dtype == torch.float32 and "aabb" not in k.lower())
+           for k, v in f.state_dict().items()}
+    rays = make_rays(4096, 1).cuda()
+    z = ot.z_schedule(1536, device="cuda")
+    gr = torch.randn(4096, 3, device="cuda")
+    gd = torch.randn(4096, device="cuda")
+    leaves = [v for v in fld.values() if v.requires_grad]
+
+    def step():
+        rgb, depth = ot.render_field(fld, rays, z)
+        torch.autograd.grad((rgb * gr).sum() + (depth * gd).sum(), leaves, allow_unused=True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / 5
+    log("torch-ROCm port train fwd+bwd ms", round(dt * 1e3, 2), "rays/s", round(4096 / dt))
+
+
+STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
