@@ -112,7 +112,7 @@ def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, density_shift=
     shade = w > weight_thres
     rgb = torch.zeros(x.shape[:2] + (3,), device=x.device)
     if shade.any():
-        vd = dh[:, None, :].expand(x.shape)[shade]
+        vd = dh[:, None, :].expand(x.shape)[shade].clone().detach()     # tensorBase.py:628
         rgb[shade] = late_view_mlp(fld, app_feature(fld, u[shade]), vd)
     rgb_map = (w[..., None] * rgb).sum(-2)
     if white_bg:

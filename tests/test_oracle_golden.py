@@ -165,3 +165,23 @@ def test_torch_port_matches_reference(name):
         rgb, depth = ot.render_field(fld, torch.from_numpy(g["rays"]), z, True, float(g["floater"]))
     assert rel_err(rgb.numpy(), g["rgb"]) < 2e-6
     assert rel_err(depth.numpy(), g["depth"]) < 2e-6
+
+
+def test_torch_port_gradients_match_reference():
+    """The ATen-op port under autograd reproduces the reference's recorded gradients
+    (incl. the detached view direction, tensorBase.py:628)."""
+    import torch
+    from oracle import vm_render_torch as ot
+    g = load_golden("field_small_train_grad")
+    fld = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in golden_field_dict(g).items()}
+    names = [k for k in fld if ("plane" in k or "line" in k or "basis" in k or "renderModule" in k)]
+    for k in names:
+        fld[k].requires_grad_(True)
+    rays = torch.from_numpy(g["rays"]).requires_grad_(True)
+    z = ot.z_schedule(int(g["N_samples"]), jitter=(torch.from_numpy(g["U"]), torch.from_numpy(g["U2"])))
+    rgb, depth = ot.render_field(fld, rays, z, True, 0.0)
+    loss = (rgb * torch.from_numpy(g["g_rgb"])).sum() + (depth * torch.from_numpy(g["g_depth"])).sum()
+    grads = torch.autograd.grad(loss, [fld[k] for k in names] + [rays])
+    for k, gr in zip(names + ["rays"], grads):
+        ref = g["grad." + k]
+        assert np.abs(gr.numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6), k
