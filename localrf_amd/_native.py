@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblrf_hip.so")
+LIB_PATH = os.environ.get("LRF_LIB", os.path.join(_HERE, "csrc", "liblrf_hip.so"))   # LRF_LIB: experiment builds
 
 LRF_FLAG_WHITE_BG = 1
 LRF_FLAG_RELU_DENS = 2

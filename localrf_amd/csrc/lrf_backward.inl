@@ -138,7 +138,6 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
     {
       float v[8];
-      v[6] = 0.0f; v[7] = 0.0f;
       bf16x8 bh, bl;
       gather_app6_plane<0>(f, u, g, v);
 #pragma unroll
@@ -354,9 +353,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         tap1d_g(u[MAT0[p]], f.pw[p], x0, x1, tx, gx);
         tap1d_g(u[MAT1[p]], f.ph[p], y0, y1, ty, gy);
         tap1d_g(u[VEC[p]],  f.ll[p], l0, l1, tl, gl);
-        const size_t i00 = ((size_t)y0 * f.pw[p] + x0) * LRF_CA + 6 * g, i10 = ((size_t)y0 * f.pw[p] + x1) * LRF_CA + 6 * g;
-        const size_t i01 = ((size_t)y1 * f.pw[p] + x0) * LRF_CA + 6 * g, i11 = ((size_t)y1 * f.pw[p] + x1) * LRF_CA + 6 * g;
-        const size_t j0l = (size_t)l0 * LRF_CA + 6 * g, j1l = (size_t)l1 * LRF_CA + 6 * g;
+        const size_t i00 = ((size_t)y0 * f.pw[p] + x0) * LRF_CAS + 8 * g, i10 = ((size_t)y0 * f.pw[p] + x1) * LRF_CAS + 8 * g;
+        const size_t i01 = ((size_t)y1 * f.pw[p] + x0) * LRF_CAS + 8 * g, i11 = ((size_t)y1 * f.pw[p] + x1) * LRF_CAS + 8 * g;
+        const size_t j0l = (size_t)l0 * LRF_CAS + 8 * g, j1l = (size_t)l1 * LRF_CAS + 8 * g;
         const float* pl = f.aplane[p];
         const float* ln = f.aline[p];
         float gix = 0.0f, giy = 0.0f, gil = 0.0f;
@@ -813,14 +812,16 @@ __global__ __launch_bounds__(256) void k_scatter_plane(DField f, BinGeom bg, Lay
       const int c00 = ((y0 - ty0) * BCELL + (x0 - tx0)) * C, c10 = ((y0 - ty0) * BCELL + (x1 - tx0)) * C;
       const int c01 = ((y1 - ty0) * BCELL + (x0 - tx0)) * C, c11 = ((y1 - ty0) * BCELL + (x1 - tx0)) * C;
       const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
-      const float* r0 = lnp + (size_t)l0 * C;
-      const float* r1 = lnp + (size_t)l1 * C;
+      constexpr int CS = APP ? LRF_CAS : C;                 // channel stride of the cache / gradient image
+      const float* r0 = lnp + (size_t)l0 * CS;
+      const float* r1 = lnp + (size_t)l1 * CS;
       const float gfi = APP ? 0.0f : gf[i];
       const float* dxr = APP ? grd + (size_t)i * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
 #pragma unroll
       for (int j = 0; j < C / 8; ++j) {
         const int c = sub + 8 * j;
-        const float Lv = r0[c] * (1.0f - tl) + r1[c] * tl;
+        const int pc = APP ? app_pc(c) : c;
+        const float Lv = r0[pc] * (1.0f - tl) + r1[pc] * tl;
         const float dP = (APP ? dxr[c] : gfi) * Lv;
         atomicAdd(&s_acc[c00 + c], dP * w00); atomicAdd(&s_acc[c10 + c], dP * w10);
         atomicAdd(&s_acc[c01 + c], dP * w01); atomicAdd(&s_acc[c11 + c], dP * w11);
@@ -833,7 +834,8 @@ __global__ __launch_bounds__(256) void k_scatter_plane(DField f, BinGeom bg, Lay
       if (v == 0.0f) continue;
       const int cell = i / C, c = i % C;
       const int x = tx0 + cell % BCELL, y = ty0 + cell / BCELL;
-      if (x < f.pw[p] && y < f.ph[p]) atomic_add_f32(gpl + ((size_t)y * f.pw[p] + x) * C + c, v);
+      if (x < f.pw[p] && y < f.ph[p])
+        atomic_add_f32(gpl + ((size_t)y * f.pw[p] + x) * (APP ? LRF_CAS : C) + (APP ? app_pc(c) : c), v);
     }
     __syncthreads();
     a = seg_end;
@@ -885,17 +887,19 @@ __global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const 
       }
       cur = l0;
     }
-    const float* q00 = plp + ((size_t)y0 * f.pw[p] + x0) * C;
-    const float* q10 = plp + ((size_t)y0 * f.pw[p] + x1) * C;
-    const float* q01 = plp + ((size_t)y1 * f.pw[p] + x0) * C;
-    const float* q11 = plp + ((size_t)y1 * f.pw[p] + x1) * C;
+    constexpr int CS = APP ? LRF_CAS : C;
+    const float* q00 = plp + ((size_t)y0 * f.pw[p] + x0) * CS;
+    const float* q10 = plp + ((size_t)y0 * f.pw[p] + x1) * CS;
+    const float* q01 = plp + ((size_t)y1 * f.pw[p] + x0) * CS;
+    const float* q11 = plp + ((size_t)y1 * f.pw[p] + x1) * CS;
     const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
     const float gfi = APP ? 0.0f : gf[i];
     const float* dxr = APP ? grd + (size_t)i * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
 #pragma unroll
     for (int j = 0; j < C / 8; ++j) {
       const int c = sub + 8 * j;
-      const float P = q00[c] * w00 + q10[c] * w10 + q01[c] * w01 + q11[c] * w11;
+      const int pc = APP ? app_pc(c) : c;
+      const float P = q00[pc] * w00 + q10[pc] * w10 + q01[pc] * w01 + q11[pc] * w11;
       const float dL = (APP ? dxr[c] : gfi) * P;
       acc0[j] += dL * (1.0f - tl);
       acc1[j] += dL * tl;
@@ -913,22 +917,23 @@ __global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const 
   float* gln = gcache + (APP ? L.aline[p] : L.dline[p]);
   for (int i = threadIdx.x; i < nl; i += 256) {
     const float v = s_acc[i];
-    if (v != 0.0f) atomic_add_f32(gln + i, v);
+    const int l = i / C, c = i % C;
+    if (v != 0.0f) atomic_add_f32(gln + (size_t)l * (APP ? LRF_CAS : C) + (APP ? app_pc(c) : c), v);
   }
 }
 
 // channel-last gradient image -> += reference layout [C,H,W]
-__global__ void k_unpack_plane_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
+__global__ void k_unpack_plane_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int CS, int app) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= W) return;
-  for (int c = 0; c < C; ++c) dst[((size_t)c * H + y) * W + x] += src[((size_t)y * W + x) * C + c];
+  for (int c = 0; c < C; ++c) dst[((size_t)c * H + y) * W + x] += src[((size_t)y * W + x) * CS + (app ? app_pc(c) : c)];
 }
-__global__ void k_unpack_line_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int Lh) {
+__global__ void k_unpack_line_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int Lh, int CS, int app) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * Lh) return;
   const int l = i / C, c = i % C;
-  dst[(size_t)c * Lh + l] += src[i];
+  dst[(size_t)c * Lh + l] += src[(size_t)l * CS + (app ? app_pc(c) : c)];
 }
 
 struct BwdWorkspace {
@@ -1060,10 +1065,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   }
   for (int q = 0; q < 3; ++q) {
     dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
-    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q]);
-    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q]);
-    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, b.gcache + L.dline[q], g->density_line[q], LRF_CD, L.ll[q]);
-    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, b.gcache + L.aline[q], g->app_line[q], LRF_CA, L.ll[q]);
+    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0);
+    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1);
+    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, b.gcache + L.dline[q], g->density_line[q], LRF_CD, L.ll[q], LRF_CD, 0);
+    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, b.gcache + L.aline[q], g->app_line[q], LRF_CA, L.ll[q], LRF_CAS, 1);
   }
   LRF_HIP(hipGetLastError());
   return 0;

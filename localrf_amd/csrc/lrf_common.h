@@ -10,11 +10,21 @@ namespace lrf {
 
 // ------------------------------------------------------------------ cache layout
 // Planes are stored channel-last [H][W][C] so one bilinear tap is one contiguous
-// 32 B (density) / 96 B (appearance) read; lines are [L][C].  Offsets are in floats and
+// 32 B (density) / 128 B (appearance, padded) read; lines are [L][C].  Offsets are in floats and
 // 64-float aligned.  The MLP image is in MFMA-fragment order (see lrf_mlp_image.h).
 constexpr int MAT0[3] = {0, 0, 1};   // matMode[p][0]  (tensorBase.py:274) -> plane W axis
 constexpr int MAT1[3] = {1, 2, 2};   // matMode[p][1]                      -> plane H axis
 constexpr int VEC[3]  = {2, 1, 0};   // vecMode[p]     (tensorBase.py:275)
+
+// Appearance planes/lines are stored with a channel stride of 32 floats (128 B = one cache
+// line per texel): the 24 channels sit in four groups of 6 + 2 zero pads, channel c at slot
+// app_pc(c) = 8*(c/6) + c%6, so lane group g of a shading tile reads its six channels as two
+// ALIGNED float4 at slot 8g.  (The dense 24-channel layout made the compiler fuse the three
+// 8-byte loads of a lane into a dwordx4 that is only 8-byte aligned for odd g; on MI355X such
+// loads occasionally delivered a stale half -- the root cause of run-to-run differences in a
+// few tiles per launch, see DESIGN.md.)
+constexpr int LRF_CAS = 32;
+__host__ __device__ constexpr int app_pc(int c) { return 8 * (c / 6) + c % 6; }
 
 // MLP image (floats)
 constexpr int IMG_BAS  = 0;                       // [t'2][p3][lane64][8]  basis_mat, 6 of 8 used
@@ -54,8 +64,8 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
   }
   for (int p = 0; p < 3; ++p) { L.dplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CD); }
   for (int p = 0; p < 3; ++p) { L.dline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CD); }
-  for (int p = 0; p < 3; ++p) { L.aplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CA); }
-  for (int p = 0; p < 3; ++p) { L.aline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CA); }
+  for (int p = 0; p < 3; ++p) { L.aplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CAS); }
+  for (int p = 0; p < 3; ++p) { L.aline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CAS); }
   L.mlp = off; off = align64(off + IMG_FLOATS);
   L.mlpb = off; off = align64(off + (size_t)IMGB_U4 * 4);
   L.total = off;

@@ -38,20 +38,24 @@ static int set_err(const char* msg, hipError_t e = hipSuccess) {
 #define LRF_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(#call, e_); } while (0)
 
 // ---------------------------------------------------------------------------- pack
-// [C,H,W] -> [H,W,C]
-__global__ void k_pack_plane(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
+// [C,H,W] -> [H,W,CS] channel-last; app=1: padded appearance layout (slot app_pc(c), zero pads)
+__global__ void k_pack_plane(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int CS, int app) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= W) return;
-  for (int c = 0; c < C; ++c)
-    dst[((size_t)y * W + x) * C + c] = src[((size_t)c * H + y) * W + x];
+  float* d = dst + ((size_t)y * W + x) * CS;
+  if (app) for (int q = 0; q < 4; ++q) { d[8 * q + 6] = 0.0f; d[8 * q + 7] = 0.0f; }
+  for (int c = 0; c < C; ++c) d[app ? app_pc(c) : c] = src[((size_t)c * H + y) * W + x];
 }
-// [C,L] -> [L,C]
-__global__ void k_pack_line(const float* __restrict__ src, float* __restrict__ dst, int C, int L) {
+// [C,L] -> [L,CS]
+__global__ void k_pack_line(const float* __restrict__ src, float* __restrict__ dst, int C, int L, int CS, int app) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * L) return;
-  const int l = i / C, c = i % C;
-  dst[i] = src[(size_t)c * L + l];
+  if (i >= CS * L) return;
+  const int l = i / CS, slot = i % CS;
+  float v = 0.0f;
+  if (app) { if ((slot & 7) < 6) v = src[(size_t)(6 * (slot >> 3) + (slot & 7)) * L + l]; }
+  else v = src[(size_t)slot * L + l];
+  dst[i] = v;
 }
 // colour network -> MFMA-fragment-ordered image (see lrf_common.h IMG_*).
 // Fragment lane l = (i = l & 15, g = l >> 4): A operand row 16t'+i, K-slot g.
@@ -285,34 +289,45 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 // appearance products for this lane's 6 channels of each plane (tensoRF.py:153-195):
 // lane (s, g) of a tile owns channels 6g..6g+5 of plane p -> K-slot g of MFMA k-step (p, j).
+// appearance products of lane group g for plane p: eight slots (six channels + two zero pads)
+// per tap, read as two aligned float4 of the padded 128-byte texel (tensoRF.py:153-195)
 template <int p>
-__device__ __forceinline__ void gather_app6_plane(const DField& f, const float u[3], int g, float X[6]) {
+__device__ __forceinline__ void gather_app6_plane(const DField& f, const float u[3], int g, float X[8]) {
   int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
   tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
   tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
   tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-  const float* pl = f.aplane[p] + 6 * g;
-  const float* q00 = pl + ((size_t)y0 * f.pw[p] + x0) * LRF_CA;
-  const float* q10 = pl + ((size_t)y0 * f.pw[p] + x1) * LRF_CA;
-  const float* q01 = pl + ((size_t)y1 * f.pw[p] + x0) * LRF_CA;
-  const float* q11 = pl + ((size_t)y1 * f.pw[p] + x1) * LRF_CA;
-  const float* r0 = f.aline[p] + (size_t)l0 * LRF_CA + 6 * g;
-  const float* r1 = f.aline[p] + (size_t)l1 * LRF_CA + 6 * g;
+  const float* pl = f.aplane[p] + 8 * g;
+  const float* q00 = pl + ((size_t)y0 * f.pw[p] + x0) * LRF_CAS;
+  const float* q10 = pl + ((size_t)y0 * f.pw[p] + x1) * LRF_CAS;
+  const float* q01 = pl + ((size_t)y1 * f.pw[p] + x0) * LRF_CAS;
+  const float* q11 = pl + ((size_t)y1 * f.pw[p] + x1) * LRF_CAS;
+  const float* r0 = f.aline[p] + (size_t)l0 * LRF_CAS + 8 * g;
+  const float* r1 = f.aline[p] + (size_t)l1 * LRF_CAS + 8 * g;
   const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
   const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
   const float wl0 = 1.0f - tl, wl1 = tl;
 #pragma unroll
-  for (int h = 0; h < 3; ++h) {
-    const float2 a = ld2(q00 + 2 * h), b = ld2(q10 + 2 * h), c = ld2(q01 + 2 * h), d = ld2(q11 + 2 * h);
-    const float2 e = ld2(r0 + 2 * h), q = ld2(r1 + 2 * h);
-    X[2 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
-    X[2 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
+  for (int h = 0; h < 2; ++h) {
+    const float4 a = ld4(q00 + 4 * h), b = ld4(q10 + 4 * h), c = ld4(q01 + 4 * h), d = ld4(q11 + 4 * h);
+    const float4 e = ld4(r0 + 4 * h), q = ld4(r1 + 4 * h);
+    X[4 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
+    X[4 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
+    X[4 * h + 2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
+    X[4 * h + 3] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + q.w * wl1);
   }
 }
 __device__ __forceinline__ void gather_app6(const DField& f, const float u[3], int g, float X[3][6]) {
-  gather_app6_plane<0>(f, u, g, X[0]);
-  gather_app6_plane<1>(f, u, g, X[1]);
-  gather_app6_plane<2>(f, u, g, X[2]);
+  float v[8];
+  gather_app6_plane<0>(f, u, g, v);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) X[0][j] = v[j];
+  gather_app6_plane<1>(f, u, g, v);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) X[1][j] = v[j];
+  gather_app6_plane<2>(f, u, g, v);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) X[2][j] = v[j];
 }
 
 // Static, contiguous split of the T = toff[R] tiles over all waves of the grid (tiles cost
@@ -501,19 +516,29 @@ __device__ __forceinline__ void settle(f32x4* acc) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[t]));
 }
-// acc += A x B on v_mfma_f32_16x16x32_bf16, ALWAYS accumulating in place (vDst == SrcC).
-// Written as inline asm with a tied "+v" accumulator because hipcc (ROCm 7.2) is free to give
-// the builtin a destination different from its SrcC, and it under-pads the resulting
-// "XDL write -> XDL read SrcC, different vDst" hazard for this gfx950 opcode: the second MFMA
-// of a chain then sometimes read a half-written accumulator (seen as basis-layer outputs
-// 25 % off in ~600 of 48K tiles, different tiles every run; scripts/gpu_diag.py stage_dump).
-// In-place accumulation is the case the hardware interlocks back to back.  Hazards the
-// compiler no longer sees because of the asm are padded by hand: operands are final 16
-// wait states before (split8), results are read 24 wait states after (settle).
+// acc += A x B on v_mfma_f32_16x16x32_bf16, hand-issued.
+// Two things the compiler-scheduled builtin got wrong on MI355X (hipcc ROCm 7.2), both
+// timing dependent -- they show up when the four waves of a SIMD contend for the matrix pipe:
+//  (1) it may give the MFMA a destination different from its SrcC and under-pads that
+//      dependent-MFMA hazard, so the next MFMA of a chain read a half-written accumulator;
+//  (2) it reloads the A-fragment registers (ds_read_b128 into the same VGPRs) right behind an
+//      MFMA that still reads them: `v_mfma ..., v[40:43], ...` / `ds_read_b128 v[40:43]`.
+// Symptom of either: basis-layer outputs tens of percent off in a few hundred of 48K tiles,
+// different tiles every run (scripts/gpu_diag.py stage_nondet / stage_dump).
+// Here the accumulator is tied ("+v": vDst == SrcC, the case the hardware forwards back to
+// back) and every MFMA is followed, inside the same asm statement, by four wait states: the
+// next instruction of this wave -- a dependent MFMA, or a load that overwrites an operand --
+// issues a full MFMA occupancy (16 cycles) later.  Hazards the compiler no longer sees because
+// of the asm are padded by hand: operands are final 16 wait states before (split8), results
+// are read 24 wait states after (settle).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void mfma_bf16_acc(bf16x8 a, bf16x8 b, f32x4& acc) {
+#ifdef LRF_MFMA_BUILTIN
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#else
   const i32x4 ai = __builtin_bit_cast(i32x4, a), bi = __builtin_bit_cast(i32x4, b);
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ai), "v"(bi));
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 3" : "+v"(acc) : "v"(ai), "v"(bi));
+#endif
 }
 __device__ __forceinline__ bf16x8 lds_frag(const uint4* img, int frag, int part, int lane) {
   return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
@@ -575,7 +600,6 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
     float xdbg[3] = {0.0f, 0.0f, 0.0f};
     {
       float v[8];
-      v[6] = 0.0f; v[7] = 0.0f;
       bf16x8 bh, bl;
       gather_app6_plane<0>(f, u, g, v);
       xdbg[0] = v[0];
@@ -680,11 +704,12 @@ __global__ __launch_bounds__(64) void k_shade_valu(
       tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
       const float* pl = f.aplane[p];
       for (int c = 0; c < LRF_CA; ++c) {
-        const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * (1.0f - ty))
-                      + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CA + c] * (tx * (1.0f - ty))
-                      + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * ty)
-                      + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CA + c] * (tx * ty);
-        const float l = f.aline[p][(size_t)l0 * LRF_CA + c] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CA + c] * tl;
+        const int pc = app_pc(c);
+        const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * (1.0f - ty))
+                      + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * (1.0f - ty))
+                      + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * ty)
+                      + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * ty);
+        const float l = f.aline[p][(size_t)l0 * LRF_CAS + pc] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CAS + pc] * tl;
         X[p * LRF_CA + c] = v * l;
       }
     }
@@ -762,11 +787,12 @@ __global__ void k_app_feature(DField f, const float* __restrict__ u, int P, floa
     tap1d(uu[VEC[p]],  f.ll[p], l0, l1, tl);
     const float* pl = f.aplane[p];
     for (int c = 0; c < LRF_CA; ++c) {
-      const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * (1.0f - ty))
-                    + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CA + c] * (tx * (1.0f - ty))
-                    + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CA + c] * ((1.0f - tx) * ty)
-                    + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CA + c] * (tx * ty);
-      const float l = f.aline[p][(size_t)l0 * LRF_CA + c] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CA + c] * tl;
+      const int pc = app_pc(c);
+      const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * (1.0f - ty))
+                    + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * (1.0f - ty))
+                    + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * ty)
+                    + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * ty);
+      const float l = f.aline[p][(size_t)l0 * LRF_CAS + pc] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CAS + pc] * tl;
       const float xv = v * l;
       for (int a = 0; a < LRF_APP_DIM; ++a) acc[a] += f.basis[a * 72 + p * LRF_CA + c] * xv;
     }
@@ -886,10 +912,10 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
   float* base = reinterpret_cast<float*>(cache);
   for (int q = 0; q < 3; ++q) {
     dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
-    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->density_plane[q], base + L.dplane[q], LRF_CD, L.ph[q], L.pw[q]);
-    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->app_plane[q], base + L.aplane[q], LRF_CA, L.ph[q], L.pw[q]);
-    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, p->density_line[q], base + L.dline[q], LRF_CD, L.ll[q]);
-    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, p->app_line[q], base + L.aline[q], LRF_CA, L.ll[q]);
+    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->density_plane[q], base + L.dplane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0);
+    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->app_plane[q], base + L.aplane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1);
+    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, p->density_line[q], base + L.dline[q], LRF_CD, L.ll[q], LRF_CD, 0);
+    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CAS + 255) / 256), dim3(256), 0, st, p->app_line[q], base + L.aline[q], LRF_CA, L.ll[q], LRF_CAS, 1);
   }
   hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
   hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p,
