@@ -493,6 +493,7 @@ __device__ __forceinline__ void split8(const float v[8], bf16x8& hi, bf16x8& lo)
   // VALU -> MFMA pad (see settle() below for the measurements): all eight operand registers
   // pass through one asm statement, so every conversion has retired 16 wait states before
   // the first MFMA that reads them and none is interleaved with the MFMA burst.
+#ifndef LRF_MFMA_BUILTIN
   {
     uint4 H = __builtin_bit_cast(uint4, hi), L = __builtin_bit_cast(uint4, lo);
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(H.x), "+v"(H.y), "+v"(H.z), "+v"(H.w),
@@ -500,21 +501,23 @@ __device__ __forceinline__ void split8(const float v[8], bf16x8& hi, bf16x8& lo)
     hi = __builtin_bit_cast(bf16x8, H);
     lo = __builtin_bit_cast(bf16x8, L);
   }
+#endif
 }
-// Explicit wait states on both sides of every v_mfma_f32_16x16x32_bf16 burst.
-// Measured on MI355X (scripts/gpu_diag.py stage_nondet, 4096 rays x 512 samples, 39 repeats):
-//   compiler-scheduled (hipcc ROCm 7.2 hazard padding only)      7-15 rays differ per run
-//   + 16 nops VALU->MFMA only                                    ~100-130 rays differ per run
-//   + 24 nops MFMA->VALU only                                    still differs
-//   + both                                                       0 rays differ
-// The differences are single tiles off by 1e-5-scale amounts (a lo-term product computed
-// from a not-yet-written / already-overwritten operand), i.e. the VALU<->XDL hazards of this
-// new gfx950 opcode are handled by hand around the asm MFMAs (see mfma_bf16_acc).  The f32
-// engine (v_mfma_f32_16x16x4_f32, compiler-scheduled) never showed any of this.
+// Explicit wait states on both sides of every v_mfma_f32_16x16x32_bf16 burst (used with the
+// hand-issued MFMA below).  Measured on MI355X, 4096 rays x 512 samples, 39 repeats of the same
+// render (scripts/gpu_diag.py stage_nondet), rays whose colour differs from the first run:
+//   compiler-scheduled builtin chain (-DLRF_MFMA_BUILTIN), aligned gathers      6-21 per run
+//   hand-issued in-place MFMA + pads, compiler-fused 8-byte-aligned dwordx4     1-11 per run
+//   hand-issued in-place MFMA + pads, aligned float4 gathers (this build)       0 in 117 runs
+// i.e. two independent hazards: the bf16 MFMA chain as hipcc (ROCm 7.2) schedules it, and
+// misaligned fused gathers (lrf_common.h, LRF_CAS).  The exact-fp32 engine
+// (v_mfma_f32_16x16x4_f32, compiler-scheduled) never showed either.
 template <int NT>
 __device__ __forceinline__ void settle(f32x4* acc) {
+#ifndef LRF_MFMA_BUILTIN
 #pragma unroll
   for (int t = 0; t < NT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[t]));
+#endif
 }
 // acc += A x B on v_mfma_f32_16x16x32_bf16, hand-issued.
 // Two things the compiler-scheduled builtin got wrong on MI355X (hipcc ROCm 7.2), both
@@ -596,7 +599,9 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
     // MFMAs directly and only six products are live at a time.  fe is zeroed (VALU writes)
     // before split8's 16-state pad, so the asm MFMAs read a settled SrcC.
     f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#ifndef LRF_MFMA_BUILTIN
     asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
+#endif
     float xdbg[3] = {0.0f, 0.0f, 0.0f};
     {
       float v[8];
