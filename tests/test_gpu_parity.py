@@ -286,3 +286,64 @@ def test_backward_accumulates_and_zero_grad_output(built_lib):
     for n, p in f.named_parameters():
         if p.requires_grad:
             assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-4, atol=1e-7), n
+
+
+# ----------------------------------------------------------------- ragged / edge shapes
+@pytest.mark.parametrize("R,N", [(1, 12), (5, 50), (67, 98), (130, 390), (4, 1200)])
+def test_ragged_shapes_forward_and_backward(built_lib, R, N):
+    """Ray counts that do not fill a 4-ray block, sample counts that are not multiples of 64 or
+    16 (S = 2*(N//6)), a single ray, a long ray: forward vs the numpy oracle, backward vs autograd
+    through the ATen-op port."""
+    from oracle import vm_render_torch as ot
+    f = quiet(make_field, [18, 22, 26], "cpu", seed=40 + R)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(4.0)
+    f = f.to(DEV)
+    rays = make_rays(R, 50 + R, pinhole=True).to(DEV).requires_grad_(True)
+    S = 2 * (N // 6)
+    rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=N)
+    fld = {k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}
+    ro, do = oracle.render_field(fld, _np(rays), oracle.z_schedule(N), True, 0.0)
+    assert ro.shape == (R, 3) and oracle.z_schedule(N).shape[0] == S
+    _check_rays(_np(rgb), ro)
+    _check_rays(_np(depth), do)
+    gr = torch.randn(R, 3, device=DEV)
+    gd = torch.randn(R, device=DEV)
+    ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    mine = {n: p.grad.clone() for n, p in f.named_parameters() if p.requires_grad}
+    mine["rays"] = rays.grad.clone()
+    tf = {k: v.detach().clone().requires_grad_(k in mine) for k, v in f.state_dict().items()}
+    trays = rays.detach().clone().requires_grad_(True)
+    rp, dp = ot.render_field(tf, trays, ot.z_schedule(N, device=DEV))
+    ((rp * gr).sum() + (dp * gd).sum()).backward()
+    ref = {k: tf[k].grad for k in mine if k != "rays"}
+    ref["rays"] = trays.grad
+    for k in mine:
+        denom = float(ref[k].abs().max())
+        err = float((mine[k] - ref[k]).abs().max())
+        # 1e-2 of the tensor's max: one sample flipping across the weight > 1e-3 shading threshold
+        # between the two fp32 implementations moves a gradient by ~1e-6 absolute
+        assert err <= 1e-2 * max(denom, 1e-6), (k, err, denom)
+
+
+def test_nothing_shaded_and_everything_masked(built_lib):
+    """All weights below the shading threshold except the forced last sample; and an all-zero
+    alpha mask (every density lookup skipped): both must reduce to the far sample only."""
+    from localrf_amd import AlphaGridMask
+    f = quiet(make_field, [16, 16, 16], "cpu", seed=3, density_shift=-30.0).to(DEV)   # sigma ~ 0
+    rays = make_rays(33, 8).to(DEV)
+    with torch.no_grad():
+        rgb, depth, w, acc, z = f.render_weights(rays, N_samples=60)
+    assert torch.allclose(acc, torch.ones_like(acc), atol=1e-6)
+    assert torch.allclose(w[:, -1], torch.ones_like(acc), atol=1e-5)               # alpha_{S-1} = 1
+    assert torch.allclose(depth * rays[:, 3:].norm(dim=-1), z[-1].expand_as(depth), rtol=1e-5)
+    fld = {k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}
+    fld["density_shift"] = -30.0
+    ro, _ = oracle.render_field(fld, _np(rays), _np(z), True, 0.0)
+    _check_rays(_np(rgb), ro)
+    g = quiet(make_field, [16, 16, 16], "cpu", seed=4).to(DEV)
+    g.alphaMask = AlphaGridMask(torch.device(DEV), g.aabb.detach(), torch.zeros(8, 8, 8, device=DEV))
+    with torch.no_grad():
+        rgb2, depth2, w2, acc2, z2 = g.render_weights(rays, N_samples=60)
+    assert float(w2[:, :-1].abs().max()) == 0.0 and torch.allclose(w2[:, -1], torch.ones_like(acc2))
