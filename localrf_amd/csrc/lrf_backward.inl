@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         h2[t1][r] = fmaxf(h2[t1][r], 0.0f);
-        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + (g * 32 + t1 * 4 + r) * 4]);
+        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
         o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
       }
       *reinterpret_cast<f32x4*>(arow + ACT_H2 + 16 * t1 + 4 * g) = h2[t1];

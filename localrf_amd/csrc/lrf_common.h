@@ -45,9 +45,10 @@ constexpr int IMGB_BAS = 0;                        // frags [t'2][ks3]
 constexpr int IMGB_W1  = IMGB_BAS + 2 * 3 * 128;   // frags [t'8][ks1]
 constexpr int IMGB_W2  = IMGB_W1 + 8 * 1 * 128;    // frags [t'8][ks4]
 constexpr int IMGB_TAIL = IMGB_W2 + 8 * 4 * 128;   // uint4 index of the float tail
-constexpr int TAIL_W3H = 0;                        // floats, same content as IMG_W3H..IMG_W3V+16
-constexpr int TAIL_B1 = 512, TAIL_B2 = 640, TAIL_W3V = 768, TAIL_FLOATS = 784;
-constexpr int IMGB_U4 = IMGB_TAIL + TAIL_FLOATS / 4;   // 6084 uint4 = 97,344 B
+constexpr int TAIL_W3H = 0;                        // floats [g4][33][4]: 32 features + one pad slot per lane
+constexpr int TAIL_W3H_GS = 132;                   // group, so the groups' float4 reads fall on different banks
+constexpr int TAIL_B1 = 528, TAIL_B2 = 656, TAIL_W3V = 784, TAIL_FLOATS = 800;
+constexpr int IMGB_U4 = IMGB_TAIL + TAIL_FLOATS / 4;   // 6088 uint4 = 97,408 B
 
 struct Layout {
   size_t dplane[3], dline[3], aplane[3], aline[3], mlp, mlpb, total;   // float offsets

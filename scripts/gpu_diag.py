@@ -239,7 +239,31 @@ def stage_torch_train():
     log("torch-ROCm port train fwd+bwd ms", round(dt * 1e3, 2), "rays/s", round(4096 / dt))
 
 
-STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200)]
+def stage_xcd():
+    """Does ray order matter?  Same rays rendered in random order vs sorted by direction."""
+    import torch
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    d = rays[:, 3:] / rays[:, 3:].norm(dim=-1, keepdim=True)
+    # direction key: octant (3 bits) then 5 bits each of |d| components (Morton-ish)
+    q = ((d.abs() * 31.99).long())
+    key = ((d[:, 0] < 0).long() << 17) | ((d[:, 1] < 0).long() << 16) | ((d[:, 2] < 0).long() << 15) \
+        | (q[:, 0] << 10) | (q[:, 1] << 5) | q[:, 2]
+    order = torch.argsort(key)
+    for name, r in (("random", rays), ("sorted", rays[order].contiguous())):
+        with torch.no_grad():
+            for _ in range(20):
+                f(r, N_samples=1536)
+            torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(200):
+                f(r, N_samples=1536)
+            torch.cuda.synchronize()
+        log("ray order", name, "ms/step", round((time.time() - t) / 200 * 1e3, 4))
+
+
+STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
