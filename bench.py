@@ -178,8 +178,22 @@ def main():
             "k_finalize": {"ms": prof["finalize_ms"]},
         }
         dom = "k_shade" if prof["shade_ms"] >= prof["march_ms"] else "k_march"
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE /
+        # WRITE_SIZE cannot be read from inside this process); the committed summary is used.
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "k_shade_bf16" if dom == "k_shade" else dom
+            traffic = pmc["kernels"][key]["traffic_bytes"]
+            traffic_src = "profiles/r01_pmc_traffic.json (" + pmc["correction"].split(":")[0] + ")"
+            for kn, kk in (("k_march", "k_march"), ("k_shade", "k_shade_bf16")):
+                kern[kn]["pmc_traffic_bytes"] = pmc["kernels"][kk]["traffic_bytes"]
+                kern[kn]["l2_hit_rate"] = pmc["kernels"][kk]["TCC_HIT"] / (pmc["kernels"][kk]["TCC_HIT"] + pmc["kernels"][kk]["TCC_MISS"])
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "whole_path_GBps": (dens_bytes + app_bytes) / (prof["total_ms"] * 1e-3) / 1e9,
                     "shaded_fraction": prof["n_shaded"] / (R_PER_GPU * S), "kernels": kern,
                     "note": "achieved = algorithmic gather bytes of the dominant kernel / its HIP-event "
