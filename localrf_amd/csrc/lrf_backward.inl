@@ -40,7 +40,7 @@ constexpr int WP_W1 = WP_W2 + 128 * 144;            // [128][32]   dz1^T [feat |
 constexpr int WP_BAS = WP_W1 + 128 * 32;            // [32][80]    dfeat^T X
 constexpr int WP_W3 = WP_BAS + 32 * 80;             // [16][144]   go^T [h2r | dhat | 1]
 constexpr int WP_FLOATS = WP_W3 + 16 * 144;
-constexpr int WGRAD_CH = 2048;                      // rows per K-chunk
+constexpr int WGRAD_CH = 1024;                      // rows per K-chunk
 
 __global__ void k_pack_mlp_t(LrfParams p, float* __restrict__ img) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,10 +398,16 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
 
 // ---------------------------------------------------------------- weight gradients
 // C[M x N] partial = A[rows, M]^T  B[rows, N] over one K-chunk of saved rows.
-// 4 waves; wave w owns M-tiles w, w+4, ...; every wave sweeps all NT N-tiles.
+// 4 waves; wave w owns M-tiles w, w+4, ...; every wave sweeps all NT N-tiles.  Rows are staged
+// 32 at a time through LDS with coalesced float4 loads (the first version fetched MFMA fragments
+// straight from global memory, one predicated dword per lane and k-step: 1.3 TB/s); the LDS row
+// stride is = 16 (mod 32) so the four 16-lane groups of a fragment read hit disjoint banks.
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                const int* __restrict__ toff, int R, float* __restrict__ wpart, int wp_off) {
+  constexpr int KT = 32, WA = MT * 16, WB = NT * 16;
+  constexpr int LD = ((WA + WB) % 32 == 16) ? (WA + WB) : (WA + WB + 16);
+  __shared__ __attribute__((aligned(16))) float s_t[KT * LD];
   const int rows = toff[R] * 16;
   const int r0 = blockIdx.x * WGRAD_CH;
   if (r0 >= rows) return;
@@ -413,20 +419,44 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   for (int m = 0; m < MW; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
-  for (int r = r0; r < r1; r += 4) {
-    const int row = r + g;
-    const bool ok = row < r1;
-    const float* ap = A + (size_t)row * lda + i;
-    const float* bp = B + (size_t)row * ldb + i;
-    float a[MW], b[NT];
+  constexpr int QA = WA / 4, QB = WB / 4;                    // float4 per row
+  constexpr int NQ = (KT * (QA + QB) + 255) / 256;           // float4 per thread and tile
+  float4 pre[NQ];
+  auto fetch = [&](int rb) {                                  // global -> registers (next tile)
 #pragma unroll
-    for (int m = 0; m < MW; ++m) a[m] = (ok && wave + 4 * m < MT) ? ap[16 * (wave + 4 * m)] : 0.0f;
+    for (int t = 0; t < NQ; ++t) {
+      const int q = threadIdx.x + 256 * t;
+      const int rr = q / (QA + QB), cq = q % (QA + QB);
+      const int row = rb + rr;
+      pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (q < KT * (QA + QB) && row < r1)
+        pre[t] = cq < QA ? *reinterpret_cast<const float4*>(A + (size_t)row * lda + 4 * cq)
+                         : *reinterpret_cast<const float4*>(B + (size_t)row * ldb + 4 * (cq - QA));
+    }
+  };
+  fetch(r0);
+  for (int rb = r0; rb < r1; rb += KT) {
+    __syncthreads();                                         // previous tile fully consumed
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b[n] = ok ? bp[16 * n] : 0.0f;
+    for (int t = 0; t < NQ; ++t) {
+      const int q = threadIdx.x + 256 * t;
+      if (q < KT * (QA + QB)) *reinterpret_cast<float4*>(&s_t[(q / (QA + QB)) * LD + 4 * (q % (QA + QB))]) = pre[t];
+    }
+    __syncthreads();
+    if (rb + KT < r1) fetch(rb + KT);                        // overlaps the MFMAs below
 #pragma unroll
-    for (int m = 0; m < MW; ++m)
+    for (int kk = 0; kk < KT / 4; ++kk) {
+      const float* rowp = &s_t[(4 * kk + g) * LD + i];
+      float a[MW], b[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], b[n], acc[m][n]);
+      for (int m = 0; m < MW; ++m) a[m] = (wave + 4 * m < MT) ? rowp[16 * (wave + 4 * m)] : 0.0f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = rowp[WA + 16 * n];
+#pragma unroll
+      for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], b[n], acc[m][n]);
+    }
   }
   float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
 #pragma unroll
