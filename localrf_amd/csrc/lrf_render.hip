@@ -1,21 +1,23 @@
 // lrf_render.hip -- gfx950 (MI355X / CDNA4) forward kernels of the localrf render path
 // and the C ABI declared in include/lrf.h.
 //
-// Pipeline of lrf_render_fwd (one field, R rays x S samples):
-//   k_march    one wavefront per ray: contracted sampling, density VM gather (channel-last
-//              planes, 2x float4 per tap), softplus, alpha, wave-level prefix product for
-//              transmittance, acc/depth, floater filter, and in-wave compaction of the
-//              samples that pass weight > thres into per-ray lists + a global work-item
-//              list (ITEM compact samples per item).
-//   k_shade    persistent, one 1024-thread workgroup per CU, the colour network's weights
-//              resident in LDS in MFMA-fragment order.  Tiles (16 compact samples of one ray)
-//              are split statically and contiguously over the waves via a prefix sum of the
-//              per-ray tile counts (k_scan_tiles); per 16-sample tile it gathers the 72 appearance products straight
-//              into the B-operand layout of v_mfma_f32_16x16x4_f32 and runs
-//              basis(72->27) -> 128 -> 128 as a register-resident MFMA chain (the D layout
-//              of one layer IS the B layout of the next after a K permutation folded into
-//              the packed weights), the 131->3 head + sigmoid + weighting on the VALU.
-//   k_finalize per-ray ordered sum of item partials + white background (deterministic).
+// Pipeline of lrf_render_fwd (one field, R rays x S samples), four launches, no atomics:
+//   k_march      one wavefront per ray: contracted sampling, density VM gather (channel-last
+//                planes, 2x float4 per tap), softplus, alpha, wave-level prefix product for
+//                transmittance, acc/depth, floater filter, and in-wave compaction of the
+//                samples that pass weight > thres into the ray's list (u16 index + weight).
+//   k_scan_tiles prefix sum of the per-ray tile counts (tile = 16 compact samples of one ray).
+//   k_shade_bf16 persistent, one 1024-thread workgroup per CU, the colour network resident in
+//                LDS in MFMA-fragment order.  Tiles are split statically and contiguously over
+//                the waves (XCD-aware block order).  Per tile the lane (s = lane&15, g = lane>>4)
+//                gathers channel group g of every appearance plane/line for sample s -- exactly the
+//                B-operand layout of the MFMA -- and runs basis(72->27) -> 128 -> 128 as a
+//                register-resident MFMA chain: the D layout of one layer IS the B layout of the
+//                next after a K permutation folded into the packed weights.  Default engine:
+//                split-bf16 (hi+lo, 3-term) on v_mfma_f32_16x16x32_bf16, hand-issued in place;
+//                k_shade = exact-fp32 engine on v_mfma_f32_16x16x4_f32; k_shade_valu = debug.
+//                The 131->3 head + sigmoid + weighting run on the VALU.
+//   k_finalize   per-ray ordered sum of tile partials + white background (deterministic).
 //
 // Reference lines (relative to /root/reference/localTensoRF) are cited at each step.
 #include <hip/hip_runtime.h>
@@ -554,10 +556,23 @@ __device__ __forceinline__ void mfma_bf16_acc(bf16x8 a, bf16x8 b, f32x4& acc) {
 __device__ __forceinline__ bf16x8 lds_frag(const uint4* img, int frag, int part, int lane) {
   return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
 }
+// Operand registers of an issued MFMA must not be rewritten for a while: the matrix pipe is
+// shared by the four waves of a SIMD and (measured) an MFMA can read its SrcA/SrcB tens of
+// cycles after the wave has moved on -- hipcc reused the B-operand VGPRs for address
+// arithmetic ~14 issue slots behind the last MFMA of a k-step and, once in ~25K tiles, that
+// MFMA multiplied garbage (first-layer outputs 25 % off; scripts/gpu_diag.py stage_dump).
+// hold() keeps a fragment allocated up to this point in program order; gemm_step ends with
+// 48 wait states during which all of its operands are still held.  tests/test_isa_checks.py
+// checks the emitted ISA for this distance.
+__device__ __forceinline__ void hold(bf16x8 v) {
+  const i32x4 u = __builtin_bit_cast(i32x4, v);
+  asm volatile("" :: "v"(u));
+}
 // acc[t1] += A(frag0 + t1*stride) x B for t1 in [0, NT), three-term split product
 template <int NT>
 __device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int stride, int lane,
                                           bf16x8 bh, bf16x8 bl, f32x4* acc) {
+  bf16x8 pah = bh, pal = bl;                                 // previous A fragments (dummy at t1 = 0)
 #pragma unroll
   for (int t1 = 0; t1 < NT; ++t1) {
     const bf16x8 ah = lds_frag(img, frag0 + t1 * stride, 0, lane);
@@ -565,6 +580,13 @@ __device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int strid
     mfma_bf16_acc(al, bh, acc[t1]);
     mfma_bf16_acc(ah, bl, acc[t1]);
     mfma_bf16_acc(ah, bh, acc[t1]);
+    hold(pah); hold(pal);                                    // >= 3 MFMAs (60 cycles) behind their last use
+    pah = ah; pal = al;
+  }
+  {
+    const i32x4 a0 = __builtin_bit_cast(i32x4, pah), a1 = __builtin_bit_cast(i32x4, pal);
+    const i32x4 b0 = __builtin_bit_cast(i32x4, bh), b1 = __builtin_bit_cast(i32x4, bl);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
   }
 }
 

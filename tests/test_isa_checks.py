@@ -55,6 +55,56 @@ def test_bf16_mfma_accumulates_in_place(asm):
         assert m[1] == m[2], m[0]
 
 
+def _kernel_lines(asm, mangled_prefix):
+    m = re.search(r"^(_ZN3lrf\d+%s[^:\s]*):[^\n]*\n(.*?)s_endpgm" % mangled_prefix, asm, re.S | re.M)
+    assert m, mangled_prefix
+    out = []
+    for ln in m[2].splitlines():
+        ln = ln.split(";")[0].strip()
+        if ln and not ln.startswith("."):
+            out.append(ln)
+    return out
+
+
+def _regs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m[1]), int(m[2]) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m[1])} if m else set()
+
+
+def test_bf16_mfma_sources_are_not_rewritten_close_behind(asm):
+    """No instruction may write a VGPR that a v_mfma_f32_16x16x32_bf16 read as SrcA/SrcB within
+    the next 24 issue slots (s_nop N counts N+1): see hold()/gemm_step in csrc/lrf_render.hip."""
+    WINDOW = 24
+    for kern in ("k_shade_bf16E", "k_bwd_shade_fwdE"):
+        lines = _kernel_lines(asm, kern)
+        checked = 0
+        for i, ln in enumerate(lines):
+            if not ln.startswith("v_mfma_f32_16x16x32_bf16"):
+                continue
+            ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
+            src = _regs(ops[1]) | _regs(ops[2])
+            slots, j = 0, i + 1
+            while j < len(lines) and slots < WINDOW:
+                w = lines[j]
+                if w.startswith("s_cbranch") or w.startswith("s_branch") or w.endswith(":"):
+                    break
+                m = re.match(r"s_nop (\d+)", w)
+                slots += int(m[1]) + 1 if m else 1
+                parts = w.split(None, 1)
+                if len(parts) == 2 and not parts[0].startswith(("s_", "global_store", "scratch_store", "ds_write",
+                                                                  "ds_add", "buffer_store")):
+                    dst = _regs(parts[1].split(",")[0].strip())
+                    if parts[0].startswith("v_mfma"):
+                        dst = set()                      # in-place accumulators are not sources
+                    assert not (dst & src), (kern, ln, w, slots)
+                j += 1
+            checked += 1
+        assert checked >= 138, (kern, checked)
+
+
 def test_scratch_use_is_bounded(asm):
     for kern, limit in (("k_marchE", 0), ("k_shade_bf16E", 128)):
         m = re.search(r"\.amdhsa_kernel _ZN3lrf\d+%s.*?\.end_amdhsa_kernel" % kern, asm, re.S)
