@@ -127,18 +127,31 @@ def stage_nondet():
     sums differ between runs (must be 0).  LRF_BF16_VARIANT selects the experiment build."""
     import torch
     from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).to("cuda:0")
+    grid = [int(v) for v in os.environ.get("DIAG_GRID", "300,300,300").split(",")]
+    nR, nN = int(os.environ.get("DIAG_R", "4096")), int(os.environ.get("DIAG_N", "1536"))
+    f = quiet(make_field, grid, "cpu", seed=0).to("cuda:0")
+    rays = make_rays(nR, 1, pinhole=bool(os.environ.get("DIAG_PINHOLE"))).to("cuda:0")
     f.mlp_engine = os.environ.get("DIAG_ENGINE", "bf16x3")
     outs = []
     with torch.no_grad():
-        for i in range(40):
-            rgb, _ = f(rays, N_samples=1536)
-            outs.append(rgb.clone())
+        nrep = int(os.environ.get("DIAG_REPS", "40"))
+        ref = None
+        for i in range(nrep):
+            rgb, _ = f(rays, N_samples=nN)
+            if nrep <= 40:
+                outs.append(rgb.clone())
+            else:                                   # long run: keep only mismatch counts
+                if ref is None:
+                    ref = rgb.clone(); outs.append(ref)
+                elif not torch.equal(rgb, ref):
+                    outs.append(rgb.clone())
+        if nrep > 40:
+            log("long run", nrep, "renders; renders differing from the first:", len(outs) - 1,
+                "max abs diff", max([float((o - ref).abs().max()) for o in outs[1:]] + [0.0]))
         torch.cuda.synchronize()
         t = time.time()
         for i in range(50):
-            f(rays, N_samples=1536)
+            f(rays, N_samples=nN)
         torch.cuda.synchronize()
         dt = (time.time() - t) / 50
     nd = [int(((o - outs[0]).abs().amax(-1) > 0).sum()) for o in outs[1:]]
@@ -263,7 +276,47 @@ def stage_xcd():
         log("ray order", name, "ms/step", round((time.time() - t) / 200 * 1e3, 4))
 
 
-STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100)]
+def stage_firstcall():
+    """Is the FIRST render of a fresh field different from later ones?  Per engine, 4 fresh
+    fields, 5 renders each: rays whose rgb / depth differ from the last render."""
+    import torch
+    from util import make_field, make_rays, quiet
+    rays = make_rays(512, 78, pinhole=True).to("cuda:0")
+    for eng in ("bf16x3", "f32", "valu"):
+        res = []
+        for trial in range(4):
+            f = quiet(make_field, [400, 360, 440], "cpu", seed=77).to("cuda:0")
+            f.mlp_engine = eng
+            outs = []
+            with torch.no_grad():
+                for i in range(5):
+                    rgb, depth = f(rays, N_samples=-1)
+                    outs.append((rgb.clone(), depth.clone()))
+            res.append([(int(((o[0] - outs[-1][0]).abs().amax(-1) > 0).sum()), int(((o[1] - outs[-1][1]).abs() > 0).sum()))
+                        for o in outs[:-1]])
+        log("firstcall", eng, res)
+
+
+def stage_fwdbwdfwd():
+    """forward (grad path) -> backward -> forward (no-grad): are the two forwards identical?"""
+    import torch
+    from util import make_field, make_rays, quiet
+    for grid, R, N in (([400, 360, 440], 512, -1), ([300, 300, 300], 4096, 1536), ([20, 24, 28], 64, 96)):
+        f = quiet(make_field, grid, "cpu", seed=77).to("cuda:0")
+        rays = make_rays(R, 78, pinhole=True).to("cuda:0").requires_grad_(True)
+        rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=N)
+        with torch.no_grad():
+            rgb_b, depth_b = f(rays.detach(), white_bg=True, is_train=False, N_samples=N)
+        (rgb.sum() + depth.sum()).backward()
+        with torch.no_grad():
+            rgb2, depth2 = f(rays.detach(), white_bg=True, is_train=False, N_samples=N)
+            rgb3, depth3 = f(rays.detach(), white_bg=True, is_train=False, N_samples=N)
+        d = lambda a, b: (int(((a - b).abs().reshape(a.shape[0], -1).amax(-1) > 0).sum()), float((a - b).abs().max()))
+        log("fwdbwdfwd", grid, "grad-fwd vs nograd-fwd (before bwd)", d(rgb.detach(), rgb_b), "vs after bwd", d(rgb.detach(), rgb2),
+            "after-bwd twice", d(rgb2, rgb3), "depth", d(depth.detach(), depth2))
+
+
+STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
