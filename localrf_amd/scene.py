@@ -219,8 +219,9 @@ class LocalTensorfs(torch.nn.Module):
     def get_cam2world(self, view_ids=None, starting_id=0):
         """[V,3,4] camera-to-world from the 6D rotation + translation params (:292-299)."""
         if view_ids is not None:
-            r = torch.stack([self.r_c2w[int(v)] for v in view_ids], dim=0)
-            t = torch.stack([self.t_c2w[int(v)] for v in view_ids], dim=0)
+            ids = view_ids.tolist() if torch.is_tensor(view_ids) else list(view_ids)   # one sync, not one per view
+            r = torch.stack([self.r_c2w[v] for v in ids], dim=0)
+            t = torch.stack([self.t_c2w[v] for v in ids], dim=0)
         else:
             r = torch.stack(list(self.r_c2w[starting_id:]), dim=0)
             t = torch.stack(list(self.t_c2w[starting_id:]), dim=0)
@@ -287,7 +288,12 @@ class LocalTensorfs(torch.nn.Module):
         return self.init_focal * self.focal_offset * W / self.W
 
     def center(self, W, H):
-        return torch.Tensor([W, H]).to(self.center_rel) * self.center_rel
+        key = (W, H, self.center_rel.device)
+        wh = getattr(self, "_wh_cache", {}).get(key)
+        if wh is None:                          # the reference uploads [W, H] on every call (:380)
+            wh = torch.tensor([float(W), float(H)], device=self.center_rel.device)
+            self._wh_cache = {key: wh}
+        return wh * self.center_rel
 
     # ----------------------------------------------------------------- the render entry point
     def forward(self, ray_ids, view_ids, W, H, white_bg=True, is_train=True, cam2world=None,

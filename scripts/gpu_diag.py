@@ -316,7 +316,57 @@ def stage_fwdbwdfwd():
             "after-bwd twice", d(rgb2, rgb3), "depth", d(depth.detach(), depth2))
 
 
-STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150)]
+def stage_scene():
+    """LocalTensorfs.forward at BASELINE configs[2]/[3] scale: 300^3 fields, 4096 rays; 1 field
+    (train-style call, no grad) and 4 blended fields (eval)."""
+    import torch
+    from localrf_amd import LocalTensorfs
+    from util import FIELD_KW, quiet
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).cuda()
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=(960, 540),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device="cuda:0", lr_upsample_reset=True,
+               aabb=aabb, gridSize=[300, 300, 300], **FIELD_KW)
+    g = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        for _ in range(3):
+            lt.append_frame()
+            with torch.no_grad():
+                lt.t_c2w[-1].add_(0.05 * torch.randn(3, generator=g).cuda())
+        quiet(lt.append_rf, 3)
+    n_frames = len(lt.r_c2w)
+    view_ids = torch.arange(n_frames - 16 if n_frames >= 16 else 0, n_frames).cuda()[:16]
+    V = view_ids.numel()
+    ray_ids = torch.randint(0, 960 * 540, (V * (4096 // V),), generator=g).cuda()
+    bw = torch.tensor([[.1, .2, .3, .4]]).repeat(V, 1).cuda()
+
+    def timeit(fn, n=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.time() - t) / n * 1e3
+    with torch.no_grad():
+        t1 = timeit(lambda: lt(ray_ids, view_ids, 960, 540, is_train=True))
+        t4 = timeit(lambda: lt(ray_ids, view_ids, 960, 540, is_train=False, blending_weights=bw.clone(), chunk=16384))
+    log("scene forward, 4096 rays, S=344: 1 field (train call, no grad) ms", round(t1, 3), "| 4 blended fields (eval) ms", round(t4, 3),
+        "| rays/s", round(ray_ids.numel() / t1 * 1e3), round(ray_ids.numel() / t4 * 1e3))
+
+    def train_step():
+        for p in lt.parameters():
+            p.grad = None
+        rgb, depth, _, _ = lt(ray_ids, view_ids, 960, 540, is_train=True)
+        (rgb.mean() + 0.01 * depth.mean()).backward()
+    t_tr = timeit(train_step, 10)
+    log("scene train step (forward + backward through poses/exposure/field), ms", round(t_tr, 3))
+
+
+STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
