@@ -132,7 +132,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
 
     import __graft_entry__ as ge
+    if world > 1 and local != 0:                              # one rank compiles, the rest wait for it
+        dist.barrier(device_ids=[local])
     ge.build()
+    if world > 1 and local == 0:
+        dist.barrier(device_ids=[local])
     from localrf_amd import TensorVMSplit
 
     torch.manual_seed(0)                                      # identical replica on every rank
@@ -207,7 +211,7 @@ def main():
                           "rays_per_gpu": R_PER_GPU, "samples_per_ray": S, "grid": GRID,
                           "parallelism": f"ray-shard x{world}", "mlp_engine": field.mlp_engine},
                "roofline": roofline}
-        if not args.no_baselines:
+        if not args.no_baselines and world == 1:              # baselines are an N=1 report
             sd = field.state_dict()
             out["torch_rocm_port"] = torch_rocm_port(sd, rays)
             out["cpu_baseline"] = cpu_baseline(sd, rays_cpu)

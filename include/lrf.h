@@ -143,6 +143,37 @@ int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size,
                         const float* jitter, int32_t R, int32_t N,
                         float* pts, float* t, uint8_t* inside, void* stream);
 
+/* Scene-level ends of the path: LocalTensorfs.forward (local_tensorfs.py:382-499).
+ * View of ray r is r / per_view (repeat_interleave at local_tensorfs.py:437); R % per_view == 0.
+ *
+ * lrf_scene_rays: ids2pixel (local_tensorfs.py:23-29) + get_ray_directions_lean / _360
+ * (utils/ray_utils.py:14-37) + cam2rf = cam2world (+) world2rf (local_tensorfs.py:427-431) +
+ * get_rays_lean (utils/ray_utils.py:39-54), for n_rf fields in one launch.
+ *   ray_ids [R] int64; cam2world [V,3,4]; world2rf [n_rf,3]; focal [1], center [2] device
+ *   scalars (NULL when fov360); outputs rays [n_rf,R,6], directions [R,3], ij [R,2] int64. */
+int lrf_scene_rays(const int64_t* ray_ids, int32_t R, int32_t per_view, const float* cam2world,
+                   const float* world2rf, int32_t n_rf, const float* focal, const float* center,
+                   int32_t W, int32_t H, int32_t fov360, float* rays, float* directions, int64_t* ij,
+                   void* stream);
+/* Gradients autograd derives for the above: g_cam2world [V,3,4]; g_intr [V,3] per-view partial
+ * sums of (d focal, d center_x, d center_y); g_world2rf [V,n_rf,3] per-view partial sums.
+ * g_directions [R,3] may be NULL. */
+int lrf_scene_rays_bwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const float* cam2world,
+                       int32_t n_rf, const float* focal, const float* center, int32_t W, int32_t H,
+                       int32_t fov360, const float* g_rays, const float* g_directions,
+                       float* g_cam2world, float* g_intr, float* g_world2rf, void* stream);
+/* lrf_scene_blend: rgbs = clamp(E_v (sum_k w[v,k] rgb_k), 0, 1), depth = sum_k w[v,k] depth_k
+ * (local_tensorfs.py:468-474,481-499).  rgb_f [n_rf,R,3], depth_f [n_rf,R], blend_w [V,n_rf],
+ * exposure [V,3,3] or NULL; pre [R,3] (blended colour before exposure, kept for the backward
+ * pass) may be NULL. */
+int lrf_scene_blend(const float* rgb_f, const float* depth_f, const float* blend_w, const float* exposure,
+                    int32_t R, int32_t per_view, int32_t n_rf, float* rgbs, float* depth, float* pre,
+                    void* stream);
+/* g_depth and g_exposure [V,3,3] may be NULL. */
+int lrf_scene_blend_bwd(const float* g_rgbs, const float* g_depth, const float* pre, const float* blend_w,
+                        const float* exposure, int32_t R, int32_t per_view, int32_t n_rf,
+                        float* g_rgb_f, float* g_depth_f, float* g_exposure, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,13 @@ SYMBOLS = {
     "lrf_app_feature": (C.c_int, [C.POINTER(LrfField), _f, C.c_int32, _f, C.c_void_p]),
     "lrf_sample_ray_aabb": (C.c_int, [_f, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _f,
                                       C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
+    "lrf_scene_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32,
+                                 C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
+    "lrf_scene_rays_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int32, _f, _f, C.c_int32,
+                                     C.c_int32, C.c_int32, _f, _f, _f, _f, _f, C.c_void_p]),
+    "lrf_scene_blend": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
+    "lrf_scene_blend_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f,
+                                      C.c_void_p]),
 }
 
 _lib = None

@@ -933,6 +933,7 @@ static int device_cus() {
 }  // namespace lrf
 
 #include "lrf_backward.inl"
+#include "lrf_scene.inl"
 
 using namespace lrf;
 

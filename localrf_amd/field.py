@@ -317,7 +317,7 @@ class TensorVMSplit(torch.nn.Module):
             raise ValueError(f"unknown mlp_engine {self.mlp_engine!r}")
         return fl
 
-    def _native_forward(self, rays, z, flags, floater, want_weights=False):
+    def _native_forward(self, rays, z, flags, floater, want_weights=False, out=None):
         self._require_gpu(rays)
         lib = N.lib()
         self._ensure_cache()
@@ -325,8 +325,14 @@ class TensorVMSplit(torch.nn.Module):
         z = z.detach().contiguous().float().view(-1)
         R, S = rays.shape[0], z.shape[0]
         dev = rays.device
-        rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
-        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        if out is not None:                 # caller-owned outputs (LocalTensorfs blends them in place)
+            rgb, depth = out
+            if (rgb.shape != (R, 3) or depth.shape != (R,) or rgb.dtype != torch.float32
+                    or depth.dtype != torch.float32 or rgb.device != dev or depth.device != dev):
+                raise ValueError("out must be (float32 [R,3], float32 [R]) on the rays' device")
+        else:
+            rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+            depth = torch.empty(R, dtype=torch.float32, device=dev)
         w_out = torch.empty(R, S, dtype=torch.float32, device=dev) if want_weights else None
         acc = torch.empty(R, dtype=torch.float32, device=dev) if want_weights else None
         if R == 0:
@@ -447,9 +453,10 @@ class TensorVMSplit(torch.nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, refine=True,
-                floater_thresh=0):
+                floater_thresh=0, out=None):
         """tensorBase.py:567-636.  rays_chunk [R,6] -> (rgb_map [R,3], depth_map [R]).
-        `refine` only matters when fea_pe > 0 (tensorBase.py:117-126); this build has fea_pe=0."""
+        `refine` only matters when fea_pe > 0 (tensorBase.py:117-126); this build has fea_pe=0.
+        `out=(rgb, depth)` (extension, no-grad calls only) renders into caller-owned tensors."""
         self._require_gpu(rays_chunk)
         z = self.z_schedule(is_train, N_samples, rays_chunk.device)
         use_white = bool(white_bg) or bool(is_train and torch.rand((1,)) < 0.5)   # :633
@@ -459,8 +466,10 @@ class TensorVMSplit(torch.nn.Module):
         if needs_grad:
             if floater_thresh > 0:
                 raise N.NativeError("floater_thresh > 0 is an eval-only filter (train.py:107,139)")
+            if out is not None:
+                raise ValueError("out= is only valid when no gradient is recorded")
             return _RenderFn.apply(self, rays_chunk, z, flags, 0.0, *self._param_list())
-        return self._native_forward(rays_chunk, z, flags, float(floater_thresh))
+        return self._native_forward(rays_chunk, z, flags, float(floater_thresh), out=out)
 
     def render_weights(self, rays_chunk, N_samples=-1, floater_thresh=0, white_bg=True):
         """Debug/test hook: forward plus the per-sample weights and acc map."""

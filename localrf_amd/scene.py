@@ -2,10 +2,11 @@
 
 Drop-in for the reference's `local_tensorfs.LocalTensorfs` (same constructor, attribute and
 state-dict names, `forward` signature/returns, `optimizer_step`, `append_frame`,
-`append_rf`, `save`/`load`).  `forward` (local_tensorfs.py:382-499) generates rays on the
-device with small differentiable torch ops and renders every active field with the native
-HIP renderer (`TensorVMSplit.forward`); poses, intrinsics and exposure keep their autograd
-path exactly as in the reference.
+`append_rf`, `save`/`load`).  `forward` (local_tensorfs.py:382-499) is three kinds of HIP launch:
+`lrf_scene_rays` (pixel ids -> per-field rays), the native field renderer
+(`TensorVMSplit.forward`) per active field, and `lrf_scene_blend` (weighted sum over fields,
+per-view exposure, clamp).  Poses, intrinsics and exposure get the gradients autograd derives
+in the reference (scene_ops.py); only the [V,3,2]->[V,3,4] pose assembly stays in torch.
 
 MI355X-first differences (results identical):
   * finished fields stay resident in HBM (288 GB) instead of being parked on the host and
@@ -19,9 +20,10 @@ import re
 
 import torch
 
+from ._native import NativeError
 from .field import AlphaGridMask, TensorVMSplit
-from .rays import (N_to_reso, get_ray_directions_360, get_ray_directions_lean, get_rays_lean,
-                   ids2pixel, mtx_to_sixD, sixD_to_mtx)
+from .rays import N_to_reso, mtx_to_sixD, sixD_to_mtx
+from .scene_ops import scene_blend, scene_rays
 
 _ADAM_BETAS = (0.9, 0.99)
 
@@ -300,60 +302,72 @@ class LocalTensorfs(torch.nn.Module):
                 world2rf=None, blending_weights=None, chunk=16384, test_id=False, floater_thresh=0):
         """Pixel ids -> rays -> per-field native render -> blend -> exposure -> clamp
         (local_tensorfs.py:382-499).  Returns (rgbs [R,3], depth [R], directions [R,3], ij [R,2])."""
-        col, row = ids2pixel(W, H, ray_ids)
-        if self.fov == 360:
-            directions = get_ray_directions_360(col, row, W, H)
-        else:
-            directions = get_ray_directions_lean(col, row, self.focal(W), self.center(W, H))
-        if blending_weights is None:
-            blending_weights = self.blending_weights[view_ids].clone()
+        if not ray_ids.is_cuda:
+            raise NativeError("localrf_amd: LocalTensorfs.forward runs only on an AMD GPU (HIP kernels); "
+                              f"got {ray_ids.device} ray ids. There is no CPU fallback.")
+        dev = ray_ids.device
+        n_rays, n_views = ray_ids.shape[0], view_ids.shape[0]
+        view_list = view_ids.tolist() if torch.is_tensor(view_ids) else list(view_ids)   # the one host sync
         if cam2world is None:
-            cam2world = self.get_cam2world(view_ids)
+            cam2world = self.get_cam2world(view_list)
         if world2rf is None:
             world2rf = self.world2rf
 
+        # which fields render, and with what per-view weight (:405-422)
         if is_train:                                            # one field trains at a time (:411-416)
-            blending_weights[:, -1] = 1
-            blending_weights[:, :-1] = 0
             active = [len(self.tensorfs) - 1]
+            bw = self._ones(n_views, dev)
         else:
-            active = torch.nonzero(torch.sum(blending_weights, dim=0))[:, 0].tolist()
-        ij = torch.stack([col, row], dim=-1)
+            if blending_weights is None:
+                host = self._blending_host()[view_list]         # host mirror: no device round trip
+                active = torch.nonzero(host.sum(0))[:, 0].tolist()
+                blending_weights = self.blending_weights[view_ids]
+            else:
+                active = torch.nonzero(torch.sum(blending_weights, dim=0))[:, 0].tolist()
+            bw = blending_weights[:, active]
+
+        pinhole = self.fov != 360
+        focal = self.focal(W) if pinhole else None
+        center = self.center(W, H) if pinhole else None
         if len(active) == 0:                                    # degenerate 5-tuple (:420-422)
             print("****** No valid RF")
-            return (torch.ones([ray_ids.shape[0], 3]), torch.ones_like(ray_ids).float(),
+            _, directions, ij = scene_rays(ray_ids, cam2world, torch.zeros(1, 3, device=dev), focal, center,
+                                           max(1, n_rays // max(1, n_views)), W, H, not pinhole)
+            return (torch.ones([n_rays, 3]), torch.ones_like(ray_ids).float(),
                     torch.ones_like(ray_ids).float(), directions, ij)
+        if n_rays % n_views:
+            raise ValueError("ray_ids must hold the same number of rays for every view")
+        per_view = n_rays // n_views
 
-        per_view = ray_ids.shape[0] // view_ids.shape[0]
-        cam2rf = {}
+        shifts = torch.stack([world2rf[rf] for rf in active], dim=0)
+        rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole)
         for rf in active:
-            m = cam2world.clone()
-            m[:, :3, 3] += world2rf[rf]
-            cam2rf[rf] = m.repeat_interleave(per_view, dim=0)
-            if self.tensorfs[rf].device != view_ids.device:
-                self.tensorfs[rf].to(view_ids.device)           # stays there (no shuttle back)
-        bw = blending_weights.repeat_interleave(per_view, dim=0)
+            if self.tensorfs[rf].device != dev:
+                self.tensorfs[rf].to(dev)                       # stays there (no shuttle back)
 
-        n_rays = ray_ids.shape[0]
         chunk = max(1, chunk // len(active))
-        rgb_parts, depth_parts = [], []
-        for lo in range(0, n_rays, chunk):
-            hi = min(lo + chunk, n_rays)
-            rgb_c = torch.zeros_like(directions[lo:hi])
-            dep_c = torch.zeros_like(directions[lo:hi, 0])
-            for rf in active:
-                rays_o, rays_d = get_rays_lean(directions[lo:hi], cam2rf[rf][lo:hi])
-                rays = torch.cat([rays_o, rays_d], -1).view(-1, 6)
-                rgb_f, dep_f = self.tensorfs[rf](
-                    rays, is_train=is_train, white_bg=white_bg, N_samples=-1,
-                    refine=self.is_refining, floater_thresh=floater_thresh)
-                rgb_c = rgb_c + rgb_f * bw[lo:hi, rf][..., None]
-                dep_c = dep_c + dep_f * bw[lo:hi, rf]
-            rgb_parts.append(rgb_c)
-            depth_parts.append(dep_c)
-        rgbs = rgb_parts[0] if len(rgb_parts) == 1 else torch.cat(rgb_parts, 0)
-        depth_maps = depth_parts[0] if len(depth_parts) == 1 else torch.cat(depth_parts, 0)
+        taped = torch.is_grad_enabled() and (rays.requires_grad or any(
+            p.requires_grad for rf in active for p in self.tensorfs[rf].parameters()))
+        if taped:
+            cols_rgb, cols_dep = [], []
+            for k, rf in enumerate(active):
+                parts = [self.tensorfs[rf](rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
+                                           N_samples=-1, refine=self.is_refining, floater_thresh=floater_thresh)
+                         for lo in range(0, n_rays, chunk)]
+                cols_rgb.append(parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], 0))
+                cols_dep.append(parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0))
+            rgb_f = cols_rgb[0][None] if len(active) == 1 else torch.stack(cols_rgb, 0)
+            dep_f = cols_dep[0][None] if len(active) == 1 else torch.stack(cols_dep, 0)
+        else:                                                   # fields write straight into the blend input
+            rgb_f = torch.empty(len(active), n_rays, 3, device=dev)
+            dep_f = torch.empty(len(active), n_rays, device=dev)
+            for lo in range(0, n_rays, chunk):                  # same chunk/field order as :440-474
+                for k, rf in enumerate(active):
+                    self.tensorfs[rf](rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
+                                      N_samples=-1, refine=self.is_refining, floater_thresh=floater_thresh,
+                                      out=(rgb_f[k, lo:lo + chunk], dep_f[k, lo:lo + chunk]))
 
+        exposure = None
         if self.lr_exposure_init > 0:                           # per-view 3x3 colour transform (:481-496)
             if test_id:
                 prev = torch.maximum(view_ids - 1, torch.tensor(0, device=view_ids.device))
@@ -364,6 +378,19 @@ class LocalTensorfs(torch.nn.Module):
                 exposure = (stacked[prev] + stacked[nxt]) / 2
             else:
                 exposure = torch.stack(list(self.exposure), dim=0)[view_ids]
-            exposure = exposure.repeat_interleave(per_view, dim=0)
-            rgbs = torch.bmm(exposure, rgbs[..., None])[..., 0]
-        return rgbs.clamp(0, 1), depth_maps, directions, ij
+        rgbs, depth_maps = scene_blend(rgb_f, dep_f, bw, exposure, per_view)
+        return rgbs, depth_maps, directions, ij
+
+    def _ones(self, n, dev):
+        key = (n, str(dev))
+        if getattr(self, "_ones_cache", (None, None))[0] != key:
+            self._ones_cache = (key, torch.ones(n, 1, device=dev))
+        return self._ones_cache[1]
+
+    def _blending_host(self):
+        """CPU mirror of the (non-trainable) blending weights, refreshed when they change."""
+        bwp = self.blending_weights
+        key = (bwp.data_ptr(), bwp._version, tuple(bwp.shape))
+        if getattr(self, "_bw_host", (None, None))[0] != key:
+            self._bw_host = (key, bwp.detach().cpu())
+        return self._bw_host[1]

@@ -1,0 +1,118 @@
+"""Autograd seams for the scene-level kernels (lrf_scene_* in include/lrf.h).
+
+`scene_rays` replaces the torch chain ids2pixel -> get_ray_directions_lean/_360 ->
+cam2rf -> repeat_interleave -> get_rays_lean -> cat (local_tensorfs.py:397-431,448-452;
+utils/ray_utils.py:14-54) and `scene_blend` replaces the weighted sum over fields, the
+per-view exposure bmm and the clamp (local_tensorfs.py:468-474,481-499), each with one
+HIP launch; their backward functions return what autograd derives for those chains
+(pose, intrinsic, world2rf and exposure gradients).  No CPU fallback.
+Cited lines are relative to /root/reference/localTensoRF."""
+import torch
+
+from . import _native as N
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _f32c(t):
+    return t.detach().contiguous().float()
+
+
+class _SceneRaysFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360):
+        dev = ray_ids.device
+        R, n_rf = ray_ids.shape[0], world2rf.shape[0]
+        ids = ray_ids.detach().contiguous().long()
+        c2w, w2rf = _f32c(cam2world), _f32c(world2rf)
+        fo = None if focal is None else _f32c(focal)
+        ce = None if center is None else _f32c(center)
+        rays = torch.empty(n_rf, R, 6, dtype=torch.float32, device=dev)
+        dirs = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        ij = torch.empty(R, 2, dtype=torch.int64, device=dev)
+        N.check(N.lib().lrf_scene_rays(ids.data_ptr(), R, per_view, N.ptr(c2w), N.ptr(w2rf), n_rf, N.ptr(fo),
+                                       N.ptr(ce), W, H, int(fov360), N.ptr(rays), N.ptr(dirs), ij.data_ptr(),
+                                       _stream(dev)), "lrf_scene_rays")
+        ctx.save_for_backward(ids, c2w, fo, ce)
+        ctx.meta = (R, per_view, n_rf, W, H, int(fov360))
+        ctx.mark_non_differentiable(ij)
+        return rays, dirs, ij
+
+    @staticmethod
+    def backward(ctx, g_rays, g_dirs, _g_ij):
+        ids, c2w, fo, ce = ctx.saved_tensors
+        R, per_view, n_rf, W, H, fov360 = ctx.meta
+        dev, V = ids.device, R // per_view
+        if g_rays is None:
+            g_rays = torch.zeros(n_rf, R, 6, dtype=torch.float32, device=dev)
+        g_rays = _f32c(g_rays)
+        g_dirs = None if g_dirs is None else _f32c(g_dirs)
+        g_c2w = torch.empty(V, 3, 4, dtype=torch.float32, device=dev)
+        g_intr = torch.zeros(V, 3, dtype=torch.float32, device=dev)
+        g_w2rf = torch.empty(V, n_rf, 3, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_scene_rays_bwd(ids.data_ptr(), R, per_view, N.ptr(c2w), n_rf, N.ptr(fo), N.ptr(ce),
+                                           W, H, fov360, N.ptr(g_rays), N.ptr(g_dirs), N.ptr(g_c2w),
+                                           N.ptr(g_intr), N.ptr(g_w2rf), _stream(dev)), "lrf_scene_rays_bwd")
+        g_focal = g_center = None
+        if not fov360:
+            s = g_intr.sum(0)
+            g_focal, g_center = s[0:1], s[1:3]
+        return None, g_c2w, g_w2rf.sum(0), g_focal, g_center, None, None, None, None
+
+
+class _SceneBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_f, dep_f, blend_w, exposure, per_view):
+        dev = rgb_f.device
+        n_rf, R = rgb_f.shape[0], rgb_f.shape[1]
+        rgb_f, dep_f, bw = _f32c(rgb_f), _f32c(dep_f), _f32c(blend_w)
+        ex = None if exposure is None else _f32c(exposure)
+        need_bwd = any(ctx.needs_input_grad)
+        rgbs = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        pre = torch.empty(R, 3, dtype=torch.float32, device=dev) if need_bwd else None
+        N.check(N.lib().lrf_scene_blend(N.ptr(rgb_f), N.ptr(dep_f), N.ptr(bw), N.ptr(ex), R, per_view, n_rf,
+                                        N.ptr(rgbs), N.ptr(depth), N.ptr(pre), _stream(dev)), "lrf_scene_blend")
+        if need_bwd:
+            ctx.save_for_backward(pre, bw, ex)
+        ctx.meta = (R, per_view, n_rf)
+        return rgbs, depth
+
+    @staticmethod
+    def backward(ctx, g_rgbs, g_depth):
+        pre, bw, ex = ctx.saved_tensors
+        R, per_view, n_rf = ctx.meta
+        dev, V = pre.device, R // per_view
+        g_rgbs = torch.zeros(R, 3, device=dev) if g_rgbs is None else _f32c(g_rgbs)
+        g_depth = None if g_depth is None else _f32c(g_depth)
+        g_rgb_f = torch.empty(n_rf, R, 3, dtype=torch.float32, device=dev)
+        g_dep_f = torch.empty(n_rf, R, dtype=torch.float32, device=dev)
+        g_ex = torch.empty(V, 3, 3, dtype=torch.float32, device=dev) if ex is not None else None
+        N.check(N.lib().lrf_scene_blend_bwd(N.ptr(g_rgbs), N.ptr(g_depth), N.ptr(pre), N.ptr(bw), N.ptr(ex),
+                                            R, per_view, n_rf, N.ptr(g_rgb_f), N.ptr(g_dep_f), N.ptr(g_ex),
+                                            _stream(dev)), "lrf_scene_blend_bwd")
+        return g_rgb_f, g_dep_f, None, g_ex, None
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise N.NativeError("localrf_amd: the scene kernels run only on an AMD GPU (HIP); got a "
+                            f"{t.device} tensor. There is no CPU fallback.")
+
+
+def scene_rays(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360=False):
+    """-> rays [n_rf,R,6] (origin | unnormalised direction, per field), directions [R,3], ij [R,2].
+    cam2world [V,3,4] (or [V,4,4]); world2rf [n_rf,3]; focal [1] / center [2] tensors (None for 360)."""
+    _require_gpu(ray_ids)
+    if ray_ids.shape[0] % per_view:
+        raise ValueError("number of rays must be a multiple of the number of views")
+    return _SceneRaysFn.apply(ray_ids, cam2world[:, :3, :], world2rf, focal, center, int(per_view),
+                              int(W), int(H), bool(fov360))
+
+
+def scene_blend(rgb_f, dep_f, blend_w, exposure, per_view):
+    """-> (clamp(E_v * sum_k w[v,k] rgb_k, 0, 1) [R,3], sum_k w[v,k] depth_k [R])."""
+    _require_gpu(rgb_f)
+    return _SceneBlendFn.apply(rgb_f, dep_f, blend_w, exposure, int(per_view))

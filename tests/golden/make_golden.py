@@ -193,6 +193,56 @@ def case_local(LocalTensorfs, name, grid, seed):
     save(name, **arrs)
 
 
+def case_local_train(LocalTensorfs, name, grid, seed):
+    """LocalTensorfs.forward in train mode (recorded jitter) + autograd gradients of poses,
+    intrinsics, exposure, world2rf and the active field: pins lrf_scene_rays/_blend backward."""
+    torch.manual_seed(seed)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    W, H = 40, 30
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=(W, H),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=1e-3, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device="cpu", lr_upsample_reset=True,
+               aabb=aabb, gridSize=list(grid), **FIELD_KW)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for i in range(len(lt.r_c2w)):
+            lt.t_c2w[i].add_(0.05 * torch.randn(3, generator=g))
+            lt.r_c2w[i].add_(0.05 * torch.randn(3, 2, generator=g))
+            lt.exposure[i].add_(0.2 * torch.randn(3, 3, generator=g))   # large: some channels clamp
+        lt.exposure[2].mul_(1.9)                     # pushes part of view 2 above 1: clamp mask
+        lt.center_rel.add_(0.02 * torch.randn(2, generator=g))
+        lt.focal_offset.add_(0.03)
+        for p in lt.tensorfs[-1].density_plane:
+            p.mul_(3.0)
+    # 4 views, not 3: with exactly 3 views the reference's dim-less torch.cross (utils/utils.py:386)
+    # picks dim 0 (across views) and builds non-orthonormal rotations -- a quirk not reproduced.
+    view_ids = torch.tensor([0, 2, 3, 4])
+    per = 40
+    ray_ids = torch.randint(0, W * H, (view_ids.numel() * per,), generator=g)
+    h = lt.tensorfs[-1].nSamples // 6
+    torch.manual_seed(seed + 2)
+    U, U2 = torch.rand(1, h), torch.rand(1, h)
+    torch.manual_seed(seed + 2)                      # forward draws (U, U2) from the same stream
+    rgbs, depths, dirs, ij = lt(ray_ids, view_ids, W, H, is_train=True, white_bg=True)
+    R = ray_ids.numel()
+    g_rgb, g_depth = torch.randn(R, 3, generator=g), torch.randn(R, generator=g)
+    g_dirs = torch.randn(R, 3, generator=g)
+    loss = (rgbs * g_rgb).sum() + (depths * g_depth).sum() + (dirs * g_dirs).sum()
+    loss.backward()
+    arrs = dict(ray_ids=ray_ids.numpy(), view_ids=view_ids.numpy(), W=np.array(W), H=np.array(H),
+                U=U[0].numpy(), U2=U2[0].numpy(), rgbs=rgbs.detach().numpy(), depths=depths.detach().numpy(),
+                dirs=dirs.detach().numpy(), ij=ij.numpy(), g_rgb=g_rgb.numpy(), g_depth=g_depth.numpy(),
+                g_dirs=g_dirs.numpy(), grid=np.array(grid), nSamples=np.array(lt.tensorfs[-1].nSamples),
+                clamped=np.array(float(((rgbs <= 0) | (rgbs >= 1)).float().mean())))
+    for k, p in lt.named_parameters():
+        if p.grad is not None:
+            arrs[f"grad.{k}"] = p.grad.numpy()
+    arrs.update({f"lt.{k}": v.detach().numpy() for k, v in lt.state_dict().items()})
+    save(name, **arrs)
+
+
 def main():
     TensorVMSplit, AlphaGridMask, LocalTensorfs = import_reference()
     # non-cubic grid: catches axis-order mistakes (first coord indexes W)
@@ -208,6 +258,7 @@ def main():
                store_field=False)
     case_train_grad(TensorVMSplit, "field_small_train_grad.npz", (20, 24, 28), 48, 96, 21)
     case_local(LocalTensorfs, "local_4fields.npz", (16, 16, 16), 31)
+    case_local_train(LocalTensorfs, "local_train_grad.npz", (20, 24, 28), 41)
 
 
 if __name__ == "__main__":

@@ -185,3 +185,44 @@ def test_torch_port_gradients_match_reference():
     for k, gr in zip(names + ["rays"], grads):
         ref = g["grad." + k]
         assert np.abs(gr.numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6), k
+
+
+def test_scene_chain_and_port_match_reference_train_golden():
+    """The plain-torch scene chain (tests/util.py::torch_scene_chain, used as the checker for the
+    lrf_scene_* kernels) + the ATen-op field port reproduce the reference's LocalTensorfs train
+    forward and its pose / intrinsic / exposure gradients."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from localrf_amd.rays import sixD_to_mtx
+    from util import torch_scene_chain
+    g = load_golden("local_train_grad")
+    sd = {k[3:]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items() if k.startswith("lt.")}
+    W, H = int(g["W"]), int(g["H"])
+    ray_ids, view_ids = torch.from_numpy(g["ray_ids"]), [int(v) for v in g["view_ids"]]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in sd
+              if k.split(".")[0] in ("r_c2w", "t_c2w", "exposure", "focal_offset", "center_rel")}
+    focal = sd["init_focal"] * leaves["focal_offset"]
+    center = torch.tensor([float(W), float(H)]) * leaves["center_rel"]
+    r = torch.stack([leaves[f"r_c2w.{v}"] for v in view_ids])
+    t = torch.stack([leaves[f"t_c2w.{v}"] for v in view_ids])
+    c2w = torch.cat([sixD_to_mtx(r), t[..., None]], -1)
+    per = ray_ids.numel() // len(view_ids)
+    rays, dirs, ij = torch_scene_chain(ray_ids, c2w, sd["world2rf.0"][None], focal, center, per, W, H, False)
+    fld = {k[len("tensorfs.0."):]: v for k, v in sd.items() if k.startswith("tensorfs.0.")}
+    z = ot.z_schedule(int(g["nSamples"]), jitter=(torch.from_numpy(g["U"]), torch.from_numpy(g["U2"])))
+    rgb, depth = ot.render_field(fld, rays[0], z, True, 0.0)
+    ex = torch.stack([leaves[f"exposure.{v}"] for v in view_ids]).repeat_interleave(per, 0)
+    rgbs = torch.bmm(ex, rgb[..., None])[..., 0].clamp(0, 1)
+    assert (ij.numpy() == g["ij"]).all() and np.abs(dirs.detach().numpy() - g["dirs"]).max() < 1e-6
+    assert rel_err(rgbs.detach().numpy(), g["rgbs"]) < 2e-6 and rel_err(depth.detach().numpy(), g["depths"]) < 2e-6
+    loss = ((rgbs * torch.from_numpy(g["g_rgb"])).sum() + (depth * torch.from_numpy(g["g_depth"])).sum()
+            + (dirs * torch.from_numpy(g["g_dirs"])).sum())
+    loss.backward()
+    checked = 0
+    for k, leaf in leaves.items():
+        if leaf.grad is None:
+            continue
+        ref = g["grad." + k]
+        assert np.abs(leaf.grad.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), k
+        checked += 1
+    assert checked >= 4 * 3 + 2

@@ -69,3 +69,19 @@ def rel_err(a, b, floor=1e-3):
 def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
+
+
+def torch_scene_chain(ray_ids, c2w, shifts, focal, center, per_view, W, H, fov360):
+    """The reference's op chain (local_tensorfs.py:397-431,448-452) in plain torch."""
+    from localrf_amd.rays import (get_ray_directions_360, get_ray_directions_lean, get_rays_lean,
+                                  ids2pixel)
+    col, row = ids2pixel(W, H, ray_ids)
+    dirs = (get_ray_directions_360(col, row, W, H) if fov360
+            else get_ray_directions_lean(col, row, focal, center))
+    rays = []
+    for k in range(shifts.shape[0]):
+        m = c2w.clone()
+        m[:, :3, 3] += shifts[k]
+        o, d = get_rays_lean(dirs, m.repeat_interleave(per_view, dim=0))
+        rays.append(torch.cat([o, d], -1))
+    return torch.stack(rays, 0), dirs, torch.stack([col, row], -1)
