@@ -97,6 +97,41 @@ __device__ __forceinline__ void contract3_bwd(const float xr[3], float g[3]) {
 }
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+// fp32 add into LDS.  The native ds_add_f32 retires ~0.33 lanes/clk/CU on MI355X (203 G lane-ops/s
+// chip-wide, scripts/ubench/lds_atomic.hip) -- 30x below ds_add_u32 -- while a compare-and-swap
+// loop on ds_cmpst_rtn_b32 sustains 1.9-2.7 T lane-ops/s at the collision rates seen here.
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+  unsigned* q = reinterpret_cast<unsigned*>(p);
+  unsigned old = *q, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(q, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}
+
+// Four independent adds with their LDS round trips overlapped; a failed compare (another lane, or
+// two of the four addresses coinciding at a clamped border) falls back to the loop.
+__device__ __forceinline__ void lds_add_retry(unsigned* q, unsigned seen, float v) {
+  unsigned assumed;
+  do {
+    assumed = seen;
+    seen = atomicCAS(q, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (seen != assumed);
+}
+__device__ __forceinline__ void lds_add4_f32(float* p0, float v0, float* p1, float v1, float* p2, float v2,
+                                             float* p3, float v3) {
+  unsigned* q0 = reinterpret_cast<unsigned*>(p0); unsigned* q1 = reinterpret_cast<unsigned*>(p1);
+  unsigned* q2 = reinterpret_cast<unsigned*>(p2); unsigned* q3 = reinterpret_cast<unsigned*>(p3);
+  const unsigned o0 = *q0, o1 = *q1, o2 = *q2, o3 = *q3;
+  const unsigned r0 = atomicCAS(q0, o0, __float_as_uint(__uint_as_float(o0) + v0));
+  const unsigned r1 = atomicCAS(q1, o1, __float_as_uint(__uint_as_float(o1) + v1));
+  const unsigned r2 = atomicCAS(q2, o2, __float_as_uint(__uint_as_float(o2) + v2));
+  const unsigned r3 = atomicCAS(q3, o3, __float_as_uint(__uint_as_float(o3) + v3));
+  if (r0 != o0) lds_add_retry(q0, r0, v0);
+  if (r1 != o1) lds_add_retry(q1, r1, v1);
+  if (r2 != o2) lds_add_retry(q2, r2, v2);
+  if (r3 != o3) lds_add_retry(q3, r3, v3);
+}
 
 // ---------------------------------------------------------------- colour chain, saving rows
 // Same arithmetic as k_shade_bf16; additionally writes rgb per shaded sample and the ACT row.
@@ -806,8 +841,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
 // Plane gradients.  The entry lists are sorted by tile; workgroup w owns the w-th equal share
 // of the concatenated list (a few tiles hold 12 % of all samples each, so one workgroup per
 // tile is badly unbalanced), accumulates tile by tile in LDS and flushes each tile once.
-template <int C, bool APP>
-__global__ __launch_bounds__(256) void k_scatter_plane(DField f, BinGeom bg, Layout L, const float* __restrict__ rays,
+template <int C, bool APP, int NT>
+__global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layout L, const float* __restrict__ rays,
                                                        const float* __restrict__ z, int S, const int* __restrict__ offs,
                                                        const uint32_t* __restrict__ list, const float* __restrict__ gf,
                                                        const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
@@ -827,10 +862,10 @@ __global__ __launch_bounds__(256) void k_scatter_plane(DField f, BinGeom bg, Lay
     const int p = bin >= bg.base[2] ? 2 : (bin >= bg.base[1] ? 1 : 0);
     const int t = bin - bg.base[p];
     const int tx0 = (t % bg.tx[p]) * BTILE, ty0 = (t / bg.tx[p]) * BTILE;
-    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += 256) s_acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) s_acc[i] = 0.0f;
     __syncthreads();
     const float* lnp = APP ? f.aline[p] : f.dline[p];
-    for (int e = a + grp; e < seg_end; e += 32) {
+    for (int e = a + grp; e < seg_end; e += NT / 8) {
       const uint32_t i = list[e];
       const uint32_t cid = APP ? rowinfo[i] : i;
       float u[3];
@@ -853,13 +888,13 @@ __global__ __launch_bounds__(256) void k_scatter_plane(DField f, BinGeom bg, Lay
         const int pc = APP ? app_pc(c) : c;
         const float Lv = r0[pc] * (1.0f - tl) + r1[pc] * tl;
         const float dP = (APP ? dxr[c] : gfi) * Lv;
-        atomicAdd(&s_acc[c00 + c], dP * w00); atomicAdd(&s_acc[c10 + c], dP * w10);
-        atomicAdd(&s_acc[c01 + c], dP * w01); atomicAdd(&s_acc[c11 + c], dP * w11);
+        lds_add4_f32(&s_acc[c00 + c], dP * w00, &s_acc[c10 + c], dP * w10,
+                     &s_acc[c01 + c], dP * w01, &s_acc[c11 + c], dP * w11);
       }
     }
     __syncthreads();
     float* gpl = gcache + (APP ? L.aplane[p] : L.dplane[p]);
-    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += 256) {
+    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) {
       const float v = s_acc[i];
       if (v == 0.0f) continue;
       const int cell = i / C, c = i % C;
@@ -910,8 +945,8 @@ __global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const 
         const int cn = min(cur + 1, f.ll[p] - 1);
 #pragma unroll
         for (int j = 0; j < C / 8; ++j) {
-          atomicAdd(&s_acc[cur * C + sub + 8 * j], acc0[j]);
-          atomicAdd(&s_acc[cn * C + sub + 8 * j], acc1[j]);
+          lds_add_f32(&s_acc[cur * C + sub + 8 * j], acc0[j]);
+          lds_add_f32(&s_acc[cn * C + sub + 8 * j], acc1[j]);
           acc0[j] = 0.0f; acc1[j] = 0.0f;
         }
       }
@@ -939,8 +974,8 @@ __global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const 
     const int cn = min(cur + 1, f.ll[p] - 1);
 #pragma unroll
     for (int j = 0; j < C / 8; ++j) {
-      atomicAdd(&s_acc[cur * C + sub + 8 * j], acc0[j]);
-      atomicAdd(&s_acc[cn * C + sub + 8 * j], acc1[j]);
+      lds_add_f32(&s_acc[cur * C + sub + 8 * j], acc0[j]);
+      lds_add_f32(&s_acc[cn * C + sub + 8 * j], acc1[j]);
     }
   }
   __syncthreads();
@@ -1062,7 +1097,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   {
     static bool lds_attr_set = false;      // dynamic LDS above 64 KB has to be opted into once
     if (!lds_attr_set) {
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true>),
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1079,14 +1114,14 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist, bg.total, b.offs, b.cursor);
     hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, app, b.tid, b.cursor, b.list);
     if (app) {
-      hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true>), dim3(cus), dim3(256), sizeof(float) * BCELL * BCELL * LRF_CA, st,
+      hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024>), dim3(cus), dim3(1024), sizeof(float) * BCELL * BCELL * LRF_CA, st,
                          d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
       for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
       hipLaunchKernelGGL((k_scatter_line<LRF_CA, true>), dim3(3 * LINE_WGS), dim3(256),
                          sizeof(float) * LRF_CA * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
                          d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
     } else {
-      hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false>), dim3(cus * 4), dim3(256), sizeof(float) * BCELL * BCELL * LRF_CD, st,
+      hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * 4), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, st,
                          d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
       hipLaunchKernelGGL((k_scatter_line<LRF_CD, false>), dim3(3 * LINE_WGS), dim3(256),
                          sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,

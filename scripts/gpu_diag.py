@@ -366,7 +366,29 @@ def stage_scene():
     log("scene train step (forward + backward through poses/exposure/field), ms", round(t_tr, 3))
 
 
-STAGES = [("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_cone():
+    """Upper bound for gather locality: per-kernel time with all rays inside a narrow cone
+    (every gather L2-resident) against the benchmark's random directions."""
+    import ctypes as C
+    import torch
+    import bench as B
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    g = torch.Generator().manual_seed(5)
+    cone = rays.clone()
+    d0 = torch.tensor([0.48, -0.62, 0.62])
+    cone[:, 3:] = (d0[None] + float(os.environ.get("DIAG_CONE", "0.02")) * torch.randn(4096, 3, generator=g)).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    for name, r in (("random", rays), ("cone", cone.contiguous())):
+        with torch.no_grad():
+            f(r, N_samples=1536)
+        p = B.kernel_profile(f, r, z)
+        log("rays", name, "march ms", round(p["march_ms"], 4), "shade ms", round(p["shade_ms"], 4),
+            "n_shaded", p["n_shaded"], "ns per shaded sample", round(p["shade_ms"] * 1e6 / max(1, p["n_shaded"]), 4))
+
+
+STAGES = [("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
