@@ -256,6 +256,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
 }
 
 // ---------------------------------------------------------------- colour chain, data gradient
+struct AppGeo { const float* pl[3]; const float* ln[3]; int pw[3], ph[3], ll[3]; float lo[3], inv[3]; };
 __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     DField f, const float* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R,
@@ -263,6 +264,17 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
     float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax) {
   __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
+  // Geometry of the appearance lookups, read back from LDS next to its use: as kernel arguments
+  // these 30 uniform values stayed live across the MFMA phases, overflowed the SGPR file and were
+  // spilled to scratch through VGPRs (47 stores up front, ~70 reloads per tile).
+  __shared__ AppGeo geo;
+  if (threadIdx.x == 0) {
+    for (int p = 0; p < 3; ++p) {
+      geo.pl[p] = f.aplane[p]; geo.ln[p] = f.aline[p];
+      geo.pw[p] = f.pw[p]; geo.ph[p] = f.ph[p]; geo.ll[p] = f.ll[p];
+      geo.lo[p] = f.lo[p]; geo.inv[p] = f.inv[p];
+    }
+  }
   {
     const float4* src = reinterpret_cast<const float4*>(imt);
     float4* dst = reinterpret_cast<float4*>(img);
@@ -316,35 +328,30 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       }
       *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];
     }
-    // dz1 = (W2^T dz2) * [h1 > 0]      (exact fp32 MFMA, transposed fragments)
-    f32x4 d1[8];
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) d1[t1] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int t0 = 0; t0 < 8; ++t0) {
-#pragma unroll
-      for (int t1 = 0; t1 < 8; ++t1) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W2T + ((t1 * 8 + t0) * 64 + lane) * 4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d1[t1] = mfma4(a[r], dz[t0][r], d1[t1]);
-      }
-    }
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) {
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d1[t1][r] = h1[r] > 0.0f ? d1[t1][r] : 0.0f;
-      *reinterpret_cast<f32x4*>(grow + GRD_DZ1 + 16 * t1 + 4 * g) = d1[t1];
-    }
-    // dfeat = W1^T dz1
+    // dz1 = (W2^T dz2) * [h1 > 0]      (exact fp32 MFMA, transposed fragments), one output tile at
+    // a time; each finished tile is masked, stored and consumed at once as k-step t1 of
+    // dfeat = W1^T dz1, so only dz2 (32 registers) stays live across the loop -- the 8x8 loop nest with
+    // all of dz1 live spilled 544 B per lane.  Summation order is unchanged.
     f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int t0 = 0; t0 < 8; ++t0) {
+    for (int t1 = 0; t1 < 8; ++t1) {
+      asm volatile("" ::: "memory");             // keep each tile's row / fragment loads next to their use
+      f32x4 d1 = {0, 0, 0, 0};
 #pragma unroll
-      for (int t1 = 0; t1 < 2; ++t1) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W1T + ((t1 * 8 + t0) * 64 + lane) * 4]);
+      for (int t0 = 0; t0 < 8; ++t0) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W2T + ((t1 * 8 + t0) * 64 + lane) * 4]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) df[t1] = mfma4(a[r], d1[t0][r], df[t1]);
+        for (int r = 0; r < 4; ++r) d1 = mfma4(a[r], dz[t0][r], d1);
+      }
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d1[r] = h1[r] > 0.0f ? d1[r] : 0.0f;
+      *reinterpret_cast<f32x4*>(grow + GRD_DZ1 + 16 * t1 + 4 * g) = d1;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W1T + ((t2 * 8 + t1) * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) df[t2] = mfma4(a[r], d1[r], df[t2]);
       }
     }
     *reinterpret_cast<f32x4*>(grow + GRD_DFEAT + 4 * g) = df[0];
@@ -380,19 +387,20 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     contract3(xc[0], xc[1], xc[2]);
     float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - f.lo[a]) * f.inv[a] - 1.0f;
+    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - geo.lo[a]) * geo.inv[a] - 1.0f;
     if (valid) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
+        asm volatile("" ::: "memory");           // one plane's 36 gathers in flight at a time
         int x0, x1, y0, y1, l0, l1; float tx, ty, tl, gx, gy, gl;
-        tap1d_g(u[MAT0[p]], f.pw[p], x0, x1, tx, gx);
-        tap1d_g(u[MAT1[p]], f.ph[p], y0, y1, ty, gy);
-        tap1d_g(u[VEC[p]],  f.ll[p], l0, l1, tl, gl);
-        const size_t i00 = ((size_t)y0 * f.pw[p] + x0) * LRF_CAS + 8 * g, i10 = ((size_t)y0 * f.pw[p] + x1) * LRF_CAS + 8 * g;
-        const size_t i01 = ((size_t)y1 * f.pw[p] + x0) * LRF_CAS + 8 * g, i11 = ((size_t)y1 * f.pw[p] + x1) * LRF_CAS + 8 * g;
+        tap1d_g(u[MAT0[p]], geo.pw[p], x0, x1, tx, gx);
+        tap1d_g(u[MAT1[p]], geo.ph[p], y0, y1, ty, gy);
+        tap1d_g(u[VEC[p]],  geo.ll[p], l0, l1, tl, gl);
+        const size_t i00 = ((size_t)y0 * geo.pw[p] + x0) * LRF_CAS + 8 * g, i10 = ((size_t)y0 * geo.pw[p] + x1) * LRF_CAS + 8 * g;
+        const size_t i01 = ((size_t)y1 * geo.pw[p] + x0) * LRF_CAS + 8 * g, i11 = ((size_t)y1 * geo.pw[p] + x1) * LRF_CAS + 8 * g;
         const size_t j0l = (size_t)l0 * LRF_CAS + 8 * g, j1l = (size_t)l1 * LRF_CAS + 8 * g;
-        const float* pl = f.aplane[p];
-        const float* ln = f.aline[p];
+        const float* pl = geo.pl[p];
+        const float* ln = geo.ln[p];
         float gix = 0.0f, giy = 0.0f, gil = 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       gu[a] += __shfl_xor(gu[a], 16, 64);
       gu[a] += __shfl_xor(gu[a], 32, 64);
     }
-    float gx3[3] = {gu[0] * f.inv[0], gu[1] * f.inv[1], gu[2] * f.inv[2]};
+    float gx3[3] = {gu[0] * geo.inv[0], gu[1] * geo.inv[1], gu[2] * geo.inv[2]};
     contract3_bwd(xr, gx3);
     float pr[6] = {gx3[0], gx3[1], gx3[2], gx3[0] * zk, gx3[1] * zk, gx3[2] * zk};
     if (!valid) { pr[0] = pr[1] = pr[2] = pr[3] = pr[4] = pr[5] = 0.0f; }
@@ -908,15 +916,15 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
 }
 
 // line gradients: LINE_WGS workgroups per line, each accumulates its slice of the entries
-template <int C, bool APP>
-__global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const float* __restrict__ rays, const float* __restrict__ z,
+template <int C, bool APP, int NT>
+__global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const float* __restrict__ rays, const float* __restrict__ z,
                                                       int R, int S, const int* __restrict__ toff, const float* __restrict__ gf,
                                                       const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
                                                       float* __restrict__ gcache) {
   extern __shared__ float s_acc[];                     // [L_p][C]
   const int p = blockIdx.x / LINE_WGS, wg = blockIdx.x % LINE_WGS;
   const int nl = f.ll[p] * C;
-  for (int i = threadIdx.x; i < nl; i += 256) s_acc[i] = 0.0f;
+  for (int i = threadIdx.x; i < nl; i += NT) s_acc[i] = 0.0f;
   __syncthreads();
   const uint32_t n = entry_count<APP>(R, S, toff);
   const uint32_t a = (uint32_t)((unsigned long long)n * wg / LINE_WGS), b = (uint32_t)((unsigned long long)n * (wg + 1) / LINE_WGS);
@@ -926,7 +934,7 @@ __global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const 
   // current line cell pair in registers, touching LDS only when the cell changes.
   const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const uint32_t len = b - a;
-  const uint32_t ga = a + (uint32_t)((unsigned long long)len * grp / 32), gb = a + (uint32_t)((unsigned long long)len * (grp + 1) / 32);
+  const uint32_t ga = a + (uint32_t)((unsigned long long)len * grp / (NT / 8)), gb = a + (uint32_t)((unsigned long long)len * (grp + 1) / (NT / 8));
   int cur = -1;
   float acc0[C / 8], acc1[C / 8];
 #pragma unroll
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(256) void k_scatter_line(DField f, Layout L, const 
   }
   __syncthreads();
   float* gln = gcache + (APP ? L.aline[p] : L.dline[p]);
-  for (int i = threadIdx.x; i < nl; i += 256) {
+  for (int i = threadIdx.x; i < nl; i += NT) {
     const float v = s_acc[i];
     const int l = i / C, c = i % C;
     if (v != 0.0f) atomic_add_f32(gln + (size_t)l * (APP ? LRF_CAS : C) + (APP ? app_pc(c) : c), v);
@@ -1099,9 +1107,9 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     if (!lds_attr_set) {
       LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true>),
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true, 1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false>),
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       lds_attr_set = true;
     }
@@ -1117,13 +1125,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
       hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024>), dim3(cus), dim3(1024), sizeof(float) * BCELL * BCELL * LRF_CA, st,
                          d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
       for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
-      hipLaunchKernelGGL((k_scatter_line<LRF_CA, true>), dim3(3 * LINE_WGS), dim3(256),
+      hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024),
                          sizeof(float) * LRF_CA * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
                          d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
     } else {
       hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * 4), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, st,
                          d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
-      hipLaunchKernelGGL((k_scatter_line<LRF_CD, false>), dim3(3 * LINE_WGS), dim3(256),
+      hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024),
                          sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
                          d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
     }
