@@ -174,6 +174,19 @@ int lrf_scene_blend_bwd(const float* g_rgbs, const float* g_depth, const float* 
                         const float* exposure, int32_t R, int32_t per_view, int32_t n_rf,
                         float* g_rgb_f, float* g_depth_f, float* g_exposure, void* stream);
 
+/* Optimiser step after the path: torch.optim.Adam with the reference's settings
+ * (local_tensorfs.py:88-97,146,245; no weight decay, no amsgrad) over up to LRF_ADAM_MAX tensors in
+ * one launch.  p, m (exp_avg), v (exp_avg_sq) are updated in place; step_size = lr / (1 - beta1^t)
+ * and bc2_sqrt = sqrt(1 - beta2^t) are evaluated by the caller in double, as torch does. */
+#define LRF_ADAM_MAX 64
+typedef struct LrfAdamTensor {
+  float* p; const float* g; float* m; float* v;
+  int64_t n;
+  float step_size, bc2_sqrt;
+} LrfAdamTensor;
+int lrf_adam_step(const LrfAdamTensor* tensors /* host array */, int32_t count, float beta1, float beta2,
+                  float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,14 @@ class LrfGrads(C.Structure):
                 ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
 
 
+LRF_ADAM_MAX = 64
+
+
+class LrfAdamTensor(C.Structure):
+    _fields_ = [("p", _f), ("g", _f), ("m", _f), ("v", _f), ("n", C.c_int64),
+                ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+
+
 # every symbol include/lrf.h declares: (restype, argtypes)
 SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
@@ -56,6 +64,7 @@ SYMBOLS = {
     "lrf_app_feature": (C.c_int, [C.POINTER(LrfField), _f, C.c_int32, _f, C.c_void_p]),
     "lrf_sample_ray_aabb": (C.c_int, [_f, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _f,
                                       C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
+    "lrf_adam_step": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "lrf_scene_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32,
                                  C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
     "lrf_scene_rays_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int32, _f, _f, C.c_int32,

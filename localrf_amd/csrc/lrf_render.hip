@@ -934,6 +934,7 @@ static int device_cus() {
 
 #include "lrf_backward.inl"
 #include "lrf_scene.inl"
+#include "lrf_adam.inl"
 
 using namespace lrf;
 

@@ -1,0 +1,97 @@
+"""FusedAdam -- torch.optim.Adam as the reference configures it (local_tensorfs.py:88-97,146,245:
+betas (0.9, 0.99), eps 1e-8, no weight decay, no amsgrad), stepped by ONE HIP launch
+(lrf_adam_step) for all tensors of all parameter groups -- and, through `step_many`, for the
+tensors of many optimiser objects at once: the reference steps one tiny Adam per frame for the
+rotation, translation and exposure parameters (local_tensorfs.py:229-243), dozens of launches
+per iteration that batch into the same table here.
+
+Same constructor arguments, param_groups (lr decay by `group["lr"] *= f` works as in
+local_tensorfs.py:224-247) and per-parameter state keys (`step`, `exp_avg`, `exp_avg_sq`) as
+torch.optim.Adam, so state dicts interchange.  No CPU fallback: parameters must live on the GPU.
+Cited lines are relative to /root/reference/localTensoRF."""
+import math
+
+import torch
+from torch.autograd.graph import increment_version
+
+from . import _native as N
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise ValueError("FusedAdam implements the reference's configuration: weight_decay=0, amsgrad=False")
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False))
+
+    # ------------------------------------------------------------------ table building
+    def _entries(self):
+        """[(param, grad, exp_avg, exp_avg_sq, step_size, bc2_sqrt, betas, eps)] for this step;
+        advances the per-parameter step counters (torch/optim/adam.py::_init_group)."""
+        out = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                if not p.is_cuda:
+                    raise N.NativeError("localrf_amd: FusedAdam steps parameters on an AMD GPU only "
+                                        f"(got {p.device}); there is no CPU fallback.")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise N.NativeError("localrf_amd: FusedAdam needs contiguous fp32 parameters")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                step = int(st["step"]) + 1
+                st["step"] = torch.tensor(float(step), dtype=torch.float32)
+                bc1 = 1.0 - b1 ** step
+                bc2_sqrt = math.sqrt(1.0 - b2 ** step)
+                g = p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.contiguous().float()
+                out.append((p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"] / bc1, bc2_sqrt, (b1, b2), group["eps"]))
+        return out
+
+    @staticmethod
+    def _launch(entries):
+        """One lrf_adam_step per (betas, eps, device) class, LRF_ADAM_MAX tensors at a time."""
+        lib = N.lib()
+        classes = {}
+        for e in entries:
+            classes.setdefault((e[6], e[7], e[0].device), []).append(e)
+        for ((b1, b2), eps, dev), es in classes.items():
+            st = torch.cuda.current_stream(dev).cuda_stream
+            for lo in range(0, len(es), N.LRF_ADAM_MAX):
+                part = es[lo:lo + N.LRF_ADAM_MAX]
+                tab = (N.LrfAdamTensor * len(part))()
+                for t, (p, g, m, v, step_size, bc2_sqrt, _, _) in zip(tab, part):
+                    t.p, t.g, t.m, t.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+                    t.n, t.step_size, t.bc2_sqrt = p.numel(), step_size, bc2_sqrt
+                N.check(lib.lrf_adam_step(tab, len(part), b1, b2, eps, st), "lrf_adam_step")
+                # the kernel rewrote the parameters behind autograd's back: bump their versions so
+                # layout caches keyed on (data_ptr, _version) (TensorVMSplit._ensure_cache) and
+                # autograd's saved-tensor checks see the change
+                increment_version([e[0] for e in part])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._launch(self._entries())
+        return loss
+
+    @staticmethod
+    @torch.no_grad()
+    def step_many(optimizers):
+        """Step several FusedAdam objects with one launch (per hyper-parameter class)."""
+        entries = []
+        for opt in optimizers:
+            if not isinstance(opt, FusedAdam):
+                raise TypeError("step_many takes FusedAdam optimisers")
+            entries.extend(opt._entries())
+        FusedAdam._launch(entries)

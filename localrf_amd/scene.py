@@ -23,6 +23,7 @@ import torch
 from ._native import NativeError
 from .field import AlphaGridMask, TensorVMSplit
 from .rays import N_to_reso, mtx_to_sixD, sixD_to_mtx
+from .optim import FusedAdam
 from .scene_ops import scene_blend, scene_rays
 
 _ADAM_BETAS = (0.9, 0.99)
@@ -79,7 +80,7 @@ class LocalTensorfs(torch.nn.Module):
         self.focal_offset = torch.nn.Parameter(torch.ones(1, device=device))
         self.center_rel = torch.nn.Parameter(0.5 * torch.ones(2, device=device))
         if lr_i_init > 0:
-            self.intrinsic_optimizer = torch.optim.Adam(
+            self.intrinsic_optimizer = FusedAdam(
                 [self.focal_offset, self.center_rel], betas=_ADAM_BETAS, lr=self.lr_i_init)
 
         self.tensorfs = torch.nn.ParameterList()
@@ -108,7 +109,7 @@ class LocalTensorfs(torch.nn.Module):
         self.tensorfs.append(TensorVMSplit(device=self.device, **self.tensorf_args))
         self.world2rf.append(world2rf.clone().detach())
         self.rf_iter.append(0)
-        self.rf_optimizer = torch.optim.Adam(
+        self.rf_optimizer = FusedAdam(
             self.tensorfs[-1].get_optparam_groups(self.rf_lr_init, self.rf_lr_basis), betas=_ADAM_BETAS)
 
     def append_frame(self):
@@ -131,10 +132,10 @@ class LocalTensorfs(torch.nn.Module):
             last_r = sixD_to_mtx(self.r_c2w[-1].clone().detach()[None])[0]
             self.r_c2w[-1] = last_r @ rel[:3, :3]
             self.t_c2w[-1].data += last_r @ rel[:3, 3]
-        self.r_optimizers.append(torch.optim.Adam([self.r_c2w[-1]], betas=_ADAM_BETAS, lr=self.lr_R_init))
-        self.t_optimizers.append(torch.optim.Adam([self.t_c2w[-1]], betas=_ADAM_BETAS, lr=self.lr_t_init))
+        self.r_optimizers.append(FusedAdam([self.r_c2w[-1]], betas=_ADAM_BETAS, lr=self.lr_R_init))
+        self.t_optimizers.append(FusedAdam([self.t_c2w[-1]], betas=_ADAM_BETAS, lr=self.lr_t_init))
         self.exp_optimizers.append(
-            torch.optim.Adam([self.exposure[-1]], betas=_ADAM_BETAS, lr=self.lr_exposure_init))
+            FusedAdam([self.exposure[-1]], betas=_ADAM_BETAS, lr=self.lr_exposure_init))
 
     # ----------------------------------------------------------------- optimisation
     def _active_pose_ids(self):
@@ -150,9 +151,8 @@ class LocalTensorfs(torch.nn.Module):
             self.r_optimizers[i].zero_grad()
             self.t_optimizers[i].zero_grad()
         loss.backward()
-        for i in ids:
-            self.r_optimizers[i].step()
-            self.t_optimizers[i].step()
+        if ids:
+            FusedAdam.step_many([o for i in ids for o in (self.r_optimizers[i], self.t_optimizers[i])])
 
     def optimizer_step(self, loss, optimize_poses):
         """One optimisation step of the current field, its linked poses/exposures and the
@@ -200,19 +200,22 @@ class LocalTensorfs(torch.nn.Module):
             reso = N_to_reso(self.N_voxel_list[self.rf_iter[-1]], self.tensorfs[-1].aabb)
             self.tensorfs[-1].upsample_volume_grid(reso)
             if self.lr_upsample_reset:
-                self.rf_optimizer = torch.optim.Adam(
+                self.rf_optimizer = FusedAdam(
                     self.tensorfs[-1].get_optparam_groups(self.rf_lr_init, self.rf_lr_basis),
                     betas=_ADAM_BETAS)
         if self.rf_iter[-1] in self.update_AlphaMask_list:      # :264-266
             self.tensorfs[-1].updateAlphaMask(tuple((self.tensorfs[-1].gridSize / 2).int().tolist()))
 
+        small = []                                              # :229-249, one launch for all of them
         for i in pose_ids:
             if optimize_poses:
-                self.r_optimizers[i].step(); self.t_optimizers[i].step()
+                small += [self.r_optimizers[i], self.t_optimizers[i]]
             if self.lr_exposure_init > 0:
-                self.exp_optimizers[i].step()
+                small.append(self.exp_optimizers[i])
         if tune_intrinsics:
-            self.intrinsic_optimizer.step()
+            small.append(self.intrinsic_optimizer)
+        if small:
+            FusedAdam.step_many(small)
         if self.is_refining:
             self.rf_iter[-1] += 1
         return self.rf_iter[-1] >= self.n_iters - 1             # can_add_rf

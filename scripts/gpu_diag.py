@@ -320,8 +320,17 @@ def stage_scene():
     """LocalTensorfs.forward at BASELINE configs[2]/[3] scale: 300^3 fields, 4096 rays; 1 field
     (train-style call, no grad) and 4 blended fields (eval)."""
     import torch
+    import localrf_amd.scene as scene_mod
     from localrf_amd import LocalTensorfs
     from util import FIELD_KW, quiet
+    if os.environ.get("DIAG_TORCH_ADAM"):               # baseline: the reference's per-object torch.optim.Adam
+        class TorchAdamShim(torch.optim.Adam):
+            @staticmethod
+            def step_many(opts):
+                for o in opts:
+                    o.step()
+        scene_mod.FusedAdam = TorchAdamShim
+        log("optimiser: torch.optim.Adam, one object per frame and kind (reference layout)")
     aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).cuda()
     lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=(960, 540),
                n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
@@ -336,6 +345,8 @@ def stage_scene():
             with torch.no_grad():
                 lt.t_c2w[-1].add_(0.05 * torch.randn(3, generator=g).cuda())
         quiet(lt.append_rf, 3)
+    for _ in range(12):                                  # frames registered against the newest field
+        lt.append_frame()
     n_frames = len(lt.r_c2w)
     view_ids = torch.arange(n_frames - 16 if n_frames >= 16 else 0, n_frames).cuda()[:16]
     V = view_ids.numel()
@@ -365,6 +376,16 @@ def stage_scene():
     t_tr = timeit(train_step, 10)
     log("scene train step (forward + backward through poses/exposure/field), ms", round(t_tr, 3))
 
+    lt.is_refining = True
+    lt.rf_iter[-1] = 0                                   # fresh field: its linked poses are optimised
+    def full_iter():
+        rgb, depth, _, _ = lt(ray_ids, view_ids, 960, 540, is_train=True)
+        loss = rgb.mean() + 0.01 * depth.mean()
+        lt.optimizer_step(loss, optimize_poses=True)
+    t_it = timeit(full_iter, 10)
+    log("scene full iteration (forward + optimizer_step: backward, Adam on field/poses/exposure), ms", round(t_it, 3),
+        "| active poses", len(lt._active_pose_ids()))
+
 
 def stage_cone():
     """Upper bound for gather locality: per-kernel time with all rays inside a narrow cone
@@ -388,7 +409,55 @@ def stage_cone():
             "n_shaded", p["n_shaded"], "ns per shaded sample", round(p["shade_ms"] * 1e6 / max(1, p["n_shaded"]), 4))
 
 
-STAGES = [("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_adam():
+    """Optimiser step of one 300^3 field: torch.optim.Adam (foreach) vs FusedAdam, and the layout
+    repack that the next forward pays."""
+    import torch
+    from localrf_amd import FusedAdam
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    for p in f.parameters():
+        p.grad = torch.randn_like(p) * 1e-3
+    groups = f.get_optparam_groups(0.02, 1e-3)
+    for name, cls in (("torch.optim.Adam", torch.optim.Adam), ("FusedAdam", FusedAdam)):
+        opt = cls([dict(g) for g in groups], betas=(0.9, 0.99))
+        for _ in range(3):
+            opt.step()
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(20):
+            opt.step()
+        torch.cuda.synchronize()
+        log(name, "step ms", round((time.time() - t) / 20 * 1e3, 3))
+    with torch.no_grad():
+        f(rays, N_samples=1536)
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(20):
+            torch.autograd.graph.increment_version(f.density_plane[0])
+            f._ensure_cache()
+        torch.cuda.synchronize()
+        log("layout repack (lrf_pack_field) ms", round((time.time() - t) / 20 * 1e3, 3))
+    def zero():
+        for p in f.parameters():
+            p.grad = None
+    gr = torch.randn(4096, 3, device="cuda"); gd = torch.randn(4096, device="cuda")
+    def fb():
+        zero()
+        rgb, depth = f(rays, is_train=True, N_samples=1536)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    for _ in range(3):
+        fb()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(10):
+        fb()
+    torch.cuda.synchronize()
+    log("fwd+bwd ms (config 2)", round((time.time() - t) / 10 * 1e3, 3))
+
+
+STAGES = [("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

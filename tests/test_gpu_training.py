@@ -231,3 +231,55 @@ def test_scene_forward_has_no_cpu_fallback():
     ray_ids, view_ids = _batch(lt)
     with pytest.raises(NativeError):
         lt(ray_ids.cpu(), view_ids.cpu(), lt.W, lt.H, is_train=False)
+
+
+def test_fused_adam_matches_torch_adam():
+    """lrf_adam_step against torch.optim.Adam (the reference's optimiser, local_tensorfs.py:88-97,146):
+    several groups with different lr, odd sizes (vector tail + unaligned views), 25 steps with lr
+    decay, a parameter that gets no gradient on some steps, and step_many across optimisers."""
+    from localrf_amd import FusedAdam
+    g = torch.Generator().manual_seed(12)
+    shapes = [(1, 8, 37, 41), (1, 24, 19, 1), (27, 72), (128,), (3, 131), (5,), (3, 2), (3,)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+
+    def make(cls, ps):
+        main = cls([{"params": ps[:2], "lr": 0.02}, {"params": ps[2:6], "lr": 1e-3}], betas=(0.9, 0.99))
+        pose = [cls([ps[6]], betas=(0.9, 0.99), lr=5e-3), cls([ps[7]], betas=(0.9, 0.99), lr=5e-4)]
+        return main, pose
+    ma, posea = make(torch.optim.Adam, pa)
+    mb, poseb = make(FusedAdam, pb)
+    for it in range(25):
+        grads = [torch.randn(*s, generator=g).to(DEV) * (10.0 ** (it % 3 - 1)) for s in shapes]
+        for ps in (pa, pb):
+            for i, (p, gr) in enumerate(zip(ps, grads)):
+                p.grad = None if (i == 3 and it % 4 == 1) else gr.clone()
+        ma.step(); [o.step() for o in posea]
+        mb.step(); FusedAdam.step_many(poseb)
+        for opts in ((ma, *posea), (mb, *poseb)):
+            for o in opts:
+                for grp in o.param_groups:
+                    grp["lr"] *= 0.97
+    for a, b, s in zip(pa, pb, shapes):
+        assert (a - b).abs().max() <= 2e-6 * max(1.0, float(a.abs().max())), s
+    sa, sb = ma.state[pa[3]], mb.state[pb[3]]
+    assert int(sa["step"]) == int(sb["step"]) == 25 - 6
+    assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    # state dicts interchange with torch.optim.Adam
+    fresh = torch.optim.Adam([{"params": pb[:2], "lr": 0.02}, {"params": pb[2:6], "lr": 1e-3}], betas=(0.9, 0.99))
+    fresh.load_state_dict(mb.state_dict())
+    v0 = pb[0]._version
+    for p in pb[:6]:
+        p.grad = torch.ones_like(p)
+    mb.step()
+    assert pb[0]._version > v0                      # layout caches keyed on _version see the update
+    with pytest.raises(Exception):
+        FusedAdam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3).step_many(
+            [FusedAdam([_cpu_param_with_grad()], lr=1e-3)])
+
+
+def _cpu_param_with_grad():
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    return p
