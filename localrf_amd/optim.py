@@ -44,11 +44,11 @@ class FusedAdam(torch.optim.Optimizer):
                     raise N.NativeError("localrf_amd: FusedAdam needs contiguous fp32 parameters")
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["step"] = 0          # plain number (torch.optim.Adam.__setstate__ accepts either form)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                step = int(st["step"]) + 1
-                st["step"] = torch.tensor(float(step), dtype=torch.float32)
+                step = int(st["step"]) + 1      # int() also reads the tensor form torch.optim.Adam stores
+                st["step"] = step
                 bc1 = 1.0 - b1 ** step
                 bc2_sqrt = math.sqrt(1.0 - b2 ** step)
                 g = p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.contiguous().float()

@@ -29,6 +29,15 @@ from .scene_ops import scene_blend, scene_rays
 _ADAM_BETAS = (0.9, 0.99)
 
 
+def _upload_ids(ids, dev):
+    """Host ids -> device int64 without a blocking copy: staged in pinned memory from torch's
+    caching host allocator (a block is not reused before the copy that reads it has run)."""
+    src = torch.as_tensor(ids, dtype=torch.int64)
+    stage = torch.empty(src.shape, dtype=torch.int64, pin_memory=True)
+    stage.copy_(src)
+    return stage.to(dev, non_blocking=True)
+
+
 class LocalTensorfs(torch.nn.Module):
     def __init__(self, fov, n_init_frames, n_overlap, WH, n_iters_per_frame, n_iters_reg,
                  lr_R_init, lr_t_init, lr_i_init, lr_exposure_init, rf_lr_init, rf_lr_basis,
@@ -305,12 +314,24 @@ class LocalTensorfs(torch.nn.Module):
                 world2rf=None, blending_weights=None, chunk=16384, test_id=False, floater_thresh=0):
         """Pixel ids -> rays -> per-field native render -> blend -> exposure -> clamp
         (local_tensorfs.py:382-499).  Returns (rgbs [R,3], depth [R], directions [R,3], ij [R,2])."""
-        if not ray_ids.is_cuda:
+        dev = self.blending_weights.device
+        if dev.type != "cuda":
             raise NativeError("localrf_amd: LocalTensorfs.forward runs only on an AMD GPU (HIP kernels); "
-                              f"got {ray_ids.device} ray ids. There is no CPU fallback.")
-        dev = ray_ids.device
-        n_rays, n_views = ray_ids.shape[0], view_ids.shape[0]
-        view_list = view_ids.tolist() if torch.is_tensor(view_ids) else list(view_ids)   # the one host sync
+                              f"the scene lives on {dev}. There is no CPU fallback.")
+        # Ids may arrive on the host (extension): they are staged through pinned memory without
+        # blocking.  Device-resident view_ids (what train.py:352 passes) cost one host sync here,
+        # as in the reference, which reads them one .item() at a time (local_tensorfs.py:294-295).
+        # Any pageable host->device copy blocks the host until the stream drains (measured,
+        # scripts/ubench/h2d_sync.py), so a caller that keeps ids on the host overlaps its next
+        # iteration's host work with this one's kernels.
+        if torch.is_tensor(view_ids) and view_ids.is_cuda:
+            view_list = view_ids.tolist()
+        else:
+            view_list = [int(v) for v in (view_ids.tolist() if hasattr(view_ids, "tolist") else view_ids)]
+            view_ids = _upload_ids(view_list, dev)
+        if not (torch.is_tensor(ray_ids) and ray_ids.is_cuda):
+            ray_ids = _upload_ids(ray_ids, dev)
+        n_rays, n_views = ray_ids.shape[0], len(view_list)
         if cam2world is None:
             cam2world = self.get_cam2world(view_list)
         if world2rf is None:
@@ -373,9 +394,9 @@ class LocalTensorfs(torch.nn.Module):
         exposure = None
         if self.lr_exposure_init > 0:                           # per-view 3x3 colour transform (:481-496)
             if test_id:
-                prev = torch.maximum(view_ids - 1, torch.tensor(0, device=view_ids.device))
+                prev = torch.clamp(view_ids - 1, min=0)         # scalar bounds: no blocking upload
                 prev[prev == view_ids] = 1
-                nxt = torch.minimum(view_ids + 1, torch.tensor(len(self.exposure) - 1, device=view_ids.device))
+                nxt = torch.clamp(view_ids + 1, max=len(self.exposure) - 1)
                 nxt[prev == view_ids] = len(self.exposure) - 2
                 stacked = torch.stack(list(self.exposure), dim=0).clone().detach()
                 exposure = (stacked[prev] + stacked[nxt]) / 2

@@ -383,6 +383,24 @@ def stage_scene():
         loss = rgb.mean() + 0.01 * depth.mean()
         lt.optimizer_step(loss, optimize_poses=True)
     t_it = timeit(full_iter, 10)
+    ray_h, view_h = ray_ids.cpu(), view_ids.cpu()
+    def full_iter_host_ids():
+        rgb, depth, _, _ = lt(ray_h, view_h, 960, 540, is_train=True)
+        loss = rgb.mean() + 0.01 * depth.mean()
+        lt.optimizer_step(loss, optimize_poses=True)
+    t_ih = timeit(full_iter_host_ids, 20)
+    log("scene full iteration with ids kept on the host (no blocking copies: host runs ahead of the GPU), ms", round(t_ih, 3))
+    if os.environ.get("DIAG_CPROFILE"):
+        import cProfile, pstats, io
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            full_iter()
+        torch.cuda.synchronize()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(45)
+        log(buf.getvalue())
     log("scene full iteration (forward + optimizer_step: backward, Adam on field/poses/exposure), ms", round(t_it, 3),
         "| active poses", len(lt._active_pose_ids()))
 

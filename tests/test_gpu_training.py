@@ -225,12 +225,28 @@ def test_scene_blend_kernel_vs_torch_chain(with_exposure):
         assert a[4] is None and b[4] is None
 
 
-def test_scene_forward_has_no_cpu_fallback():
-    from localrf_amd import NativeError
+def test_scene_forward_host_ids_and_no_cpu_fallback():
+    """Ids may be handed over on the host (staged through pinned memory, no blocking copy) and give
+    the same render; a scene that lives on the CPU has no render path at all."""
+    from localrf_amd import LocalTensorfs, NativeError
     lt = _scene()
     ray_ids, view_ids = _batch(lt)
+    with torch.no_grad():
+        a = lt(ray_ids, view_ids, lt.W, lt.H, is_train=False)
+        b = lt(ray_ids.cpu(), view_ids.cpu().numpy(), lt.W, lt.H, is_train=False)
+        c = lt(ray_ids.cpu(), view_ids.tolist(), lt.W, lt.H, is_train=False, test_id=True)
+        d = lt(ray_ids, view_ids, lt.W, lt.H, is_train=False, test_id=True)
+    for x, y in zip(a + c, b + d):
+        assert torch.equal(x, y)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    cpu = quiet(LocalTensorfs, fov=85.6, n_init_frames=4, n_overlap=3, WH=(40, 30),
+                n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+                lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+                lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+                camera_prior=None, device="cpu", lr_upsample_reset=True,
+                aabb=aabb, gridSize=[16, 16, 16], **FIELD_KW)
     with pytest.raises(NativeError):
-        lt(ray_ids.cpu(), view_ids.cpu(), lt.W, lt.H, is_train=False)
+        cpu(ray_ids.cpu(), view_ids.cpu(), 40, 30, is_train=False)
 
 
 def test_fused_adam_matches_torch_adam():
