@@ -256,6 +256,16 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
 }
 
 // ---------------------------------------------------------------- colour chain, data gradient
+// aligned 16-byte load from a pointer known to be global memory
+__device__ __forceinline__ void ld4g(const float* p, float* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef f32x4 __attribute__((address_space(1))) gf32x4;
+  const f32x4 v = *(const gf32x4*)p;
+#else
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#endif
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+}
 struct AppGeo { const float* pl[3]; const float* ln[3]; int pw[3], ph[3], ll[3]; float lo[3], inv[3]; };
 __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     DField f, const float* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
@@ -391,28 +401,39 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     if (valid) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        asm volatile("" ::: "memory");           // one plane's 36 gathers in flight at a time
+        asm volatile("" ::: "memory");           // one plane's 12 gathers in flight at a time
         int x0, x1, y0, y1, l0, l1; float tx, ty, tl, gx, gy, gl;
         tap1d_g(u[MAT0[p]], geo.pw[p], x0, x1, tx, gx);
         tap1d_g(u[MAT1[p]], geo.ph[p], y0, y1, ty, gy);
         tap1d_g(u[VEC[p]],  geo.ll[p], l0, l1, tl, gl);
-        const size_t i00 = ((size_t)y0 * geo.pw[p] + x0) * LRF_CAS + 8 * g, i10 = ((size_t)y0 * geo.pw[p] + x1) * LRF_CAS + 8 * g;
-        const size_t i01 = ((size_t)y1 * geo.pw[p] + x0) * LRF_CAS + 8 * g, i11 = ((size_t)y1 * geo.pw[p] + x1) * LRF_CAS + 8 * g;
-        const size_t j0l = (size_t)l0 * LRF_CAS + 8 * g, j1l = (size_t)l1 * LRF_CAS + 8 * g;
-        const float* pl = geo.pl[p];
-        const float* ln = geo.ln[p];
+        // the lane's 6 channels of every tap as two aligned float4 of the padded texel (slots 6,7
+        // are zero pads); the pointers come out of LDS, so the loads are pinned to the global
+        // address space by hand (a generic pointer would make them flat_load)
+        const float* pl = geo.pl[p] + 8 * g;
+        const float* ln = geo.ln[p] + 8 * g;
+        const float* q00 = pl + ((size_t)y0 * geo.pw[p] + x0) * LRF_CAS;
+        const float* q10 = pl + ((size_t)y0 * geo.pw[p] + x1) * LRF_CAS;
+        const float* q01 = pl + ((size_t)y1 * geo.pw[p] + x0) * LRF_CAS;
+        const float* q11 = pl + ((size_t)y1 * geo.pw[p] + x1) * LRF_CAS;
+        const float* r0 = ln + (size_t)l0 * LRF_CAS;
+        const float* r1 = ln + (size_t)l1 * LRF_CAS;
+        float v00[8], v10[8], v01[8], v11[8], e0[8], e1[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          ld4g(q00 + 4 * h, v00 + 4 * h); ld4g(q10 + 4 * h, v10 + 4 * h);
+          ld4g(q01 + 4 * h, v01 + 4 * h); ld4g(q11 + 4 * h, v11 + 4 * h);
+          ld4g(r0 + 4 * h, e0 + 4 * h);   ld4g(r1 + 4 * h, e1 + 4 * h);
+        }
         float gix = 0.0f, giy = 0.0f, gil = 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          const float v00 = pl[i00 + c], v10 = pl[i10 + c], v01 = pl[i01 + c], v11 = pl[i11 + c];
-          const float e0 = ln[j0l + c], e1 = ln[j1l + c];
-          const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
-          const float Lv = e0 * (1.0f - tl) + e1 * tl;
+          const float P = (v00[c] * (1.0f - tx) + v10[c] * tx) * (1.0f - ty) + (v01[c] * (1.0f - tx) + v11[c] * tx) * ty;
+          const float Lv = e0[c] * (1.0f - tl) + e1[c] * tl;
           const float d = dX[p * 6 + c];
           const float dP = d * Lv, dL = d * P;
-          gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
-          giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
-          gil += dL * (e1 - e0);
+          gix += dP * ((v10[c] - v00[c]) * (1.0f - ty) + (v11[c] - v01[c]) * ty);
+          giy += dP * ((v01[c] - v00[c]) * (1.0f - tx) + (v11[c] - v10[c]) * tx);
+          gil += dL * (e1[c] - e0[c]);
         }
         gu[MAT0[p]] += gix * gx; gu[MAT1[p]] += giy * gy; gu[VEC[p]] += gil * gl;
       }
