@@ -187,6 +187,20 @@ typedef struct LrfAdamTensor {
 int lrf_adam_step(const LrfAdamTensor* tensors /* host array */, int32_t count, float beta1, float beta2,
                   float eps, void* stream);
 
+/* density_L1 regulariser (tensoRF.py:83-92), on by default while
+ * rf_iter < n_iters_reg (opt.py:111, local_tensorfs.py:361-375):
+ *   out = mean_i sqrt(max(feature2density(sum_p sum_c plane_p[c, i / L_p] line_p[c, i % L_p]), 1e-5))
+ * over the g0*g1*g2 lattice, with the reference's per-plane flattening orders.  plane[p]: the
+ * density plane [8, hw[p]] (the [1,8,H,W] parameter), line[p]: [8, ll[p]]; hw[p]*ll[p] is the
+ * same for all p.  The forward leaves d out_i / d feat_i in the workspace for the backward. */
+size_t lrf_density_l1_workspace(const int32_t hw[3], const int32_t ll[3]);
+int lrf_density_l1_fwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                       const int32_t ll[3], float density_shift, int32_t relu, void* workspace,
+                       float* out /* device [1] */, void* stream);
+int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                       const int32_t ll[3], const void* workspace, const float* g_out /* device [1] */,
+                       float* const g_plane[3], float* const g_line[3], void* stream);
+
 #ifdef __cplusplus
 }
 #endif

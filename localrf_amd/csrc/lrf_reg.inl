@@ -1,0 +1,193 @@
+// density_L1 regulariser (tensoRF.py:83-92), the one regulariser that is on by
+// default (opt.py:111: L1_weight 1e-2) while rf_iter < n_iters_reg.  The reference materialises
+// the 8-channel outer product of every plane with its line (8 x g^3 floats per plane: 864 MB at
+// 300^3) before summing; here each lattice value is formed in registers.
+//
+//   feat[i] = sum_p sum_c plane_p[c, i / L_p] * line_p[c, i % L_p]          i in [0, g0 g1 g2)
+//   out     = mean_i sqrt(max(feature2density(feat[i]), 1e-5))
+//
+// NOTE the index arithmetic is the reference's: the three planes flatten the lattice in three
+// different orders (plane-major, its own line fastest) and are added element by element in those
+// orders -- reproduced as is, not "fixed".
+#pragma once
+
+namespace lrf {
+
+constexpr int L1_TPB = 256;
+constexpr int L1_QCHUNK = 256;       // plane texels per workgroup in the line-gradient pass
+
+struct L1Geo {
+  const float* plane[3]; const float* line[3];
+  int hw[3], ll[3];
+  long long n;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float s = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return s;
+}
+
+// dfeat[i] = d sqrt(max(sig,1e-5)) / d feat[i]; partial[block] = sum of the block's values
+__global__ __launch_bounds__(L1_TPB) void k_l1_fwd(L1Geo G, float shift, int relu, float* __restrict__ dfeat,
+                                                   float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.0f;
+  for (long long i = (long long)blockIdx.x * L1_TPB + threadIdx.x; i < G.n; i += (long long)gridDim.x * L1_TPB) {
+    float feat = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int q = (int)(i / G.ll[p]), r = (int)(i - (long long)q * G.ll[p]);
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < LRF_CD; ++c) s += G.plane[p][(size_t)c * G.hw[p] + q] * G.line[p][c * G.ll[p] + r];
+      feat += s;
+    }
+    float sig, dsig;
+    if (relu) { sig = fmaxf(feat, 0.0f); dsig = feat > 0.0f ? 1.0f : 0.0f; }
+    else {
+      const float x = feat + shift;
+      sig = x > 20.0f ? x : log1pf(expf(x));                 // F.softplus, threshold 20
+      dsig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+    }
+    const float cl = fmaxf(sig, 1e-5f);
+    const float y = sqrtf(cl);
+    acc += y;
+    dfeat[i] = sig >= 1e-5f ? 0.5f / y * dsig : 0.0f;        // clamp(min) passes the gradient where sig >= min
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(L1_TPB) void k_l1_mean(const float* __restrict__ partial, int nb, long long n,
+                                                    float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < nb; i += L1_TPB) acc += partial[i];
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+// g_plane_p[c, q] = scale * sum_r dfeat[q L + r] line_p[c, r]: one wavefront per texel q
+__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_plane(L1Geo G, int p, const float* __restrict__ dfeat,
+                                                         const float* __restrict__ g_out, float* __restrict__ g_plane) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * (L1_TPB / 64) + (threadIdx.x >> 6);
+  if (q >= G.hw[p]) return;
+  const int L = G.ll[p];
+  float acc[LRF_CD];
+#pragma unroll
+  for (int c = 0; c < LRF_CD; ++c) acc[c] = 0.0f;
+  for (int r = lane; r < L; r += 64) {
+    const float v = dfeat[(size_t)q * L + r];
+#pragma unroll
+    for (int c = 0; c < LRF_CD; ++c) acc[c] += v * G.line[p][c * L + r];
+  }
+  const float scale = g_out[0] / (float)G.n;
+#pragma unroll
+  for (int c = 0; c < LRF_CD; ++c) {
+    const float s = wave_sum(acc[c]);
+    if (lane == 0) g_plane[(size_t)c * G.hw[p] + q] = s * scale;
+  }
+}
+
+// lpart[chunk][c][r] = sum over the chunk's texels q of dfeat[q L + r] plane_p[c, q]
+__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line(L1Geo G, int p, const float* __restrict__ dfeat,
+                                                        float* __restrict__ lpart) {
+  const int L = G.ll[p];
+  const int q0 = blockIdx.x * L1_QCHUNK, q1 = min(q0 + L1_QCHUNK, G.hw[p]);
+  for (int r = threadIdx.x; r < L; r += L1_TPB) {
+    float acc[LRF_CD];
+#pragma unroll
+    for (int c = 0; c < LRF_CD; ++c) acc[c] = 0.0f;
+    for (int q = q0; q < q1; ++q) {
+      const float v = dfeat[(size_t)q * L + r];
+#pragma unroll
+      for (int c = 0; c < LRF_CD; ++c) acc[c] += v * G.plane[p][(size_t)c * G.hw[p] + q];   // wave-uniform operand
+    }
+#pragma unroll
+    for (int c = 0; c < LRF_CD; ++c) lpart[((size_t)blockIdx.x * LRF_CD + c) * L + r] = acc[c];
+  }
+}
+
+__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line_reduce(const float* __restrict__ lpart, int nchunk, int L,
+                                                               long long n, const float* __restrict__ g_out,
+                                                               float* __restrict__ g_line) {
+  const int i = blockIdx.x * L1_TPB + threadIdx.x;           // (c, r)
+  if (i >= LRF_CD * L) return;
+  float acc = 0.0f;
+  for (int k = 0; k < nchunk; ++k) acc += lpart[(size_t)k * LRF_CD * L + i];   // fixed order: deterministic
+  g_line[i] = acc * (g_out[0] / (float)n);
+}
+
+static int l1_geo(const float* const plane[3], const float* const line[3], const int32_t hw[3], const int32_t ll[3],
+                  L1Geo& G) {
+  long long n = -1;
+  for (int p = 0; p < 3; ++p) {
+    if (!plane[p] || !line[p] || hw[p] <= 0 || ll[p] <= 0) return 1;
+    G.plane[p] = plane[p]; G.line[p] = line[p]; G.hw[p] = hw[p]; G.ll[p] = ll[p];
+    const long long np = (long long)hw[p] * ll[p];
+    if (n >= 0 && np != n) return 1;                         // every plane x line spans the same lattice
+    n = np;
+  }
+  G.n = n;
+  return 0;
+}
+static int l1_blocks(long long n) {
+  const long long want = (n + L1_TPB - 1) / L1_TPB, cap = (long long)device_cus() * 16;
+  return (int)(want < cap ? want : cap);
+}
+static int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+static int l1_chunks(const int32_t hw[3]) { return (max3(hw[0], hw[1], hw[2]) + L1_QCHUNK - 1) / L1_QCHUNK; }
+
+}  // namespace lrf
+
+extern "C" size_t lrf_density_l1_workspace(const int32_t hw[3], const int32_t ll[3]) {
+  using namespace lrf;
+  const long long n = (long long)hw[0] * ll[0];
+  const size_t lmax = (size_t)max3(ll[0], ll[1], ll[2]);
+  return sizeof(float) * ((size_t)n + (size_t)device_cus() * 16 + (size_t)l1_chunks(hw) * LRF_CD * lmax) + 1024;
+}
+
+extern "C" int lrf_density_l1_fwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                                  const int32_t ll[3], float density_shift, int32_t relu, void* workspace,
+                                  float* out, void* stream) {
+  using namespace lrf;
+  L1Geo G;
+  if (!plane || !line || !hw || !ll || !workspace || !out || l1_geo(plane, line, hw, ll, G))
+    return set_err("lrf_density_l1_fwd: null argument or planes/lines that do not span one lattice");
+  float* dfeat = static_cast<float*>(workspace);
+  float* partial = dfeat + G.n;
+  const int nb = l1_blocks(G.n);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_l1_fwd, dim3(nb), dim3(L1_TPB), 0, st, G, density_shift, relu, dfeat, partial);
+  hipLaunchKernelGGL(k_l1_mean, dim3(1), dim3(L1_TPB), 0, st, partial, nb, G.n, out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                                  const int32_t ll[3], const void* workspace, const float* g_out,
+                                  float* const g_plane[3], float* const g_line[3], void* stream) {
+  using namespace lrf;
+  L1Geo G;
+  if (!plane || !line || !hw || !ll || !workspace || !g_out || !g_plane || !g_line || l1_geo(plane, line, hw, ll, G))
+    return set_err("lrf_density_l1_bwd: null argument or planes/lines that do not span one lattice");
+  const float* dfeat = static_cast<const float*>(workspace);
+  float* lpart = const_cast<float*>(dfeat) + G.n + (size_t)device_cus() * 16;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int p = 0; p < 3; ++p) {
+    if (!g_plane[p] || !g_line[p]) return set_err("lrf_density_l1_bwd: null gradient pointer");
+    hipLaunchKernelGGL(k_l1_bwd_plane, dim3((G.hw[p] + L1_TPB / 64 - 1) / (L1_TPB / 64)), dim3(L1_TPB), 0, st,
+                       G, p, dfeat, g_out, g_plane[p]);
+    const int nchunk = (G.hw[p] + L1_QCHUNK - 1) / L1_QCHUNK;
+    hipLaunchKernelGGL(k_l1_bwd_line, dim3(nchunk), dim3(L1_TPB), 0, st, G, p, dfeat, lpart);
+    hipLaunchKernelGGL(k_l1_bwd_line_reduce, dim3((LRF_CD * G.ll[p] + L1_TPB - 1) / L1_TPB), dim3(L1_TPB), 0, st,
+                       lpart, nchunk, G.ll[p], G.n, g_out, g_line[p]);
+  }
+  LRF_HIP(hipGetLastError());
+  return 0;
+}

@@ -935,6 +935,7 @@ static int device_cus() {
 #include "lrf_backward.inl"
 #include "lrf_scene.inl"
 #include "lrf_adam.inl"
+#include "lrf_reg.inl"
 
 using namespace lrf;
 

@@ -88,6 +88,49 @@ class _RenderFn(torch.autograd.Function):
         return (None, g_rays, None, None, None) + tuple(g_params)
 
 
+class _DensityL1Fn(torch.autograd.Function):
+    """Seam between autograd and lrf_density_l1_fwd / lrf_density_l1_bwd."""
+
+    @staticmethod
+    def _args(tensors):
+        planes, lines = tensors[:3], tensors[3:]
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != 8:
+                raise N.NativeError("localrf_amd: density_L1 needs contiguous fp32 planes/lines with 8 components")
+        hw = (C.c_int32 * 3)(*[int(p.shape[2] * p.shape[3]) for p in planes])
+        ll = (C.c_int32 * 3)(*[int(l.shape[2]) for l in lines])
+        pp = (C.c_void_p * 3)(*[p.data_ptr() for p in planes])
+        lp = (C.c_void_p * 3)(*[l.data_ptr() for l in lines])
+        return pp, lp, hw, ll
+
+    @staticmethod
+    def forward(ctx, field, *tensors):
+        lib = N.lib()
+        tensors = tuple(t.detach() for t in tensors)
+        pp, lp, hw, ll = _DensityL1Fn._args(tensors)
+        dev = tensors[0].device
+        ws = torch.empty(lib.lrf_density_l1_workspace(hw, ll), dtype=torch.uint8, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_density_l1_fwd(pp, lp, hw, ll, float(field.density_shift),
+                                       1 if field.fea2denseAct == "relu" else 0, ws.data_ptr(), N.ptr(out), st),
+                "lrf_density_l1_fwd")
+        ctx.save_for_backward(ws, *tensors)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ws, *tensors = ctx.saved_tensors
+        pp, lp, hw, ll = _DensityL1Fn._args(tensors)
+        grads = [torch.empty_like(t) for t in tensors]
+        gp = (C.c_void_p * 3)(*[g.data_ptr() for g in grads[:3]])
+        gl = (C.c_void_p * 3)(*[g.data_ptr() for g in grads[3:]])
+        g = g_out.detach().reshape(1).contiguous().float()
+        st = torch.cuda.current_stream(g.device).cuda_stream
+        N.check(N.lib().lrf_density_l1_bwd(pp, lp, hw, ll, ws.data_ptr(), N.ptr(g), gp, gl, st), "lrf_density_l1_bwd")
+        return (None, *grads)
+
+
 class TensorVMSplit(torch.nn.Module):
     # constructor signature and defaults: tensorBase.py:236-257, tensoRF.py:10-12
     def __init__(self, device, aabb, gridSize, density_n_comp=8, appearance_n_comp=24, app_dim=27,
@@ -495,14 +538,11 @@ class TensorVMSplit(torch.nn.Module):
         return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
 
     def density_L1(self):
-        """tensoRF.py:83-92."""
-        n = int(torch.prod(self.gridSize))
-        feat = torch.zeros((n,), device=self.gridSize.device)
-        for i in range(3):
-            pl = self.density_plane[i].view(-1, int(torch.prod(self.gridSize[self.matMode[i]])))
-            ln = self.density_line[i].view(-1, int(self.gridSize[self.vecMode[i]]))
-            feat = feat + torch.bmm(pl[..., None], ln[:, None]).view(-1, n).sum(0)
-        return torch.sqrt(self.feature2density(feat).clamp(1e-5)).mean()
+        """tensoRF.py:83-92 through lrf_density_l1_fwd/_bwd: the lattice values are formed in
+        registers instead of materialising 8 x g^3 floats per plane (same arithmetic and the
+        reference's per-plane flattening orders)."""
+        self._require_gpu(self.density_plane[0])
+        return _DensityL1Fn.apply(self, *self.density_plane, *self.density_line)
 
     def TV_loss_density(self, reg):
         """tensoRF.py:94-101."""

@@ -475,7 +475,49 @@ def stage_adam():
     log("fwd+bwd ms (config 2)", round((time.time() - t) / 10 * 1e3, 3))
 
 
-STAGES = [("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_reg():
+    """Regularisers of the reference (tensoRF.py:83-110) at 300^3: cost per training iteration while
+    rf_iter < n_iters_reg (L1 weight 1e-2 by default, TV weights 0 by default, opt.py:111-113)."""
+    import torch
+    from util import make_field, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+
+    class TV(torch.nn.Module):                         # utils/utils.py:293-309
+        def forward(self, x):
+            h, w = x.size(2), x.size(3)
+            tv = 0
+            if h > 1:
+                tv = tv + torch.pow(x[:, :, 1:, :] - x[:, :, :h - 1, :], 2).mean()
+            if w > 1:
+                tv = tv + torch.pow(x[:, :, :, 1:] - x[:, :, :, :w - 1], 2).mean()
+            return 2 * tv
+    reg = TV()
+
+    def timeit(fn, n=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.time() - t) / n * 1e3
+
+    def l1():
+        for p in f.parameters():
+            p.grad = None
+        (f.density_L1() * 1e-2).backward()
+
+    def tv():
+        for p in f.parameters():
+            p.grad = None
+        (f.TV_loss_density(reg) + f.TV_loss_app(reg)).backward()
+    torch.cuda.reset_peak_memory_stats()
+    log("density_L1 forward+backward ms", round(timeit(l1), 3), "| peak memory GB", round(torch.cuda.max_memory_allocated() / 2**30, 2))
+    log("TV_loss_density + TV_loss_app forward+backward ms", round(timeit(tv), 3))
+
+
+STAGES = [("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -299,3 +299,38 @@ def _cpu_param_with_grad():
     p = torch.nn.Parameter(torch.zeros(3))
     p.grad = torch.ones(3)
     return p
+
+
+@pytest.mark.parametrize("grid,act", [((20, 24, 28), "softplus"), ((33, 17, 9), "relu"), ((64, 64, 64), "softplus")])
+def test_density_l1_kernel_vs_reference_formula(grid, act):
+    """lrf_density_l1_fwd/_bwd against the reference's materialising formula (tensoRF.py:83-92),
+    non-cubic grids included: its three planes flatten the lattice in three different orders."""
+    from util import make_field
+    f = quiet(make_field, list(grid), "cpu", seed=8, fea2denseAct=act).to(DEV)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(6.0)                           # spread the features over both sides of the clamp / relu
+
+    def reference(fld):                           # verbatim arithmetic of the reference method
+        n = int(torch.prod(fld.gridSize))
+        feat = torch.zeros((n,), device=DEV)
+        for i in range(3):
+            pl = fld.density_plane[i].view(-1, int(torch.prod(fld.gridSize[fld.matMode[i]])))
+            ln = fld.density_line[i].view(-1, int(fld.gridSize[fld.vecMode[i]]))
+            feat = feat + torch.sum(torch.bmm(pl[..., None], ln[:, None]).view(-1, n), dim=0)
+        return torch.sqrt(fld.feature2density(feat).clamp(1e-5)).mean()
+    res = []
+    for fn in (f.density_L1, lambda: reference(f)):
+        for p in f.parameters():
+            p.grad = None
+        out = fn()
+        (out * 0.37).backward()
+        res.append((out.detach().clone(), [p.grad.clone() for p in list(f.density_plane) + list(f.density_line)]))
+    (a, ga), (b, gb) = res
+    assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b))
+    for x, y in zip(ga, gb):
+        assert float(y.abs().max()) > 0
+        # sqrt' = 0.5/sqrt(sig) is steep just above the 1e-5 clamp: summation-order rounding of feat
+        # there moves single lattice terms by ~1e-4 relative (seen with relu, whose sig = feat)
+        assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max())
+    assert all(p.grad is None for n, p in f.named_parameters() if "density" not in n)
