@@ -201,6 +201,17 @@ int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], 
                        const int32_t ll[3], const void* workspace, const float* g_out /* device [1] */,
                        float* const g_plane[3], float* const g_line[3], void* stream);
 
+/* Pose assembly: LocalTensorfs.get_cam2world (local_tensorfs.py:292-299) with sixD_to_mtx
+ * (utils/utils.py:381-388): per frame a 6D rotation [3,2] (Gram-Schmidt -> columns b1, b2, b1 x b2)
+ * and a translation [3] -> cam2world [V,3,4].  r6d / trans are HOST arrays of V device pointers (the
+ * per-frame parameters are separate tensors), 1 <= V <= LRF_POSE_MAX per call. */
+#define LRF_POSE_MAX 64
+int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_t V, float* cam2world,
+                      void* stream);
+/* g_cam2world [V,3,4] -> g_r6d [V,3,2], g_trans [V,3] */
+int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, const float* g_cam2world, float* g_r6d,
+                          float* g_trans, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

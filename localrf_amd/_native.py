@@ -37,6 +37,7 @@ class LrfGrads(C.Structure):
 
 
 LRF_ADAM_MAX = 64
+LRF_POSE_MAX = 64
 
 
 class LrfAdamTensor(C.Structure):
@@ -70,6 +71,8 @@ SYMBOLS = {
                                      C.c_float, C.c_int32, C.c_void_p, _f, C.c_void_p]),
     "lrf_density_l1_bwd": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.c_void_p, _f, C.POINTER(_f), C.POINTER(_f), C.c_void_p]),
+    "lrf_pose_assemble": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.c_int32, _f, C.c_void_p]),
+    "lrf_pose_assemble_bwd": (C.c_int, [C.POINTER(_f), C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_scene_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32,
                                  C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
     "lrf_scene_rays_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int32, _f, _f, C.c_int32,

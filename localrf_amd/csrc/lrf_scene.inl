@@ -278,3 +278,100 @@ extern "C" int lrf_scene_blend_bwd(const float* g_rgbs, const float* g_depth, co
   LRF_HIP(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pose assembly: LocalTensorfs.get_cam2world (local_tensorfs.py:292-299) + sixD_to_mtx
+// (utils/utils.py:381-388) for up to LRF_POSE_MAX frames per launch.  The per-frame parameters are
+// separate tensors (ParameterList), so their device pointers travel in the kernel-argument table.
+namespace lrf {
+
+struct PoseTable { const float* r[LRF_POSE_MAX]; const float* t[LRF_POSE_MAX]; };
+
+struct Frame6D { float a1[3], a2[3], n1, b1[3], s, u[3], n2, b2[3], b3[3]; };
+__device__ __forceinline__ Frame6D gram_schmidt(const float* r /*[3,2] row-major*/) {
+  Frame6D F;
+  for (int i = 0; i < 3; ++i) { F.a1[i] = r[2 * i]; F.a2[i] = r[2 * i + 1]; }
+  F.n1 = sqrtf(F.a1[0] * F.a1[0] + F.a1[1] * F.a1[1] + F.a1[2] * F.a1[2]);
+  for (int i = 0; i < 3; ++i) F.b1[i] = F.a1[i] / F.n1;
+  F.s = F.b1[0] * F.a2[0] + F.b1[1] * F.a2[1] + F.b1[2] * F.a2[2];
+  for (int i = 0; i < 3; ++i) F.u[i] = F.a2[i] - F.s * F.b1[i];
+  F.n2 = sqrtf(F.u[0] * F.u[0] + F.u[1] * F.u[1] + F.u[2] * F.u[2]);
+  for (int i = 0; i < 3; ++i) F.b2[i] = F.u[i] / F.n2;
+  F.b3[0] = F.b1[1] * F.b2[2] - F.b1[2] * F.b2[1];
+  F.b3[1] = F.b1[2] * F.b2[0] - F.b1[0] * F.b2[2];
+  F.b3[2] = F.b1[0] * F.b2[1] - F.b1[1] * F.b2[0];
+  return F;
+}
+
+__global__ void k_pose_assemble(PoseTable tab, int V, float* __restrict__ c2w) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const Frame6D F = gram_schmidt(tab.r[v]);
+  float* M = c2w + (size_t)v * 12;                       // columns (b1, b2, b3, t)
+  for (int i = 0; i < 3; ++i) {
+    M[4 * i + 0] = F.b1[i]; M[4 * i + 1] = F.b2[i]; M[4 * i + 2] = F.b3[i]; M[4 * i + 3] = tab.t[v][i];
+  }
+}
+
+__global__ void k_pose_assemble_bwd(PoseTable tab, int V, const float* __restrict__ g_c2w,
+                                    float* __restrict__ g_r, float* __restrict__ g_t) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const Frame6D F = gram_schmidt(tab.r[v]);
+  const float* G = g_c2w + (size_t)v * 12;
+  float g1[3], g2[3], g3[3];
+  for (int i = 0; i < 3; ++i) { g1[i] = G[4 * i]; g2[i] = G[4 * i + 1]; g3[i] = G[4 * i + 2]; g_t[3 * v + i] = G[4 * i + 3]; }
+  // b3 = b1 x b2
+  float gb1[3] = {g1[0] + F.b2[1] * g3[2] - F.b2[2] * g3[1], g1[1] + F.b2[2] * g3[0] - F.b2[0] * g3[2],
+                  g1[2] + F.b2[0] * g3[1] - F.b2[1] * g3[0]};
+  float gb2[3] = {g2[0] + g3[1] * F.b1[2] - g3[2] * F.b1[1], g2[1] + g3[2] * F.b1[0] - g3[0] * F.b1[2],
+                  g2[2] + g3[0] * F.b1[1] - g3[1] * F.b1[0]};
+  // b2 = u / |u|
+  const float d2 = F.b2[0] * gb2[0] + F.b2[1] * gb2[1] + F.b2[2] * gb2[2];
+  float gu[3];
+  for (int i = 0; i < 3; ++i) gu[i] = (gb2[i] - F.b2[i] * d2) / F.n2;
+  // u = a2 - s b1, s = b1 . a2
+  const float gs = -(gu[0] * F.b1[0] + gu[1] * F.b1[1] + gu[2] * F.b1[2]);
+  float ga2[3];
+  for (int i = 0; i < 3; ++i) { ga2[i] = gu[i] + gs * F.b1[i]; gb1[i] += -F.s * gu[i] + gs * F.a2[i]; }
+  // b1 = a1 / |a1|
+  const float d1 = F.b1[0] * gb1[0] + F.b1[1] * gb1[1] + F.b1[2] * gb1[2];
+  for (int i = 0; i < 3; ++i) {
+    g_r[(size_t)v * 6 + 2 * i] = (gb1[i] - F.b1[i] * d1) / F.n1;
+    g_r[(size_t)v * 6 + 2 * i + 1] = ga2[i];
+  }
+}
+
+static int pose_table(const float* const* r, const float* const* t, int V, PoseTable& tab) {
+  if (!r || V <= 0 || V > LRF_POSE_MAX) return 1;
+  for (int i = 0; i < V; ++i) {
+    if (!r[i] || (t && !t[i])) return 1;
+    tab.r[i] = r[i]; tab.t[i] = t ? t[i] : nullptr;
+  }
+  return 0;
+}
+
+}  // namespace lrf
+
+extern "C" int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_t V, float* cam2world,
+                                 void* stream) {
+  using namespace lrf;
+  PoseTable tab;
+  if (!trans || !cam2world || pose_table(r6d, trans, V, tab))
+    return set_err("lrf_pose_assemble: null argument or V outside [1, LRF_POSE_MAX]");
+  hipLaunchKernelGGL(k_pose_assemble, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tab, V, cam2world);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, const float* g_cam2world, float* g_r6d,
+                                     float* g_trans, void* stream) {
+  using namespace lrf;
+  PoseTable tab;
+  if (!g_cam2world || !g_r6d || !g_trans || pose_table(r6d, nullptr, V, tab))
+    return set_err("lrf_pose_assemble_bwd: null argument or V outside [1, LRF_POSE_MAX]");
+  hipLaunchKernelGGL(k_pose_assemble_bwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tab, V,
+                     g_cam2world, g_r6d, g_trans);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}

@@ -6,7 +6,7 @@ state-dict names, `forward` signature/returns, `optimizer_step`, `append_frame`,
 `lrf_scene_rays` (pixel ids -> per-field rays), the native field renderer
 (`TensorVMSplit.forward`) per active field, and `lrf_scene_blend` (weighted sum over fields,
 per-view exposure, clamp).  Poses, intrinsics and exposure get the gradients autograd derives
-in the reference (scene_ops.py); only the [V,3,2]->[V,3,4] pose assembly stays in torch.
+in the reference (scene_ops.py); the [V,3,2]->[V,3,4] pose assembly is `lrf_pose_assemble`.
 
 MI355X-first differences (results identical):
   * finished fields stay resident in HBM (288 GB) instead of being parked on the host and
@@ -24,7 +24,7 @@ from ._native import NativeError
 from .field import AlphaGridMask, TensorVMSplit
 from .rays import N_to_reso, mtx_to_sixD, sixD_to_mtx
 from .optim import FusedAdam
-from .scene_ops import scene_blend, scene_rays
+from .scene_ops import pose_assemble, scene_blend, scene_rays
 
 _ADAM_BETAS = (0.9, 0.99)
 
@@ -234,12 +234,14 @@ class LocalTensorfs(torch.nn.Module):
         """[V,3,4] camera-to-world from the 6D rotation + translation params (:292-299)."""
         if view_ids is not None:
             ids = view_ids.tolist() if torch.is_tensor(view_ids) else list(view_ids)   # one sync, not one per view
-            r = torch.stack([self.r_c2w[v] for v in ids], dim=0)
-            t = torch.stack([self.t_c2w[v] for v in ids], dim=0)
+            r = [self.r_c2w[v] for v in ids]
+            t = [self.t_c2w[v] for v in ids]
         else:
-            r = torch.stack(list(self.r_c2w[starting_id:]), dim=0)
-            t = torch.stack(list(self.t_c2w[starting_id:]), dim=0)
-        return torch.cat([sixD_to_mtx(r), t[..., None]], dim=-1)
+            r = list(self.r_c2w[starting_id:])
+            t = list(self.t_c2w[starting_id:])
+        if r[0].is_cuda:                                        # one launch (per 64 frames) each way
+            return pose_assemble(r, t)
+        return torch.cat([sixD_to_mtx(torch.stack(r, 0)), torch.stack(t, 0)[..., None]], dim=-1)
 
     def get_kwargs(self):
         """local_tensorfs.py:301-324."""

@@ -7,6 +7,8 @@ per-view exposure bmm and the clamp (local_tensorfs.py:468-474,481-499), each wi
 HIP launch; their backward functions return what autograd derives for those chains
 (pose, intrinsic, world2rf and exposure gradients).  No CPU fallback.
 Cited lines are relative to /root/reference/localTensoRF."""
+import ctypes as C
+
 import torch
 
 from . import _native as N
@@ -94,6 +96,47 @@ class _SceneBlendFn(torch.autograd.Function):
                                             R, per_view, n_rf, N.ptr(g_rgb_f), N.ptr(g_dep_f), N.ptr(g_ex),
                                             _stream(dev)), "lrf_scene_blend_bwd")
         return g_rgb_f, g_dep_f, None, g_ex, None
+
+
+class _PoseFn(torch.autograd.Function):
+    """lrf_pose_assemble / _bwd over V <= LRF_POSE_MAX frames: inputs r_0..r_{V-1}, t_0..t_{V-1}."""
+
+    @staticmethod
+    def _ptrs(tensors):
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    @staticmethod
+    def forward(ctx, *params):
+        V = len(params) // 2
+        rs = [_f32c(p) for p in params[:V]]
+        ts = [_f32c(p) for p in params[V:]]
+        dev = rs[0].device
+        c2w = torch.empty(V, 3, 4, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_pose_assemble(_PoseFn._ptrs(rs), _PoseFn._ptrs(ts), V, N.ptr(c2w), _stream(dev)),
+                "lrf_pose_assemble")
+        ctx.save_for_backward(*rs)
+        return c2w
+
+    @staticmethod
+    def backward(ctx, g_c2w):
+        rs = ctx.saved_tensors
+        V, dev = len(rs), rs[0].device
+        g_r = torch.empty(V, 3, 2, dtype=torch.float32, device=dev)
+        g_t = torch.empty(V, 3, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_pose_assemble_bwd(_PoseFn._ptrs(rs), V, N.ptr(_f32c(g_c2w)), N.ptr(g_r), N.ptr(g_t),
+                                              _stream(dev)), "lrf_pose_assemble_bwd")
+        return tuple(g_r.unbind(0)) + tuple(g_t.unbind(0))
+
+
+def pose_assemble(r_list, t_list):
+    """[V,3,4] camera-to-world from per-frame 6D rotations [3,2] and translations [3]
+    (LocalTensorfs.get_cam2world, local_tensorfs.py:292-299; sixD_to_mtx, utils/utils.py:381-388)."""
+    _require_gpu(r_list[0])
+    parts = []
+    for lo in range(0, len(r_list), N.LRF_POSE_MAX):
+        hi = lo + N.LRF_POSE_MAX
+        parts.append(_PoseFn.apply(*r_list[lo:hi], *t_list[lo:hi]))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
 
 def _require_gpu(t):

@@ -517,7 +517,42 @@ def stage_reg():
     log("TV_loss_density + TV_loss_app forward+backward ms", round(timeit(tv), 3))
 
 
-STAGES = [("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_big():
+    """BASELINE configs[4] grid sizes: forward and forward+backward at 500^3 and 640^3 (4096 rays,
+    native sample count), plus the optimiser step and the layout repack."""
+    import torch
+    from localrf_amd import FusedAdam
+    from util import make_field, make_rays, quiet
+    for g in (500, 640):
+        f = quiet(make_field, [g, g, g], "cpu", seed=0).to("cuda:0")
+        rays = make_rays(4096, 1).cuda()
+        gr = torch.randn(4096, 3, device="cuda"); gd = torch.randn(4096, device="cuda")
+        opt = FusedAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        with torch.no_grad():
+            for _ in range(3):
+                f(rays)
+            torch.cuda.synchronize(); t = time.time()
+            for _ in range(20):
+                f(rays)
+            torch.cuda.synchronize(); t_f = (time.time() - t) / 20 * 1e3
+        def it():
+            opt.zero_grad()
+            rgb, depth = f(rays, is_train=True)
+            ((rgb * gr).sum() + (depth * gd).sum()).backward()
+            opt.step()
+        for _ in range(2):
+            it()
+        torch.cuda.synchronize(); t = time.time()
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize(); t_i = (time.time() - t) / 5 * 1e3
+        log(f"grid {g}^3: S={f.nSamples // 6 * 2}, forward ms {t_f:.3f} ({4096 / t_f * 1e3:.0f} rays/s), "
+            f"forward+backward+FusedAdam+repack ms {t_i:.3f}, peak memory GB {torch.cuda.max_memory_allocated() / 2**30:.2f}")
+        del f, opt
+        torch.cuda.empty_cache()
+
+
+STAGES = [("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

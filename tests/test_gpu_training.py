@@ -334,3 +334,30 @@ def test_density_l1_kernel_vs_reference_formula(grid, act):
         # there moves single lattice terms by ~1e-4 relative (seen with relu, whose sig = feat)
         assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max())
     assert all(p.grad is None for n, p in f.named_parameters() if "density" not in n)
+
+
+def test_pose_assemble_kernel_vs_torch_chain():
+    """lrf_pose_assemble/_bwd against stack + sixD_to_mtx + cat (local_tensorfs.py:292-299), more
+    frames than one launch holds, one frame used twice."""
+    from localrf_amd.rays import sixD_to_mtx
+    from localrf_amd.scene_ops import pose_assemble
+    g = torch.Generator().manual_seed(6)
+    V = 70
+    base_r = [torch.eye(3, 2) + 0.3 * torch.randn(3, 2, generator=g) for _ in range(V)]
+    base_t = [torch.randn(3, generator=g) for _ in range(V)]
+    gout = torch.randn(V + 1, 3, 4, generator=g).to(DEV)
+    res = []
+    for native in (True, False):
+        rs = [b.clone().to(DEV).requires_grad_(True) for b in base_r]
+        ts = [b.clone().to(DEV).requires_grad_(True) for b in base_t]
+        rl, tl = rs + [rs[3]], ts + [ts[3]]
+        if native:
+            c2w = pose_assemble(rl, tl)
+        else:
+            c2w = torch.cat([sixD_to_mtx(torch.stack(rl, 0)), torch.stack(tl, 0)[..., None]], -1)
+        (c2w * gout).sum().backward()
+        res.append((c2w.detach(), torch.stack([r.grad for r in rs]), torch.stack([t.grad for t in ts])))
+    a, b = res
+    assert torch.allclose(a[0], b[0], rtol=1e-6, atol=1e-6)
+    assert (a[1] - b[1]).abs().max() <= 1e-5 * b[1].abs().max()
+    assert (a[2] - b[2]).abs().max() <= 1e-6 * b[2].abs().max()
