@@ -884,7 +884,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
   int lo = 0, hi = bg.total;                           // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
   int bin = lo;
-  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;   // 8 lanes share one entry, lane owns channels sub+8j
+  const int sub = threadIdx.x & 7;                           // 8 lanes share one entry, lane owns channels sub+8j
   while (a < b) {
     while (offs[bin + 1] <= a) ++bin;
     const int seg_end = min(b, offs[bin + 1]);
@@ -894,32 +894,73 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
     for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) s_acc[i] = 0.0f;
     __syncthreads();
     const float* lnp = APP ? f.aline[p] : f.dline[p];
-    for (int e = a + grp; e < seg_end; e += NT / 8) {
-      const uint32_t i = list[e];
-      const uint32_t cid = APP ? rowinfo[i] : i;
-      float u[3];
-      cid_point(f, rays, z, S, cid, u);
-      int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-      tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-      tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-      tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-      const int c00 = ((y0 - ty0) * BCELL + (x0 - tx0)) * C, c10 = ((y0 - ty0) * BCELL + (x1 - tx0)) * C;
-      const int c01 = ((y1 - ty0) * BCELL + (x0 - tx0)) * C, c11 = ((y1 - ty0) * BCELL + (x1 - tx0)) * C;
-      const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
-      constexpr int CS = APP ? LRF_CAS : C;                 // channel stride of the cache / gradient image
-      const float* r0 = lnp + (size_t)l0 * CS;
-      const float* r1 = lnp + (size_t)l1 * CS;
-      const float gfi = APP ? 0.0f : gf[i];
-      const float* dxr = APP ? grd + (size_t)i * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
-#pragma unroll
-      for (int j = 0; j < C / 8; ++j) {
-        const int c = sub + 8 * j;
-        const int pc = APP ? app_pc(c) : c;
-        const float Lv = r0[pc] * (1.0f - tl) + r1[pc] * tl;
-        const float dP = (APP ? dxr[c] : gfi) * Lv;
-        lds_add4_f32(&s_acc[c00 + c], dP * w00, &s_acc[c10 + c], dP * w10,
-                     &s_acc[c01 + c], dP * w01, &s_acc[c11 + c], dP * w11);
+    // Two phases per 64 entries of a wave.  A: lane = entry -- list / row lookup, sample position,
+    // taps (one dependent-load chain per 64 entries instead of one per 8).  B: the 8-lane groups
+    // take the entries 8 at a time, fetch the packed taps of theirs with a cross-lane read, and each
+    // lane adds its channels.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int e0 = a + wv * 64; e0 < seg_end; e0 += NT) {
+      const int e = e0 + lane;
+      int i_row = 0, c00 = 0, lpk = 0;
+      float tx = 0.0f, ty = 0.0f, tl = 0.0f;
+      if (e < seg_end) {
+        const uint32_t i = list[e];
+        const uint32_t cid = APP ? rowinfo[i] : i;
+        float u[3];
+        cid_point(f, rays, z, S, cid, u);
+        int x0, x1, y0, y1, l0, l1;
+        tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+        tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+        tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+        i_row = (int)i;
+        c00 = (((y0 - ty0) * BCELL + (x0 - tx0)) << 2) | ((y1 - y0) << 1) | (x1 - x0);   // +1 taps are clamped: step 0 or 1
+        lpk = (l0 << 1) | (l1 - l0);
       }
+      const int n_here = min(64, seg_end - e0);
+      // Group g takes entries 8g..8g+7 IN LIST ORDER: the list keeps consecutive samples of a ray
+      // adjacent, and those mostly share their base texel, so their contributions are summed in
+      // registers and reach LDS once per run (same-address CAS adds from neighbouring lanes
+      // would serialise instead).
+      int cur = -1;
+      float acc[4][C / 8];
+#pragma unroll
+      for (int j = 0; j < C / 8; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f; }
+      auto flush = [&](int cp) {
+        const int b00 = (cp >> 2) * C, b10 = b00 + (cp & 1) * C, b01 = b00 + ((cp >> 1) & 1) * BCELL * C, b11 = b01 + (cp & 1) * C;
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+          const int c = sub + 8 * j;
+          lds_add4_f32(&s_acc[b00 + c], acc[0][j], &s_acc[b10 + c], acc[1][j],
+                       &s_acc[b01 + c], acc[2][j], &s_acc[b11 + c], acc[3][j]);
+          acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f;
+        }
+      };
+#pragma unroll 1
+      for (int q = 0; q < 8; ++q) {
+        const int src = 8 * (lane >> 3) + q;
+        const int ir = __shfl(i_row, src, 64), cp = __shfl(c00, src, 64), lp = __shfl(lpk, src, 64);
+        const float sx = __shfl(tx, src, 64), sy = __shfl(ty, src, 64), sl = __shfl(tl, src, 64);
+        if (src >= n_here) continue;
+        if (cp != cur) {
+          if (cur >= 0) flush(cur);
+          cur = cp;
+        }
+        const float w00 = (1.0f - sx) * (1.0f - sy), w10 = sx * (1.0f - sy), w01 = (1.0f - sx) * sy, w11 = sx * sy;
+        constexpr int CS = APP ? LRF_CAS : C;               // channel stride of the cache / gradient image
+        const float* r0 = lnp + (size_t)(lp >> 1) * CS;
+        const float* r1 = r0 + (size_t)(lp & 1) * CS;
+        const float gfi = APP ? 0.0f : gf[ir];
+        const float* dxr = APP ? grd + (size_t)ir * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+          const int c = sub + 8 * j;
+          const int pc = APP ? app_pc(c) : c;
+          const float Lv = r0[pc] * (1.0f - sl) + r1[pc] * sl;
+          const float dP = (APP ? dxr[c] : gfi) * Lv;
+          acc[0][j] += dP * w00; acc[1][j] += dP * w10; acc[2][j] += dP * w01; acc[3][j] += dP * w11;
+        }
+      }
+      if (cur >= 0) flush(cur);
     }
     __syncthreads();
     float* gpl = gcache + (APP ? L.aplane[p] : L.dplane[p]);
