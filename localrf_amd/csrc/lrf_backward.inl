@@ -884,7 +884,6 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
   int lo = 0, hi = bg.total;                           // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
   int bin = lo;
-  const int sub = threadIdx.x & 7;                           // 8 lanes share one entry, lane owns channels sub+8j
   while (a < b) {
     while (offs[bin + 1] <= a) ++bin;
     const int seg_end = min(b, offs[bin + 1]);
@@ -917,27 +916,31 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
         lpk = (l0 << 1) | (l1 - l0);
       }
       const int n_here = min(64, seg_end - e0);
-      // Group g takes entries 8g..8g+7 IN LIST ORDER: the list keeps consecutive samples of a ray
-      // adjacent, and those mostly share their base texel, so their contributions are summed in
-      // registers and reach LDS once per run (same-address CAS adds from neighbouring lanes
-      // would serialise instead).
+      // A group of LPE lanes takes LPE consecutive entries IN LIST ORDER: the list keeps consecutive
+      // samples of a ray adjacent, and those mostly share their base texel, so their contributions
+      // are summed in registers and reach LDS once per run (same-address CAS adds from neighbouring
+      // lanes would serialise instead).  Appearance: 4 lanes per entry, lane owns the aligned group of
+      // 6 channels 6s..6s+5 (two float4 of the padded texel per tap -- the texture path retires one
+      // wave-level load per ~16 cycles whatever its width, so wide loads are what counts);
+      // density: 8 lanes per entry, one channel each.
+      constexpr int LPE = APP ? 4 : 8, CPL = C / LPE;
+      const int sub = lane % LPE, grp = lane / LPE;
       int cur = -1;
-      float acc[4][C / 8];
+      float acc[4][CPL];
 #pragma unroll
-      for (int j = 0; j < C / 8; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f; }
+      for (int j = 0; j < CPL; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f; }
       auto flush = [&](int cp) {
-        const int b00 = (cp >> 2) * C, b10 = b00 + (cp & 1) * C, b01 = b00 + ((cp >> 1) & 1) * BCELL * C, b11 = b01 + (cp & 1) * C;
+        const int b00 = (cp >> 2) * C + CPL * sub, b10 = b00 + (cp & 1) * C, b01 = b00 + ((cp >> 1) & 1) * BCELL * C, b11 = b01 + (cp & 1) * C;
 #pragma unroll
-        for (int j = 0; j < C / 8; ++j) {
-          const int c = sub + 8 * j;
-          lds_add4_f32(&s_acc[b00 + c], acc[0][j], &s_acc[b10 + c], acc[1][j],
-                       &s_acc[b01 + c], acc[2][j], &s_acc[b11 + c], acc[3][j]);
+        for (int j = 0; j < CPL; ++j) {
+          lds_add4_f32(&s_acc[b00 + j], acc[0][j], &s_acc[b10 + j], acc[1][j],
+                       &s_acc[b01 + j], acc[2][j], &s_acc[b11 + j], acc[3][j]);
           acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f;
         }
       };
 #pragma unroll 1
-      for (int q = 0; q < 8; ++q) {
-        const int src = 8 * (lane >> 3) + q;
+      for (int q = 0; q < LPE; ++q) {
+        const int src = LPE * grp + q;
         const int ir = __shfl(i_row, src, 64), cp = __shfl(c00, src, 64), lp = __shfl(lpk, src, 64);
         const float sx = __shfl(tx, src, 64), sy = __shfl(ty, src, 64), sl = __shfl(tl, src, 64);
         if (src >= n_here) continue;
@@ -949,14 +952,20 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
         constexpr int CS = APP ? LRF_CAS : C;               // channel stride of the cache / gradient image
         const float* r0 = lnp + (size_t)(lp >> 1) * CS;
         const float* r1 = r0 + (size_t)(lp & 1) * CS;
-        const float gfi = APP ? 0.0f : gf[ir];
-        const float* dxr = APP ? grd + (size_t)ir * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
+        float e0v[8], e1v[8], dv[6];
+        if (APP) {
+          ld4g(r0 + 8 * sub, e0v); ld4g(r0 + 8 * sub + 4, e0v + 4);
+          ld4g(r1 + 8 * sub, e1v); ld4g(r1 + 8 * sub + 4, e1v + 4);
+          const float2* dx2 = reinterpret_cast<const float2*>(grd + (size_t)ir * GRD_LD + GRD_DX + p * LRF_CA + 6 * sub);
 #pragma unroll
-        for (int j = 0; j < C / 8; ++j) {
-          const int c = sub + 8 * j;
-          const int pc = APP ? app_pc(c) : c;
-          const float Lv = r0[pc] * (1.0f - sl) + r1[pc] * sl;
-          const float dP = (APP ? dxr[c] : gfi) * Lv;
+          for (int h = 0; h < 3; ++h) { const float2 t2 = dx2[h]; dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
+        } else {
+          e0v[0] = r0[sub]; e1v[0] = r1[sub]; dv[0] = gf[ir];
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const float Lv = e0v[j] * (1.0f - sl) + e1v[j] * sl;
+          const float dP = dv[j] * Lv;
           acc[0][j] += dP * w00; acc[1][j] += dP * w10; acc[2][j] += dP * w01; acc[3][j] += dP * w11;
         }
       }
@@ -991,62 +1000,86 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
   const uint32_t n = entry_count<APP>(R, S, toff);
   const uint32_t a = (uint32_t)((unsigned long long)n * wg / LINE_WGS), b = (uint32_t)((unsigned long long)n * (wg + 1) / LINE_WGS);
   const float* plp = APP ? f.aplane[p] : f.dplane[p];
-  // 8 lanes per entry (lane `sub` owns channels sub, sub+8, ...); each 8-lane group walks a
-  // CONTIGUOUS run of entries -- consecutive samples of a ray -- and keeps the sums for the
-  // current line cell pair in registers, touching LDS only when the cell changes.
-  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  // Same two phases as k_scatter_plane.  A: lane = entry (row lookup, sample position, taps) for 64
+  // consecutive entries.  B: 8-lane group g (lane `sub` owns channels sub, sub+8, ...) takes entries
+  // 8g..8g+7 in order -- consecutive samples of a ray -- and keeps the sums for the current line cell
+  // pair in registers, touching LDS only when the cell changes.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int NW = NT / 64;
   const uint32_t len = b - a;
-  const uint32_t ga = a + (uint32_t)((unsigned long long)len * grp / (NT / 8)), gb = a + (uint32_t)((unsigned long long)len * (grp + 1) / (NT / 8));
-  int cur = -1;
-  float acc0[C / 8], acc1[C / 8];
-#pragma unroll
-  for (int j = 0; j < C / 8; ++j) { acc0[j] = 0.0f; acc1[j] = 0.0f; }
-  for (uint32_t i = ga; i < gb; ++i) {
-    const uint32_t cid = entry_cid<APP>(i, gf, rowinfo);
-    if (cid == 0xffffffffu) continue;
-    float u[3];
-    cid_point(f, rays, z, S, cid, u);
-    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-    if (l0 != cur) {
-      if (cur >= 0) {
-        const int cn = min(cur + 1, f.ll[p] - 1);
-#pragma unroll
-        for (int j = 0; j < C / 8; ++j) {
-          lds_add_f32(&s_acc[cur * C + sub + 8 * j], acc0[j]);
-          lds_add_f32(&s_acc[cn * C + sub + 8 * j], acc1[j]);
-          acc0[j] = 0.0f; acc1[j] = 0.0f;
-        }
+  const uint32_t wa = a + (uint32_t)((unsigned long long)len * wv / NW), wb = a + (uint32_t)((unsigned long long)len * (wv + 1) / NW);
+  for (uint32_t i0 = wa; i0 < wb; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    int ppk = 0, lpk = -1;
+    float tx = 0.0f, ty = 0.0f, tl = 0.0f;
+    if (i < wb) {
+      const uint32_t cid = entry_cid<APP>(i, gf, rowinfo);
+      if (cid != 0xffffffffu) {
+        float u[3];
+        cid_point(f, rays, z, S, cid, u);
+        int x0, x1, y0, y1, l0, l1;
+        tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+        tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+        tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+        ppk = ((y0 * f.pw[p] + x0) << 2) | ((y1 - y0) << 1) | (x1 - x0);
+        lpk = (l0 << 1) | (l1 - l0);
       }
-      cur = l0;
     }
-    constexpr int CS = APP ? LRF_CAS : C;
-    const float* q00 = plp + ((size_t)y0 * f.pw[p] + x0) * CS;
-    const float* q10 = plp + ((size_t)y0 * f.pw[p] + x1) * CS;
-    const float* q01 = plp + ((size_t)y1 * f.pw[p] + x0) * CS;
-    const float* q11 = plp + ((size_t)y1 * f.pw[p] + x1) * CS;
-    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
-    const float gfi = APP ? 0.0f : gf[i];
-    const float* dxr = APP ? grd + (size_t)i * GRD_LD + GRD_DX + p * LRF_CA : nullptr;
+    const int n_here = (int)min(64u, wb - i0);
+    constexpr int LPE = APP ? 4 : 8, CPL = C / LPE;     // lanes per entry / channels per lane, see k_scatter_plane
+    const int sub = lane % LPE, grp = lane / LPE;
+    int cur = -1;
+    float acc0[CPL], acc1[CPL];
 #pragma unroll
-    for (int j = 0; j < C / 8; ++j) {
-      const int c = sub + 8 * j;
-      const int pc = APP ? app_pc(c) : c;
-      const float P = q00[pc] * w00 + q10[pc] * w10 + q01[pc] * w01 + q11[pc] * w11;
-      const float dL = (APP ? dxr[c] : gfi) * P;
-      acc0[j] += dL * (1.0f - tl);
-      acc1[j] += dL * tl;
-    }
-  }
-  if (cur >= 0) {
-    const int cn = min(cur + 1, f.ll[p] - 1);
+    for (int j = 0; j < CPL; ++j) { acc0[j] = 0.0f; acc1[j] = 0.0f; }
+    auto flush = [&](int lp) {
+      const int c0 = (lp >> 1) * C + CPL * sub, c1 = c0 + (lp & 1) * C;
 #pragma unroll
-    for (int j = 0; j < C / 8; ++j) {
-      lds_add_f32(&s_acc[cur * C + sub + 8 * j], acc0[j]);
-      lds_add_f32(&s_acc[cn * C + sub + 8 * j], acc1[j]);
+      for (int j = 0; j < CPL; ++j) {
+        lds_add_f32(&s_acc[c0 + j], acc0[j]);
+        lds_add_f32(&s_acc[c1 + j], acc1[j]);
+        acc0[j] = 0.0f; acc1[j] = 0.0f;
+      }
+    };
+#pragma unroll 1
+    for (int q = 0; q < LPE; ++q) {
+      const int src = LPE * grp + q;
+      const int pp = __shfl(ppk, src, 64), lp = __shfl(lpk, src, 64);
+      const float sx = __shfl(tx, src, 64), sy = __shfl(ty, src, 64), sl = __shfl(tl, src, 64);
+      if (src >= n_here || lp < 0) continue;
+      if (lp != cur) {
+        if (cur >= 0) flush(cur);
+        cur = lp;
+      }
+      constexpr int CS = APP ? LRF_CAS : C;
+      const float* q00 = plp + (size_t)(pp >> 2) * CS;
+      const float* q10 = q00 + (size_t)(pp & 1) * CS;
+      const float* q01 = q00 + (size_t)((pp >> 1) & 1) * f.pw[p] * CS;
+      const float* q11 = q01 + (size_t)(pp & 1) * CS;
+      const float w00 = (1.0f - sx) * (1.0f - sy), w10 = sx * (1.0f - sy), w01 = (1.0f - sx) * sy, w11 = sx * sy;
+      const uint32_t ie = i0 + src;
+      float v00[8], v10[8], v01[8], v11[8], dv[6];
+      if (APP) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          ld4g(q00 + 8 * sub + 4 * h, v00 + 4 * h); ld4g(q10 + 8 * sub + 4 * h, v10 + 4 * h);
+          ld4g(q01 + 8 * sub + 4 * h, v01 + 4 * h); ld4g(q11 + 8 * sub + 4 * h, v11 + 4 * h);
+        }
+        const float2* dx2 = reinterpret_cast<const float2*>(grd + (size_t)ie * GRD_LD + GRD_DX + p * LRF_CA + 6 * sub);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) { const float2 t2 = dx2[h]; dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
+      } else {
+        v00[0] = q00[sub]; v10[0] = q10[sub]; v01[0] = q01[sub]; v11[0] = q11[sub]; dv[0] = gf[ie];
+      }
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const float P = v00[j] * w00 + v10[j] * w10 + v01[j] * w01 + v11[j] * w11;
+        const float dL = dv[j] * P;
+        acc0[j] += dL * (1.0f - sl);
+        acc1[j] += dL * sl;
+      }
     }
+    if (cur >= 0) flush(cur);
   }
   __syncthreads();
   float* gln = gcache + (APP ? L.aline[p] : L.dline[p]);
