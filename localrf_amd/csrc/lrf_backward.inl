@@ -466,18 +466,23 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
 // 32 at a time through LDS with coalesced float4 loads (the first version fetched MFMA fragments
 // straight from global memory, one predicated dword per lane and k-step: 1.3 TB/s); the LDS row
 // stride is = 16 (mod 32) so the four 16-lane groups of a fragment read hit disjoint banks.
-template <int MT, int NT>
+// KSPLIT = false: wave w owns M-tiles w, w+4, ... (the 128 x 144 product: 18 accumulator tiles per
+// wave).  KSPLIT = true, for the narrow products (M-tiles < 4 would leave waves idle, and one
+// M-tile per wave means one LDS read per MFMA): every wave holds ALL MT x NT accumulator tiles and
+// takes every fourth k-step; the four partial sums meet in LDS at the end, in wave order.
+template <int MT, int NT, bool KSPLIT>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                const int* __restrict__ toff, int R, float* __restrict__ wpart, int wp_off) {
   constexpr int KT = 32, WA = MT * 16, WB = NT * 16;
   constexpr int LD = ((WA + WB) % 32 == 16) ? (WA + WB) : (WA + WB + 16);
+  static_assert(!KSPLIT || MT * NT * 256 <= KT * LD, "cross-wave reduction reuses the staging tile");
   __shared__ __attribute__((aligned(16))) float s_t[KT * LD];
   const int rows = toff[R] * 16;
   const int r0 = blockIdx.x * WGRAD_CH;
   if (r0 >= rows) return;
   const int r1 = min(r0 + WGRAD_CH, rows);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-  constexpr int MW = (MT + 3) / 4;
+  constexpr int MW = KSPLIT ? MT : (MT + 3) / 4;
   f32x4 acc[MW][NT];
 #pragma unroll
   for (int m = 0; m < MW; ++m)
@@ -509,11 +514,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
     __syncthreads();
     if (rb + KT < r1) fetch(rb + KT);                        // overlaps the MFMAs below
 #pragma unroll
-    for (int kk = 0; kk < KT / 4; ++kk) {
+    for (int ks = 0; ks < (KSPLIT ? KT / 16 : KT / 4); ++ks) {
+      const int kk = KSPLIT ? 4 * ks + wave : ks;
       const float* rowp = &s_t[(4 * kk + g) * LD + i];
       float a[MW], b[NT];
 #pragma unroll
-      for (int m = 0; m < MW; ++m) a[m] = (wave + 4 * m < MT) ? rowp[16 * (wave + 4 * m)] : 0.0f;
+      for (int m = 0; m < MW; ++m) {
+        const int mt = KSPLIT ? m : wave + 4 * m;
+        a[m] = (mt < MT) ? rowp[16 * mt] : 0.0f;
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) b[n] = rowp[WA + 16 * n];
 #pragma unroll
@@ -522,10 +531,32 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
         for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], b[n], acc[m][n]);
     }
   }
+  if (KSPLIT) {                                              // waves 1..3 hand their sums to wave 0, in order
+    for (int w = 1; w < 4; ++w) {
+      __syncthreads();
+      if (wave == w) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(&s_t[((m * NT + n) * 64 + lane) * 4]) = acc[m][n];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(&s_t[((m * NT + n) * 64 + lane) * 4]);
+            acc[m][n] += o;
+          }
+      }
+    }
+    if (wave != 0) return;
+  }
   float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
-    const int mt = wave + 4 * m;
+    const int mt = KSPLIT ? m : wave + 4 * m;
     if (mt < MT) {
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -1172,13 +1203,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
                      w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax);
   const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
-  hipLaunchKernelGGL((k_wgrad<8, 9>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
                      w.toff, R, b.wpart, WP_W2);
-  hipLaunchKernelGGL((k_wgrad<8, 2>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
                      w.toff, R, b.wpart, WP_W1);
-  hipLaunchKernelGGL((k_wgrad<2, 5>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
-  hipLaunchKernelGGL((k_wgrad<1, 9>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
                      w.toff, R, b.wpart, WP_W3);
   auto reduce = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld) {
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((m * n * 16 + 255) / 256), dim3(256), 0, st, b.wpart, w.toff, R,
