@@ -396,8 +396,14 @@ class TensorVMSplit(torch.nn.Module):
         R, S = rays.shape[0], z.shape[0]
         dev = rays.device
         cp, keep = self._c_params()
-        grads = [torch.zeros_like(p) for p in keep]
-        g_rays = torch.zeros(R, 6, dtype=torch.float32, device=dev)
+        # one zero-filled buffer, one launch: the 19 gradients (and d/d rays) are views into it
+        sizes = [p.numel() for p in keep] + [R * 6]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 63) // 64 * 64)         # 256-byte aligned views
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
+        g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
         if R == 0:
             return g_rays, grads
         cg = N.LrfGrads()

@@ -25,6 +25,18 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False))
 
+    def zero_grad(self, set_to_none=True):
+        """Same effect as Optimizer.zero_grad without its per-call profiler / compile wrappers: the
+        scene calls this on dozens of one-tensor optimisers per iteration (local_tensorfs.py:224-243)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.detach_()
+                        p.grad.zero_()
+
     # ------------------------------------------------------------------ table building
     def _entries(self):
         """[(param, grad, exp_avg, exp_avg_sq, step_size, bc2_sqrt, betas, eps)] for this step;
