@@ -552,7 +552,26 @@ def stage_big():
         torch.cuda.empty_cache()
 
 
-STAGES = [("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_batch():
+    """Forward throughput against the batch size (300^3, 512 samples): renderer.py evaluates whole
+    images in large chunks, train.py uses 4096 rays."""
+    import torch
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    for R in (1024, 4096, 16384, 65536, 262144):
+        rays = make_rays(R, 1).cuda()
+        with torch.no_grad():
+            for _ in range(3):
+                f(rays, N_samples=1536)
+            torch.cuda.synchronize(); t = time.time()
+            n = 20 if R <= 65536 else 5
+            for _ in range(n):
+                f(rays, N_samples=1536)
+            torch.cuda.synchronize(); dt = (time.time() - t) / n
+        log(f"R={R}: {dt * 1e3:.3f} ms/step, {R / dt / 1e6:.2f} M rays/s")
+
+
+STAGES = [("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
