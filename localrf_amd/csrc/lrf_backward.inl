@@ -566,19 +566,26 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   }
 }
 
-// dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in order)
-__global__ void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
-                               int off, int ld, int n_off, int m_count, int n_count,
-                               float* __restrict__ dst, int dst_ld) {
-  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;   // 16 lanes per element
-  const bool ok = idx < m_count * n_count;
-  const int m = ok ? idx / n_count : 0, n = ok ? idx % n_count : 0;
+// dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in a fixed order) for
+// the seven weight / bias tensors in one launch: 16 lanes per output element.
+struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem; float* dst; };
+struct WgradSegs { WgradSeg s[7]; int total_elems; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
+                                                      WgradSegs segs) {
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const bool ok = idx < segs.total_elems;
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < 7; ++q) k += (ok && idx >= segs.s[q].first_elem) ? 1 : 0;
+  const WgradSeg sg = segs.s[k];
+  const int e = ok ? idx - sg.first_elem : 0;
+  const int m = e / sg.n_count, n = e % sg.n_count;
   const int nch = (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
   float acc = 0.0f;
-  for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + off + m * ld + n_off + n];
+  for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + sg.off + m * sg.ld + sg.n_off + n];
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);          // fixed tree: deterministic
-  if (ok && sub == 0) dst[m * dst_ld + n] += acc;
+  if (ok && sub == 0) sg.dst[m * sg.dst_ld + n] += acc;
 }
 
 // ---------------------------------------------------------------- per-ray backward
@@ -1211,17 +1218,23 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                      w.toff, R, b.wpart, WP_BAS);
   hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
                      w.toff, R, b.wpart, WP_W3);
-  auto reduce = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld) {
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((m * n * 16 + 255) / 256), dim3(256), 0, st, b.wpart, w.toff, R,
-                       off, ld, n_off, m, n, dst, dst_ld);
-  };
-  reduce(WP_W2, 144, 0, 128, 128, g->w2, 128);
-  reduce(WP_W2, 144, 128, 128, 1, g->b2, 1);
-  reduce(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM);
-  reduce(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1);
-  reduce(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72);
-  reduce(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
-  reduce(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
+  {
+    WgradSegs segs;
+    int nseg = 0, elems = 0;
+    auto seg = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld) {
+      segs.s[nseg++] = WgradSeg{off, ld, n_off, m, n, dst_ld, elems, dst};
+      elems += m * n;
+    };
+    seg(WP_W2, 144, 0, 128, 128, g->w2, 128);
+    seg(WP_W2, 144, 128, 128, 1, g->b2, 1);
+    seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM);
+    seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1);
+    seg(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72);
+    seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
+    seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
+    segs.total_elems = elems;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, st, b.wpart, w.toff, R, segs);
+  }
   hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), st,
                      d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
                      b.rpart, w.pmax, g_rays);
