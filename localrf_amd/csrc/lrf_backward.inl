@@ -1128,18 +1128,17 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
   }
 }
 
-// channel-last gradient image -> += reference layout [C,H,W]
-__global__ void k_unpack_plane_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int CS, int app) {
+// channel-last gradient images -> += the reference layouts ([C,H,W] planes, [C,L] lines taken as
+// H = 1), all twelve tensors in one launch: blockIdx.z selects the tensor.
+struct UnpackSeg { const float* src; float* dst; int C, H, W, CS, app; };
+struct UnpackTab { UnpackSeg s[12]; };
+__global__ __launch_bounds__(128) void k_unpack_grads(UnpackTab tab) {
+  const UnpackSeg sg = tab.s[blockIdx.z];
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
-  if (x >= W) return;
-  for (int c = 0; c < C; ++c) dst[((size_t)c * H + y) * W + x] += src[((size_t)y * W + x) * CS + (app ? app_pc(c) : c)];
-}
-__global__ void k_unpack_line_grad(const float* __restrict__ src, float* __restrict__ dst, int C, int Lh, int CS, int app) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * Lh) return;
-  const int l = i / C, c = i % C;
-  dst[(size_t)c * Lh + l] += src[(size_t)l * CS + (app ? app_pc(c) : c)];
+  if (x >= sg.W || y >= sg.H) return;
+  for (int c = 0; c < sg.C; ++c)
+    sg.dst[((size_t)c * sg.H + y) * sg.W + x] += sg.src[((size_t)y * sg.W + x) * sg.CS + (sg.app ? app_pc(c) : c)];
 }
 
 struct BwdWorkspace {
@@ -1275,12 +1274,18 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                          d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
     }
   }
-  for (int q = 0; q < 3; ++q) {
-    dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
-    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0);
-    hipLaunchKernelGGL(k_unpack_plane_grad, grid, dim3(128), 0, st, b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1);
-    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, b.gcache + L.dline[q], g->density_line[q], LRF_CD, L.ll[q], LRF_CD, 0);
-    hipLaunchKernelGGL(k_unpack_line_grad, dim3((L.ll[q] * LRF_CA + 255) / 256), dim3(256), 0, st, b.gcache + L.aline[q], g->app_line[q], LRF_CA, L.ll[q], LRF_CAS, 1);
+  {
+    UnpackTab tab;
+    int wmax = 1, hmax = 1;
+    for (int q = 0; q < 3; ++q) {
+      tab.s[4 * q + 0] = UnpackSeg{b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0};
+      tab.s[4 * q + 1] = UnpackSeg{b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1};
+      tab.s[4 * q + 2] = UnpackSeg{b.gcache + L.dline[q], g->density_line[q], LRF_CD, 1, L.ll[q], LRF_CD, 0};
+      tab.s[4 * q + 3] = UnpackSeg{b.gcache + L.aline[q], g->app_line[q], LRF_CA, 1, L.ll[q], LRF_CAS, 1};
+      wmax = max(wmax, max(L.pw[q], L.ll[q]));
+      hmax = max(hmax, L.ph[q]);
+    }
+    hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 12), dim3(128), 0, st, tab);
   }
   LRF_HIP(hipGetLastError());
   return 0;
