@@ -127,15 +127,19 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created even for one rank, so the
+    # RCCL code path below is the same for every N
+    ddp = world > 1 or "RANK" in os.environ
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
 
     import __graft_entry__ as ge
-    if world > 1 and local != 0:                              # one rank compiles, the rest wait for it
+    if ddp and local != 0:                                    # one rank compiles, the rest wait for it
         dist.barrier(device_ids=[local])
     ge.build()
-    if world > 1 and local == 0:
+    if ddp and local == 0:
         dist.barrier(device_ids=[local])
     from localrf_amd import TensorVMSplit
 
@@ -147,7 +151,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if ddp:
             dist.barrier(device_ids=[local])
             torch.cuda.synchronize(dev)
 
@@ -161,7 +165,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if ddp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -217,7 +221,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, rays_cpu)
             out["speedup_vs_torch_rocm_port"] = value / world / out["torch_rocm_port"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
