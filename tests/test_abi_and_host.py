@@ -132,3 +132,46 @@ def test_local_tensorfs_surface_and_checkpoint_roundtrip(tmp_path):
     d = get_ray_directions_lean(col, row, lt2.focal(32), lt2.center(32, 24)).detach().numpy()
     assert np.abs(d - g["dirs"]).max() < 1e-6
     assert (torch.stack([col, row], -1).numpy() == g["ij"]).all()
+
+
+def test_fused_adam_host_logic_and_no_cpu_fallback():
+    """Constructor checks, param_groups / state layout of torch.optim.Adam, cheap zero_grad, and no
+    CPU arithmetic: stepping host tensors raises."""
+    from localrf_amd import FusedAdam, LocalTensorfs, NativeError
+    p = torch.nn.Parameter(torch.zeros(4))
+    q = torch.nn.Parameter(torch.ones(2, 3))
+    opt = FusedAdam([{"params": [p], "lr": 0.02}, {"params": [q]}], lr=1e-3, betas=(0.9, 0.99))
+    assert [g["lr"] for g in opt.param_groups] == [0.02, 1e-3]
+    assert all(g["betas"] == (0.9, 0.99) and g["eps"] == 1e-8 for g in opt.param_groups)
+    for bad in (dict(weight_decay=0.1), dict(amsgrad=True), dict(lr=-1.0), dict(betas=(1.0, 0.9))):
+        with pytest.raises(ValueError):
+            FusedAdam([torch.nn.Parameter(torch.zeros(1))], **bad)
+    opt.step()                                   # nothing has a gradient: no launch, no error
+    p.grad = torch.ones(4)
+    with pytest.raises(NativeError):
+        opt.step()
+    with pytest.raises(NativeError):
+        FusedAdam.step_many([opt])
+    opt.zero_grad()
+    assert p.grad is None
+    p.grad = torch.ones(4)
+    opt.zero_grad(set_to_none=False)
+    assert p.grad is not None and float(p.grad.abs().sum()) == 0.0
+    # a torch.optim.Adam state dict (tensor step counters) loads, and ours loads back into torch's
+    ref = torch.optim.Adam([{"params": [p], "lr": 0.02}, {"params": [q]}], lr=1e-3, betas=(0.9, 0.99))
+    p.grad, q.grad = torch.ones(4), torch.ones(2, 3)
+    ref.step()
+    opt.load_state_dict(ref.state_dict())
+    assert int(opt.state[p]["step"]) == 1 and torch.equal(opt.state[p]["exp_avg"], ref.state[p]["exp_avg"])
+    ref.load_state_dict(opt.state_dict())
+    # the scene creates FusedAdam objects everywhere the reference creates torch.optim.Adam
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=3, n_overlap=3, WH=(32, 24),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=1e-3, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device="cpu", lr_upsample_reset=True,
+               aabb=aabb, gridSize=[16, 16, 16], **FIELD_KW)
+    opts = [lt.rf_optimizer, lt.intrinsic_optimizer] + lt.r_optimizers + lt.t_optimizers + lt.exp_optimizers
+    assert len(opts) == 2 + 3 * 3 and all(isinstance(o, FusedAdam) for o in opts)
+    assert [g["lr"] for g in lt.rf_optimizer.param_groups][:2] == [0.02, 0.02]
