@@ -36,6 +36,7 @@ extern "C" {
 #define LRF_FLAG_MLP_VALU   4u   /* debug engine: colour MLP on the vector ALU, natural-layout weights */
 #define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
                                     split-bf16 (hi+lo, 3-term) MFMA chain */
+#define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
  * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with
@@ -120,8 +121,16 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
 /* Bytes of scratch lrf_render_bwd needs (worst case: every sample shaded). */
 size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]);
 
+/* Training forward: same outputs as lrf_render_fwd (split-bf16 engine, floater_thresh 0), but the
+ * per-sample state the backward needs (density features, shaded-sample lists, per-sample colours,
+ * activation rows) is left in `workspace` (lrf_workspace_bytes_bwd bytes) instead of being
+ * recomputed by lrf_render_bwd: pass the SAME workspace, field, rays and z to lrf_render_bwd with
+ * LRF_FLAG_ROWS_SAVED set.  Memory for recompute: 2.6 GB at 4096 x 512 against 288 GB of HBM. */
+int lrf_render_fwd_train(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                         uint32_t flags, float* rgb, float* depth, void* workspace, void* stream);
+
 /* Backward of lrf_render_fwd (replaces autograd through tensorBase.py:567-636,
- * tensoRF.py:112-196): recomputes the forward, scatters parameter gradients into `g`
+ * tensoRF.py:112-196): recomputes the forward (unless LRF_FLAG_ROWS_SAVED), scatters parameter gradients into `g`
  * (reference layout, +=) and writes d(loss)/d(rays) [R,6]. The floater filter is eval-only
  * (train.py:107,139) and not differentiated. `workspace`: lrf_workspace_bytes_bwd bytes. */
 int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, const float* z,

@@ -12,6 +12,7 @@ LRF_FLAG_WHITE_BG = 1
 LRF_FLAG_RELU_DENS = 2
 LRF_FLAG_MLP_VALU = 4
 LRF_FLAG_MLP_F32 = 8
+LRF_FLAG_ROWS_SAVED = 16
 
 _f = C.c_void_p  # device float*
 
@@ -58,6 +59,8 @@ SYMBOLS = {
     "lrf_render_fwd_profile": (C.c_int, [C.POINTER(LrfField), _f, _f, C.c_int32, C.c_int32, C.c_uint32,
                                          C.c_float, _f, _f, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "lrf_render_fwd_train": (C.c_int, [C.POINTER(LrfField), _f, _f, C.c_int32, C.c_int32, C.c_uint32, _f, _f,
+                                       C.c_void_p, C.c_void_p]),
     "lrf_workspace_bytes_bwd": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "lrf_render_bwd": (C.c_int, [C.POINTER(LrfField), C.POINTER(LrfParams), _f, _f, C.c_int32, C.c_int32,
                                  C.c_uint32, _f, _f, C.POINTER(LrfGrads), _f, C.c_void_p, C.c_void_p]),

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
-    float* __restrict__ crgb, float* __restrict__ act) {
+    float* __restrict__ crgb, float* __restrict__ act,
+    const float* __restrict__ cw /* with part: also emit the per-tile weighted colours of k_shade_bf16 */,
+    float* __restrict__ part, int pmax) {
   __shared__ uint4 img[IMGB_U4];
   for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
   __syncthreads();
@@ -251,6 +253,20 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       cp[0] = 1.0f / (1.0f + expf(-(o0 + vb[0])));
       cp[1] = 1.0f / (1.0f + expf(-(o1 + vb[1])));
       cp[2] = 1.0f / (1.0f + expf(-(o2 + vb[2])));
+    }
+    if (part) {                                   // lrf_render_fwd_train: this kernel IS the forward shade
+      const float w = valid ? cw[(size_t)ray * S + j0 + s] : 0.0f;
+      float cr = w / (1.0f + expf(-(o0 + vb[0])));
+      float cg = w / (1.0f + expf(-(o1 + vb[1])));
+      float cb = w / (1.0f + expf(-(o2 + vb[2])));
+#pragma unroll
+      for (int dd = 1; dd < 16; dd <<= 1) {
+        cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
+      }
+      if (lane == 0) {
+        float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
+        pp[0] = cr; pp[1] = cg; pp[2] = cb;
+      }
     }
   }
 }
@@ -1186,6 +1202,28 @@ extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t gr
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
 }
 
+extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                                    uint32_t flags, float* rgb, float* depth, void* workspace, void* stream) {
+  using namespace lrf;
+  if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd_train: null argument");
+  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd_train: need R > 0 and 2 <= S <= 4096");
+  if (flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))
+    return set_err("lrf_render_fwd_train: the row-saving forward runs the split-bf16 engine only");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const DField d = make_dfield(f);
+  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
+  const Workspace& w = b.fw;
+  hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
+                     d, rays, z, R, S, flags, 0.0f, depth, w.acc, (float*)nullptr, w.ncomp, w.cidx, w.cw, b.feat);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+  hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
+                     b.crgb, b.act, w.cw, w.part, w.pmax);
+  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
+                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, const float* z,
                               int32_t R, int32_t S, uint32_t flags, const float* g_rgb, const float* g_depth,
                               const LrfGrads* g, float* g_rays, void* workspace, void* stream) {
@@ -1201,11 +1239,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int cus = device_cus();
   LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
   hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
-  hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
-                     d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, (float*)nullptr, w.ncomp, w.cidx, w.cw, b.feat);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-  hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                     b.crgb, b.act);
+  if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
+    hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
+                       d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, (float*)nullptr, w.ncomp, w.cidx, w.cw, b.feat);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+    hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
+                       b.crgb, b.act, (const float*)nullptr, (float*)nullptr, 0);
+  }
   hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
                      w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax);
   const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);

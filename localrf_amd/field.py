@@ -76,7 +76,14 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, field, rays, z, flags, floater, *params):
-        rgb, depth = field._native_forward(rays, z, flags, floater)
+        # Default engine: the forward already leaves what the backward needs (density features,
+        # shaded-sample lists, per-sample colours, activation rows) in a workspace owned by this
+        # graph node -- 2.6 GB at 4096 x 512 against 288 GB of HBM -- instead of recomputing it.
+        if not flags & (N.LRF_FLAG_MLP_VALU | N.LRF_FLAG_MLP_F32):
+            rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, flags)
+        else:
+            rgb, depth = field._native_forward(rays, z, flags, floater)
+            ctx.ws = None
         ctx.field, ctx.flags = field, flags
         ctx.save_for_backward(rays, z)
         return rgb, depth
@@ -84,7 +91,11 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth):
         rays, z = ctx.saved_tensors
-        g_rays, g_params = ctx.field._native_backward(rays, z, ctx.flags, g_rgb, g_depth)
+        ws = ctx.ws
+        if ws is not None and ctx.versions != ctx.field._param_versions():
+            ws = None                            # parameters changed since the forward: recompute
+        g_rays, g_params = ctx.field._native_backward(rays, z, ctx.flags, g_rgb, g_depth, saved_ws=ws)
+        ctx.ws = None
         return (None, g_rays, None, None, None) + tuple(g_params)
 
 
@@ -388,7 +399,31 @@ class TensorVMSplit(torch.nn.Module):
                                    ws.data_ptr(), st), "lrf_render_fwd")
         return (rgb, depth, w_out, acc) if want_weights else (rgb, depth)
 
-    def _native_backward(self, rays, z, flags, g_rgb, g_depth):
+    def _param_versions(self):
+        return tuple((p.data_ptr(), p._version) for p in self._param_list())
+
+    def _native_forward_train(self, rays, z, flags):
+        """lrf_render_fwd_train: forward that keeps the backward's per-sample state in a workspace."""
+        self._require_gpu(rays)
+        lib = N.lib()
+        self._ensure_cache()
+        rays = rays.detach().contiguous().float()
+        z = z.detach().contiguous().float().view(-1)
+        R, S = rays.shape[0], z.shape[0]
+        dev = rays.device
+        rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        if R == 0:
+            return rgb, depth, None, None
+        grid = (C.c_int32 * 3)(*self._grid_host)
+        ws = torch.empty(lib.lrf_workspace_bytes_bwd(R, S, grid), dtype=torch.uint8, device=dev)
+        f = self._c_field()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_render_fwd_train(C.byref(f), N.ptr(rays), N.ptr(z), R, S, flags, N.ptr(rgb), N.ptr(depth),
+                                         ws.data_ptr(), st), "lrf_render_fwd_train")
+        return rgb, depth, ws, self._param_versions()
+
+    def _native_backward(self, rays, z, flags, g_rgb, g_depth, saved_ws=None):
         lib = N.lib()
         self._ensure_cache()
         rays = rays.detach().contiguous().float()
@@ -414,10 +449,14 @@ class TensorVMSplit(torch.nn.Module):
             cg.app_line[i] = grads[9 + i].data_ptr()
         (cg.basis, cg.w1, cg.b1, cg.w2, cg.b2, cg.w3, cg.b3) = [g.data_ptr() for g in grads[12:]]
         nbytes = lib.lrf_workspace_bytes_bwd(R, S, cp.grid)
-        if getattr(self, "_ws_bwd", None) is None or self._ws_bwd.numel() < nbytes or self._ws_bwd.device != dev:
-            self._ws_bwd = None
-            self._ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        ws = self._ws_bwd
+        if saved_ws is not None:                 # filled by lrf_render_fwd_train for exactly this call
+            ws = saved_ws
+            flags = flags | N.LRF_FLAG_ROWS_SAVED
+        else:
+            if getattr(self, "_ws_bwd", None) is None or self._ws_bwd.numel() < nbytes or self._ws_bwd.device != dev:
+                self._ws_bwd = None
+                self._ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = self._ws_bwd
         f = self._c_field()
         st = torch.cuda.current_stream(dev).cuda_stream
         N.check(lib.lrf_render_bwd(C.byref(f), C.byref(cp), N.ptr(rays), N.ptr(z), R, S, flags,

@@ -377,3 +377,57 @@ def test_large_noncubic_grid_forward_backward(built_lib):
     with torch.no_grad():
         rgb2, _ = f(rays.detach(), white_bg=True, is_train=False, N_samples=-1)
     assert float((rgb.detach() - rgb2).abs().max()) < 1e-5          # (bitwise in 3000-render soak runs)
+
+
+def test_row_saving_forward_equals_recomputing_backward(built_lib):
+    """lrf_render_fwd_train + lrf_render_bwd(LRF_FLAG_ROWS_SAVED) against the recomputing backward:
+    same outputs bit for bit, same gradients up to the order of the scatter atomics; a second
+    backward through the same graph and a parameter update between forward and backward both fall
+    back to recomputation."""
+    f = quiet(make_field, [40, 36, 44], "cpu", seed=3).to(DEV)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(3.0)
+    rays = make_rays(300, 5, pinhole=True).to(DEV)
+    gr, gd = torch.randn(300, 3, device=DEV), torch.randn(300, device=DEV)
+
+    def run(force_recompute, retain=False):
+        for p in f.parameters():
+            p.grad = None
+        r = rays.clone().requires_grad_(True)
+        if force_recompute:
+            orig = f._native_forward_train
+            f._native_forward_train = lambda *a: orig(*a)[:2] + (None, None)
+        try:
+            rgb, depth = f(r, is_train=False, N_samples=96)
+        finally:
+            if force_recompute:
+                del f._native_forward_train
+        loss = (rgb * gr).sum() + (depth * gd).sum()
+        loss.backward(retain_graph=retain)
+        g1 = [p.grad.clone() for p in f.parameters() if p.grad is not None] + [r.grad.clone()]
+        if retain:
+            for p in f.parameters():
+                p.grad = None
+            r.grad = None
+            loss.backward()
+            return rgb.detach(), depth.detach(), g1, [p.grad.clone() for p in f.parameters() if p.grad is not None] + [r.grad.clone()]
+        return rgb.detach(), depth.detach(), g1
+
+    a = run(False)
+    b = run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-12)
+    c = run(False, retain=True)
+    for x, y in zip(c[2], c[3]):
+        assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-12)
+    # parameters updated between forward and backward: the saved rows are stale and are not used
+    for p in f.parameters():
+        p.grad = None
+    rgb, depth = f(rays.clone().requires_grad_(True), is_train=False, N_samples=96)
+    with torch.no_grad():
+        f.basis_mat.weight.mul_(1.0)              # bumps the version only
+    ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    for p, y in zip([p for p in f.parameters() if p.grad is not None], b[2]):
+        assert float((p.grad - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-12)
