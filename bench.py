@@ -82,6 +82,29 @@ def torch_rocm_port(field_sd, rays, iters=5):
             "what": "oracle/vm_render_torch.py on cuda:0 (PyTorch-ROCm ATen ops, fp32)"}
 
 
+def train_step_time(field, rays, iters=10):
+    """Informational (not the headline metric): forward with a graph + backward of the same batch
+    (train.py's use of the path), parameter gradients into the reference layout."""
+    gr = torch.randn(rays.shape[0], 3, device=rays.device)
+    gd = torch.randn(rays.shape[0], device=rays.device)
+
+    def step():
+        for p in field.parameters():
+            p.grad = None
+        rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=N_SAMPLES_ARG)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"ms_per_step": dt * 1e3, "rays_per_s": rays.shape[0] / dt,
+            "what": "lrf_render_fwd_train + lrf_render_bwd, 4096 rays x 512 samples, jittered samples"}
+
+
 def kernel_profile(field, rays, z, reps=5):
     """Per-kernel HIP-event timing through lrf_render_fwd_profile (same stream, same inputs)."""
     from localrf_amd import _native as N
@@ -114,6 +137,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / torch-ROCm baselines")
+    ap.add_argument("--preroll-ms", type=float, default=150.0, help="untimed GPU clock ramp before the warm-up steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +180,14 @@ def main():
             torch.cuda.synchronize(dev)
 
     with torch.no_grad():
+        # clock ramp: the first ~10 ms of work after an idle period run at a lower GPU clock (50 timed
+        # steps right after start-up read 0.273 ms/step, 200 steps 0.249); render untimed for
+        # --preroll-ms before the W warm-up steps so that K is measured at the sustained clock
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+            for _ in range(20):
+                field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
+            torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
             field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
         sync()
@@ -216,6 +248,7 @@ def main():
                           "parallelism": f"ray-shard x{world}", "mlp_engine": field.mlp_engine},
                "roofline": roofline}
         if not args.no_baselines and world == 1:              # baselines are an N=1 report
+            out["train_step"] = train_step_time(field, rays)
             sd = field.state_dict()
             out["torch_rocm_port"] = torch_rocm_port(sd, rays)
             out["cpu_baseline"] = cpu_baseline(sd, rays_cpu)
