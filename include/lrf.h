@@ -221,6 +221,18 @@ int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_
 int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, const float* g_cam2world, float* g_r6d,
                           float* g_trans, void* stream);
 
+/* TV regulariser (utils/utils.py:293-309 as applied by tensoRF.py:94-110; weights 0 by default,
+ * opt.py:112-113): loss = sum_t scale_t * 2 w (sum_h (dx)^2 / (C (H-1) W) + sum_w (dx)^2 / (C H (W-1)))
+ * over up to LRF_TV_MAX tensors x_t [C,H,W] (a line is [C,L,1]); scale 1e-2 for planes, 1e-3 for
+ * lines.  `segs` is a host array; g (gradient, same shape, written not accumulated) is used by _bwd. */
+#define LRF_TV_MAX 16
+typedef struct LrfTvSeg { const float* x; float* g; int32_t C, H, W; float scale; } LrfTvSeg;
+size_t lrf_tv_workspace(const LrfTvSeg* segs, int32_t count);
+int lrf_tv_loss_fwd(const LrfTvSeg* segs, int32_t count, float weight, void* workspace, float* out /* device [1] */,
+                    void* stream);
+int lrf_tv_loss_bwd(const LrfTvSeg* segs, int32_t count, float weight, const float* g_out /* device [1] */,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

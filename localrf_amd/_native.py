@@ -46,6 +46,10 @@ class LrfAdamTensor(C.Structure):
                 ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
 
 
+class LrfTvSeg(C.Structure):
+    _fields_ = [("x", _f), ("g", _f), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("scale", C.c_float)]
+
+
 # every symbol include/lrf.h declares: (restype, argtypes)
 SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
@@ -76,6 +80,9 @@ SYMBOLS = {
                                      C.c_void_p, _f, C.POINTER(_f), C.POINTER(_f), C.c_void_p]),
     "lrf_pose_assemble": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.c_int32, _f, C.c_void_p]),
     "lrf_pose_assemble_bwd": (C.c_int, [C.POINTER(_f), C.c_int32, _f, _f, _f, C.c_void_p]),
+    "lrf_tv_workspace": (C.c_size_t, [C.POINTER(LrfTvSeg), C.c_int32]),
+    "lrf_tv_loss_fwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, C.c_void_p, _f, C.c_void_p]),
+    "lrf_tv_loss_bwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, _f, C.c_void_p]),
     "lrf_scene_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32,
                                  C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
     "lrf_scene_rays_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int32, _f, _f, C.c_int32,

@@ -191,3 +191,123 @@ extern "C" int lrf_density_l1_bwd(const float* const plane[3], const float* cons
   LRF_HIP(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// TV regulariser (utils/utils.py:293-309 applied as tensoRF.py:94-110): for every tensor x [C,H,W]
+// (lines: W = 1)  tv = 2 w (sum (x[y]-x[y-1])^2 / (C (H-1) W) + sum (x[,x]-x[,x-1])^2 / (C H (W-1))),
+// loss = sum over tensors of scale * tv (1e-2 for planes, 1e-3 for lines).  Off by default in the
+// reference (opt.py:112-113); one launch each way for up to LRF_TV_MAX tensors.
+namespace lrf {
+
+constexpr int TV_CHUNK = 4096;
+struct TvTable { LrfTvSeg s[LRF_TV_MAX]; int first_block[LRF_TV_MAX + 1]; int count; };
+
+__device__ __forceinline__ int tv_seg_of(const TvTable& tab) {
+  int k = 0;
+  while (k + 1 < tab.count && (int)blockIdx.x >= tab.first_block[k + 1]) ++k;
+  return k;
+}
+
+// partial[block] = (sum of squared differences along H, along W) of this block's elements
+__global__ __launch_bounds__(L1_TPB) void k_tv_fwd(TvTable tab, float2* __restrict__ partial) {
+  __shared__ float red[4];
+  const int k = tv_seg_of(tab);
+  const LrfTvSeg sg = tab.s[k];
+  const long long n = (long long)sg.C * sg.H * sg.W;
+  const long long base = (long long)((int)blockIdx.x - tab.first_block[k]) * TV_CHUNK;
+  float sh = 0.0f, sw = 0.0f;
+  for (int it = 0; it < TV_CHUNK / L1_TPB; ++it) {
+    const long long i = base + it * L1_TPB + threadIdx.x;
+    if (i < n) {
+      const int x = (int)(i % sg.W), y = (int)((i / sg.W) % sg.H);
+      const float v = sg.x[i];
+      if (y > 0) { const float d = v - sg.x[i - sg.W]; sh += d * d; }
+      if (x > 0) { const float d = v - sg.x[i - 1]; sw += d * d; }
+    }
+  }
+  const float a = block_sum_256(sh, red), b = block_sum_256(sw, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_float2(a, b);
+}
+
+__global__ void k_tv_final(TvTable tab, const float2* __restrict__ partial, float weight, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float total = 0.0f;
+  for (int k = 0; k < tab.count; ++k) {                         // fixed order: deterministic
+    const LrfTvSeg sg = tab.s[k];
+    float sh = 0.0f, sw = 0.0f;
+    for (int b = tab.first_block[k]; b < tab.first_block[k + 1]; ++b) { sh += partial[b].x; sw += partial[b].y; }
+    float tv = 0.0f;
+    if (sg.H > 1) tv += sh / ((float)sg.C * (float)(sg.H - 1) * (float)sg.W);
+    if (sg.W > 1) tv += sw / ((float)sg.C * (float)sg.H * (float)(sg.W - 1));
+    total += weight * 2.0f * tv * sg.scale;
+  }
+  out[0] = total;
+}
+
+__global__ __launch_bounds__(L1_TPB) void k_tv_bwd(TvTable tab, float weight, const float* __restrict__ g_out) {
+  const int k = tv_seg_of(tab);
+  const LrfTvSeg sg = tab.s[k];
+  const long long n = (long long)sg.C * sg.H * sg.W;
+  const long long base = (long long)((int)blockIdx.x - tab.first_block[k]) * TV_CHUNK;
+  const float ch = sg.H > 1 ? 2.0f / ((float)sg.C * (float)(sg.H - 1) * (float)sg.W) : 0.0f;
+  const float cw = sg.W > 1 ? 2.0f / ((float)sg.C * (float)sg.H * (float)(sg.W - 1)) : 0.0f;
+  const float s = g_out[0] * weight * 2.0f * sg.scale;
+  for (int it = 0; it < TV_CHUNK / L1_TPB; ++it) {
+    const long long i = base + it * L1_TPB + threadIdx.x;
+    if (i >= n) break;
+    const int x = (int)(i % sg.W), y = (int)((i / sg.W) % sg.H);
+    const float v = sg.x[i];
+    float gh = 0.0f, gw = 0.0f;
+    if (y > 0) gh += v - sg.x[i - sg.W];
+    if (y < sg.H - 1) gh -= sg.x[i + sg.W] - v;
+    if (x > 0) gw += v - sg.x[i - 1];
+    if (x < sg.W - 1) gw -= sg.x[i + 1] - v;
+    sg.g[i] = s * (ch * gh + cw * gw);
+  }
+}
+
+static int tv_table(const LrfTvSeg* segs, int count, TvTable& tab) {
+  if (!segs || count <= 0 || count > LRF_TV_MAX) return -1;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!segs[i].x || segs[i].C <= 0 || segs[i].H <= 0 || segs[i].W <= 0) return -1;
+    tab.s[i] = segs[i];
+    tab.first_block[i] = blocks;
+    blocks += (int)(((long long)segs[i].C * segs[i].H * segs[i].W + TV_CHUNK - 1) / TV_CHUNK);
+  }
+  tab.first_block[count] = blocks;
+  tab.count = count;
+  return blocks;
+}
+
+}  // namespace lrf
+
+extern "C" size_t lrf_tv_workspace(const LrfTvSeg* segs, int32_t count) {
+  lrf::TvTable tab;
+  const int blocks = lrf::tv_table(segs, count, tab);
+  return blocks < 0 ? 0 : sizeof(float) * 2 * (size_t)blocks + 256;
+}
+
+extern "C" int lrf_tv_loss_fwd(const LrfTvSeg* segs, int32_t count, float weight, void* workspace, float* out,
+                               void* stream) {
+  using namespace lrf;
+  TvTable tab;
+  const int blocks = tv_table(segs, count, tab);
+  if (blocks < 0 || !workspace || !out) return set_err("lrf_tv_loss_fwd: null argument or bad tensor table");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_tv_fwd, dim3(blocks), dim3(L1_TPB), 0, st, tab, static_cast<float2*>(workspace));
+  hipLaunchKernelGGL(k_tv_final, dim3(1), dim3(64), 0, st, tab, static_cast<const float2*>(workspace), weight, out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lrf_tv_loss_bwd(const LrfTvSeg* segs, int32_t count, float weight, const float* g_out, void* stream) {
+  using namespace lrf;
+  TvTable tab;
+  const int blocks = tv_table(segs, count, tab);
+  if (blocks < 0 || !g_out) return set_err("lrf_tv_loss_bwd: null argument or bad tensor table");
+  for (int i = 0; i < count; ++i) if (!segs[i].g) return set_err("lrf_tv_loss_bwd: null gradient pointer");
+  hipLaunchKernelGGL(k_tv_bwd, dim3(blocks), dim3(L1_TPB), 0, reinterpret_cast<hipStream_t>(stream), tab, weight, g_out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}

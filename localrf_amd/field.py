@@ -142,6 +142,46 @@ class _DensityL1Fn(torch.autograd.Function):
         return (None, *grads)
 
 
+class _TVLossFn(torch.autograd.Function):
+    """Seam between autograd and lrf_tv_loss_fwd / lrf_tv_loss_bwd (3 planes then 3 lines)."""
+
+    @staticmethod
+    def _table(tensors, grads=None):
+        tab = (N.LrfTvSeg * len(tensors))()
+        for i, (sg, t) in enumerate(zip(tab, tensors)):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise N.NativeError("localrf_amd: TV loss needs contiguous fp32 planes/lines")
+            sg.x = t.data_ptr()
+            sg.g = None if grads is None else grads[i].data_ptr()
+            sg.C, sg.H, sg.W = int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
+            sg.scale = 1e-2 if i < 3 else 1e-3
+        return tab
+
+    @staticmethod
+    def forward(ctx, weight, *tensors):
+        lib = N.lib()
+        tensors = tuple(t.detach() for t in tensors)
+        tab = _TVLossFn._table(tensors)
+        dev = tensors[0].device
+        ws = torch.empty(lib.lrf_tv_workspace(tab, len(tensors)), dtype=torch.uint8, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(lib.lrf_tv_loss_fwd(tab, len(tensors), weight, ws.data_ptr(), N.ptr(out), st), "lrf_tv_loss_fwd")
+        ctx.weight = weight
+        ctx.save_for_backward(*tensors)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        tensors = ctx.saved_tensors
+        grads = [torch.empty_like(t) for t in tensors]
+        tab = _TVLossFn._table(tensors, grads)
+        g = g_out.detach().reshape(1).contiguous().float()
+        st = torch.cuda.current_stream(g.device).cuda_stream
+        N.check(N.lib().lrf_tv_loss_bwd(tab, len(tensors), ctx.weight, N.ptr(g), st), "lrf_tv_loss_bwd")
+        return (None, *grads)
+
+
 class TensorVMSplit(torch.nn.Module):
     # constructor signature and defaults: tensorBase.py:236-257, tensoRF.py:10-12
     def __init__(self, device, aabb, gridSize, density_n_comp=8, appearance_n_comp=24, app_dim=27,
@@ -589,21 +629,25 @@ class TensorVMSplit(torch.nn.Module):
         self._require_gpu(self.density_plane[0])
         return _DensityL1Fn.apply(self, *self.density_plane, *self.density_line)
 
-    def TV_loss_density(self, reg):
-        """tensoRF.py:94-101."""
+    def _tv_loss(self, reg, planes, lines):
+        """tensoRF.py:94-110.  With the reference's TVLoss module (utils/utils.py:293-309, recognised
+        by its `TVLoss_weight`) on the GPU all six tensors go through lrf_tv_loss_fwd/_bwd in one
+        launch each way; any other `reg` callable is applied tensor by tensor as the reference does."""
+        w = getattr(reg, "TVLoss_weight", None)
+        if w is not None and planes[0].is_cuda:
+            return _TVLossFn.apply(float(w), *planes, *lines)
         total = 0
         for i in range(3):
-            total = total + reg(self.density_plane[i].transpose(0, 1)) * 1e-2 \
-                + reg(self.density_line[i].transpose(0, 1)) * 1e-3
+            total = total + reg(planes[i].transpose(0, 1)) * 1e-2 + reg(lines[i].transpose(0, 1)) * 1e-3
         return total
+
+    def TV_loss_density(self, reg):
+        """tensoRF.py:94-101."""
+        return self._tv_loss(reg, list(self.density_plane), list(self.density_line))
 
     def TV_loss_app(self, reg):
         """tensoRF.py:103-110."""
-        total = 0
-        for i in range(3):
-            total = total + reg(self.app_plane[i].transpose(0, 1)) * 1e-2 \
-                + reg(self.app_line[i].transpose(0, 1)) * 1e-3
-        return total
+        return self._tv_loss(reg, list(self.app_plane), list(self.app_line))
 
     @torch.no_grad()
     def up_sampling_VM(self, plane_coef, line_coef, res_target):

@@ -483,6 +483,8 @@ def stage_reg():
     f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
 
     class TV(torch.nn.Module):                         # utils/utils.py:293-309
+        TVLoss_weight = 1.0
+
         def forward(self, x):
             h, w = x.size(2), x.size(3)
             tv = 0
@@ -514,7 +516,13 @@ def stage_reg():
         (f.TV_loss_density(reg) + f.TV_loss_app(reg)).backward()
     torch.cuda.reset_peak_memory_stats()
     log("density_L1 forward+backward ms", round(timeit(l1), 3), "| peak memory GB", round(torch.cuda.max_memory_allocated() / 2**30, 2))
-    log("TV_loss_density + TV_loss_app forward+backward ms", round(timeit(tv), 3))
+    log("TV_loss_density + TV_loss_app forward+backward ms (lrf_tv_loss_*)", round(timeit(tv), 3))
+    plain = lambda x: reg(x)                              # a callable without TVLoss_weight: torch op chain
+    def tv_torch():
+        for p in f.parameters():
+            p.grad = None
+        (f.TV_loss_density(plain) + f.TV_loss_app(plain)).backward()
+    log("TV_loss_density + TV_loss_app forward+backward ms (reference op chain in torch)", round(timeit(tv_torch), 3))
 
 
 def stage_big():

@@ -361,3 +361,49 @@ def test_pose_assemble_kernel_vs_torch_chain():
     assert torch.allclose(a[0], b[0], rtol=1e-6, atol=1e-6)
     assert (a[1] - b[1]).abs().max() <= 1e-5 * b[1].abs().max()
     assert (a[2] - b[2]).abs().max() <= 1e-6 * b[2].abs().max()
+
+
+def test_tv_loss_kernel_vs_reference_module():
+    """lrf_tv_loss_fwd/_bwd against the reference's TVLoss module arithmetic (utils/utils.py:293-309)
+    applied as tensoRF.py:94-110, non-cubic grid, non-default weight."""
+    from util import make_field
+
+    class TVLoss(torch.nn.Module):                      # the reference module, verbatim arithmetic
+        def __init__(self, TVLoss_weight=1):
+            super().__init__()
+            self.TVLoss_weight = TVLoss_weight
+
+        def forward(self, x):
+            h_x, w_x = x.size()[2], x.size()[3]
+            tv = 0
+            if h_x > 1:
+                tv += torch.pow((x[:, :, 1:, :] - x[:, :, :h_x - 1, :]), 2).mean()
+            if w_x > 1:
+                tv += torch.pow((x[:, :, :, 1:] - x[:, :, :, :w_x - 1]), 2).mean()
+            return self.TVLoss_weight * 2 * tv
+    f = quiet(make_field, [37, 41, 29], "cpu", seed=9).to(DEV)
+    reg = TVLoss(0.7)
+
+    def reference(planes, lines):
+        total = 0
+        for i in range(3):
+            total = total + reg(planes[i].transpose(0, 1)) * 1e-2 + reg(lines[i].transpose(0, 1)) * 1e-3
+        return total
+    for native, ref_args in ((f.TV_loss_density, (f.density_plane, f.density_line)),
+                             (f.TV_loss_app, (f.app_plane, f.app_line))):
+        res = []
+        for fn in (lambda: native(reg), lambda: reference(*ref_args)):
+            for p in f.parameters():
+                p.grad = None
+            out = fn()
+            (out * 1.3).backward()
+            res.append((out.detach().clone(), [p.grad.clone() for p in list(ref_args[0]) + list(ref_args[1])]))
+        (a, ga), (b, gb) = res
+        assert abs(float(a) - float(b)) <= 1e-5 * abs(float(b))
+        for x, y in zip(ga, gb):
+            assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max())
+    # any other callable is applied tensor by tensor, as in the reference
+    plain = lambda x: (x ** 2).mean()
+    want = sum(plain(f.density_plane[i].transpose(0, 1)) * 1e-2 + plain(f.density_line[i].transpose(0, 1)) * 1e-3
+               for i in range(3))
+    assert abs(float(f.TV_loss_density(plain).detach()) - float(want.detach())) <= 1e-6 * abs(float(want.detach()))
