@@ -1,26 +1,32 @@
 // lrf_backward.inl -- backward of the render path for gfx950 (included by lrf_render.hip).
 //
-// lrf_render_bwd replaces autograd through tensorBase.py:567-636 + tensoRF.py:112-196
-// (paths relative to /root/reference/localTensoRF).  Nothing from the forward call is kept:
-// the forward is recomputed (it costs ~0.2 ms) and the backward runs as
+// lrf_render_fwd_train + lrf_render_bwd replace autograd through tensorBase.py:567-636 +
+// tensoRF.py:112-196 (paths relative to /root/reference/localTensoRF).
 //
-//   k_march (+feat)      density features of every sample, compaction lists (as in forward)
+// forward with a graph (lrf_render_fwd_train; the same three kernels run at the head of
+// lrf_render_bwd when the caller has no saved workspace):
+//   k_march (+feat)      density features of every sample, compaction lists (as in the forward)
 //   k_scan_tiles         tile offsets
-//   k_bwd_shade_fwd      split-bf16 colour chain again, now saving per shaded sample: rgb and
-//                        the activation row ACT = [X | feat,1 | relu(h1),1 | relu(h2), dhat,1]
+//   k_bwd_shade_fwd      the split-bf16 colour chain of k_shade_bf16, additionally saving per
+//                        shaded sample: rgb and the activation row
+//                        ACT = [X | feat,1 | relu(h1),1 | relu(h2), dhat,1]
+// backward:
 //   k_bwd_shade_dgrad    per tile: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX as an
 //                        exact-fp32 MFMA chain on TRANSPOSED weight fragments (same register-
 //                        resident trick as the forward: D layout of one layer = B operand of
-//                        the next), gradient row GRD = [go | dfeat | dz1 | dz2]; appearance
-//                        plane/line gradients by fp32 hardware atomics into a channel-last
-//                        gradient image; d/d(position) -> per-tile ray-gradient partials
-//   k_wgrad<MT,NT> x4    weight gradients as tall-skinny GEMMs C = A^T B over the saved rows
+//                        the next), gradient row GRD = [go | dfeat | dz1 | dz2 | dX];
+//                        d/d(position) of the appearance lookups -> per-tile ray partials
+//   k_wgrad<MT,NT,KS> x4 weight gradients as tall-skinny GEMMs C = A^T B over the saved rows
 //                        (K = shaded samples) on v_mfma_f32_16x16x4_f32, per-chunk partials
-//   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts
+//   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts (1 launch)
 //   k_bwd_ray            one wavefront per ray: weights, d(loss)/d(w), suffix sums ->
-//                        d/d(alpha) -> d/d(density feature); density plane/line gradients by
-//                        atomics; position gradients through the contraction to (o, d)
-//   k_unpack_grad        channel-last gradient image -> += the reference's [1,C,H,W] grads
+//                        d/d(alpha) -> d/d(density feature); position gradients through
+//                        normalise / contraction to d(loss)/d(rays)
+//   k_bin_hist/scan/fill counting sort of the (sample, plane) entries by 32x32-texel tile
+//   k_scatter_plane/line plane / line gradients accumulated per workgroup in LDS (CAS-loop fp32
+//                        adds; ds_add_f32 is 30x slower on this chip), runs of consecutive
+//                        same-cell entries merged in registers first
+//   k_unpack_grads       channel-last gradient images -> += the reference's layouts (1 launch)
 #pragma once
 
 namespace lrf {

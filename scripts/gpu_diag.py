@@ -523,6 +523,8 @@ def stage_reg():
             p.grad = None
         (f.TV_loss_density(plain) + f.TV_loss_app(plain)).backward()
     log("TV_loss_density + TV_loss_app forward+backward ms (reference op chain in torch)", round(timeit(tv_torch), 3))
+    log("updateAlphaMask((150,150,150)) ms", round(timeit(lambda: f.updateAlphaMask((150, 150, 150)), 3), 2),
+        "| upsample_volume_grid 300->330->300 ms", round(timeit(lambda: (f.upsample_volume_grid([330, 330, 330]), f.upsample_volume_grid([300, 300, 300])), 3), 2))
 
 
 def stage_big():
