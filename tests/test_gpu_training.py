@@ -407,3 +407,30 @@ def test_tv_loss_kernel_vs_reference_module():
     want = sum(plain(f.density_plane[i].transpose(0, 1)) * 1e-2 + plain(f.density_line[i].transpose(0, 1)) * 1e-3
                for i in range(3))
     assert abs(float(f.TV_loss_density(plain).detach()) - float(want.detach())) <= 1e-6 * abs(float(want.detach()))
+
+
+def test_scene_360_forward_backward():
+    """fov = 360 (equirectangular directions, utils/ray_utils.py:26-37): the scene renders, its
+    directions / rays equal the torch chain, and pose gradients flow (intrinsics get none)."""
+    from localrf_amd import LocalTensorfs
+    from localrf_amd.rays import get_ray_directions_360, ids2pixel
+    torch.manual_seed(2)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).to(DEV)
+    lt = quiet(LocalTensorfs, fov=360, n_init_frames=4, n_overlap=3, WH=(64, 32),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device=DEV, lr_upsample_reset=True,
+               aabb=aabb, gridSize=[16, 20, 24], **FIELD_KW)
+    with torch.no_grad():
+        for p in lt.tensorfs[-1].density_plane:
+            p.mul_(3.0)
+    ray_ids, view_ids = _batch(lt, n_views=4, per=32)
+    rgb, depth, dirs, ij = lt(ray_ids, view_ids, lt.W, lt.H, is_train=True)
+    col, row = ids2pixel(lt.W, lt.H, ray_ids)
+    assert torch.allclose(dirs, get_ray_directions_360(col, row, lt.W, lt.H), atol=1e-6)
+    assert (ij == torch.stack([col, row], -1)).all()
+    assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+    (rgb.sum() + depth.sum()).backward()
+    assert all(lt.r_c2w[i].grad is not None and torch.isfinite(lt.r_c2w[i].grad).all() for i in range(4))
+    assert lt.focal_offset.grad is None and lt.center_rel.grad is None
