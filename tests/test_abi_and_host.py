@@ -175,3 +175,29 @@ def test_fused_adam_host_logic_and_no_cpu_fallback():
     opts = [lt.rf_optimizer, lt.intrinsic_optimizer] + lt.r_optimizers + lt.t_optimizers + lt.exp_optimizers
     assert len(opts) == 2 + 3 * 3 and all(isinstance(o, FusedAdam) for o in opts)
     assert [g["lr"] for g in lt.rf_optimizer.param_groups][:2] == [0.02, 0.02]
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """Entry points reject bad arguments with a non-zero code and a message (no kernel is launched
+    on these paths, so this runs on the CPU-only container)."""
+    import ctypes as C
+    from localrf_amd import _native as N
+    lib = N.lib()
+    st = None
+    assert lib.lrf_adam_step(None, 0, 0.9, 0.99, 1e-8, st) == 0                  # empty table: no-op
+    assert lib.lrf_adam_step(None, 3, 0.9, 0.99, 1e-8, st) != 0
+    assert b"lrf_adam_step" in lib.lrf_last_error()
+    assert lib.lrf_adam_step(None, N.LRF_ADAM_MAX + 1, 0.9, 0.99, 1e-8, st) != 0
+    assert lib.lrf_render_fwd(None, None, None, 4, 8, 0, 0.0, None, None, None, None, None, st) != 0
+    assert b"null argument" in lib.lrf_last_error()
+    assert lib.lrf_scene_rays(None, 4, 2, None, None, 1, None, None, 8, 8, 0, None, None, None, st) != 0
+    assert lib.lrf_scene_blend(None, None, None, None, 4, 2, 1, None, None, None, st) != 0
+    assert lib.lrf_pose_assemble(None, None, 1, None, st) != 0
+    hw = (C.c_int32 * 3)(64, 64, 64)
+    ll = (C.c_int32 * 3)(8, 8, 9)                                              # planes x lines spanning different lattices
+    assert lib.lrf_density_l1_fwd(None, None, hw, ll, -5.0, 0, None, None, st) != 0
+    assert lib.lrf_tv_loss_fwd(None, 0, 1.0, None, None, st) != 0
+    assert lib.lrf_tv_workspace(None, 0) == 0
+    grid = (C.c_int32 * 3)(300, 300, 300)
+    assert lib.lrf_workspace_bytes_bwd(4096, 512, grid) > lib.lrf_workspace_bytes(4096, 512) > 0
+    assert lib.lrf_cache_bytes(grid) >= 34_800_000
