@@ -581,7 +581,45 @@ def stage_batch():
         log(f"R={R}: {dt * 1e3:.3f} ms/step, {R / dt / 1e6:.2f} M rays/s")
 
 
-STAGES = [("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_soak_train():
+    """Long training loop at scene level: memory must stay flat (the row-saving forward allocates its
+    workspace per call), the loss must stay finite and go down on a fixed target."""
+    import torch
+    from localrf_amd import LocalTensorfs
+    from util import FIELD_KW, quiet
+    torch.manual_seed(0)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).cuda()
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=8, n_overlap=3, WH=(320, 180),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device="cuda:0", lr_upsample_reset=True,
+               aabb=aabb, gridSize=[128, 128, 128], **FIELD_KW)
+    lt.is_refining = True
+    g = torch.Generator().manual_seed(1)
+    view_ids = torch.arange(8)
+    ray_ids = torch.randint(0, 320 * 180, (8 * 512,), generator=g)
+    target = torch.rand(ray_ids.numel(), 3, generator=g).cuda() * 0.5 + 0.25
+    n_it = int(os.environ.get("DIAG_ITERS", "600"))
+    losses, mem = [], []
+    t = time.time()
+    for it in range(n_it):
+        rgb, depth, _, _ = lt(ray_ids, view_ids, 320, 180, is_train=True)
+        loss = ((rgb - target) ** 2).mean() + 1e-2 * lt.tensorfs[-1].density_L1()
+        lt.optimizer_step(loss, optimize_poses=True)
+        if it % 100 == 0 or it == n_it - 1:
+            losses.append(float(loss))
+            mem.append(torch.cuda.memory_allocated() / 2**20)
+    torch.cuda.synchronize()
+    log("soak:", n_it, "iterations,", round((time.time() - t) / n_it * 1e3, 3), "ms/iteration; loss every 100:",
+        [round(v, 5) for v in losses], "| allocated MiB:", [round(m) for m in mem],
+        "| peak MiB", round(torch.cuda.max_memory_allocated() / 2**20))
+    assert all(v == v and v < 1e3 for v in losses), "loss diverged"
+    assert losses[-1] < losses[0], "loss did not go down"
+    assert max(mem[1:]) - min(mem[1:]) < 64, "allocated memory keeps growing"
+
+
+STAGES = [("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
