@@ -1287,7 +1287,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const BinGeom bg = make_bins(L);
   if (bg.total > BIN_MAX) return set_err("lrf_render_bwd: grid too large for the tile binning (BIN_MAX)");
   {
-    static bool lds_attr_set = false;      // dynamic LDS above 64 KB has to be opted into once
+    static bool lds_attr_done[64] = {};    // dynamic LDS above 64 KB has to be opted into once per device
+    int dev_id = 0;
+    LRF_HIP(hipGetDevice(&dev_id));
+    bool& lds_attr_set = lds_attr_done[dev_id & 63];
     if (!lds_attr_set) {
       LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

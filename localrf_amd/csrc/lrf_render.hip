@@ -919,12 +919,14 @@ static Workspace carve(void* ws, int R, int S) {
 
 static float* g_dump = nullptr;
 
-static int device_cus() {
-  static int cus = 0;
+static int device_cus() {                 // of the current device (one process may drive several)
+  static int cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int& cus = cache[dev & 63];
   if (!cus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
   return cus;
