@@ -619,7 +619,125 @@ def stage_soak_train():
     assert max(mem[1:]) - min(mem[1:]) < 64, "allocated memory keeps growing"
 
 
-STAGES = [("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_fuzz():
+    """Randomised shapes / options against the ATen-op port on the same GPU: eval forward (all
+    cases) and forward+backward (small cases).  Reports the worst deviations; threshold flips
+    (weight > 1e-3, tensorBase.py:622) may move single rays, counted separately."""
+    import numpy as np
+    import torch
+    from localrf_amd import AlphaGridMask
+    from oracle import vm_render_torch as ot
+    from util import make_field, make_rays, quiet
+    rng = np.random.default_rng(int(os.environ.get("DIAG_SEED", "0")))
+    n_cases = int(os.environ.get("DIAG_CASES", "40"))
+    worst = {"rgb": 0.0, "depth": 0.0, "grad": 0.0, "outlier_rays": 0, "cases": 0, "grad_cases": 0}
+    for case in range(n_cases):
+        grid = [int(rng.integers(8, 97)) for _ in range(3)]
+        R = int(rng.choice([1, 3, 63, 64, 65, 200, 511, 700]))
+        ns = int(rng.choice([-1, 36, 96, 200, 402]))
+        act = str(rng.choice(["softplus", "relu"]))
+        white = bool(rng.integers(0, 2))
+        pin = bool(rng.integers(0, 2))
+        f = quiet(make_field, grid, "cpu", seed=int(rng.integers(0, 1 << 30)), fea2denseAct=act).to("cuda:0")
+        with torch.no_grad():
+            for p in f.density_plane:
+                p.mul_(float(rng.choice([1.0, 3.0, 6.0])))
+        if rng.integers(0, 2):
+            vol = (torch.rand(6, 7, 5, generator=torch.Generator().manual_seed(case)) > 0.3).float()
+            vol = torch.nn.functional.interpolate(vol[None, None], size=(20, 22, 18), mode="nearest")[0, 0]
+            f.alphaMask = AlphaGridMask(torch.device("cuda:0"), f.aabb.detach(), vol.cuda())
+        rays = make_rays(R, 100 + case, pinhole=pin).cuda()
+        z = f.z_schedule(False, ns, rays.device)
+        fld = {k: v for k, v in f.state_dict().items()}
+        with torch.no_grad():
+            rgb, depth = f(rays, white_bg=white, is_train=False, N_samples=ns)
+            rgb_p, depth_p = ot.render_field(fld, rays, z[None], white, 0.0,
+                                             weight_thres=f.rayMarch_weight_thres) if act == "softplus" else (None, None)
+        if rgb_p is not None:
+            e_rgb = (rgb - rgb_p).abs().amax(-1)
+            e_dep = (depth - depth_p).abs() / depth_p.abs().clamp(min=1e-3)
+            out = int((e_rgb > 1e-4).sum())
+            worst["outlier_rays"] += out
+            worst["rgb"] = max(worst["rgb"], float(e_rgb[e_rgb <= 1e-4].max()) if (e_rgb <= 1e-4).any() else 0.0)
+            worst["depth"] = max(worst["depth"], float(e_dep.max()))
+            assert float(e_rgb.max()) < 5e-3 and out <= max(1, R // 50), (case, grid, R, ns, float(e_rgb.max()), out)
+            assert float(e_dep.max()) < 1e-4, (case, grid, R, ns, float(e_dep.max()))
+            worst["cases"] += 1
+        if rgb_p is not None and R <= 200 and f.alphaMask is None:
+            gr = torch.randn(R, 3, device="cuda"); gd = torch.randn(R, device="cuda")
+            f.z_override = z.clone()
+            for p in f.parameters():
+                p.grad = None
+            r1 = rays.clone().requires_grad_(True)
+            a, b = f(r1, white_bg=white, is_train=True, N_samples=ns)
+            ((a * gr).sum() + (b * gd).sum()).backward()
+            g_native = {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}
+            g_native["rays"] = r1.grad.clone()
+            leaves = {k: v.detach().clone().requires_grad_(True) for k, v in f.named_parameters()}
+            fl = {**fld, **leaves}
+            r2 = rays.clone().requires_grad_(True)
+            a2, b2 = ot.render_field(fl, r2, z[None], white, 0.0)
+            ((a2 * gr).sum() + (b2 * gd).sum()).backward()
+            for n, gn in g_native.items():
+                gp = r2.grad if n == "rays" else leaves[n].grad
+                den = float(gp.abs().max())
+                if den > 0:
+                    l2 = float((gn - gp).norm() / gp.norm())
+                    if l2 > worst["grad"]:
+                        worst["grad_where"] = (n, case, grid, R, ns, "max-norm err %.2e" % (float((gn - gp).abs().max()) / den))
+                    worst["grad"] = max(worst["grad"], l2)
+                    assert l2 < 2e-2, (case, grid, R, ns, n, l2)
+            worst["grad_cases"] += 1
+            f.z_override = None
+    log("fuzz:", worst)
+
+
+def stage_fuzz_case():
+    """Re-run one fuzz case (DIAG_SEED, DIAG_CASE) and localise the gradient difference."""
+    import numpy as np
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import make_field, make_rays, quiet
+    rng = np.random.default_rng(int(os.environ.get("DIAG_SEED", "0")))
+    want = int(os.environ.get("DIAG_CASE", "0"))
+    for case in range(want + 1):
+        grid = [int(rng.integers(8, 97)) for _ in range(3)]
+        R = int(rng.choice([1, 3, 63, 64, 65, 200, 511, 700]))
+        ns = int(rng.choice([-1, 36, 96, 200, 402]))
+        act = str(rng.choice(["softplus", "relu"]))
+        white = bool(rng.integers(0, 2)); pin = bool(rng.integers(0, 2))
+        seed = int(rng.integers(0, 1 << 30)); scale = float(rng.choice([1.0, 3.0, 6.0])); mask = rng.integers(0, 2)
+    f = quiet(make_field, grid, "cpu", seed=seed, fea2denseAct=act).to("cuda:0")
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(scale)
+    rays = make_rays(R, 100 + want, pinhole=pin).cuda()
+    z = f.z_schedule(False, ns, rays.device)
+    log("case", want, grid, R, ns, act, white, pin, "mask", int(mask), "S", z.numel())
+    rgbw = f.render_weights(rays, N_samples=ns, white_bg=white)
+    w = rgbw[2]
+    near = ((w - f.rayMarch_weight_thres).abs() < 2e-7).sum()
+    log("samples with |w - thres| < 2e-7:", int(near), "| shaded:", int((w > f.rayMarch_weight_thres).sum()))
+    gr = torch.randn(R, 3, device="cuda"); gd = torch.randn(R, device="cuda")
+    f.z_override = z.clone()
+    r1 = rays.clone().requires_grad_(True)
+    a, b = f(r1, white_bg=white, is_train=True, N_samples=ns)
+    ((a * gr).sum() + (b * gd).sum()).backward()
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in f.named_parameters()}
+    fl = {**{k: v for k, v in f.state_dict().items()}, **leaves}
+    r2 = rays.clone().requires_grad_(True)
+    a2, b2 = ot.render_field(fl, r2, z[None], white, 0.0)
+    ((a2 * gr).sum() + (b2 * gd).sum()).backward()
+    for n, p in f.named_parameters():
+        if p.grad is None or "plane" not in n:
+            continue
+        d = (p.grad - leaves[n].grad)[0]                     # [C,H,W]
+        hot = (d.abs().amax(0) > 1e-3 * leaves[n].grad.abs().max())
+        log(n, "max err / max", round(float(d.abs().max() / leaves[n].grad.abs().max()), 5), "| texels off by > 1e-3 of max:", int(hot.sum()),
+            "at", hot.nonzero()[:6].tolist())
+
+
+STAGES = [("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
