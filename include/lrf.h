@@ -215,11 +215,13 @@ int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], 
  * and a translation [3] -> cam2world [V,3,4].  r6d / trans are HOST arrays of V device pointers (the
  * per-frame parameters are separate tensors), 1 <= V <= LRF_POSE_MAX per call. */
 #define LRF_POSE_MAX 64
-int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_t V, float* cam2world,
-                      void* stream);
+/* cross_views != 0 (V == 3 only): b3 is the cross product over the VIEW axis, which is what the
+ * reference's dim-less torch.cross (utils/utils.py:386) computes for a stack of exactly 3 views. */
+int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_t V, int32_t cross_views,
+                      float* cam2world, void* stream);
 /* g_cam2world [V,3,4] -> g_r6d [V,3,2], g_trans [V,3] */
-int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, const float* g_cam2world, float* g_r6d,
-                          float* g_trans, void* stream);
+int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, int32_t cross_views, const float* g_cam2world,
+                          float* g_r6d, float* g_trans, void* stream);
 
 /* TV regulariser (utils/utils.py:293-309 as applied by tensoRF.py:94-110; weights 0 by default,
  * opt.py:112-113): loss = sum_t scale_t * 2 w (sum_h (dx)^2 / (C (H-1) W) + sum_w (dx)^2 / (C H (W-1)))

@@ -78,8 +78,8 @@ SYMBOLS = {
                                      C.c_float, C.c_int32, C.c_void_p, _f, C.c_void_p]),
     "lrf_density_l1_bwd": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.c_void_p, _f, C.POINTER(_f), C.POINTER(_f), C.c_void_p]),
-    "lrf_pose_assemble": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.c_int32, _f, C.c_void_p]),
-    "lrf_pose_assemble_bwd": (C.c_int, [C.POINTER(_f), C.c_int32, _f, _f, _f, C.c_void_p]),
+    "lrf_pose_assemble": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.c_int32, C.c_int32, _f, C.c_void_p]),
+    "lrf_pose_assemble_bwd": (C.c_int, [C.POINTER(_f), C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_tv_workspace": (C.c_size_t, [C.POINTER(LrfTvSeg), C.c_int32]),
     "lrf_tv_loss_fwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, C.c_void_p, _f, C.c_void_p]),
     "lrf_tv_loss_bwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, _f, C.c_void_p]),

@@ -303,17 +303,24 @@ __device__ __forceinline__ Frame6D gram_schmidt(const float* r /*[3,2] row-major
   return F;
 }
 
-__global__ void k_pose_assemble(PoseTable tab, int V, float* __restrict__ c2w) {
+// cross_views (V == 3 only): the reference calls torch.cross(b1, b2) without `dim`
+// (utils/utils.py:386), which runs over the FIRST axis of size 3 -- for a stack of exactly three
+// views that is the view axis: b3[v][c] = b1[v+1][c] b2[v+2][c] - b1[v+2][c] b2[v+1][c] (indices mod 3).
+__global__ void k_pose_assemble(PoseTable tab, int V, int cross_views, float* __restrict__ c2w) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  const Frame6D F = gram_schmidt(tab.r[v]);
+  Frame6D F = gram_schmidt(tab.r[v]);
+  if (cross_views) {
+    const Frame6D P = gram_schmidt(tab.r[(v + 1) % 3]), Q = gram_schmidt(tab.r[(v + 2) % 3]);
+    for (int c = 0; c < 3; ++c) F.b3[c] = P.b1[c] * Q.b2[c] - Q.b1[c] * P.b2[c];
+  }
   float* M = c2w + (size_t)v * 12;                       // columns (b1, b2, b3, t)
   for (int i = 0; i < 3; ++i) {
     M[4 * i + 0] = F.b1[i]; M[4 * i + 1] = F.b2[i]; M[4 * i + 2] = F.b3[i]; M[4 * i + 3] = tab.t[v][i];
   }
 }
 
-__global__ void k_pose_assemble_bwd(PoseTable tab, int V, const float* __restrict__ g_c2w,
+__global__ void k_pose_assemble_bwd(PoseTable tab, int V, int cross_views, const float* __restrict__ g_c2w,
                                     float* __restrict__ g_r, float* __restrict__ g_t) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
@@ -326,6 +333,17 @@ __global__ void k_pose_assemble_bwd(PoseTable tab, int V, const float* __restric
                   g1[2] + F.b2[0] * g3[1] - F.b2[1] * g3[0]};
   float gb2[3] = {g2[0] + g3[1] * F.b1[2] - g3[2] * F.b1[1], g2[1] + g3[2] * F.b1[0] - g3[0] * F.b1[2],
                   g2[2] + g3[0] * F.b1[1] - g3[1] * F.b1[0]};
+  if (cross_views) {                   // b3[w] = b1[w+1] * b2[w+2] - b1[w+2] * b2[w+1], element-wise over xyz
+    const int vp = (v + 1) % 3, vm = (v + 2) % 3;
+    const Frame6D P = gram_schmidt(tab.r[vp]), Q = gram_schmidt(tab.r[vm]);
+    const float* Gp = g_c2w + (size_t)vp * 12;
+    const float* Gm = g_c2w + (size_t)vm * 12;
+    for (int c = 0; c < 3; ++c) {
+      const float g3p = Gp[4 * c + 2], g3m = Gm[4 * c + 2];
+      gb1[c] = g1[c] + g3m * P.b2[c] - g3p * Q.b2[c];
+      gb2[c] = g2[c] + g3p * Q.b1[c] - g3m * P.b1[c];
+    }
+  }
   // b2 = u / |u|
   const float d2 = F.b2[0] * gb2[0] + F.b2[1] * gb2[1] + F.b2[2] * gb2[2];
   float gu[3];
@@ -353,24 +371,26 @@ static int pose_table(const float* const* r, const float* const* t, int V, PoseT
 
 }  // namespace lrf
 
-extern "C" int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_t V, float* cam2world,
-                                 void* stream) {
+extern "C" int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_t V, int32_t cross_views,
+                                 float* cam2world, void* stream) {
   using namespace lrf;
   PoseTable tab;
   if (!trans || !cam2world || pose_table(r6d, trans, V, tab))
     return set_err("lrf_pose_assemble: null argument or V outside [1, LRF_POSE_MAX]");
-  hipLaunchKernelGGL(k_pose_assemble, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tab, V, cam2world);
+  if (cross_views && V != 3) return set_err("lrf_pose_assemble: cross_views needs exactly 3 views");
+  hipLaunchKernelGGL(k_pose_assemble, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tab, V, cross_views, cam2world);
   LRF_HIP(hipGetLastError());
   return 0;
 }
 
-extern "C" int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, const float* g_cam2world, float* g_r6d,
-                                     float* g_trans, void* stream) {
+extern "C" int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, int32_t cross_views, const float* g_cam2world,
+                                     float* g_r6d, float* g_trans, void* stream) {
   using namespace lrf;
   PoseTable tab;
   if (!g_cam2world || !g_r6d || !g_trans || pose_table(r6d, nullptr, V, tab))
     return set_err("lrf_pose_assemble_bwd: null argument or V outside [1, LRF_POSE_MAX]");
-  hipLaunchKernelGGL(k_pose_assemble_bwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tab, V,
+  if (cross_views && V != 3) return set_err("lrf_pose_assemble_bwd: cross_views needs exactly 3 views");
+  hipLaunchKernelGGL(k_pose_assemble_bwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tab, V, cross_views,
                      g_cam2world, g_r6d, g_trans);
   LRF_HIP(hipGetLastError());
   return 0;

@@ -83,7 +83,7 @@ class _RenderFn(torch.autograd.Function):
             rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, flags)
         else:
             rgb, depth = field._native_forward(rays, z, flags, floater)
-            ctx.ws = None
+            ctx.ws, ctx.versions = None, field._param_versions()
         ctx.field, ctx.flags = field, flags
         ctx.save_for_backward(rays, z)
         return rgb, depth
@@ -92,10 +92,14 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_rgb, g_depth):
         rays, z = ctx.saved_tensors
         ws = ctx.ws
-        if ws is not None and ctx.versions != ctx.field._param_versions():
-            ws = None                            # parameters changed since the forward: recompute
+        if ctx.versions is not None and ctx.versions != ctx.field._param_versions():
+            # the reference's autograd raises here too ("modified by an inplace operation"): the
+            # gradients of the recorded forward cannot be formed from updated parameters
+            raise RuntimeError(
+                "localrf_amd: a field parameter was modified (optimizer step, upsample, load_state_dict) "
+                "between forward and backward of the same render graph")
         g_rays, g_params = ctx.field._native_backward(rays, z, ctx.flags, g_rgb, g_depth, saved_ws=ws)
-        ctx.ws = None
+        ctx.ws = None                            # a second backward through this graph recomputes
         return (None, g_rays, None, None, None) + tuple(g_params)
 
 
@@ -255,6 +259,7 @@ class TensorVMSplit(torch.nn.Module):
         # host copies, so the render call never synchronises to read them back
         self._grid_host = [int(g) for g in gridSize]
         self._aabb_host = [float(v) for v in self.aabb.detach().reshape(-1).tolist()]
+        self._aabb_key = (self.aabb.data_ptr(), self.aabb._version)
         self._z_cache = {}
 
     def init_svd_volume(self, res, device):
@@ -350,7 +355,11 @@ class TensorVMSplit(torch.nn.Module):
         changed (optimizer step, upsample tensoRF.py:224-233, load_state_dict, .to())."""
         lib = N.lib()
         ps = self._param_list()
-        key = tuple((p.data_ptr(), p._version) for p in ps) + tuple(self._grid_host)
+        akey = (self.aabb.data_ptr(), self.aabb._version)
+        if akey != getattr(self, "_aabb_key", None):          # load_state_dict / .to() replaced the bbox:
+            self._aabb_host = [float(v) for v in self.aabb.detach().reshape(-1).tolist()]   # kernels read it live,
+            self._aabb_key = akey                             # as normalize_coord does (tensorBase.py:342-345)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + tuple(self._grid_host) + tuple(self._aabb_host)
         if self._cache is not None and key == self._cache_key:
             return
         cp, keep = self._c_params()
@@ -499,8 +508,10 @@ class TensorVMSplit(torch.nn.Module):
             ws = self._ws_bwd
         f = self._c_field()
         st = torch.cuda.current_stream(dev).cuda_stream
+        g_rgb_c = g_rgb.contiguous().float()         # named: must outlive the launch below
+        g_depth_c = g_depth.contiguous().float()
         N.check(lib.lrf_render_bwd(C.byref(f), C.byref(cp), N.ptr(rays), N.ptr(z), R, S, flags,
-                                   N.ptr(g_rgb.contiguous().float()), N.ptr(g_depth.contiguous().float()),
+                                   N.ptr(g_rgb_c), N.ptr(g_depth_c),
                                    C.byref(cg), N.ptr(g_rays), ws.data_ptr(), st), "lrf_render_bwd")
         return g_rays, grads
 

@@ -44,13 +44,16 @@ def get_rays_lean(directions, c2w):
     return c2w[:, :3, 3], rays_d
 
 
-def sixD_to_mtx(r):
-    """Gram-Schmidt 6D -> rotation matrix, columns (b1,b2,b3) (utils/utils.py:381-388)."""
+def sixD_to_mtx(r, reference_cross=True):
+    """Gram-Schmidt 6D -> rotation matrix, columns (b1,b2,b3) (utils/utils.py:381-388).
+    The reference's `torch.cross(b1, b2)` has no `dim`, i.e. it runs over the first axis of size
+    3 -- the view axis when exactly 3 views are stacked.  reference_cross=True reproduces that."""
     a1, a2 = r[..., 0], r[..., 1]
     b1 = a1 / torch.norm(a1, dim=-1)[:, None]
     b2 = a2 - torch.sum(b1 * a2, dim=-1)[:, None] * b1
     b2 = b2 / torch.norm(b2, dim=-1)[:, None]
-    b3 = torch.linalg.cross(b1, b2, dim=-1)
+    dim = 0 if (reference_cross and b1.dim() == 2 and b1.shape[0] == 3) else -1
+    b3 = torch.linalg.cross(b1, b2, dim=dim)
     return torch.stack([b1, b2, b3], dim=-1)
 
 

@@ -61,6 +61,11 @@ class LocalTensorfs(torch.nn.Module):
         self.tensorf_args = tensorf_args
         self.is_refining = False
         self.lr_upsample_reset = lr_upsample_reset
+        # utils/utils.py:386 calls torch.cross without `dim`, which picks the FIRST axis of size 3:
+        # for a batch of exactly 3 views that is the view axis, not xyz.  True reproduces the
+        # reference result (checked against a reference-recorded golden); False = the cross product
+        # the reference meant.  Only batches of exactly 3 views differ.
+        self.reference_cross = True
 
         self.lr_factor = 1
         self.regularize = True
@@ -239,9 +244,13 @@ class LocalTensorfs(torch.nn.Module):
         else:
             r = list(self.r_c2w[starting_id:])
             t = list(self.t_c2w[starting_id:])
+        # with camera priors append_frame stores full [3,3] rotations (local_tensorfs.py:171-176);
+        # sixD_to_mtx reads columns 0 and 1 only (utils/utils.py:381-384): slice before the kernel so
+        # autograd maps the [3,2] gradient back into the [3,3] parameter
+        r = [x if x.shape[-1] == 2 else x[:, :2] for x in r]
         if r[0].is_cuda:                                        # one launch (per 64 frames) each way
-            return pose_assemble(r, t)
-        return torch.cat([sixD_to_mtx(torch.stack(r, 0)), torch.stack(t, 0)[..., None]], dim=-1)
+            return pose_assemble(r, t, cross_over_views=self.reference_cross and len(r) == 3)
+        return torch.cat([sixD_to_mtx(torch.stack(r, 0), self.reference_cross), torch.stack(t, 0)[..., None]], dim=-1)
 
     def get_kwargs(self):
         """local_tensorfs.py:301-324."""

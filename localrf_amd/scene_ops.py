@@ -106,15 +106,16 @@ class _PoseFn(torch.autograd.Function):
         return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
     @staticmethod
-    def forward(ctx, *params):
+    def forward(ctx, quirk, *params):
         V = len(params) // 2
         rs = [_f32c(p) for p in params[:V]]
         ts = [_f32c(p) for p in params[V:]]
         dev = rs[0].device
         c2w = torch.empty(V, 3, 4, dtype=torch.float32, device=dev)
-        N.check(N.lib().lrf_pose_assemble(_PoseFn._ptrs(rs), _PoseFn._ptrs(ts), V, N.ptr(c2w), _stream(dev)),
-                "lrf_pose_assemble")
+        N.check(N.lib().lrf_pose_assemble(_PoseFn._ptrs(rs), _PoseFn._ptrs(ts), V, int(quirk), N.ptr(c2w),
+                                          _stream(dev)), "lrf_pose_assemble")
         ctx.save_for_backward(*rs)
+        ctx.quirk = int(quirk)
         return c2w
 
     @staticmethod
@@ -123,19 +124,24 @@ class _PoseFn(torch.autograd.Function):
         V, dev = len(rs), rs[0].device
         g_r = torch.empty(V, 3, 2, dtype=torch.float32, device=dev)
         g_t = torch.empty(V, 3, dtype=torch.float32, device=dev)
-        N.check(N.lib().lrf_pose_assemble_bwd(_PoseFn._ptrs(rs), V, N.ptr(_f32c(g_c2w)), N.ptr(g_r), N.ptr(g_t),
+        g_c = _f32c(g_c2w)
+        N.check(N.lib().lrf_pose_assemble_bwd(_PoseFn._ptrs(rs), V, ctx.quirk, N.ptr(g_c), N.ptr(g_r), N.ptr(g_t),
                                               _stream(dev)), "lrf_pose_assemble_bwd")
-        return tuple(g_r.unbind(0)) + tuple(g_t.unbind(0))
+        return (None,) + tuple(g_r.unbind(0)) + tuple(g_t.unbind(0))
 
 
-def pose_assemble(r_list, t_list):
+def pose_assemble(r_list, t_list, cross_over_views=False):
     """[V,3,4] camera-to-world from per-frame 6D rotations [3,2] and translations [3]
-    (LocalTensorfs.get_cam2world, local_tensorfs.py:292-299; sixD_to_mtx, utils/utils.py:381-388)."""
+    (LocalTensorfs.get_cam2world, local_tensorfs.py:292-299; sixD_to_mtx, utils/utils.py:381-388).
+    cross_over_views (V == 3 only): b3 = cross(b1, b2) over the VIEW axis, which is what the
+    reference's dim-less torch.cross computes for a batch of exactly three views."""
     _require_gpu(r_list[0])
+    if cross_over_views and len(r_list) != 3:
+        raise ValueError("cross_over_views reproduces a reference quirk that exists for exactly 3 views")
     parts = []
     for lo in range(0, len(r_list), N.LRF_POSE_MAX):
         hi = lo + N.LRF_POSE_MAX
-        parts.append(_PoseFn.apply(*r_list[lo:hi], *t_list[lo:hi]))
+        parts.append(_PoseFn.apply(bool(cross_over_views), *r_list[lo:hi], *t_list[lo:hi]))
     return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
 

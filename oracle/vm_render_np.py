@@ -295,12 +295,14 @@ def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, refine=True,
 
 # ---------------------------------------------------------------- LocalTensorfs side
 def sixd_to_mtx(r):
-    """utils/utils.py:381-388 -- Gram-Schmidt 6D -> 3x3 (columns b1,b2,b3)."""
+    """utils/utils.py:381-388 -- Gram-Schmidt 6D -> 3x3 (columns b1,b2,b3).  The reference's
+    torch.cross has no `dim` and so runs over the first axis of size 3: the VIEW axis when exactly
+    three views are stacked (reproduced here; pinned by tests/golden/sixd_to_mtx.npz)."""
     b1 = r[..., 0]
     b1 = b1 / np.linalg.norm(b1, axis=-1)[:, None]
     b2 = r[..., 1] - (b1 * r[..., 1]).sum(-1)[:, None] * b1
     b2 = b2 / np.linalg.norm(b2, axis=-1)[:, None]
-    b3 = np.cross(b1, b2)
+    b3 = np.cross(b1, b2, axis=0) if r.shape[0] == 3 else np.cross(b1, b2)
     return np.stack([b1, b2, b3], -1).astype(r.dtype)
 
 
@@ -322,9 +324,9 @@ def render_local(fields, world2rf, ray_ids, view_ids, W, H, r_c2w, t_c2w, focal,
     fields: list of fld dicts; world2rf: [F,3]; r_c2w [V,3,2]; t_c2w [V,3];
     blending_weights [V,F]; exposure [V,3,3] or None; z_per_field: list of z arrays."""
     dirs, ij = pixel_rays(ray_ids, W, H, np.float32(focal), np.asarray(center, np.float32))
-    rot = sixd_to_mtx(np.asarray(r_c2w, np.float32))
+    rot = sixd_to_mtx(np.asarray(r_c2w, np.float32)[view_ids])          # get_cam2world(view_ids), :292-299
     per = ray_ids.shape[0] // view_ids.shape[0]
-    rot_r = np.repeat(rot[view_ids], per, 0)
+    rot_r = np.repeat(rot, per, 0)
     t_r = np.repeat(np.asarray(t_c2w, np.float32)[view_ids], per, 0)
     bw = np.repeat(np.asarray(blending_weights, np.float32), per, 0)
     active = np.nonzero(np.asarray(blending_weights).sum(0))[0].tolist()

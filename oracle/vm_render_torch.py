@@ -118,3 +118,85 @@ def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, density_shift=
     if white_bg:
         rgb_map = rgb_map + (1.0 - acc[:, None])
     return rgb_map, depth
+
+
+# ------------------------------------------------------------- rows either side of the path
+def sample_ray_aabb(rays_o, rays_d, aabb, step_size, n_samples, near_far, jitter=None):
+    """models/tensorBase.py:396-417 (TensoRF AABB march; jitter [R,1] replaces rand_like)."""
+    vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+    rate_a = (aabb[1] - rays_o) / vec
+    rate_b = (aabb[0] - rays_o) / vec
+    t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near_far[0], max=near_far[1])
+    rng = torch.arange(n_samples)[None].float()
+    if jitter is not None:
+        rng = rng.repeat(rays_d.shape[-2], 1) + jitter
+    interpx = t_min[..., None] + step_size * rng.to(rays_o.device)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+    outside = ((aabb[0] > pts) | (pts > aabb[1])).any(dim=-1)
+    return pts, interpx, ~outside
+
+
+def sixd_to_mtx(r):
+    """utils/utils.py:381-388.  torch.cross there has no `dim`: it runs over the first axis of size
+    3, i.e. over the VIEWS when exactly three are stacked (a reference quirk, reproduced)."""
+    b1 = r[..., 0]
+    b1 = b1 / torch.norm(b1, dim=-1)[:, None]
+    b2 = r[..., 1] - torch.sum(b1 * r[..., 1], dim=-1)[:, None] * b1
+    b2 = b2 / torch.norm(b2, dim=-1)[:, None]
+    b3 = torch.linalg.cross(b1, b2, dim=0 if (b1.dim() == 2 and b1.shape[0] == 3) else -1)
+    return torch.stack([b1, b2, b3], dim=-1)
+
+
+def density_l1(fld, grid, density_shift=-5.0):
+    """models/tensoRF.py:83-92: every plane x line product over the dense lattice, each plane in
+    its own flattening order, summed element by element; sqrt(clamp(softplus)).mean()."""
+    n = int(grid[0]) * int(grid[1]) * int(grid[2])
+    feat = torch.zeros(n)
+    for p in range(3):
+        pl = fld[f"density_plane.{p}"]
+        ln = fld[f"density_line.{p}"]
+        a = pl.reshape(pl.shape[1], -1)
+        b = ln.reshape(ln.shape[1], -1)
+        feat = feat + torch.bmm(a[..., None], b[:, None]).reshape(a.shape[0], n).sum(0)
+    return torch.sqrt(F.softplus(feat + density_shift).clamp(1e-5)).mean()
+
+
+def tv_loss(fld, kind, weight=1.0):
+    """models/tensoRF.py:94-110 with utils/utils.py:293-309 (TVLoss) as `reg`."""
+    def reg(x):
+        tv = 0
+        if x.shape[2] > 1:
+            tv = tv + torch.pow(x[:, :, 1:, :] - x[:, :, :-1, :], 2).mean()
+        if x.shape[3] > 1:
+            tv = tv + torch.pow(x[:, :, :, 1:] - x[:, :, :, :-1], 2).mean()
+        return weight * 2 * tv
+    total = 0
+    for p in range(3):
+        total = total + reg(fld[f"{kind}_plane.{p}"].transpose(0, 1)) * 1e-2 \
+                      + reg(fld[f"{kind}_line.{p}"].transpose(0, 1)) * 1e-3
+    return total
+
+
+def update_alpha_mask(fld, grid_size, step_size, alpha_mask_thres=1e-4, density_shift=-5.0):
+    """models/tensorBase.py:501-558: dense alpha on the lattice (through the current mask, if any),
+    3x3x3 max-pool, threshold.  Returns the binary volume [gz,gy,gx] (the new mask's alpha_volume)."""
+    aabb = fld["aabb"]
+    lin = [torch.linspace(0, 1, int(g)) for g in grid_size]
+    dense = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)
+    dense = aabb[0] * (1 - dense) + aabb[1] * dense
+    alpha = torch.zeros_like(dense[..., 0])
+    for i in range(int(grid_size[0])):
+        x = dense[i].reshape(-1, 3)
+        keep = torch.ones(x.shape[0], dtype=torch.bool)
+        if fld.get("alphaMask.alpha_volume") is not None:
+            maabb = fld["alphaMask.aabb"]
+            pm = (x - maabb[0]) * (1.0 / (maabb[1] - maabb[0]) * 2) - 1
+            keep = F.grid_sample(fld["alphaMask.alpha_volume"], pm.view(1, -1, 1, 1, 3), align_corners=True).view(-1) > 0
+        sigma = torch.zeros(x.shape[0])
+        if keep.any():
+            u = (x[keep] - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1
+            sigma[keep] = F.softplus(density_feature(fld, u) + density_shift)
+        alpha[i] = (1 - torch.exp(-sigma * step_size)).view(int(grid_size[1]), int(grid_size[2]))
+    alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+    alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(tuple(int(g) for g in grid_size)[::-1])
+    return (alpha >= alpha_mask_thres).float()

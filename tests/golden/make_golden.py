@@ -243,8 +243,279 @@ def case_local_train(LocalTensorfs, name, grid, seed):
     save(name, **arrs)
 
 
+# ----------------------------------------------------------------------------- round 2 cases
+def field_checksum(sd):
+    return np.array([float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))])
+
+
+def case_config2(TensorVMSplit, name):
+    """BASELINE.json configs[1] at full size: 300^3 field (seed 0, regenerated by the tests from the
+    seed and pinned by checksum), ALL 4096 bench rays x 512 samples (N_samples=1536).  Also records,
+    per ray, how close the reference's own weights come to the shading threshold (tensorBase.py:622):
+    a ray whose colour differs by more than the tolerance must be explained by such a sample."""
+    import models.tensorBase as tb
+    f = make_field(TensorVMSplit, (300, 300, 300), 0)
+    rays = make_rays(4096, 1)
+    seen = {}
+    orig = tb.alpha2weights
+
+    def spy(alpha):
+        w, T = orig(alpha)
+        seen["w"] = w.detach().clone()
+        return w, T
+    tb.alpha2weights = spy
+    try:
+        with torch.no_grad():
+            rgb, depth = f(rays.clone(), white_bg=True, is_train=False, N_samples=1536)
+    finally:
+        tb.alpha2weights = orig
+    w = seen["w"]
+    thres = f.rayMarch_weight_thres
+    save(name, rays=rays.numpy(), rgb=rgb.numpy(), depth=depth.numpy(), N_samples=np.array(1536),
+         seed=np.array(0), grid=np.array([300, 300, 300]), field_sum=field_checksum(f.state_dict()),
+         near_thres=(w - thres).abs().amin(-1).numpy(), n_shaded=np.array(int((w > thres).sum())),
+         acc=w.sum(-1).numpy())
+
+
+def pack_grad(arrs, key, g, rng, keep=16384):
+    """Full tensor when small; for the big plane gradients a seeded random subset + max + L2."""
+    g = g.detach().reshape(-1)
+    arrs[f"gmax.{key}"] = np.array(float(g.abs().max()))
+    arrs[f"gl2.{key}"] = np.array(float(g.double().norm()))
+    if g.numel() <= 4 * keep:
+        arrs[f"grad.{key}"] = g.numpy()
+    else:
+        idx = np.sort(rng.choice(g.numel(), keep, replace=False))
+        top = torch.topk(g.abs(), 2048).indices.numpy()          # and the largest entries
+        idx = np.unique(np.concatenate([idx, top]))
+        arrs[f"gidx.{key}"] = idx.astype(np.int64)
+        arrs[f"grad.{key}"] = g.numpy()[idx]
+
+
+def case_train_grad_big(TensorVMSplit, name, grid=(128, 128, 128), R=512, seed=5):
+    """Train-mode forward (recorded jitter, default sample count) + autograd gradients at 128^3;
+    field regenerated from the seed by the tests."""
+    f = make_field(TensorVMSplit, grid, seed, scale_density=3.0)
+    rays = make_rays(R, seed + 1, pinhole=True).requires_grad_(True)
+    h = f.nSamples // 6
+    torch.manual_seed(seed + 2)
+    U, U2 = torch.rand(1, h), torch.rand(1, h)
+    torch.manual_seed(seed + 2)
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=-1)
+    g = torch.Generator().manual_seed(seed + 3)
+    g_rgb, g_depth = torch.randn(R, 3, generator=g), torch.randn(R, generator=g)
+    loss = (rgb * g_rgb).sum() + (depth * g_depth).sum()
+    params = {k: v for k, v in f.named_parameters() if v.requires_grad}
+    grads = torch.autograd.grad(loss, list(params.values()) + [rays], allow_unused=True)
+    arrs = dict(rays=rays.detach().numpy(), U=U[0].numpy(), U2=U2[0].numpy(), nSamples=np.array(f.nSamples),
+                rgb=rgb.detach().numpy(), depth=depth.detach().numpy(), g_rgb=g_rgb.numpy(),
+                g_depth=g_depth.numpy(), grid=np.array(grid), seed=np.array(seed),
+                scale_density=np.array(3.0, np.float32), field_sum=field_checksum(f.state_dict()))
+    rng = np.random.default_rng(seed)
+    for (k, _), gr in zip(list(params.items()) + [("rays", None)], grads):
+        pack_grad(arrs, k, gr if gr is not None else torch.zeros(1), rng)
+    save(name, **arrs)
+
+
+def case_sample_ray(TensorVMSplit, name):
+    """TensorBase.sample_ray (tensorBase.py:396-417; dead code on train.py's path, named by north_star)."""
+    f = make_field(TensorVMSplit, (32, 32, 32), 5)
+    rays = make_rays(64, 9, pinhole=True)
+    rays[0, 4] = 0.0                                     # exercises the d == 0 branch
+    rays[1, :3] = torch.tensor([2.5, 0.1, -0.2])         # origin outside the box
+    with torch.no_grad():
+        pts, t, inside = f.sample_ray(rays[:, :3], rays[:, 3:], is_train=False, N_samples=50)
+        torch.manual_seed(77)
+        U = torch.rand(64, 1)
+        torch.manual_seed(77)
+        pts_j, t_j, inside_j = f.sample_ray(rays[:, :3], rays[:, 3:], is_train=True, N_samples=50)
+    save(name, rays=rays.numpy(), pts=pts.numpy(), t=t.numpy(), inside=inside.numpy(), U=U[:, 0].numpy(),
+         pts_j=pts_j.numpy(), t_j=t_j.numpy(), inside_j=inside_j.numpy(), N_samples=np.array(50),
+         stepSize=np.array(float(f.stepSize)), aabb=f.aabb.numpy(), near_far=np.array(f.near_far, np.float32))
+
+
+def case_reg(TensorVMSplit, name, grid=(20, 24, 28), seed=51):
+    """density_L1 (tensoRF.py:83-92), TV_loss_density / TV_loss_app (tensoRF.py:94-110) with the
+    reference's TVLoss module (utils/utils.py:293-309): values and autograd gradients."""
+    from utils.utils import TVLoss
+    f = make_field(TensorVMSplit, grid, seed, scale_density=20.0)
+    arrs = dict(grid=np.array(grid), seed=np.array(seed), scale_density=np.array(20.0, np.float32),
+                field_sum=field_checksum(f.state_dict()))
+    reg = TVLoss()
+    for key, fn in (("l1", lambda: f.density_L1()), ("tv_density", lambda: f.TV_loss_density(reg)),
+                    ("tv_app", lambda: f.TV_loss_app(reg))):
+        for p in f.parameters():
+            p.grad = None
+        out = fn()
+        out = out.mean() if out.dim() else out
+        out.backward()
+        arrs[f"{key}.value"] = np.array(float(out))
+        for n, p in f.named_parameters():
+            if p.grad is not None:
+                arrs[f"{key}.grad.{n}"] = p.grad.numpy().copy()
+    save(name, **arrs)
+
+
+def case_alpha_mask(TensorVMSplit, name, grid=(40, 36, 44), seed=61):
+    """updateAlphaMask (tensorBase.py:501-536) on a field with real structure (density_shift -10 and
+    strong planes, so a good part of the lattice falls below alphaMask_thres), twice: the second
+    rebuild goes through the first mask (compute_alpha, :538-558)."""
+    f = make_field(TensorVMSplit, grid, seed, scale_density=60.0, density_shift=-10)
+    g1 = tuple(int(x) // 2 for x in grid)
+    quiet(f.updateAlphaMask, g1)
+    m1 = f.alphaMask.alpha_volume.detach().numpy()[0, 0].copy()
+    g2 = tuple(int(x) * 3 // 4 for x in grid)
+    quiet(f.updateAlphaMask, g2)
+    m2 = f.alphaMask.alpha_volume.detach().numpy()[0, 0].copy()
+    rays = make_rays(64, seed + 1)
+    with torch.no_grad():
+        rgb, depth = f(rays.clone(), white_bg=True, is_train=False, N_samples=120)
+    print("alpha mask kept fractions", m1.mean(), m2.mean())
+    assert 0.05 < m1.mean() < 0.95 and 0.05 < m2.mean() < 0.95
+    save(name, grid=np.array(grid), seed=np.array(seed), scale_density=np.array(60.0, np.float32),
+         density_shift=np.array(-10.0, np.float32), field_sum=field_checksum({k: v for k, v in f.state_dict().items() if "alphaMask" not in k}),
+         g1=np.array(g1), g2=np.array(g2), m1=np.packbits(m1.astype(np.uint8)), m2=np.packbits(m2.astype(np.uint8)),
+         m1_shape=np.array(m1.shape), m2_shape=np.array(m2.shape), rays=rays.numpy(), rgb=rgb.numpy(),
+         depth=depth.numpy(), N_samples=np.array(120))
+
+
+def case_sixd(name):
+    """sixD_to_mtx (utils/utils.py:381-388) including its dim-less torch.cross: with exactly three
+    views the cross product runs over the view axis."""
+    import warnings
+    from utils.utils import sixD_to_mtx
+    arrs = {}
+    g = torch.Generator().manual_seed(7)
+    for V in (1, 2, 3, 4, 7):
+        r = (torch.eye(3, 2)[None] + 0.3 * torch.randn(V, 3, 2, generator=g)).requires_grad_(True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = sixD_to_mtx(r)
+        ct = torch.randn(V, 3, 3, generator=g)
+        (m * ct).sum().backward()
+        arrs.update({f"r{V}": r.detach().numpy(), f"m{V}": m.detach().numpy(), f"ct{V}": ct.numpy(),
+                     f"g{V}": r.grad.numpy()})
+    save(name, **arrs)
+
+
+def build_local(LocalTensorfs, grid, seed, WH, camera_prior=None, lr_i=1e-3):
+    torch.manual_seed(seed)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    return quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=WH,
+                 n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+                 lr_i_init=lr_i, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+                 lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+                 camera_prior=camera_prior, device="cpu", lr_upsample_reset=True,
+                 aabb=aabb, gridSize=list(grid), **FIELD_KW)
+
+
+def small_state(lt):
+    """Everything in the state dict except the field tensors (those are regenerated from the seed)."""
+    return {f"lt.{k}": v.detach().numpy() for k, v in lt.state_dict().items() if not k.startswith("tensorfs.")}
+
+
+def case_local_train_views(LocalTensorfs, name, grid, seed, view_ids, camera_prior=False):
+    """LocalTensorfs train-mode forward + gradients with the field regenerated from the seed:
+    (a) exactly 3 views (the torch.cross quirk of sixD_to_mtx), (b) camera priors, which make
+    r_c2w [3,3] parameters (local_tensorfs.py:171-176)."""
+    W, H = 40, 30
+    prior = None
+    g = torch.Generator().manual_seed(seed + 1)
+    if camera_prior:
+        rel = []
+        for _ in range(8):
+            a = 0.08 * torch.randn(3, generator=g)
+            K = torch.tensor([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            m = torch.eye(4)
+            m[:3, :3] = torch.matrix_exp(K)
+            m[:3, 3] = 0.05 * torch.randn(3, generator=g)
+            rel.append(m)
+        prior = {"transforms": {"fl_x": 30.0, "w": 44.0}, "rel_poses": torch.stack(rel)}
+    lt = build_local(LocalTensorfs, grid, seed, (W, H), prior)
+    with torch.no_grad():
+        for i in range(len(lt.r_c2w)):
+            lt.t_c2w[i].add_(0.05 * torch.randn(3, generator=g))
+            lt.r_c2w[i].add_(0.05 * torch.randn(*lt.r_c2w[i].shape, generator=g))
+            lt.exposure[i].add_(0.1 * torch.randn(3, 3, generator=g))
+        for p in lt.tensorfs[-1].density_plane:
+            p.mul_(3.0)
+    view_ids = torch.tensor(view_ids)
+    per = 40
+    ray_ids = torch.randint(0, W * H, (view_ids.numel() * per,), generator=g)
+    h = lt.tensorfs[-1].nSamples // 6
+    torch.manual_seed(seed + 2)
+    U, U2 = torch.rand(1, h), torch.rand(1, h)
+    torch.manual_seed(seed + 2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rgbs, depths, dirs, ij = lt(ray_ids, view_ids, W, H, is_train=True, white_bg=True)
+    R = ray_ids.numel()
+    g_rgb, g_depth = torch.randn(R, 3, generator=g), torch.randn(R, generator=g)
+    ((rgbs * g_rgb).sum() + (depths * g_depth).sum()).backward()
+    arrs = dict(ray_ids=ray_ids.numpy(), view_ids=view_ids.numpy(), W=np.array(W), H=np.array(H),
+                U=U[0].numpy(), U2=U2[0].numpy(), rgbs=rgbs.detach().numpy(), depths=depths.detach().numpy(),
+                g_rgb=g_rgb.numpy(), g_depth=g_depth.numpy(), grid=np.array(grid), seed=np.array(seed),
+                field_sum=field_checksum({k: v for k, v in lt.state_dict().items() if k.startswith("tensorfs.")}))
+    if prior is not None:
+        arrs["rel_poses"] = prior["rel_poses"].numpy()
+    for k, p in lt.named_parameters():
+        if p.grad is not None and not k.startswith("tensorfs."):
+            arrs[f"grad.{k}"] = p.grad.numpy()
+    rng = np.random.default_rng(seed)
+    for k, p in lt.named_parameters():
+        if p.grad is not None and k.startswith("tensorfs."):
+            pack_grad(arrs, k, p.grad, rng, keep=4096)
+    arrs.update(small_state(lt))
+    save(name, **arrs)
+
+
+def case_config3(LocalTensorfs, name, grid=(300, 300, 300), seed=33):
+    """BASELINE.json configs[2] at full size: 4 overlapping 300^3 fields, 4096 rays, blended with
+    explicit weights, exposure on.  Fields are regenerated from the seed by the tests."""
+    W, H = 64, 48
+    lt = build_local(LocalTensorfs, grid, seed, (W, H), lr_i=0)
+    g = torch.Generator().manual_seed(seed + 1)
+    for _ in range(3):
+        for _ in range(3):
+            quiet(lt.append_frame)
+            with torch.no_grad():
+                lt.t_c2w[-1].add_(0.05 * torch.randn(3, generator=g))
+                lt.r_c2w[-1].add_(0.05 * torch.randn(3, 2, generator=g))
+                lt.exposure[-1].add_(0.05 * torch.randn(3, 3, generator=g))
+        quiet(lt.append_rf, 3)
+    n_frames = len(lt.r_c2w)
+    view_ids = torch.tensor([2, 7, 11, n_frames - 1])
+    per = 1024
+    ray_ids = torch.randint(0, W * H, (view_ids.numel() * per,), generator=g)
+    bw = torch.tensor([[.1, .2, .3, .4]]).repeat(view_ids.numel(), 1)
+    with torch.no_grad():
+        rgbs, depths, dirs, ij = lt(ray_ids, view_ids, W, H, is_train=False,
+                                    blending_weights=bw.clone(), chunk=4096, floater_thresh=0.0)
+    arrs = dict(ray_ids=ray_ids.numpy(), view_ids=view_ids.numpy(), W=np.array(W), H=np.array(H), bw=bw.numpy(),
+                rgbs=rgbs.numpy(), depths=depths.numpy(), grid=np.array(grid), seed=np.array(seed),
+                n_fields=np.array(len(lt.tensorfs)), nSamples=np.array([f.nSamples for f in lt.tensorfs]),
+                field_sum=field_checksum({k: v for k, v in lt.state_dict().items() if k.startswith("tensorfs.")}))
+    arrs.update(small_state(lt))
+    save(name, **arrs)
+
+
 def main():
     TensorVMSplit, AlphaGridMask, LocalTensorfs = import_reference()
+    only = set(sys.argv[1:])
+    if only:                                    # python make_golden.py config2 sixd ...  (round-2 cases by key)
+        r2 = {"config2": lambda: case_config2(TensorVMSplit, "config2_300cube.npz"),
+              "train128": lambda: case_train_grad_big(TensorVMSplit, "field_128_train_grad.npz"),
+              "sample_ray": lambda: case_sample_ray(TensorVMSplit, "sample_ray.npz"),
+              "reg": lambda: case_reg(TensorVMSplit, "reg_losses.npz"),
+              "alpha_mask": lambda: case_alpha_mask(TensorVMSplit, "alpha_mask_rebuild.npz"),
+              "sixd": lambda: case_sixd("sixd_to_mtx.npz"),
+              "local3": lambda: case_local_train_views(LocalTensorfs, "local_train_3views.npz", (20, 24, 28), 43, [0, 2, 4]),
+              "prior": lambda: case_local_train_views(LocalTensorfs, "local_train_prior.npz", (20, 24, 28), 45, [0, 1, 3, 4], camera_prior=True),
+              "config3": lambda: case_config3(LocalTensorfs, "config3_4x300.npz")}
+        for k in only:
+            r2[k]()
+        return
     # non-cubic grid: catches axis-order mistakes (first coord indexes W)
     case_field(TensorVMSplit, AlphaGridMask, "field_small_eval.npz", (20, 24, 28), 64, 96, 11,
                scale_density=3.0)
@@ -259,6 +530,16 @@ def main():
     case_train_grad(TensorVMSplit, "field_small_train_grad.npz", (20, 24, 28), 48, 96, 21)
     case_local(LocalTensorfs, "local_4fields.npz", (16, 16, 16), 31)
     case_local_train(LocalTensorfs, "local_train_grad.npz", (20, 24, 28), 41)
+    # round 2
+    case_config2(TensorVMSplit, "config2_300cube.npz")
+    case_train_grad_big(TensorVMSplit, "field_128_train_grad.npz")
+    case_sample_ray(TensorVMSplit, "sample_ray.npz")
+    case_reg(TensorVMSplit, "reg_losses.npz")
+    case_alpha_mask(TensorVMSplit, "alpha_mask_rebuild.npz")
+    case_sixd("sixd_to_mtx.npz")
+    case_local_train_views(LocalTensorfs, "local_train_3views.npz", (20, 24, 28), 43, [0, 2, 4])
+    case_local_train_views(LocalTensorfs, "local_train_prior.npz", (20, 24, 28), 45, [0, 1, 3, 4], camera_prior=True)
+    case_config3(LocalTensorfs, "config3_4x300.npz")
 
 
 if __name__ == "__main__":

@@ -192,7 +192,7 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert b"null argument" in lib.lrf_last_error()
     assert lib.lrf_scene_rays(None, 4, 2, None, None, 1, None, None, 8, 8, 0, None, None, None, st) != 0
     assert lib.lrf_scene_blend(None, None, None, None, 4, 2, 1, None, None, None, st) != 0
-    assert lib.lrf_pose_assemble(None, None, 1, None, st) != 0
+    assert lib.lrf_pose_assemble(None, None, 1, 0, None, st) != 0
     hw = (C.c_int32 * 3)(64, 64, 64)
     ll = (C.c_int32 * 3)(8, 8, 9)                                              # planes x lines spanning different lattices
     assert lib.lrf_density_l1_fwd(None, None, hw, ll, -5.0, 0, None, None, st) != 0

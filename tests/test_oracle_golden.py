@@ -226,3 +226,188 @@ def test_scene_chain_and_port_match_reference_train_golden():
         assert np.abs(leaf.grad.numpy() - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), k
         checked += 1
     assert checked >= 4 * 3 + 2
+
+
+
+# ----------------------------------------------------------------------------- round-2 goldens
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_sample_ray_aabb_matches_reference():
+    """TensorBase.sample_ray (tensorBase.py:396-417) recorded from the reference, eval and jittered."""
+    import torch
+    from oracle import vm_render_torch as ot
+    g = load_golden("sample_ray")
+    o, d = g["rays"][:, :3], g["rays"][:, 3:]
+    nf = [float(v) for v in g["near_far"]]
+    for jit, sfx in ((None, ""), (g["U"], "_j")):
+        pts, t, inside = oracle.sample_ray_aabb(o, d, g["aabb"], float(g["stepSize"]), int(g["N_samples"]), nf, jitter=jit)
+        assert np.abs(t - g["t" + sfx]).max() < 1e-6 and np.abs(pts - g["pts" + sfx]).max() < 2e-5
+        assert (inside != g["inside" + sfx]).mean() < 1e-3          # points within fp32 rounding of a box face
+        tp, tt, ti = ot.sample_ray_aabb(_t(o), _t(d), _t(g["aabb"]), float(g["stepSize"]), int(g["N_samples"]), nf,
+                                        jitter=None if jit is None else _t(jit)[:, None])
+        assert torch.equal(tt, _t(g["t" + sfx])) and torch.equal(tp, _t(g["pts" + sfx]))
+        assert torch.equal(ti, _t(g["inside" + sfx]))
+
+
+def test_sixd_to_mtx_matches_reference_including_the_three_view_case():
+    import torch
+    from oracle import vm_render_torch as ot
+    from localrf_amd.rays import sixD_to_mtx
+    g = load_golden("sixd_to_mtx")
+    for V in (1, 2, 3, 4, 7):
+        assert np.abs(oracle.sixd_to_mtx(g[f"r{V}"]) - g[f"m{V}"]).max() < 1e-6, V
+        for fn in (ot.sixd_to_mtx, sixD_to_mtx):
+            r = _t(g[f"r{V}"]).requires_grad_(True)
+            m = fn(r)
+            assert np.abs(m.detach().numpy() - g[f"m{V}"]).max() < 1e-6, V
+            (m * _t(g[f"ct{V}"])).sum().backward()
+            assert np.abs(r.grad.numpy() - g[f"g{V}"]).max() < 1e-5, V
+    # the quirk is real: for 3 views the result is not a rotation
+    m3 = g["m3"]
+    assert np.abs(np.einsum("vij,vkj->vik", m3, m3) - np.eye(3)).max() > 1e-2
+    assert np.abs(sixD_to_mtx(_t(g["r3"]), reference_cross=False).numpy() - m3).max() > 1e-2
+
+
+def test_regularisers_match_reference():
+    """density_L1 / TV losses: values and autograd gradients recorded from the reference."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import field_from_seed
+    g = load_golden("reg_losses")
+    f = field_from_seed(g)
+    fld = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and ("plane" in k or "line" in k))
+           for k, v in f.state_dict().items()}
+    for key, fn in (("l1", lambda: ot.density_l1(fld, g["grid"])), ("tv_density", lambda: ot.tv_loss(fld, "density")),
+                    ("tv_app", lambda: ot.tv_loss(fld, "app"))):
+        for v in fld.values():
+            v.grad = None
+        out = fn()
+        out.backward()
+        ref = float(g[key + ".value"])
+        assert abs(float(out) - ref) <= 2e-6 * abs(ref), key
+        n = 0
+        for k, v in fld.items():
+            gk = f"{key}.grad.{k}"
+            if gk in g:
+                assert np.abs(v.grad.numpy() - g[gk]).max() <= 1e-5 * max(np.abs(g[gk]).max(), 1e-12), gk
+                n += 1
+        assert n == 6, (key, n)
+
+
+def test_alpha_mask_rebuild_matches_reference():
+    """updateAlphaMask (tensorBase.py:501-536): identical binary volume, also through an existing mask."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import field_from_seed
+    g = load_golden("alpha_mask_rebuild")
+    f = field_from_seed(g)
+    fld = dict(f.state_dict())
+    step = float(f.stepSize)
+    m1 = ot.update_alpha_mask(fld, g["g1"], step, 1e-4, float(g["density_shift"]))
+    ref1 = np.unpackbits(g["m1"])[:int(np.prod(g["m1_shape"]))].reshape(g["m1_shape"])
+    assert (m1.numpy() == ref1).all() and 0.05 < ref1.mean() < 0.95
+    fld["alphaMask.alpha_volume"] = m1[None, None]
+    fld["alphaMask.aabb"] = fld["aabb"]
+    m2 = ot.update_alpha_mask(fld, g["g2"], step, 1e-4, float(g["density_shift"]))
+    ref2 = np.unpackbits(g["m2"])[:int(np.prod(g["m2_shape"]))].reshape(g["m2_shape"])
+    assert (m2.numpy() == ref2).all()
+    fld["alphaMask.alpha_volume"] = m2[None, None]
+    with torch.no_grad():
+        rgb, depth = ot.render_field(fld, _t(g["rays"]), ot.z_schedule(int(g["N_samples"])), True, 0.0,
+                                     density_shift=float(g["density_shift"]))
+    assert rel_err(rgb.numpy(), g["rgb"]) < 2e-6 and rel_err(depth.numpy(), g["depth"]) < 2e-6
+
+
+def test_config2_full_size_port_vs_reference_golden():
+    """BASELINE.json configs[1] (300^3, 512 samples): seed-regenerated field, a 256-ray subset of the
+    recorded 4096 through the ATen-op port.  (The HIP path is checked on all 4096 in -m gpu.)"""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import field_from_seed
+    g = load_golden("config2_300cube")
+    f = field_from_seed(g)
+    fld = dict(f.state_dict())
+    idx = np.arange(0, 4096, 16)
+    with torch.no_grad():
+        rgb, depth = ot.render_field(fld, _t(g["rays"][idx]), ot.z_schedule(1536), True, 0.0)
+    e = np.abs(rgb.numpy() - g["rgb"][idx]).max(-1)
+    flips = e > 1e-4                                   # a sample sitting on the weight > 1e-3 threshold
+    assert flips.sum() <= 1 and (g["near_thres"][idx][flips] < 1e-6).all()
+    assert rel_err(rgb.numpy()[~flips], g["rgb"][idx][~flips]) < 5e-6
+    assert rel_err(depth.numpy(), g["depth"][idx]) < 5e-6
+    assert 0.3 < int(g["n_shaded"]) / (4096 * 512) < 0.4
+
+
+def test_train_grad_128_port_vs_reference_golden():
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import field_from_seed, packed_grad_check
+    g = load_golden("field_128_train_grad")
+    f = field_from_seed(g)
+    fld = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    names = [k for k in fld if ("plane" in k or "line" in k or "basis" in k or "renderModule" in k)]
+    for k in names:
+        fld[k].requires_grad_(True)
+    rays = _t(g["rays"]).requires_grad_(True)
+    z = ot.z_schedule(int(g["nSamples"]), jitter=(_t(g["U"]), _t(g["U2"])))
+    rgb, depth = ot.render_field(fld, rays, z, True, 0.0)
+    assert rel_err(rgb.detach().numpy(), g["rgb"]) < 5e-6
+    ((rgb * _t(g["g_rgb"])).sum() + (depth * _t(g["g_depth"])).sum()).backward()
+    for k in names:
+        packed_grad_check(g, k, fld[k].grad.numpy(), 2e-5)
+    packed_grad_check(g, "rays", rays.grad.numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("name,prior", [("local_train_3views", False), ("local_train_prior", True)])
+def test_local_seeded_goldens_regenerate_and_match_port(name, prior):
+    """LocalTensorfs built by THIS package from the golden's seed has the reference's parameters
+    (checksum), and scene chain + ATen port reproduce the recorded train forward / pose gradients --
+    for exactly three views (torch.cross quirk) and with camera priors ([3,3] r_c2w parameters)."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import local_from_golden_seed, torch_scene_chain
+    g = load_golden(name)
+    cp = {"transforms": {"fl_x": 30.0, "w": 44.0}, "rel_poses": _t(g["rel_poses"])} if prior else None
+    lt = local_from_golden_seed(g, camera_prior=cp, scale_density_last=3.0)
+    assert tuple(lt.r_c2w[0].shape) == ((3, 3) if prior else (3, 2))
+    sd = lt.state_dict()
+    W, H = int(g["W"]), int(g["H"])
+    ray_ids, view_ids = _t(g["ray_ids"]), [int(v) for v in g["view_ids"]]
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in sd
+              if k.split(".")[0] in ("r_c2w", "t_c2w", "exposure", "focal_offset", "center_rel")}
+    focal = sd["init_focal"] * leaves["focal_offset"]
+    center = torch.tensor([float(W), float(H)]) * leaves["center_rel"]
+    r = torch.stack([leaves[f"r_c2w.{v}"] for v in view_ids])
+    t = torch.stack([leaves[f"t_c2w.{v}"] for v in view_ids])
+    c2w = torch.cat([ot.sixd_to_mtx(r), t[..., None]], -1)
+    per = ray_ids.numel() // len(view_ids)
+    rays, dirs, ij = torch_scene_chain(ray_ids, c2w, sd["world2rf.0"][None], focal, center, per, W, H, False)
+    fld = {k[len("tensorfs.0."):]: v for k, v in sd.items() if k.startswith("tensorfs.0.")}
+    z = ot.z_schedule(int(lt.tensorfs[0].nSamples), jitter=(_t(g["U"]), _t(g["U2"])))
+    rgb, depth = ot.render_field(fld, rays[0], z, True, 0.0)
+    ex = torch.stack([leaves[f"exposure.{v}"] for v in view_ids]).repeat_interleave(per, 0)
+    rgbs = torch.bmm(ex, rgb[..., None])[..., 0].clamp(0, 1)
+    assert rel_err(rgbs.detach().numpy(), g["rgbs"]) < 5e-6 and rel_err(depth.detach().numpy(), g["depths"]) < 5e-6
+    ((rgbs * _t(g["g_rgb"])).sum() + (depth * _t(g["g_depth"])).sum()).backward()
+    n = 0
+    for k, leaf in leaves.items():
+        if ("grad." + k) in g:
+            ref = g["grad." + k]
+            got = np.zeros_like(ref) if leaf.grad is None else leaf.grad.numpy()   # the reference stacks every
+            assert got.shape == ref.shape, k                                       # exposure: unused ones get zeros
+            assert np.abs(got - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-6), k
+            n += 1
+    assert n >= 3 * len(view_ids)
+
+
+def test_config3_seeded_scene_regenerates():
+    """BASELINE.json configs[2] at full size (4 x 300^3): the scene regrown from the seed by this
+    package has the reference's fields (checksum) and blending weights; rendering is checked in -m gpu."""
+    from util import local_from_golden_seed
+    g = load_golden("config3_4x300")
+    lt = local_from_golden_seed(g, lr_i=0, n_grow=3)
+    assert len(lt.tensorfs) == int(g["n_fields"]) == 4
+    assert [f.nSamples for f in lt.tensorfs] == [int(v) for v in g["nSamples"]]

@@ -85,3 +85,76 @@ def torch_scene_chain(ray_ids, c2w, shifts, focal, center, per_view, W, H, fov36
         o, d = get_rays_lean(dirs, m.repeat_interleave(per_view, dim=0))
         rays.append(torch.cat([o, d], -1))
     return torch.stack(rays, 0), dirs, torch.stack([col, row], -1)
+
+
+# ----------------------------------------------------------------- seed-regenerated goldens (round 2)
+def state_checksum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))
+
+
+def field_from_seed(g, device="cpu", **over):
+    """Rebuild the field a golden was recorded on from its seed (the package creates parameters in
+    the reference's order, so torch.manual_seed(seed) reproduces it); verified by checksum."""
+    if "density_shift" in g:
+        over.setdefault("density_shift", float(g["density_shift"]))
+    f = quiet(make_field, [int(v) for v in g["grid"]], "cpu", seed=int(g["seed"]), **over)
+    sc = float(g["scale_density"]) if "scale_density" in g else 1.0
+    if sc != 1.0:
+        with torch.no_grad():
+            for p in f.density_plane:
+                p.mul_(sc)
+    got = state_checksum(f.state_dict())
+    want = float(g["field_sum"][0])
+    assert abs(got - want) <= 1e-6 * want, ("seeded field differs from the reference's", got, want)
+    return f.to(device) if str(device) != "cpu" else f
+
+
+def packed_grad_check(g, key, grad, tol, floor=1e-12):
+    """Compare a gradient tensor with a golden written by make_golden.pack_grad (full tensor, or a
+    seeded subset + the largest entries + max + L2).  Returns max|diff| / max|ref|."""
+    a = np.asarray(grad, np.float64).reshape(-1)
+    ref = g["grad." + key].astype(np.float64).reshape(-1)
+    if ("gidx." + key) in g:
+        a = a[g["gidx." + key]]
+    gmax = max(float(g["gmax." + key]), floor)
+    err = float(np.abs(a - ref).max() / gmax)
+    assert err <= tol, (key, err, tol)
+    return err
+
+
+def local_from_golden_seed(g, device="cpu", camera_prior=None, lr_i=1e-3, n_grow=0, scale_density_last=1.0):
+    """LocalTensorfs rebuilt from the seed of a golden written by make_golden.build_local (+ the
+    recorded poses / exposure / intrinsics loaded on top); fields verified by checksum."""
+    from localrf_amd import LocalTensorfs
+    torch.manual_seed(int(g["seed"]))
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=(int(g["W"]), int(g["H"])),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=lr_i, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=camera_prior, device="cpu", lr_upsample_reset=True,
+               aabb=aabb, gridSize=[int(v) for v in g["grid"]], **FIELD_KW)
+    for _ in range(n_grow):                       # make_golden.case_config3: 3 x (3 frames, 1 field)
+        for _ in range(3):
+            quiet(lt.append_frame)
+        quiet(lt.append_rf, 3)
+    small = {k[3:]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items() if k.startswith("lt.")}
+    sd = lt.state_dict()
+    missing = [k for k in sd if not k.startswith("tensorfs.") and k not in small]
+    assert not missing, missing
+    with torch.no_grad():
+        for k, v in small.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(v)
+        if scale_density_last != 1.0:
+            for p in lt.tensorfs[-1].density_plane:
+                p.mul_(scale_density_last)
+    got = state_checksum({k: v for k, v in lt.state_dict().items() if k.startswith("tensorfs.")})
+    want = float(g["field_sum"][0])
+    assert abs(got - want) <= 1e-6 * want, ("seeded fields differ from the reference's", got, want)
+    if str(device) != "cpu":
+        lt = lt.to(device)
+        lt.device = torch.device(device)
+        for f in lt.tensorfs:
+            f.to(device)
+    return lt
