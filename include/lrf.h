@@ -21,7 +21,9 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 1
+#define LRF_ABI_VERSION 2
+#define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
+#define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
 /* Fixed shape of the VM field this build is specialised for (opt.py:117-119,155-157:
  * n_lamb_sigma=[8,8,8], n_lamb_sh=[24,24,24], data_dim_color=27, featureC=128). */
@@ -36,6 +38,8 @@ extern "C" {
 #define LRF_FLAG_MLP_VALU   4u   /* debug engine: colour MLP on the vector ALU, natural-layout weights */
 #define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
                                     split-bf16 (hi+lo, 3-term) MFMA chain */
+#define LRF_FLAG_MLP_FUSED  32u  /* colour stage as round 1's single fused kernel (k_shade_bf16) instead of the
+                                  * default k_app + k_mlp pair; same arithmetic, bit-identical results */
 #define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
@@ -70,6 +74,11 @@ typedef struct LrfField {
   float   density_shift;   /* tensorBase.py:497 */
   float   distance_scale;  /* tensorBase.py:610 */
   float   weight_thres;    /* rayMarch_weight_thres, tensorBase.py:622 */
+  float   term_T;          /* early termination of the march: once the transmittance entering a 64-sample
+                            * chunk is below term_T the remaining density lookups are skipped and those
+                            * samples count as empty (the forced last sample takes the rest).  No sample
+                            * behind that point can pass weight_thres; sum(w z) moves by <= term_T * z_max.
+                            * 0 = off (the reference evaluates every sample, tensorBase.py:600-610). */
   /* natural-layout MLP weights, used only by the LRF_FLAG_MLP_VALU debug engine */
   const float* basis; const float* w1; const float* b1;
   const float* w2; const float* b2; const float* w3; const float* b3;
@@ -89,6 +98,7 @@ int         lrf_abi_version(void);
 /* Debug: when set (device buffer of R*S*64 floats), the split-bf16 shade kernel stores 16
  * intermediate values per (compact sample, lane group); NULL (default) disables it. */
 void        lrf_debug_set_dump(float* buf);
+void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);
 
 /* Bytes of the layout cache for a grid (x,y,z). */
@@ -111,7 +121,7 @@ int lrf_render_fwd(const LrfField* f, const float* rays, const float* z,
                    void* workspace, void* stream);
 
 /* Measurement variant of lrf_render_fwd (bench.py only): brackets each kernel with HIP
- * events on `stream`, SYNCHRONISES, and returns ms_out[4] (host) = {march, shade, finalize,
+ * events on `stream`, SYNCHRONISES, and returns ms_out[5] (host) = {march, shade, finalize,
  * total} plus the number of shaded samples (sum over rays of weight > thres). */
 int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            int32_t R, int32_t S, uint32_t flags, float floater_thresh,
@@ -222,6 +232,17 @@ int lrf_pose_assemble(const float* const* r6d, const float* const* trans, int32_
 /* g_cam2world [V,3,4] -> g_r6d [V,3,2], g_trans [V,3] */
 int lrf_pose_assemble_bwd(const float* const* r6d, int32_t V, int32_t cross_views, const float* g_cam2world,
                           float* g_r6d, float* g_trans, void* stream);
+
+/* Alpha-mask rebuild on the device: TensorBase.getDenseAlpha + updateAlphaMask
+ * (tensorBase.py:501-536) as two launches, no host synchronisation.
+ * lrf_dense_alpha: alpha = 1 - exp(-sigma * length) at every point of the gx x gy x gz lattice spanning the
+ * field aabb (lin_* = device arrays torch.linspace(0, 1, g), as :504-508), through the field's CURRENT mask
+ * when it has one (compute_alpha, :538-558); output [gz][gy][gx], the order :523 transposes to.
+ * lrf_alpha_pool_threshold: clamp(0,1), 3x3x3 max-pool (stride 1, padding 1), out = pooled >= thres ? 1 : 0. */
+int lrf_dense_alpha(const LrfField* f, const float* lin_x, const float* lin_y, const float* lin_z,
+                    int32_t gx, int32_t gy, int32_t gz, float length, uint32_t flags, float* alpha, void* stream);
+int lrf_alpha_pool_threshold(const float* alpha, int32_t gx, int32_t gy, int32_t gz, float thres, float* out,
+                             void* stream);
 
 /* TV regulariser (utils/utils.py:293-309 as applied by tensoRF.py:94-110; weights 0 by default,
  * opt.py:112-113): loss = sum_t scale_t * 2 w (sum_h (dx)^2 / (C (H-1) W) + sum_w (dx)^2 / (C H (W-1)))

@@ -13,6 +13,7 @@ LRF_FLAG_RELU_DENS = 2
 LRF_FLAG_MLP_VALU = 4
 LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
+LRF_FLAG_MLP_FUSED = 32
 
 _f = C.c_void_p  # device float*
 
@@ -28,6 +29,7 @@ class LrfField(C.Structure):
     _fields_ = [("cache", C.c_void_p), ("alpha_vol", _f), ("alpha_dim", C.c_int32 * 3),
                 ("alpha_aabb", C.c_float * 6), ("aabb", C.c_float * 6), ("grid", C.c_int32 * 3),
                 ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
+                ("term_T", C.c_float),
                 ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
 
 
@@ -55,6 +57,7 @@ SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
     "lrf_last_error": (C.c_char_p, []),
     "lrf_debug_set_dump": (None, [C.c_void_p]),
+    "lrf_debug_set_mlp_policy": (None, [C.c_int]),
     "lrf_cache_bytes": (C.c_size_t, [C.POINTER(C.c_int32)]),
     "lrf_pack_field": (C.c_int, [C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),
     "lrf_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
@@ -80,6 +83,9 @@ SYMBOLS = {
                                      C.c_void_p, _f, C.POINTER(_f), C.POINTER(_f), C.c_void_p]),
     "lrf_pose_assemble": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_pose_assemble_bwd": (C.c_int, [C.POINTER(_f), C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
+    "lrf_dense_alpha": (C.c_int, [C.POINTER(LrfField), _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                  C.c_uint32, _f, C.c_void_p]),
+    "lrf_alpha_pool_threshold": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_float, _f, C.c_void_p]),
     "lrf_tv_workspace": (C.c_size_t, [C.POINTER(LrfTvSeg), C.c_int32]),
     "lrf_tv_loss_fwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, C.c_void_p, _f, C.c_void_p]),
     "lrf_tv_loss_bwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, _f, C.c_void_p]),
@@ -112,7 +118,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if h.lrf_abi_version() != 1:
+        if h.lrf_abi_version() != 2:
             raise NativeError("localrf_amd: ABI version mismatch")
         _lib = h
     return _lib

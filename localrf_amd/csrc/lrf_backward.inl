@@ -1212,7 +1212,8 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
                                     uint32_t flags, float* rgb, float* depth, void* workspace, void* stream) {
   using namespace lrf;
   if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd_train: null argument");
-  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd_train: need R > 0 and 2 <= S <= 4096");
+  if (R <= 0 || S < 2 || S > LRF_MAX_S_TRAIN)
+    return set_err("lrf_render_fwd_train: need R > 0 and 2 <= S <= LRF_MAX_S_TRAIN (2048: the per-ray backward keeps 16 B per sample in LDS)");
   if (flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))
     return set_err("lrf_render_fwd_train: the row-saving forward runs the split-bf16 engine only");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1236,13 +1237,31 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   using namespace lrf;
   if (!f || !f->cache || !p || !rays || !z || !g_rgb || !g_depth || !g || !g_rays || !workspace)
     return set_err("lrf_render_bwd: null argument");
-  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_bwd: need R > 0 and 2 <= S <= 4096");
+  if (R <= 0 || S < 2 || S > LRF_MAX_S_TRAIN)
+    return set_err("lrf_render_bwd: need R > 0 and 2 <= S <= LRF_MAX_S_TRAIN (2048: the per-ray backward keeps 16 B per sample in LDS)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const DField d = make_dfield(f);
   const Layout L = make_layout(f->grid);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
   const int cus = device_cus();
+  {
+    static bool lds_attr_done[64] = {};    // dynamic LDS above 64 KB has to be opted into once per device
+    int dev_id = 0;
+    LRF_HIP(hipGetDevice(&dev_id));
+    bool& lds_attr_set = lds_attr_done[dev_id & 63];
+    if (!lds_attr_set) {
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true, 1024>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4));
+      lds_attr_set = true;
+    }
+  }
   LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
   hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
@@ -1286,21 +1305,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // binned scatter of the plane/line gradients: density entries (all samples), then appearance rows
   const BinGeom bg = make_bins(L);
   if (bg.total > BIN_MAX) return set_err("lrf_render_bwd: grid too large for the tile binning (BIN_MAX)");
-  {
-    static bool lds_attr_done[64] = {};    // dynamic LDS above 64 KB has to be opted into once per device
-    int dev_id = 0;
-    LRF_HIP(hipGetDevice(&dev_id));
-    bool& lds_attr_set = lds_attr_done[dev_id & 63];
-    if (!lds_attr_set) {
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true, 1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      lds_attr_set = true;
-    }
-  }
   const int nblk = (int)((b.nmax + BIN_CHUNK - 1) / BIN_CHUNK);
   for (int app = 0; app < 2; ++app) {
     LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * bg.total, st));

@@ -83,7 +83,9 @@ struct DField {
   const float* alpha_vol; int ax, ay, az;
   float m_lo[3], m_inv[3];     // alpha-mask aabb: lo and 2/size   (tensorBase.py:57-58)
   float lo[3], inv[3];         // field aabb: lo and 2/size        (tensorBase.py:342-345)
+  float hi[3];                 // field aabb: hi (lattice of the alpha-mask rebuild)
   float density_shift, distance_scale, weight_thres;
+  float term_T;                // early termination: skip density gathers once transmittance < term_T (0 = off)
   const float* basis; const float* w1; const float* b1; const float* w2; const float* b2;
   const float* w3; const float* b3;
   float* dump;                 // debug: per-sample stage values (lrf_debug_set_dump), else null

@@ -180,26 +180,46 @@ __global__ __launch_bounds__(256) void k_march(
   const bool relu = flags & LRF_FLAG_RELU_DENS;
   const int nchunk = (S + 63) >> 6;
 
-  // pass A: alpha per sample -> LDS
-  for (int c = 0; c < nchunk; ++c) {
-    const int k = (c << 6) + lane;
-    float alpha = 0.0f, fk = -INFINITY;
-    if (k < S - 1) {                               // last sample is never valid (:600)
-      const float zk = z[k];
-      float x[3], u[3];
-      sample_point(f, o, dh, zk, x, u);
-      bool valid = true;
-      if (f.alpha_vol) valid = alpha_mask_sample(f, x[0], x[1], x[2]) > 0.0f;   // :593-598
-      if (valid) {
-        fk = density_feature(f, u);
-        const float sigma = feature2density(fk, f.density_shift, relu);            // :603-608
-        const float dist = z[k + 1] - zk;                                          // :584-587
-        alpha = 1.0f - expf(-sigma * dist * f.distance_scale);                     // :610
+  // pass A: alpha per sample -> LDS.
+  //
+  // Early termination: `carry` is the transmittance entering the next 64-sample chunk (a wave-level
+  // product of this chunk's 1 - alpha + 1e-10, the same value in every lane).  Once it is below
+  // f.term_T no later sample can pass weight > weight_thres (w_k = alpha_k T_k <= T_k <= carry), so the
+  // remaining density gathers are skipped and those samples count as empty (alpha = 0, feature "not
+  // evaluated"): exactly what the reference computes for a field that is empty behind that point --
+  // the forced last sample (:24) picks up the remaining transmittance.  acc is unchanged; sum(w z)
+  // moves by at most carry * z[S-1] (term_T = 1e-9, z <= 1000.1: 1e-6 absolute against depth * |d| >= 0.1).
+  // term_T = 0 disables it.
+  {
+    float carry = 1.0f;
+    bool live = true;                                      // wave-uniform
+    for (int c = 0; c < nchunk; ++c) {
+      const int k = (c << 6) + lane;
+      float alpha = 0.0f, fk = -INFINITY;
+      if (live && k < S - 1) {                             // last sample is never valid (:600)
+        const float zk = z[k];
+        float x[3], u[3];
+        sample_point(f, o, dh, zk, x, u);
+        bool valid = true;
+        if (f.alpha_vol) valid = alpha_mask_sample(f, x[0], x[1], x[2]) > 0.0f;   // :593-598
+        if (valid) {
+          fk = density_feature(f, u);
+          const float sigma = feature2density(fk, f.density_shift, relu);            // :603-608
+          const float dist = z[k + 1] - zk;                                          // :584-587
+          alpha = 1.0f - expf(-sigma * dist * f.distance_scale);                     // :610
+        }
       }
-    }
-    if (k < S) {
-      s_alpha[k] = alpha;
-      if (feat_out) feat_out[(size_t)ray * S + k] = fk;
+      if (k < S) {
+        s_alpha[k] = alpha;
+        if (feat_out) feat_out[(size_t)ray * S + k] = fk;
+      }
+      if (live && f.term_T > 0.0f) {
+        float v = (k < S - 1) ? (1.0f - alpha + 1e-10f) : 1.0f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v *= __shfl_xor(v, d, 64);
+        carry *= v;
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(carry)) < __float_as_int(f.term_T)) live = false;
+      }
     }
   }
   // (each wave only touches its own LDS slice: no barrier needed, LDS ops are in order per wave)
@@ -713,6 +733,10 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
   }
 }
 
+}  // namespace lrf
+#include "lrf_shade2.inl"
+namespace lrf {
+
 // Debug engine (LRF_FLAG_MLP_VALU): same work list, one lane per compact sample,
 // natural-layout weights from global memory, plain loops.  Slow by design; exists so a
 // parity failure can be bisected between the gather/compositing and the MFMA chain.
@@ -887,11 +911,13 @@ static DField make_dfield(const LrfField* f) {
   d.ax = f->alpha_dim[0]; d.ay = f->alpha_dim[1]; d.az = f->alpha_dim[2];
   for (int a = 0; a < 3; ++a) {
     d.lo[a] = f->aabb[a];
+    d.hi[a] = f->aabb[3 + a];
     d.inv[a] = 2.0f / (f->aabb[3 + a] - f->aabb[a]);                      // tensorBase.py:321
     d.m_lo[a] = f->alpha_aabb[a];
     d.m_inv[a] = 1.0f / (f->alpha_aabb[3 + a] - f->alpha_aabb[a]) * 2.0f;  // tensorBase.py:44
   }
   d.density_shift = f->density_shift; d.distance_scale = f->distance_scale; d.weight_thres = f->weight_thres;
+  d.term_T = f->term_T > 0.0f ? f->term_T : 0.0f;
   d.dump = nullptr;
   d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
   return d;
@@ -899,6 +925,7 @@ static DField make_dfield(const LrfField* f) {
 
 struct Workspace {
   int* toff; int* ncomp; float* acc; uint16_t* cidx; float* cw; float* part;
+  uint4* ffrag;            // k_app -> k_mlp: layer-1 B fragments, 2 KB per 16-sample tile
   int pmax; size_t bytes;
 };
 static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -913,11 +940,13 @@ static Workspace carve(void* ws, int R, int S) {
   w.cidx  = reinterpret_cast<uint16_t*>(p + off);  off += up256((size_t)R * S * 2);
   w.cw    = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
   w.part  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
+  w.ffrag = reinterpret_cast<uint4*>(p + off);     off += up256((size_t)R * w.pmax * 2048);
   w.bytes = off;
   return w;
 }
 
 static float* g_dump = nullptr;
+static int g_mlp_policy = 0;       // lrf_debug_set_mlp_policy: MFMA issue policy of k_mlp (lrf_shade2.inl)
 
 static int device_cus() {                 // of the current device (one process may drive several)
   static int cache[64] = {};
@@ -938,6 +967,7 @@ static int device_cus() {                 // of the current device (one process 
 #include "lrf_scene.inl"
 #include "lrf_adam.inl"
 #include "lrf_reg.inl"
+#include "lrf_mask.inl"
 
 using namespace lrf;
 
@@ -945,6 +975,7 @@ extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
+void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = (policy >= 0 && policy <= 3) ? policy : 0; }
 const char* lrf_last_error(void) { return g_err; }
 
 size_t lrf_cache_bytes(const int32_t grid[3]) { return make_layout(grid).total * sizeof(float); }
@@ -972,10 +1003,35 @@ size_t lrf_workspace_bytes(int32_t R, int32_t S) {
   return carve(nullptr, R, S).bytes;
 }
 
+// default colour engine: k_app (gather + basis) then k_mlp (27 -> 128 -> 128 -> 3), lrf_shade2.inl
+static int launch_shade_split(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
+                              hipStream_t st, hipEvent_t mid) {
+  const int cus = device_cus();
+  const size_t lds_app = (size_t)IMGB_W1 * sizeof(uint4) + (size_t)S * sizeof(float);
+  static int app_blocks_per_cu[64] = {};
+  int dev = 0;
+  LRF_HIP(hipGetDevice(&dev));
+  int& occ = app_blocks_per_cu[dev & 63];
+  if (!occ) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_app, 256, 28 * 1024) != hipSuccess || n <= 0) n = 4;
+    occ = n > 8 ? 8 : n;
+  }
+  hipLaunchKernelGGL(k_app, dim3(cus * occ), dim3(256), lds_app, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.ffrag);
+  if (mid) LRF_HIP(hipEventRecord(mid, st));
+  switch (g_mlp_policy) {
+    case 1: hipLaunchKernelGGL(k_mlp<1>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 2: hipLaunchKernelGGL(k_mlp<2>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 3: hipLaunchKernelGGL(k_mlp<3>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    default: hipLaunchKernelGGL(k_mlp<0>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+  }
+  return 0;
+}
+
 static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                            uint32_t flags, float floater_thresh, float* rgb, float* depth,
                            float* weight_out, float* acc_out, void* workspace, hipStream_t st,
-                           hipEvent_t* ev /* 4 events or null */) {
+                           hipEvent_t* ev /* 5 events or null: start, after march, after shade, end, between k_app and k_mlp */) {
   if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
   if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
   DField d = make_dfield(f);
@@ -994,9 +1050,12 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
     if (flags & LRF_FLAG_MLP_F32)
       hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st,
                          d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
-    else
+    else if (flags & LRF_FLAG_MLP_FUSED)
       hipLaunchKernelGGL(k_shade_bf16, dim3(device_cus()), dim3(1024), 0, st,
                          d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+    else {
+      if (int rc = launch_shade_split(d, rays, z, S, R, w, st, ev ? ev[4] : nullptr)) return rc;
+    }
   }
   if (ev) LRF_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
@@ -1018,8 +1077,9 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            void* workspace, void* stream, float* ms_out, int32_t* n_shaded_out) {
   if (!ms_out) return set_err("lrf_render_fwd_profile: null ms_out");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipEvent_t ev[4];
-  for (int i = 0; i < 4; ++i) LRF_HIP(hipEventCreate(&ev[i]));
+  hipEvent_t ev[5];
+  for (int i = 0; i < 5; ++i) LRF_HIP(hipEventCreate(&ev[i]));
+  LRF_HIP(hipEventRecord(ev[4], st));      // re-recorded between k_app and k_mlp by the default engine
   int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, nullptr, nullptr, workspace, st, ev);
   if (rc == 0) {
     hipError_t e = hipEventSynchronize(ev[3]);
@@ -1028,6 +1088,9 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
   if (rc == 0) {
     for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
     (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
+    ms_out[4] = 0.0f;                      // k_app alone (default engine); shade = k_scan_tiles + k_app + k_mlp
+    if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED)))
+      (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[4]);
     if (n_shaded_out) {
       // shaded-sample count of this batch = sum of ncomp (host copy; measurement only)
       const Workspace w = carve(workspace, R, S);
@@ -1039,7 +1102,7 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
       free(h);
     }
   }
-  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+  for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
 }
 

@@ -1,0 +1,307 @@
+// lrf_shade2.inl -- the colour stage as TWO kernels (default engine), included by lrf_render.hip.
+//
+// Round 1's k_shade_bf16 does gather -> basis -> 128 -> 128 -> head per 16-sample tile in one
+// persistent kernel.  Its counters (profiles/r01v_round_end.md) say the waves sit parked on
+// s_waitcnt 63 % of the time: each tile walks ~7 dependent memory round trips (tile header chain,
+// then three gather rounds, each consumed by its MFMAs before the next is issued) with only four
+// waves per SIMD to hide them, because the 97 KB weight image and the 128-register budget of a
+// 1024-thread workgroup cap the occupancy.  The two halves want different machines:
+//
+//   k_app   gather + basis(72 -> 27).  Memory-latency / texture-path bound, 18 MFMAs per tile.
+//           Needs only the 12 KB basis fragments in LDS -> 256-thread workgroups, several per CU;
+//           the tile header is prefetched one tile ahead and the sample distances sit in LDS, so a
+//           tile costs three gather rounds and nothing else.  Writes the 27 features of every shaded
+//           sample ALREADY as the split-bf16 B fragment of layer 1 (hi + lo, 2 x 16 B per lane,
+//           2 KB per tile, coalesced): 128 B per sample against the 1728 B it gathered.
+//   k_mlp   27 -> 128 -> 128 -> 3 + sigmoid + weighting.  Matrix-pipe / VALU bound, no gathers: the
+//           only global reads are the next tile's fragment (prefetched) and its weights.  Persistent,
+//           one 1024-thread workgroup per CU with the W1/W2 image (83 KB) resident in LDS.
+//
+// Arithmetic is identical to k_shade_bf16 (same fragments, same MFMA order, same head): the two
+// engines agree bit for bit, which tests/test_gpu_parity.py checks.
+#pragma once
+
+namespace lrf {
+
+// Tile walk with the per-ray state cached: consecutive tiles of a wave mostly belong to the same ray,
+// so the header of a tile is ONE dependent load (the sample index) unless the ray changes.
+struct TileWalk2 {
+  int ray, tile0, next_off, nc;     // current ray, its first tile, first tile of the next ray, ncomp[ray]
+};
+__device__ __forceinline__ void tile_range(const int* __restrict__ toff, int R, int& t0, int& t1) {
+  const int T = toff[R];
+  const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int nb = gridDim.x;                                    // XCD-aware block order, see tile_walk_begin
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const long long wid = (long long)lb * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  t0 = __builtin_amdgcn_readfirstlane((int)(wid * T / waves));
+  t1 = __builtin_amdgcn_readfirstlane((int)((wid + 1) * T / waves));
+}
+__device__ __forceinline__ TileWalk2 tile_walk2_begin(const int* __restrict__ toff, const int* __restrict__ ncomp,
+                                                      int R, int t) {
+  int lo = 0, hi = R;                                          // largest ray with toff[ray] <= t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (toff[mid] <= t) lo = mid; else hi = mid;
+  }
+  TileWalk2 tw;
+  tw.ray = lo; tw.tile0 = toff[lo]; tw.next_off = toff[lo + 1]; tw.nc = ncomp[lo];
+  return tw;
+}
+// advance to the ray owning tile t (skips rays without shaded samples); true if the ray changed
+__device__ __forceinline__ bool tile_walk2_seek(TileWalk2& tw, const int* __restrict__ toff,
+                                                const int* __restrict__ ncomp, int t) {
+  bool moved = false;
+  while (tw.next_off <= t) { ++tw.ray; tw.tile0 = tw.next_off; tw.next_off = toff[tw.ray + 1]; moved = true; }
+  if (moved) tw.nc = ncomp[tw.ray];
+  return moved;
+}
+
+struct RayGeo { float o[3], dh[3]; };
+__device__ __forceinline__ RayGeo load_ray(const float* __restrict__ rays, int ray) {
+  const float* rp = rays + (size_t)ray * 6;
+  RayGeo g;
+  g.o[0] = rp[0]; g.o[1] = rp[1]; g.o[2] = rp[2];
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);      // tensorBase.py:578-580
+  g.dh[0] = rp[3] / dn; g.dh[1] = rp[4] / dn; g.dh[2] = rp[5] / dn;
+  return g;
+}
+
+// ------------------------------------------------------------------------------- k_app
+__global__ __launch_bounds__(256) void k_app(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    uint4* __restrict__ ffrag /* [tile][hi, lo][lane] */) {
+  extern __shared__ uint4 s_dyn[];                             // basis fragments, then z[S]
+  uint4* bas = s_dyn;
+  float* s_z = reinterpret_cast<float*>(s_dyn + IMGB_W1);
+  for (int i = threadIdx.x; i < IMGB_W1; i += blockDim.x) bas[i] = f.mlpb[i];
+  for (int i = threadIdx.x; i < S; i += blockDim.x) s_z[i] = z[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  int t0, t1;
+  tile_range(toff, R, t0, t1);
+  if (t0 >= t1) return;
+  TileWalk2 tw = tile_walk2_begin(toff, ncomp, R, t0);
+  tile_walk2_seek(tw, toff, ncomp, t0);
+  RayGeo rg = load_ray(rays, tw.ray);
+  int j0 = (t0 - tw.tile0) * ITEM;
+  int cnt = min(ITEM, tw.nc - j0);
+  int k = cidx[(size_t)tw.ray * S + j0 + (s < cnt ? s : 0)];
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("" ::: "memory");     // keep the LDS fragment reads inside the loop
+    float x[3], u[3];
+    sample_point(f, rg.o, rg.dh, s_z[k], x, u);
+    // header of the next tile: one dependent load, issued before this tile's gathers and consumed
+    // after them
+    int k_n = 0, j0_n = 0, cnt_n = 0;
+    RayGeo rg_n = rg;
+    if (t + 1 < t1) {
+      if (tile_walk2_seek(tw, toff, ncomp, t + 1)) rg_n = load_ray(rays, tw.ray);
+      j0_n = (t + 1 - tw.tile0) * ITEM;
+      cnt_n = min(ITEM, tw.nc - j0_n);
+      k_n = cidx[(size_t)tw.ray * S + j0_n + (s < cnt_n ? s : 0)];
+    }
+    // basis 72 -> 27 (tensoRF.py:196), one k-step per plane, exactly as in k_shade_bf16
+    f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
+    {
+      float v[8];
+      bf16x8 bh, bl;
+      gather_app6_plane<0>(f, u, g, v);
+      split8(v, bh, bl);
+      gemm_step<2>(bas, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
+      gather_app6_plane<1>(f, u, g, v);
+      split8(v, bh, bl);
+      gemm_step<2>(bas, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
+      gather_app6_plane<2>(f, u, g, v);
+      split8(v, bh, bl);
+      gemm_step<2>(bas, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
+      settle<2>(fe);
+    }
+    {
+      const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      ffrag[((size_t)t * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, bh);
+      ffrag[((size_t)t * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, bl);
+    }
+    k = k_n; j0 = j0_n; cnt = cnt_n; rg = rg_n;
+  }
+}
+
+// ------------------------------------------------------------------------------- k_mlp
+// MFMA issue policy of the layer-1 / layer-2 chains (runtime choice for the hazard experiments of
+// DESIGN.md "gfx950 / hipcc findings"; the shipped default is POLICY 0):
+//   0  hand-issued in-place MFMA, 4 wait states behind each, operands held 48 wait states (= k_shade_bf16)
+//   1  hand-issued in-place MFMA, 2 wait states behind each, A fragments held for two further
+//      fragments (>= 6 MFMAs) by register rotation instead of wait states, no tail pad
+//   2  compiler-scheduled builtin, operands kept live the same way (hold), no wait states
+//   3  compiler-scheduled builtin, nothing else (the build that showed run-to-run differences in round 1)
+template <int POLICY>
+__device__ __forceinline__ void mfma_p(bf16x8 a, bf16x8 b, f32x4& acc) {
+  if (POLICY >= 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  } else {
+    const i32x4 ai = __builtin_bit_cast(i32x4, a), bi = __builtin_bit_cast(i32x4, b);
+    if (POLICY == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 3" : "+v"(acc) : "v"(ai), "v"(bi));
+    else             asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 1" : "+v"(acc) : "v"(ai), "v"(bi));
+  }
+}
+template <int POLICY>
+__device__ __forceinline__ void split8_p(const float v[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+  if (POLICY == 0) {
+    uint4 H = __builtin_bit_cast(uint4, hi), L = __builtin_bit_cast(uint4, lo);
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(H.x), "+v"(H.y), "+v"(H.z), "+v"(H.w),
+                                          "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w));
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
+  }
+}
+template <int POLICY, int NT>
+__device__ __forceinline__ void settle_p(f32x4* acc) {
+  if (POLICY <= 1) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[t]));
+  }
+}
+// acc[t1] += A(frag0 + t1*stride) x B, three-term split product (see gemm_step)
+template <int POLICY, int NT>
+__device__ __forceinline__ void gemm_step_q(const uint4* img, int frag0, int stride, int lane,
+                                            bf16x8 bh, bf16x8 bl, f32x4* acc) {
+  if (POLICY == 0) { gemm_step<NT>(img, frag0, stride, lane, bh, bl, acc); return; }
+  bf16x8 p1h = bh, p1l = bl, p2h = bh, p2l = bl;               // the two previous A fragments (dummies at first)
+#pragma unroll
+  for (int t1 = 0; t1 < NT; ++t1) {
+    const bf16x8 ah = lds_frag(img, frag0 + t1 * stride, 0, lane);
+    const bf16x8 al = lds_frag(img, frag0 + t1 * stride, 1, lane);
+    mfma_p<POLICY>(al, bh, acc[t1]);
+    mfma_p<POLICY>(ah, bl, acc[t1]);
+    mfma_p<POLICY>(ah, bh, acc[t1]);
+    if (POLICY <= 2) { hold(p2h); hold(p2l); }                 // >= 6 MFMAs behind their last use
+    p2h = p1h; p2l = p1l; p1h = ah; p1l = al;
+  }
+  if (POLICY <= 2) { hold(p1h); hold(p1l); hold(p2h); hold(p2l); }
+}
+
+template <int POLICY>
+__global__ __launch_bounds__(1024) void k_mlp(
+    DField f, const float* __restrict__ rays, int S, const int* __restrict__ toff, int R,
+    const int* __restrict__ ncomp, const float* __restrict__ cw, const uint4* __restrict__ ffrag,
+    float* __restrict__ part, int pmax) {
+  __shared__ uint4 img[IMGB_U4 - IMGB_W1];                     // W1, W2 fragments + fp32 tail (83 KB)
+  for (int i = threadIdx.x; i < IMGB_U4 - IMGB_W1; i += blockDim.x) img[i] = f.mlpb[IMGB_W1 + i];
+  __syncthreads();
+  constexpr int F_W1 = 0, F_W2 = (IMGB_W2 - IMGB_W1) / 128;    // fragment indices inside img
+  const float* tail = reinterpret_cast<const float*>(img + (IMGB_TAIL - IMGB_W1));
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  int t0, t1;
+  tile_range(toff, R, t0, t1);
+  if (t0 >= t1) return;
+  TileWalk2 tw = tile_walk2_begin(toff, ncomp, R, t0);
+  tile_walk2_seek(tw, toff, ncomp, t0);
+  // state of the current tile: (ray, j0, cnt) are wave-uniform and were found one tile ahead; the
+  // fragment is prefetched one tile ahead; weight and view direction are only needed at the end of a
+  // tile and are loaded at its top
+  int ray = tw.ray, j0 = (t0 - tw.tile0) * ITEM;
+  int cnt = min(ITEM, tw.nc - j0);
+  uint4 fh = ffrag[((size_t)t0 * 2 + 0) * 64 + lane], fl = ffrag[((size_t)t0 * 2 + 1) * 64 + lane];
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
+    ray = __builtin_amdgcn_readfirstlane(ray); j0 = __builtin_amdgcn_readfirstlane(j0);
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    const float w = s < cnt ? cw[(size_t)ray * S + j0 + s] : 0.0f;
+    const float* rp = rays + (size_t)ray * 6;
+    const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
+    int ray_n = ray, j0_n = 0, cnt_n = 0;
+    uint4 fh_n = fh, fl_n = fl;
+    if (t + 1 < t1) {
+      tile_walk2_seek(tw, toff, ncomp, t + 1);
+      ray_n = tw.ray;
+      j0_n = (t + 1 - tw.tile0) * ITEM;
+      cnt_n = min(ITEM, tw.nc - j0_n);
+      fh_n = ffrag[((size_t)(t + 1) * 2 + 0) * 64 + lane];
+      fl_n = ffrag[((size_t)(t + 1) * 2 + 1) * 64 + lane];
+    }
+    // layer 1 (tensorBase.py:129-130): one k-step, B = the fragment k_app wrote
+    f32x4 h1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h1[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * q + 4 * g]);
+    {
+      bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
+      if (POLICY <= 1) {                                       // loaded operands: settle before the asm MFMAs
+        uint4 H = __builtin_bit_cast(uint4, bh), L = __builtin_bit_cast(uint4, bl);
+        asm volatile("s_nop 1" : "+v"(H.x), "+v"(H.y), "+v"(H.z), "+v"(H.w), "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w),
+                                 "+v"(h1[0]), "+v"(h1[1]), "+v"(h1[2]), "+v"(h1[3]), "+v"(h1[4]), "+v"(h1[5]), "+v"(h1[6]), "+v"(h1[7]));
+        bh = __builtin_bit_cast(bf16x8, H);
+        bl = __builtin_bit_cast(bf16x8, L);
+      }
+      gemm_step_q<POLICY, 8>(img, F_W1, 1, lane, bh, bl, h1);
+      settle_p<POLICY, 8>(h1);
+    }
+    // layer 2: 4 k-steps, k-step ks consumes relu(h1) tiles 2ks and 2ks+1
+    f32x4 h2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h2[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * q + 4 * g]);
+    if (POLICY <= 1) {
+      asm volatile("s_nop 1" : "+v"(h2[0]), "+v"(h2[1]), "+v"(h2[2]), "+v"(h2[3]), "+v"(h2[4]), "+v"(h2[5]), "+v"(h2[6]), "+v"(h2[7]));
+    }
+    bf16x8 pbh = {}, pbl = {};                                  // previous k-step's B operands
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[2 * ks + (j >> 2)][j & 3], 0.0f);
+      bf16x8 bh, bl;
+      split8_p<POLICY>(v, bh, bl);
+      gemm_step_q<POLICY, 8>(img, F_W2 + ks, 4, lane, bh, bl, h2);
+      if (POLICY == 1 || POLICY == 2) { if (ks) { hold(pbh); hold(pbl); } pbh = bh; pbl = bl; }
+    }
+    if (POLICY == 1 || POLICY == 2) { hold(pbh); hold(pbl); }
+    settle_p<POLICY, 8>(h2);
+    // head on the VALU in fp32 (tensorBase.py:131-133)
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float hv = fmaxf(h2[q][r], 0.0f);
+        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (q * 4 + r) * 4]);
+        o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
+      }
+    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+    // view-direction part of mlp_view.0 + bias: constant per ray (tensorBase.py:131-132; viewdirs
+    // detached :628)
+    float vb[3];
+    {
+      const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);                       // tensorBase.py:578-580
+      const float dh[3] = {d0 / dn, d1 / dn, d2 / dn};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
+        vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
+      }
+    }
+    float cr = w / (1.0f + expf(-(o0 + vb[0])));               // :133, :632
+    float cg = w / (1.0f + expf(-(o1 + vb[1])));
+    float cb = w / (1.0f + expf(-(o2 + vb[2])));
+#pragma unroll
+    for (int dd = 1; dd < 16; dd <<= 1) {
+      cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
+    }
+    if (lane == 0) {
+      float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
+      pp[0] = cr; pp[1] = cg; pp[2] = cb;
+    }
+    ray = ray_n; j0 = j0_n; cnt = cnt_n; fh = fh_n; fl = fl_n;
+  }
+}
+
+}  // namespace lrf

@@ -223,10 +223,13 @@ class TensorVMSplit(torch.nn.Module):
         self._cache = None
         self._cache_key = None
         self._ws = None
-        # colour-MLP engine: "bf16x3" split-bf16 MFMA chain (default) | "f32" exact fp32 MFMA
-        # chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
+        # colour-MLP engine: "bf16x3" split-bf16 MFMA chain as k_app + k_mlp (default) |
+        # "bf16x3_fused" the same arithmetic in round 1's single kernel (LRF_FLAG_MLP_FUSED) | "f32"
+        # exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
         self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
+        # early termination of the march (LrfField.term_T in include/lrf.h): 0 = evaluate every sample
+        self.early_term_T = 1e-9
 
     # ------------------------------------------------------------------ construction
     def _check_supported(self, shadingMode, pos_pe, view_pe, fea_pe, featureC):
@@ -376,7 +379,8 @@ class TensorVMSplit(torch.nn.Module):
         mask = self.alphaMask
         key = (self._cache.data_ptr(), self._cache_key, id(mask),
                None if mask is None else mask.alpha_volume.data_ptr(),
-               float(self.density_shift), float(self.distance_scale), float(self.rayMarch_weight_thres))
+               float(self.density_shift), float(self.distance_scale), float(self.rayMarch_weight_thres),
+               float(self.early_term_T), tuple(self._aabb_host))
         if getattr(self, "_cfield_key", None) == key:
             return self._cfield
         f = N.LrfField()
@@ -395,6 +399,7 @@ class TensorVMSplit(torch.nn.Module):
         f.density_shift = float(self.density_shift)
         f.distance_scale = float(self.distance_scale)
         f.weight_thres = float(self.rayMarch_weight_thres)
+        f.term_T = float(self.early_term_T)
         ps = self._param_list()[12:]
         (f.basis, f.w1, f.b1, f.w2, f.b2, f.w3, f.b3) = [p.data_ptr() for p in ps]
         self._cfield, self._cfield_key = f, key
@@ -416,6 +421,8 @@ class TensorVMSplit(torch.nn.Module):
             fl |= N.LRF_FLAG_MLP_VALU
         elif self.mlp_engine == "f32":
             fl |= N.LRF_FLAG_MLP_F32
+        elif self.mlp_engine == "bf16x3_fused":
+            fl |= N.LRF_FLAG_MLP_FUSED
         elif self.mlp_engine != "bf16x3":
             raise ValueError(f"unknown mlp_engine {self.mlp_engine!r}")
         return fl
@@ -540,14 +547,18 @@ class TensorVMSplit(torch.nn.Module):
             self._z_cache[(h, str(device))] = z
         return z
 
-    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):
-        """AABB march (tensorBase.py:396-417), via lrf_sample_ray_aabb."""
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1, jitter=None):
+        """AABB march (tensorBase.py:396-417), via lrf_sample_ray_aabb.  `jitter` [R] (extension)
+        replaces the per-ray torch.rand draw of train mode (:408-409) so a recorded draw can be replayed."""
         self._require_gpu(rays_o)
         lib = N.lib()
         n = N_samples if N_samples > 0 else self.nSamples
         rays = torch.cat([rays_o, rays_d], -1).contiguous().float()
         R, dev = rays.shape[0], rays.device
-        jit = torch.rand(R, 1, device=dev)[:, 0].contiguous() if is_train else None
+        if jitter is not None:
+            jit = jitter.to(dev).reshape(R).contiguous().float()
+        else:
+            jit = torch.rand(R, 1, device=dev)[:, 0].contiguous() if is_train else None
         pts = torch.empty(R, n, 3, device=dev)
         t = torch.empty(R, n, device=dev)
         inside = torch.empty(R, n, dtype=torch.uint8, device=dev)
@@ -697,24 +708,32 @@ class TensorVMSplit(torch.nn.Module):
 
     @torch.no_grad()
     def getDenseAlpha(self, gridSize=None):
-        """tensorBase.py:501-516, evaluated on the field's device."""
+        """tensorBase.py:501-516 as ONE launch (lrf_dense_alpha): alpha at every lattice point, through
+        the current mask if there is one.  Returned in the reference's [X][Y][Z] indexing (a view of the
+        [Z][Y][X] buffer the kernel writes, which is the order updateAlphaMask wants)."""
         gridSize = self.gridSize if gridSize is None else gridSize
+        gx, gy, gz = (int(g) for g in gridSize)
         dev = self.aabb.device
-        lin = [torch.linspace(0, 1, int(g), device=dev) for g in gridSize]
-        dense = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)
-        dense = self.aabb[0] * (1 - dense) + self.aabb[1] * dense
-        alpha = torch.zeros_like(dense[..., 0])
-        for i in range(int(gridSize[0])):
-            alpha[i] = self.compute_alpha(dense[i].view(-1, 3), self.stepSize).view(
-                int(gridSize[1]), int(gridSize[2]))
-        return alpha
+        self._require_gpu(self.aabb)
+        self._ensure_cache()
+        # torch.linspace on the host, as the reference builds its lattice (:504-508), then uploaded
+        lin = [torch.linspace(0, 1, g).to(dev) for g in (gx, gy, gz)]
+        alpha = torch.empty(gz, gy, gx, dtype=torch.float32, device=dev)
+        f = self._c_field()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        N.check(N.lib().lrf_dense_alpha(C.byref(f), N.ptr(lin[0]), N.ptr(lin[1]), N.ptr(lin[2]), gx, gy, gz,
+                                        float(self.stepSize), self._flags(False), N.ptr(alpha), st), "lrf_dense_alpha")
+        return alpha.permute(2, 1, 0)
 
     @torch.no_grad()
     def updateAlphaMask(self, gridSize=(200, 200, 200)):
-        """tensorBase.py:518-536 without the round trip through host memory."""
-        gridSize = tuple(int(g) for g in gridSize)
-        alpha = self.getDenseAlpha(gridSize)
-        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
-        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(gridSize[::-1])
-        alpha = (alpha >= self.alphaMask_thres).float()
-        self.alphaMask = AlphaGridMask(self.aabb.device, self.aabb.detach(), alpha)
+        """tensorBase.py:518-536 on the device: lrf_dense_alpha + lrf_alpha_pool_threshold, two launches,
+        no host round trip and no per-slab synchronisation."""
+        gx, gy, gz = (int(g) for g in gridSize)
+        alpha = self.getDenseAlpha((gx, gy, gz)).permute(2, 1, 0)          # back to the kernel's [Z][Y][X]
+        assert alpha.is_contiguous()
+        out = torch.empty_like(alpha)
+        st = torch.cuda.current_stream(alpha.device).cuda_stream
+        N.check(N.lib().lrf_alpha_pool_threshold(N.ptr(alpha), gx, gy, gz, float(self.alphaMask_thres), N.ptr(out), st),
+                "lrf_alpha_pool_threshold")
+        self.alphaMask = AlphaGridMask(self.aabb.device, self.aabb.detach(), out)

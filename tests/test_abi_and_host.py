@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert getattr(built_lib, name) is not None
-    assert built_lib.lrf_abi_version() == 1
+    assert built_lib.lrf_abi_version() == 2
 
 
 def test_cache_and_workspace_sizes(built_lib):
@@ -31,7 +31,9 @@ def test_cache_and_workspace_sizes(built_lib):
     n = built_lib.lrf_cache_bytes(grid)
     # 3 planes x (8 + 32: appearance texels are padded to 128 B) ch x 300^2 + lines + MLP images, fp32
     assert 3 * 40 * 300 * 300 * 4 <= n <= 3 * 40 * 300 * 300 * 4 + 600_000
-    assert built_lib.lrf_workspace_bytes(4096, 512) < 64 << 20
+    # lists + partials (12.6 MB) + the k_app -> k_mlp fragment buffer at its worst case (every sample
+    # shaded: 4096 x 32 tiles x 2 KB = 268 MB; the benchmark touches 99 MB of it)
+    assert built_lib.lrf_workspace_bytes(4096, 512) < 300 << 20
 
 
 def test_state_dict_surface_matches_reference():
