@@ -11,15 +11,30 @@ collective on the forward path); value = N*4096*K / max-over-ranks time.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the task contract), with `roofline` (HIP-event timing of
-the dominant kernel, algorithmic gather bytes / time vs 8 TB/s HBM) and `cpu_baseline`
-(oracle/vm_render_torch.py, the reference's ATen op chain, timed on this box's host cores).
+Prints ONE JSON line on rank 0 (see the task contract) with
+  roofline      the dominant kernel: HIP-event time on the launch stream, algorithmic bytes (or flops) per
+                launch, HBM-side traffic from rocprofv3 --pmc passes of THIS run (child processes; falls back
+                to the committed profiles/ summary and says so), plus what the counters say binds it:
+                l2_frac / mfma_frac / hbm_frac and the per-kernel table
+  cpu_baseline  the reference's TensorVMSplit itself on the host cores when /root/reference is importable
+                ("reference"), else oracle/vm_render_torch.py, its ATen op chain ("port", with the reason)
+  train_step    forward with a graph + backward + (N>1) the gradient all-reduce over RCCL + FusedAdam, on every
+                N -- the design's only collective is inside this timed region
+  workloads     N=1 only: the exact-fp32 colour engine, a trained-like scene (walls + rebuilt alpha mask:
+                early termination), BASELINE configs[2] (4 blended 300^3 fields)
 """
 import argparse
+import contextlib
 import ctypes as C
+import glob
+import io
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -30,14 +45,18 @@ sys.path.insert(0, ROOT)
 GRID, R_PER_GPU, N_SAMPLES_ARG = 300, 4096, 1536          # -> S = 2*(1536//6) = 512
 DENS_BYTES_PER_SAMPLE = 3 * 4 * 8 * 4 + 3 * 2 * 8 * 4      # 576  B
 APP_BYTES_PER_SAMPLE = 3 * 4 * 24 * 4 + 3 * 2 * 24 * 4     # 1728 B
-MLP_FLOP_PER_SAMPLE = 2 * (72 * 27 + 27 * 128 + 128 * 128 + 131 * 3)
-HBM_PEAK_GBS = 8000.0
+FRAG_BYTES_PER_SLOT = 128                                  # k_app -> k_mlp: layer-1 B fragment, hi + lo bf16 x 32
+BASIS_FLOP = 2 * 72 * 27
+MLP_FLOP = 2 * (27 * 128 + 128 * 128 + 131 * 3)           # per shaded sample, after the basis
+MFMA_FLOP = 2 * 16 * 16 * 32                               # one v_mfma_f32_16x16x32_bf16
+HBM_PEAK_GBS, L2_PEAK_GBS, MFMA_BF16_PEAK_TF = 8000.0, 34500.0, 2500.0   # MI355X_MICROARCH.md
 
 FIELD_KW = dict(density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=27,
                 shadingMode="MLP_Fea_late_view", near_far=[0.1, 1e3], density_shift=-5,
                 alphaMask_thres=1e-4, distance_scale=25, rayMarch_weight_thres=1e-3,
                 pos_pe=0, view_pe=0, fea_pe=0, featureC=128, step_ratio=0.5,
                 fea2denseAct="softplus")
+REF = "/root/reference/localTensoRF"
 
 
 def make_rays(R, seed):
@@ -47,66 +66,107 @@ def make_rays(R, seed):
     return torch.cat([o, d / d.norm(dim=-1, keepdim=True)], -1)
 
 
+# ------------------------------------------------------------------------------ baselines
+def import_reference():
+    """The reference's own TensorVMSplit (read-only import; five third-party modules it never calls on
+    this path are stubbed, as tests/golden/make_golden.py does).  None + reason where it does not exist
+    (the GPU box has no /root/reference)."""
+    if not os.path.isdir(REF):
+        return None, f"{REF} is not present on this box (it exists only in the build container)"
+    import types
+    try:
+        for name, attrs in (("kornia", {"create_meshgrid": None}), ("cv2", {"COLORMAP_JET": 2}), ("torchvision", {}),
+                            ("torchvision.transforms", {}), ("plyfile", {}), ("skimage", {}), ("skimage.measure", {})):
+            if name not in sys.modules:
+                m = types.ModuleType(name)
+                m.__dict__.update(attrs)
+                sys.modules[name] = m
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        from models.tensoRF import TensorVMSplit as RefVM
+        return RefVM, None
+    except Exception as e:                                   # noqa: BLE001
+        return None, f"import of the reference failed: {e!r}"
+
+
+def _ref_field(RefVM, sd, device):
+    with contextlib.redirect_stdout(io.StringIO()):
+        aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+        f = RefVM(device, aabb.to(device), [GRID] * 3, **FIELD_KW)
+    f.load_state_dict({k: v.to(device) for k, v in sd.items()})
+    return f.to(device)
+
+
 def cpu_baseline(field_sd, rays_cpu, runs=3):
-    """Reference-equivalent ATen op chain on the host cores (kind 'port')."""
-    from oracle import vm_render_torch as ot
-    fld = {k: v.detach().cpu() for k, v in field_sd.items()}
-    z = ot.z_schedule(N_SAMPLES_ARG)
+    """The reference on the host cores: its own module when importable, else its ATen op chain."""
+    RefVM, why = import_reference()
+    sd = {k: v.detach().cpu() for k, v in field_sd.items()}
+    if RefVM is not None:
+        f = _ref_field(RefVM, sd, "cpu")
+        fn = lambda r: f(r, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)          # noqa: E731
+        kind, what = "reference", "localTensoRF/models/tensoRF.py TensorVMSplit.forward (the real reference module)"
+    else:
+        from oracle import vm_render_torch as ot
+        z = ot.z_schedule(N_SAMPLES_ARG)
+        fn = lambda r: ot.render_field(sd, r, z)                                             # noqa: E731
+        kind, what = "port", "oracle/vm_render_torch.py (F.grid_sample/cumprod/Linear, pinned to the reference goldens)"
     with torch.no_grad():
-        ot.render_field(fld, rays_cpu[:512], z)                       # warm-up
+        fn(rays_cpu[:512])                                            # warm-up
         t0 = time.perf_counter()
         for _ in range(runs):
-            ot.render_field(fld, rays_cpu, z)
+            fn(rays_cpu)
         dt = (time.perf_counter() - t0) / runs
-    return {"value": rays_cpu.shape[0] / dt, "unit": "rays/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{runs} x {rays_cpu.shape[0]} rays x 512 samples on the 300^3 field, "
-                      f"oracle/vm_render_torch.py (F.grid_sample/cumprod/Linear), {dt * 1e3:.0f} ms/batch"}
+    out = {"value": rays_cpu.shape[0] / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": kind,
+           "sample": f"{runs} x {rays_cpu.shape[0]} rays x 512 samples on the 300^3 field, {what}, {dt * 1e3:.0f} ms/batch"}
+    if why:
+        out["why_port"] = why
+    return out
 
 
-def torch_rocm_port(field_sd, rays, iters=5):
-    """The same ATen op chain on the GPU (stock PyTorch-ROCm): denominator of the >=10x target."""
-    from oracle import vm_render_torch as ot
-    fld = {k: v.detach() for k, v in field_sd.items()}
-    z = ot.z_schedule(N_SAMPLES_ARG, device=rays.device)
+def torch_rocm_baseline(field_sd, rays, iters=5):
+    """The reference path under stock PyTorch-ROCm on this GPU: denominator of the >=10x target."""
+    RefVM, why = import_reference()
+    if RefVM is not None:
+        f = _ref_field(RefVM, {k: v.detach() for k, v in field_sd.items()}, rays.device)
+        fn = lambda: f(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)         # noqa: E731
+        kind = "reference"
+    else:
+        from oracle import vm_render_torch as ot
+        fld = {k: v.detach() for k, v in field_sd.items()}
+        z = ot.z_schedule(N_SAMPLES_ARG, device=rays.device)
+        fn = lambda: ot.render_field(fld, rays, z)                                           # noqa: E731
+        kind = "port"
     with torch.no_grad():
         for _ in range(2):
-            ot.render_field(fld, rays, z)
+            fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            ot.render_field(fld, rays, z)
+            fn()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
-    return {"value": rays.shape[0] / dt, "unit": "rays/s", "ms_per_step": dt * 1e3,
-            "what": "oracle/vm_render_torch.py on cuda:0 (PyTorch-ROCm ATen ops, fp32)"}
+    out = {"value": rays.shape[0] / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "kind": kind,
+           "what": "the reference module on cuda:0" if kind == "reference" else
+                   "oracle/vm_render_torch.py on cuda:0 (the reference's ATen op chain under PyTorch-ROCm, fp32)"}
+    if why:
+        out["why_port"] = why
+    return out
 
 
-def train_step_time(field, rays, iters=10):
-    """Informational (not the headline metric): forward with a graph + backward of the same batch
-    (train.py's use of the path), parameter gradients into the reference layout."""
-    gr = torch.randn(rays.shape[0], 3, device=rays.device)
-    gd = torch.randn(rays.shape[0], device=rays.device)
-
-    def step():
-        for p in field.parameters():
-            p.grad = None
-        rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=N_SAMPLES_ARG)
-        ((rgb * gr).sum() + (depth * gd).sum()).backward()
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
+# ------------------------------------------------------------------------------ measurement helpers
+def timed(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
     t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
-    return {"ms_per_step": dt * 1e3, "rays_per_s": rays.shape[0] / dt,
-            "what": "lrf_render_fwd_train + lrf_render_bwd, 4096 rays x 512 samples, jittered samples"}
+    for _ in range(steps):
+        fn()
+    sync()
+    return time.perf_counter() - t0
 
 
 def kernel_profile(field, rays, z, reps=5):
-    """Per-kernel HIP-event timing through lrf_render_fwd_profile (same stream, same inputs)."""
+    """Per-kernel HIP-event timing through lrf_render_fwd_profile (events on the launch stream)."""
     from localrf_amd import _native as N
     lib = N.lib()
     field._ensure_cache()
@@ -117,18 +177,171 @@ def kernel_profile(field, rays, z, reps=5):
     ws = field._workspace(R, S, dev)
     f = field._c_field()
     st = torch.cuda.current_stream(dev).cuda_stream
-    ms = (C.c_float * 4)()
+    ms = (C.c_float * 6)()
     nsh = C.c_int32(0)
-    acc = [0.0] * 4
+    acc = [0.0] * 6
     for i in range(reps + 1):
         N.check(lib.lrf_render_fwd_profile(C.byref(f), N.ptr(rays), N.ptr(z), R, S, field._flags(True), 0.0,
                                            N.ptr(rgb), N.ptr(depth), ws.data_ptr(), st, ms, C.byref(nsh)),
                 "lrf_render_fwd_profile")
         if i:                                   # first call is a warm-up
-            for j in range(4):
+            for j in range(6):
                 acc[j] += ms[j] / reps
     return {"march_ms": acc[0], "shade_ms": acc[1], "finalize_ms": acc[2], "total_ms": acc[3],
+            "scan_ms": acc[4], "app_ms": acc[5], "mlp_ms": max(acc[1] - acc[4] - acc[5], 0.0),
             "n_shaded": int(nsh.value)}
+
+
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"))
+
+
+def pmc_traffic(timeout_s=240):
+    """HBM-side bytes per launch of every lrf kernel, measured now: one rocprofv3 --kernel-trace --pmc
+    child per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass), each re-running this script
+    for a few steps.  traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half the bytes
+    of 16-B-per-lane reads on gfx950 (MI355X_MICROARCH.md, HBM).  None if rocprofv3 is unavailable."""
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    per = {}
+    for ctrs in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="lrf_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--child"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=timeout_s,
+                               capture_output=True, text=True)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 pass {ctrs} failed (rc {r.returncode}): {r.stderr[-300:]}"
+            db = sqlite3.connect(dbs[0])
+            q = ("select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection "
+                 "group by kernel_name, counter_name, dispatch_id")
+            acc = {}
+            for name, ctr, _, val in db.execute(q):
+                short = name.split("(")[0].replace("lrf::", "").replace("void ", "")
+                if short.startswith("k_"):
+                    acc.setdefault((short.split("<")[0], ctr), []).append(val)
+            for (k, ctr), vals in acc.items():
+                per.setdefault(k, {})[ctr] = sum(vals) / len(vals)
+        except Exception as e:                               # noqa: BLE001
+            return None, f"rocprofv3 pass {ctrs}: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k, c in per.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out[k] = {"traffic_bytes": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
+                      "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0)}
+    return out, "rocprofv3 --kernel-trace --pmc, 2 passes of this run; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"
+
+
+def committed_traffic():
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            out = {k.replace("k_shade_bf16", "k_shade"): {"traffic_bytes": v["traffic_bytes"],
+                                                           "l2_hit_rate": v["TCC_HIT"] / max(v["TCC_HIT"] + v["TCC_MISS"], 1.0)}
+                   for k, v in pmc["kernels"].items()}
+            return out, f"NOT measured in this run: committed profiles/{name} ({pmc.get('source', '')[:80]})"
+        except Exception:                                    # noqa: BLE001
+            continue
+    return {}, None
+
+
+def roofline_object(prof, S, traffic, traffic_src):
+    """SURVEY.md s8d figures per launch over HIP-event durations; see DESIGN.md s5 for how to read them."""
+    n_sh = prof["n_shaded"]
+    tiles = (n_sh + 15) // 16                              # lower bound (rays pad their last tile)
+    dens_bytes = R_PER_GPU * S * DENS_BYTES_PER_SAMPLE
+    app_bytes = n_sh * APP_BYTES_PER_SAMPLE
+    kern = {"k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes, "bound": "hbm"},
+            "k_finalize": {"ms": prof["finalize_ms"]}, "k_scan_tiles": {"ms": prof["scan_ms"]}}
+    if prof["app_ms"] > 0:
+        kern["k_app"] = {"ms": prof["app_ms"], "alg_bytes": app_bytes + n_sh * FRAG_BYTES_PER_SLOT, "bound": "hbm",
+                         "alg_flop": n_sh * BASIS_FLOP, "issued_mfma_flop": tiles * 18 * MFMA_FLOP}
+        kern["k_mlp"] = {"ms": prof["mlp_ms"], "alg_bytes": n_sh * (FRAG_BYTES_PER_SLOT + 4), "bound": "mfma",
+                         "alg_flop": n_sh * MLP_FLOP, "issued_mfma_flop": tiles * 120 * MFMA_FLOP}
+    else:
+        kern["k_shade"] = {"ms": prof["shade_ms"] - prof["scan_ms"], "alg_bytes": app_bytes, "bound": "hbm",
+                           "alg_flop": n_sh * (BASIS_FLOP + MLP_FLOP), "issued_mfma_flop": tiles * 138 * MFMA_FLOP}
+    for name, k in kern.items():
+        t = k["ms"] * 1e-3
+        if "alg_bytes" in k and t > 0:
+            k["GBps"] = k["alg_bytes"] / t / 1e9
+            k["l2_frac"] = k["GBps"] / L2_PEAK_GBS        # against the aggregate L2 bandwidth: gathers are cache-served
+        if "alg_flop" in k and t > 0:
+            k["alg_TFLOPs"] = k["alg_flop"] / t / 1e12
+            k["mfma_frac"] = k["issued_mfma_flop"] / t / 1e12 / MFMA_BF16_PEAK_TF   # matrix-pipe occupancy, 3 MFMAs per product
+        tr = traffic.get(name)
+        if tr:
+            k["pmc_traffic_bytes"] = tr["traffic_bytes"]
+            k["l2_hit_rate"] = tr["l2_hit_rate"]
+            if t > 0:
+                k["hbm_frac"] = tr["traffic_bytes"] / t / 1e9 / HBM_PEAK_GBS
+    cands = [n for n in ("k_march", "k_app", "k_mlp", "k_shade") if n in kern]
+    dom = max(cands, key=lambda n: kern[n]["ms"])
+    d = kern[dom]
+    if d["bound"] == "mfma":
+        ach, peak, unit = d["alg_TFLOPs"], MFMA_BF16_PEAK_TF, "TFLOP/s"
+    else:
+        ach, peak, unit = d["GBps"], HBM_PEAK_GBS, "GB/s"
+    return {"bound": d["bound"], "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+            "traffic": d.get("pmc_traffic_bytes"), "traffic_source": traffic_src,
+            "l2_frac": d.get("l2_frac"), "mfma_frac": d.get("mfma_frac"), "hbm_frac": d.get("hbm_frac"),
+            "limiter": "none of the three roofs binds: the 43.5 MB field is cache-resident (hbm_frac), the gathers run "
+                       "at l2_frac of the aggregate L2 rate, the matrix pipe at mfma_frac; what is left is issue / "
+                       "memory-latency per wave (DESIGN.md s4)",
+            "whole_path_GBps": (dens_bytes + app_bytes) / (prof["total_ms"] * 1e-3) / 1e9,
+            "shaded_fraction": n_sh / (R_PER_GPU * S), "kernels": kern,
+            "note": "achieved = SURVEY.md s8d algorithmic bytes (flops for an MFMA-bound kernel) of the dominant kernel "
+                    "per launch / its HIP-event duration; cache-resident gathers can exceed the HBM figure"}
+
+
+def walls_field(dev, grid=GRID):
+    """Trained-like scene: near-empty space (density planes x 0.1) inside a closed box of dense walls at
+    |x|,|y|,|z| ~ 0.9 (six rank-1 components: plane = 1, line = smooth bump of height 40), then the
+    alpha mask rebuilt on the device as train.py does at its update iterations."""
+    from localrf_amd import TensorVMSplit
+    torch.manual_seed(0)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    f = TensorVMSplit(torch.device("cpu"), aabb, [grid] * 3, **FIELD_KW)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(0.1)
+        c = torch.linspace(-2, 2, grid)
+        for p in range(3):
+            for comp, centre in ((0, 0.9), (1, -0.9)):
+                f.density_plane[p][0, comp].fill_(1.0)
+                f.density_line[p][0, comp, :, 0] = 40.0 * torch.exp(-((c - centre) / 0.08) ** 2)
+    return f.to(dev)
+
+
+def config3_scene(dev):
+    """BASELINE.json configs[2]: LocalTensorfs with 4 overlapping 300^3 fields, built as SURVEY.md s8d says."""
+    from localrf_amd import LocalTensorfs
+    torch.manual_seed(33)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        lt = LocalTensorfs(fov=85.6, n_init_frames=5, n_overlap=3, WH=(64, 48), n_iters_per_frame=600, n_iters_reg=100,
+                           lr_R_init=5e-3, lr_t_init=5e-4, lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02,
+                           rf_lr_basis=1e-3, lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+                           camera_prior=None, device="cpu", lr_upsample_reset=True, aabb=aabb, gridSize=[GRID] * 3, **FIELD_KW)
+        g = torch.Generator().manual_seed(34)
+        for _ in range(3):
+            for _ in range(3):
+                lt.append_frame()
+                with torch.no_grad():
+                    lt.t_c2w[-1].add_(0.05 * torch.randn(3, generator=g))
+                    lt.r_c2w[-1].add_(0.05 * torch.randn(3, 2, generator=g))
+            lt.append_rf(3)
+    lt = lt.to(dev)
+    lt.device = torch.device(dev)
+    for f in lt.tensorfs:
+        f.to(dev)
+    view_ids = [2, 7, 11, len(lt.r_c2w) - 1]
+    ray_ids = torch.randint(0, 64 * 48, (4 * 1024,), generator=g)
+    bw = torch.tensor([[.1, .2, .3, .4]]).repeat(4, 1).to(dev)
+    return lt, ray_ids, view_ids, bw
 
 
 def main():
@@ -136,7 +349,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / torch-ROCm baselines")
+    ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / torch-ROCm baselines and extra workloads")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
+    ap.add_argument("--child", action="store_true", help="(internal) the timed loop only: what the PMC passes profile")
     ap.add_argument("--preroll-ms", type=float, default=150.0, help="untimed GPU clock ramp before the warm-up steps")
     args = ap.parse_args()
 
@@ -153,7 +368,7 @@ def main():
     dev = torch.device("cuda", local)
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so the
     # RCCL code path below is the same for every N
-    ddp = world > 1 or "RANK" in os.environ
+    ddp = (world > 1 or "RANK" in os.environ) and not args.child
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -165,7 +380,8 @@ def main():
     ge.build()
     if ddp and local == 0:
         dist.barrier(device_ids=[local])
-    from localrf_amd import TensorVMSplit
+    from localrf_amd import FusedAdam, TensorVMSplit
+    from localrf_amd.dist import allreduce_grads
 
     torch.manual_seed(0)                                      # identical replica on every rank
     aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
@@ -179,23 +395,20 @@ def main():
             dist.barrier(device_ids=[local])
             torch.cuda.synchronize(dev)
 
+    def fwd():
+        return field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
+
     with torch.no_grad():
-        # clock ramp: the first ~10 ms of work after an idle period run at a lower GPU clock (50 timed
-        # steps right after start-up read 0.273 ms/step, 200 steps 0.249); render untimed for
-        # --preroll-ms before the W warm-up steps so that K is measured at the sustained clock
+        # clock ramp: the first ~10 ms of work after an idle period run at a lower GPU clock; render untimed
+        # for --preroll-ms before the W warm-up steps so that K is measured at the sustained clock
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
             for _ in range(20):
-                field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
+                fwd()
             torch.cuda.synchronize(dev)
-        for _ in range(args.warmup):
-            field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            rgb, depth = field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
-        sync()
-        dt = time.perf_counter() - t0
+        dt = timed(fwd, args.steps, args.warmup, sync)
+    if args.child:
+        return
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if ddp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -203,56 +416,111 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * R_PER_GPU * args.steps / dt
 
+    # ---- training step, every N: forward with a graph, backward, gradient all-reduce (RCCL), FusedAdam
+    opt = FusedAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    gr = torch.randn(R_PER_GPU, 3, device=dev)
+    gd = torch.randn(R_PER_GPU, device=dev)
+    reduced = [0]
+
+    def train_step():
+        opt.zero_grad()
+        rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=N_SAMPLES_ARG)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+        if ddp:
+            reduced[0] = allreduce_grads(field)
+        opt.step()
+    t_steps = max(5, min(args.steps, 20))
+    dtt = timed(train_step, t_steps, 3, sync)
+    tmax = torch.tensor([dtt], device=dev, dtype=torch.float64)
+    if ddp:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dtt = float(tmax.item())
+
     if rank == 0:
         z = field.z_schedule(False, N_SAMPLES_ARG, dev).contiguous()
         S = z.shape[0]
         prof = kernel_profile(field, rays, z)
-        dens_bytes = R_PER_GPU * S * DENS_BYTES_PER_SAMPLE
-        app_bytes = prof["n_shaded"] * APP_BYTES_PER_SAMPLE
-        kern = {
-            "k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes,
-                        "GBps": dens_bytes / (prof["march_ms"] * 1e-3) / 1e9},
-            "k_shade": {"ms": prof["shade_ms"], "alg_bytes": app_bytes,
-                        "GBps": app_bytes / (prof["shade_ms"] * 1e-3) / 1e9,
-                        "mlp_TFLOPs": prof["n_shaded"] * MLP_FLOP_PER_SAMPLE / (prof["shade_ms"] * 1e-3) / 1e12},
-            "k_finalize": {"ms": prof["finalize_ms"]},
-        }
-        dom = "k_shade" if prof["shade_ms"] >= prof["march_ms"] else "k_march"
-        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE /
-        # WRITE_SIZE cannot be read from inside this process); the committed summary is used.
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "k_shade_bf16" if dom == "k_shade" else dom
-            traffic = pmc["kernels"][key]["traffic_bytes"]
-            traffic_src = "profiles/r01_pmc_traffic.json (" + pmc["correction"].split(":")[0] + ")"
-            for kn, kk in (("k_march", "k_march"), ("k_shade", "k_shade_bf16")):
-                kern[kn]["pmc_traffic_bytes"] = pmc["kernels"][kk]["traffic_bytes"]
-                kern[kn]["l2_hit_rate"] = pmc["kernels"][kk]["TCC_HIT"] / (pmc["kernels"][kk]["TCC_HIT"] + pmc["kernels"][kk]["TCC_MISS"])
-        except Exception:
-            pass
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "whole_path_GBps": (dens_bytes + app_bytes) / (prof["total_ms"] * 1e-3) / 1e9,
-                    "shaded_fraction": prof["n_shaded"] / (R_PER_GPU * S), "kernels": kern,
-                    "note": "achieved = algorithmic gather bytes of the dominant kernel / its HIP-event "
-                            "duration; the 35 MB field is cache-resident, so this can exceed HBM peak"}
+        traffic, traffic_src = ({}, None)
+        if world == 1 and not args.no_pmc:
+            traffic, traffic_src = pmc_traffic()
+        if not traffic:
+            why = traffic_src
+            traffic, traffic_src = committed_traffic()
+            if why and traffic_src:
+                traffic_src += f" [{why}]"
+        roofline = roofline_object(prof, S, traffic or {}, traffic_src)
+        n_sh = prof["n_shaded"]
+        rows = ((n_sh + 15) // 16) * 16
+        # bytes the training step moves through HBM-side memory by construction: the saved activation /
+        # gradient rows (ACT 400 + GRD 384 floats per row: written once; wgrad reads both, dgrad re-reads
+        # h1/h2), the density features (R*S floats, written + read twice), gradient images + reference-layout
+        # gradients (3 x 35 MB) + Adam (param, m, v read+write) -- cache-served gathers not counted
+        n_par = sum(p.numel() for p in field.parameters() if p.requires_grad)
+        train_bytes = rows * 4 * (400 * 2 + 256 + 384 * 2) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
+        train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
+                 "what": "lrf_render_fwd_train + lrf_render_bwd + "
+                         + (f"allreduce_grads over RCCL ({reduced[0] / 1e6:.1f} MB in place) + " if ddp else "")
+                         + "FusedAdam, 4096 rays x 512 samples per GPU, jittered samples",
+                 "roofline": {"bound": "hbm", "achieved": train_bytes / (dtt / t_steps) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": train_bytes / (dtt / t_steps) / 1e9 / HBM_PEAK_GBS,
+                              "bytes_per_step": train_bytes,
+                              "note": "materialised rows + feature / gradient buffers + Adam, by construction; per-kernel "
+                                      "times in profiles/"}}
         out = {"metric": "rays/sec (4096-ray batch, 512 samples, 300^3 grid)", "value": value,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f32 (colour MLP on split-bf16 x3 MFMA, fp32 accumulate; gathers, compositing fp32)",
+               "data": "synthetic",
                "config": {"workload": "configs[1]: single 300^3 TensorVMSplit, 4096 rays x 512 samples "
                                       "per GPU, full density+appearance+MLP render, eval forward",
                           "rays_per_gpu": R_PER_GPU, "samples_per_ray": S, "grid": GRID,
                           "parallelism": f"ray-shard x{world}", "mlp_engine": field.mlp_engine},
-               "roofline": roofline}
-        if not args.no_baselines and world == 1:              # baselines are an N=1 report
-            out["train_step"] = train_step_time(field, rays)
+               "roofline": roofline, "train_step": train}
+        if not args.no_baselines and world == 1:              # baselines and extra workloads are an N=1 report
+            with torch.no_grad():
+                field.mlp_engine = "f32"
+                d32 = timed(fwd, 20, 3, sync)
+                field.mlp_engine = "bf16x3_fused"
+                dfu = timed(fwd, 20, 3, sync)
+                field.mlp_engine = "bf16x3"
+            work = {"exact_f32_engine": {"rays_per_s": R_PER_GPU * 20 / d32, "ms_per_step": d32 / 20 * 1e3,
+                                         "what": "same batch, colour MLP on v_mfma_f32_16x16x4_f32 (LRF_FLAG_MLP_F32)"},
+                    "fused_bf16x3_engine": {"rays_per_s": R_PER_GPU * 20 / dfu, "ms_per_step": dfu / 20 * 1e3,
+                                            "what": "same batch, round 1's single colour kernel (LRF_FLAG_MLP_FUSED)"}}
+            try:
+                wf = walls_field(dev)
+                wf.updateAlphaMask((GRID // 2,) * 3)
+                with torch.no_grad():
+                    wfwd = lambda: wf(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)   # noqa: E731
+                    d_on = timed(wfwd, 20, 3, sync)
+                    p_on = kernel_profile(wf, rays, z)
+                    wf.early_term_T = 0.0
+                    d_off = timed(wfwd, 20, 3, sync)
+                    p_off = kernel_profile(wf, rays, z)
+                work["trained_like"] = {
+                    "what": "300^3 field, empty space inside a box of dense walls + device-rebuilt alpha mask, same 4096 x 512 batch",
+                    "rays_per_s": R_PER_GPU * 20 / d_on, "ms_per_step": d_on / 20 * 1e3,
+                    "k_march_ms": p_on["march_ms"], "shaded_fraction": p_on["n_shaded"] / (R_PER_GPU * S),
+                    "without_early_termination": {"rays_per_s": R_PER_GPU * 20 / d_off, "ms_per_step": d_off / 20 * 1e3,
+                                                  "k_march_ms": p_off["march_ms"]}}
+                del wf
+            except Exception as e:                           # noqa: BLE001
+                work["trained_like"] = {"error": repr(e)}
+            try:
+                lt, ray_ids, view_ids, bw = config3_scene(dev)
+                with torch.no_grad():
+                    c3 = lambda: lt(ray_ids, view_ids, 64, 48, is_train=False, blending_weights=bw, chunk=4096)   # noqa: E731
+                    d3 = timed(c3, 20, 3, sync)
+                work["config3_4x300"] = {"what": "configs[2]: LocalTensorfs, 4 blended 300^3 fields, 4096 rays, default S=344, "
+                                                 "ids handed over on the host", "rays_per_s": 4096 * 20 / d3, "ms_per_step": d3 / 20 * 1e3}
+                del lt
+            except Exception as e:                           # noqa: BLE001
+                work["config3_4x300"] = {"error": repr(e)}
+            out["workloads"] = work
             sd = field.state_dict()
-            out["torch_rocm_port"] = torch_rocm_port(sd, rays)
+            out["torch_rocm_baseline"] = torch_rocm_baseline(sd, rays)
             out["cpu_baseline"] = cpu_baseline(sd, rays_cpu)
-            out["speedup_vs_torch_rocm_port"] = value / world / out["torch_rocm_port"]["value"]
+            out["speedup_vs_torch_rocm"] = value / world / out["torch_rocm_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if ddp:
         dist.barrier(device_ids=[local])

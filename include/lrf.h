@@ -121,8 +121,9 @@ int lrf_render_fwd(const LrfField* f, const float* rays, const float* z,
                    void* workspace, void* stream);
 
 /* Measurement variant of lrf_render_fwd (bench.py only): brackets each kernel with HIP
- * events on `stream`, SYNCHRONISES, and returns ms_out[5] (host) = {march, shade, finalize,
- * total} plus the number of shaded samples (sum over rays of weight > thres). */
+ * events on `stream`, SYNCHRONISES, and returns ms_out[6] (host) = {march, shade, finalize,
+ * total, k_scan_tiles, k_app} (shade = k_scan_tiles + k_app + k_mlp with the default engine; the last is 0
+ * with the others) plus the number of shaded samples (sum over rays of weight > thres). */
 int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            int32_t R, int32_t S, uint32_t flags, float floater_thresh,
                            float* rgb, float* depth, void* workspace, void* stream,
@@ -148,6 +149,11 @@ int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, con
                    const float* g_rgb, const float* g_depth,
                    const LrfGrads* g, float* g_rays,
                    void* workspace, void* stream);
+
+/* Debug / parity diagnostics: byte offsets inside the training workspace of {activation rows, gradient rows,
+ * rowinfo (row -> ray*S+k or ~0), toff} and the row strides / column offsets {ACT_LD, GRD_LD, ACT_H1, ACT_H2}
+ * in floats.  Rows are indexed tile*16 + lane; valid after lrf_render_bwd of the same workspace. */
+void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[8]);
 
 /* Pieces of the path exposed on their own (unit parity tests; also used by
  * TensorVMSplit.compute_densityfeature / compute_appfeature / compute_alpha):

@@ -1031,7 +1031,7 @@ static int launch_shade_split(const DField& d, const float* rays, const float* z
 static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                            uint32_t flags, float floater_thresh, float* rgb, float* depth,
                            float* weight_out, float* acc_out, void* workspace, hipStream_t st,
-                           hipEvent_t* ev /* 5 events or null: start, after march, after shade, end, between k_app and k_mlp */) {
+                           hipEvent_t* ev /* 6 events or null: start, after march, after shade, end, between k_app and k_mlp, after k_scan_tiles */) {
   if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
   if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
   DField d = make_dfield(f);
@@ -1047,6 +1047,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
                        d, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   } else {
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+    if (ev) LRF_HIP(hipEventRecord(ev[5], st));
     if (flags & LRF_FLAG_MLP_F32)
       hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st,
                          d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
@@ -1077,9 +1078,10 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            void* workspace, void* stream, float* ms_out, int32_t* n_shaded_out) {
   if (!ms_out) return set_err("lrf_render_fwd_profile: null ms_out");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipEvent_t ev[5];
-  for (int i = 0; i < 5; ++i) LRF_HIP(hipEventCreate(&ev[i]));
+  hipEvent_t ev[6];
+  for (int i = 0; i < 6; ++i) LRF_HIP(hipEventCreate(&ev[i]));
   LRF_HIP(hipEventRecord(ev[4], st));      // re-recorded between k_app and k_mlp by the default engine
+  LRF_HIP(hipEventRecord(ev[5], st));      // re-recorded after k_scan_tiles by the MFMA engines
   int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, nullptr, nullptr, workspace, st, ev);
   if (rc == 0) {
     hipError_t e = hipEventSynchronize(ev[3]);
@@ -1088,9 +1090,10 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
   if (rc == 0) {
     for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
     (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
-    ms_out[4] = 0.0f;                      // k_app alone (default engine); shade = k_scan_tiles + k_app + k_mlp
+    ms_out[4] = ms_out[5] = 0.0f;          // shade = k_scan_tiles [4] + k_app [5] + k_mlp (default engine)
+    if (!(flags & LRF_FLAG_MLP_VALU)) (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[5]);
     if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED)))
-      (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[4]);
+      (void)hipEventElapsedTime(&ms_out[5], ev[5], ev[4]);
     if (n_shaded_out) {
       // shaded-sample count of this batch = sum of ncomp (host copy; measurement only)
       const Workspace w = carve(workspace, R, S);
@@ -1102,7 +1105,7 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
       free(h);
     }
   }
-  for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
+  for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
 }
 

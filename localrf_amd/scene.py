@@ -66,6 +66,9 @@ class LocalTensorfs(torch.nn.Module):
         # reference result (checked against a reference-recorded golden); False = the cross product
         # the reference meant.  Only batches of exactly 3 views differ.
         self.reference_cross = True
+        # data-parallel hook (localrf_amd/dist.py): called between backward and the optimiser steps of
+        # optimizer_step with this module; None = single process, as the reference
+        self.grad_sync = None
 
         self.lr_factor = 1
         self.regularize = True
@@ -205,6 +208,8 @@ class LocalTensorfs(torch.nn.Module):
         self.rf_optimizer.zero_grad()
 
         loss.backward()
+        if self.grad_sync is not None:          # data parallel: localrf_amd.dist.allreduce_grads(self)
+            self.grad_sync(self)
 
         self.rf_optimizer.step()
         if self.is_refining:

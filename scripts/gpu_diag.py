@@ -737,7 +737,45 @@ def stage_fuzz_case():
             "at", hot.nonzero()[:6].tolist())
 
 
-STAGES = [("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_mfma_policy():
+    """The hazard experiment of DESIGN.md 'gfx950 / hipcc findings': k_mlp under its four MFMA issue
+    policies (lrf_shade2.inl) -- run-to-run determinism of 150 renders of the config-2 batch, agreement
+    with policy 0, and kernel time."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+    ref = None
+    for pol in (0, 1, 2, 3, 0):
+        lib.lrf_debug_set_mlp_policy(pol)
+        with torch.no_grad():
+            first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            ndiff, nray, maxd = 0, 0, 0.0
+            for _ in range(150):
+                again, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                if not torch.equal(first, again):
+                    ndiff += 1
+                    d = (first - again).abs().amax(-1)
+                    nray = max(nray, int((d > 0).sum()))
+                    maxd = max(maxd, float(d.max()))
+        if ref is None:
+            ref = first.clone()
+        prof = bench.kernel_profile(f, rays, z, reps=10)
+        log(f"policy {pol}: renders differing from the first {ndiff}/150 (max rays {nray}, max |diff| {maxd:.2e}) | "
+            f"max |rgb - policy0| {float((first - ref).abs().max()):.2e} | k_app {prof['app_ms'] * 1e3:.1f} us "
+            f"k_mlp {prof['mlp_ms'] * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
+    lib.lrf_debug_set_mlp_policy(0)
+    f.mlp_engine = "bf16x3_fused"
+    prof = bench.kernel_profile(f, rays, z, reps=10)
+    log(f"fused engine: k_shade {(prof['shade_ms'] - prof['scan_ms']) * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
+
+
+STAGES = [("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -11,7 +11,8 @@ import pytest
 import torch
 
 from oracle import vm_render_np as oracle
-from util import field_from_golden, golden_field_dict, load_golden, make_field, make_rays, quiet, rel_err
+from util import (capture_train_ws, check_grads_with_flips, field_from_golden, field_from_seed, golden_field_dict,
+                  load_golden, make_field, make_rays, quiet, rel_err, relu_flip_report)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -34,7 +35,7 @@ def _check_rays(got, ref, tol=TOL, max_outliers=0, outlier_abs=2e-3):
         assert np.abs(got - ref).max() < outlier_abs
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "f32", "valu"])
+@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_fused", "f32", "valu"])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_field_forward_vs_reference_golden(built_lib, name, engine):
     g = load_golden(name)
@@ -155,6 +156,89 @@ def test_sample_ray_aabb_vs_oracle(built_lib):
     assert (inside.cpu().numpy() != io).mean() < 0.002     # points within rounding of the box faces
 
 
+def test_sample_ray_aabb_vs_reference_golden(built_lib):
+    """TensorBase.sample_ray recorded from the reference (eval, and train mode with the recorded jitter)."""
+    g = load_golden("sample_ray")
+    f = quiet(make_field, [32, 32, 32], "cpu", seed=5).to(DEV)
+    o, d = torch.from_numpy(g["rays"][:, :3]).to(DEV), torch.from_numpy(g["rays"][:, 3:]).to(DEV)
+    assert abs(float(f.stepSize) - float(g["stepSize"])) < 1e-9
+    for train, sfx, jit in ((False, "", None), (True, "_j", torch.from_numpy(g["U"]))):
+        pts, t, inside = f.sample_ray(o, d, is_train=train, N_samples=int(g["N_samples"]), jitter=jit)
+        assert np.abs(_np(t) - g["t" + sfx]).max() < 2e-6 * np.abs(g["t" + sfx]).max()
+        assert (np.abs(_np(pts) - g["pts" + sfx]) / np.maximum(np.abs(g["pts" + sfx]), 1.0)).max() < 2e-6
+        assert (inside.cpu().numpy() != g["inside" + sfx]).mean() < 0.002   # points within rounding of a box face
+
+
+def test_alpha_mask_rebuild_vs_reference_golden(built_lib):
+    """updateAlphaMask on the device (lrf_dense_alpha + lrf_alpha_pool_threshold) against the binary
+    volumes the reference's updateAlphaMask produced (tensorBase.py:518-536), including a rebuild
+    through an existing mask, then a render through the rebuilt mask."""
+    g = load_golden("alpha_mask_rebuild")
+    f = field_from_seed(g, DEV)
+    f.updateAlphaMask(tuple(int(v) for v in g["g1"]))
+    ref1 = np.unpackbits(g["m1"])[:int(np.prod(g["m1_shape"]))].reshape(g["m1_shape"])
+    got1 = f.alphaMask.alpha_volume[0, 0].cpu().numpy()
+    assert got1.shape == ref1.shape and (got1 == ref1).all(), int((got1 != ref1).sum())
+    f.updateAlphaMask(tuple(int(v) for v in g["g2"]))
+    ref2 = np.unpackbits(g["m2"])[:int(np.prod(g["m2_shape"]))].reshape(g["m2_shape"])
+    got2 = f.alphaMask.alpha_volume[0, 0].cpu().numpy()
+    assert got2.shape == ref2.shape and (got2 == ref2).all(), int((got2 != ref2).sum())
+    with torch.no_grad():
+        rgb, depth = f(torch.from_numpy(g["rays"]).to(DEV), white_bg=True, is_train=False, N_samples=int(g["N_samples"]))
+    _check_rays(_np(rgb), g["rgb"])
+    _check_rays(_np(depth), g["depth"])
+    # the reference's Python loop on the same device (getDenseAlpha semantics): same dense alpha
+    dense = f.getDenseAlpha(tuple(int(v) for v in g["g1"]))
+    assert tuple(dense.shape) == tuple(int(v) for v in g["g1"])
+
+
+def _walls_field(grid, seed, dev):
+    """Trained-like scene: near-empty space (density planes x 0.1) inside a closed box of dense walls
+    at |x|,|y|,|z| ~ 0.9 -- six rank-1 components (plane = 1, line = a smooth bump of height 40)."""
+    f = quiet(make_field, grid, "cpu", seed=seed)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(0.1)
+        for p in range(3):                              # line p runs along axis vecMode[p] = 2 - p
+            L = f.density_line[p].shape[2]
+            c = torch.linspace(-2, 2, L)
+            for comp, centre in ((0, 0.9), (1, -0.9)):
+                f.density_plane[p][0, comp].fill_(1.0)
+                f.density_line[p][0, comp, :, 0] = 40.0 * torch.exp(-((c - centre) / 0.08) ** 2)
+    return f.to(dev)
+
+
+def test_early_termination_on_a_trained_like_scene(built_lib):
+    """k_march stops gathering once the transmittance is below term_T (LrfField.term_T): colours and
+    acc are unchanged, depth moves by <= term_T * z_max / |d|, and the samples behind the walls are
+    really skipped (their weights are exactly zero)."""
+    f = _walls_field([96, 96, 96], 7, DEV)
+    rays = make_rays(512, 8, pinhole=True).to(DEV)
+    assert f.early_term_T == 1e-9
+    with torch.no_grad():
+        rgb, depth, w, acc, z = f.render_weights(rays, N_samples=600)
+        f.early_term_T = 0.0
+        rgb0, depth0, w0, acc0, _ = f.render_weights(rays, N_samples=600)
+        f.early_term_T = 1e-9
+    assert float((rgb - rgb0).abs().max()) < 2e-7            # same shaded samples; acc may round differently
+    assert float((depth - depth0).abs().max()) <= 1e-9 * 1000.2 / float(rays[:, 3:].norm(dim=-1).min()) + 1e-7
+    assert torch.allclose(acc, acc0, atol=1e-6)
+    S = z.numel()
+    dead = (w[:, :S - 1] == 0) & (w0[:, :S - 1] > 0)       # evaluated without termination, skipped with it
+    assert int(dead.any(-1).sum()) > 400                    # almost every ray hits a wall
+    assert float(w0[dead].max()) < 1e-9
+    fld = {k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}
+    ro, do = oracle.render_field(fld, _np(rays[::8]), _np(z), True, 0.0)
+    _check_rays(_np(rgb[::8]), ro)
+    _check_rays(_np(depth[::8]), do)
+    # training path: same forward, finite gradients, skipped samples carry none
+    r = rays.clone().requires_grad_(True)
+    a, b = f(r, white_bg=True, is_train=False, N_samples=600)
+    assert float((a.detach() - rgb).abs().max()) < 1e-6
+    (a.sum() + b.sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in f.parameters() if p.grad is not None)
+
+
 # ----------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def big(built_lib):
@@ -164,17 +248,47 @@ def big(built_lib):
     return f, rays
 
 
-def test_full_size_subset_vs_oracle(big):
+@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_fused", "f32"])
+def test_config2_all_rays_vs_reference_golden(big, engine):
+    """BASELINE.json configs[1] at full size against the REFERENCE's own output for all 4096 rays
+    (tests/golden/config2_300cube.npz: 300^3 field from seed 0, 512 samples).  A ray may miss the 1e-4
+    bar only because a sample sits on the shading threshold weight > 1e-3 (tensorBase.py:622): at most
+    0.2 % of the rays, each with a sample whose weight is within 1e-6 of the threshold in the reference's
+    or in this path's own weights, and then by less than 2e-3."""
     f, rays = big
+    g = load_golden("config2_300cube")
+    assert np.array_equal(_np(rays), g["rays"])
+    s = float(sum(v.double().abs().sum() for v in f.state_dict().values()))
+    assert abs(s - float(g["field_sum"][0])) < 1e-6 * float(g["field_sum"][0])
+    f.mlp_engine = engine
     with torch.no_grad():
-        rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=1536)
-    idx = torch.arange(0, 4096, 64)
-    fld = {k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}
-    z = oracle.z_schedule(1536)
-    assert z.shape[0] == 512
-    ro, do = oracle.render_field(fld, _np(rays[idx]), z, True, 0.0)
-    _check_rays(_np(rgb[idx]), ro, max_outliers=1)
-    _check_rays(_np(depth[idx]), do)
+        rgb, depth, w, acc, z = f.render_weights(rays, N_samples=1536)
+    f.mlp_engine = "bf16x3"
+    e_rgb = (np.abs(_np(rgb) - g["rgb"]) / np.maximum(np.abs(g["rgb"]), 1e-3)).max(-1)
+    e_dep = np.abs(_np(depth) - g["depth"]) / np.maximum(np.abs(g["depth"]), 1e-3)
+    assert e_dep.max() < TOL, e_dep.max()
+    assert np.abs(_np(acc) - g["acc"]).max() < 1e-5
+    bad = e_rgb > TOL
+    assert bad.sum() <= 8, (int(bad.sum()), float(e_rgb.max()))
+    near_mine = _np((w - f.rayMarch_weight_thres).abs().amin(-1))
+    for r in np.nonzero(bad)[0]:
+        assert min(near_mine[r], g["near_thres"][r]) < 1e-6, (r, near_mine[r], g["near_thres"][r], e_rgb[r])
+        assert np.abs(_np(rgb[r]) - g["rgb"][r]).max() < 2e-3
+    n_sh = int((w > f.rayMarch_weight_thres).sum())
+    assert abs(n_sh - int(g["n_shaded"])) <= 16, (n_sh, int(g["n_shaded"]))
+
+
+def test_split_and_fused_colour_engines_are_bit_identical(big):
+    """k_app + k_mlp (default) runs the arithmetic of k_shade_bf16 (bf16x3_fused) in the same order."""
+    f, rays = big
+    outs = {}
+    for eng in ("bf16x3", "bf16x3_fused"):
+        f.mlp_engine = eng
+        with torch.no_grad():
+            outs[eng] = f(rays, white_bg=True, is_train=False, N_samples=1536)
+    f.mlp_engine = "bf16x3"
+    assert torch.equal(outs["bf16x3"][0], outs["bf16x3_fused"][0])
+    assert torch.equal(outs["bf16x3"][1], outs["bf16x3_fused"][1])
 
 
 def test_full_size_properties(big):
@@ -205,7 +319,7 @@ def test_full_size_properties(big):
     assert rel_err(_np(outs["bf16x3"]), _np(outs["valu"])) < 3e-5
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "f32"])
+@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_fused", "f32"])
 def test_repeat_runs_are_bitwise_identical(big, engine):
     """Guards the hand-issued bf16 MFMA chain (mfma_bf16_acc / hold / settle in lrf_render.hip):
     200 renders of the same 4096x512 batch must agree bit for bit.  Every flaky build seen during
@@ -254,26 +368,57 @@ def _grad_rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
 
 
+def _train_grads(f, rays_np, z, g_rgb, g_depth, white=True):
+    """Row-saving forward + backward; returns outputs, gradients by name (+ "rays") and the ReLU flip
+    report of this very pass (tests/util.py::relu_flip_report)."""
+    f.z_override = z.clone()
+    for p in f.parameters():
+        p.grad = None
+    rays = torch.as_tensor(rays_np).to(DEV).clone().requires_grad_(True)
+    with capture_train_ws(f) as cap:
+        rgb, depth = f(rays, white_bg=white, is_train=False, N_samples=-1)    # z comes from z_override; eval mode
+        ((rgb * g_rgb).sum() + (depth * g_depth).sum()).backward()            # keeps the background deterministic
+        torch.cuda.synchronize()
+        rep = relu_flip_report(f, rays, f.z_override.to(DEV), cap.ws)
+    f.z_override = None
+    grads = {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}
+    grads["rays"] = rays.grad.clone()
+    return rgb.detach(), depth.detach(), grads, rep
+
+
 def test_backward_vs_reference_autograd_golden(built_lib):
-    """Train-mode forward with the recorded jitter, then lrf_render_bwd against the gradients
-    the reference's autograd produced (tests/golden/field_small_train_grad.npz)."""
+    """Train-mode forward with the recorded jitter, then lrf_render_bwd against the gradients the
+    reference's autograd produced (tests/golden/field_small_train_grad.npz): 1e-4 of each tensor's
+    largest magnitude, except entries a detected ReLU-mask flip can touch (tests/util.py)."""
     g = load_golden("field_small_train_grad")
     f = quiet(field_from_golden, g, DEV)
-    z = oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"]))
-    f.z_override = torch.from_numpy(z)
-    rays = torch.from_numpy(g["rays"]).to(DEV).requires_grad_(True)
-    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    z = torch.from_numpy(oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"])))
+    rgb, depth, grads, rep = _train_grads(f, g["rays"], z, torch.from_numpy(g["g_rgb"]).to(DEV),
+                                          torch.from_numpy(g["g_depth"]).to(DEV))
     _check_rays(_np(rgb), g["rgb"])
-    loss = (rgb * torch.from_numpy(g["g_rgb"]).to(DEV)).sum() + (depth * torch.from_numpy(g["g_depth"]).to(DEV)).sum()
-    loss.backward()
-    worst = {}
-    for name, p in f.named_parameters():
-        if not p.requires_grad:
-            continue
-        worst[name] = _grad_rel(_np(p.grad), g["grad." + name])
-    worst["rays"] = _grad_rel(_np(rays.grad), g["grad.rays"])
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
-    assert not bad, (bad, worst)
+    ref = {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in grads}
+    worst = check_grads_with_flips(grads, ref, rep)
+    assert rep["n_shaded"] > 1000, rep
+    print("flips", rep["n_flips"], "worst", {k: "%.1e/%.1e" % v for k, v in worst.items()})
+
+
+def test_backward_128cube_vs_reference_autograd_golden(built_lib):
+    """The same at 128^3 (default sample count, 512 rays; field regenerated from its seed): gradients
+    recorded from the reference, plane gradients as a seeded subset + the largest entries."""
+    g = load_golden("field_128_train_grad")
+    f = field_from_seed(g, DEV)
+    z = torch.from_numpy(oracle.z_schedule(int(g["nSamples"]), np.float32, jitter=(g["U"], g["U2"])))
+    rgb, depth, grads, rep = _train_grads(f, g["rays"], z, torch.from_numpy(g["g_rgb"]).to(DEV),
+                                          torch.from_numpy(g["g_depth"]).to(DEV))
+    _check_rays(_np(rgb), g["rgb"], max_outliers=1)
+    _check_rays(_np(depth), g["depth"])
+    ref = {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in grads}
+    subset = {n: torch.from_numpy(g["gidx." + n]).to(DEV) for n in grads if ("gidx." + n) in g}
+    gmax = {n: float(g["gmax." + n]) for n in grads}
+    worst = check_grads_with_flips(grads, ref, rep, subset=subset, gmax=gmax)
+    for n in grads:                                   # the whole tensor, through its L2 norm
+        assert abs(float(grads[n].double().norm()) - float(g["gl2." + n])) <= 2e-3 * float(g["gl2." + n]), n
+    print("flips", rep["n_flips"], "worst", {k: "%.1e/%.1e" % v for k, v in worst.items()})
 
 
 def test_backward_accumulates_and_zero_grad_output(built_lib):
@@ -330,8 +475,8 @@ def test_ragged_shapes_forward_and_backward(built_lib, R, N):
     for k in mine:
         denom = float(ref[k].abs().max())
         err = float((mine[k] - ref[k]).abs().max())
-        # 1e-2 of the tensor's max: one sample flipping across the weight > 1e-3 shading threshold
-        # between the two fp32 implementations moves a gradient by ~1e-6 absolute
+        # tiny batches (down to one ray): a single ReLU-mask or shading-threshold flip is a visible
+        # fraction of a gradient here; the flip-aware 1e-4 checks are the golden and fuzz tests
         assert err <= 1e-2 * max(denom, 1e-6), (k, err, denom)
 
 
@@ -382,8 +527,8 @@ def test_large_noncubic_grid_forward_backward(built_lib):
 def test_row_saving_forward_equals_recomputing_backward(built_lib):
     """lrf_render_fwd_train + lrf_render_bwd(LRF_FLAG_ROWS_SAVED) against the recomputing backward:
     same outputs bit for bit, same gradients up to the order of the scatter atomics; a second
-    backward through the same graph and a parameter update between forward and backward both fall
-    back to recomputation."""
+    backward through the same graph falls back to recomputation; a parameter update between forward
+    and backward raises."""
     f = quiet(make_field, [40, 36, 44], "cpu", seed=3).to(DEV)
     with torch.no_grad():
         for p in f.density_plane:
@@ -422,12 +567,78 @@ def test_row_saving_forward_equals_recomputing_backward(built_lib):
     c = run(False, retain=True)
     for x, y in zip(c[2], c[3]):
         assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-12)
-    # parameters updated between forward and backward: the saved rows are stale and are not used
+    # parameters updated between forward and backward: the reference's autograd refuses ("modified by
+    # an inplace operation"); so does this path
     for p in f.parameters():
         p.grad = None
     rgb, depth = f(rays.clone().requires_grad_(True), is_train=False, N_samples=96)
     with torch.no_grad():
         f.basis_mat.weight.mul_(1.0)              # bumps the version only
-    ((rgb * gr).sum() + (depth * gd).sum()).backward()
-    for p, y in zip([p for p in f.parameters() if p.grad is not None], b[2]):
-        assert float((p.grad - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-12)
+    with pytest.raises(RuntimeError, match="modified"):
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+
+
+# ----------------------------------------------------------------- randomised sweep (was scripts/gpu_diag.py fuzz)
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fuzz_forward_and_gradients_vs_aten_port(built_lib, seed):
+    """Random grids (8..96 per axis, non-cubic), ray counts, sample counts, white background, ray family,
+    alpha masks, density scales, softplus/relu against the reference's ATen op chain
+    (oracle/vm_render_torch.py, pinned to the reference goldens) on the same GPU.  Forward: 1e-4, a ray
+    may miss only with a sample within 1e-6 of the shading threshold.  Gradients (cases without mask):
+    1e-4 of each tensor's maximum outside entries a detected ReLU-mask flip can touch."""
+    from localrf_amd import AlphaGridMask
+    from oracle import vm_render_torch as ot
+    rng = np.random.default_rng(seed)
+    stats = {"cases": 0, "grad_cases": 0, "outlier_rays": 0, "flip_cases": 0, "flips": 0, "worst_out": 0.0, "worst_in": 0.0}
+    for case in range(24):
+        grid = [int(rng.integers(8, 97)) for _ in range(3)]
+        R = int(rng.choice([1, 3, 63, 64, 65, 200, 511, 700]))
+        ns = int(rng.choice([-1, 36, 96, 200, 402]))
+        act = str(rng.choice(["softplus", "relu"]))
+        white = bool(rng.integers(0, 2))
+        pin = bool(rng.integers(0, 2))
+        f = quiet(make_field, grid, "cpu", seed=int(rng.integers(0, 1 << 30)), fea2denseAct=act).to(DEV)
+        with torch.no_grad():
+            for p in f.density_plane:
+                p.mul_(float(rng.choice([1.0, 3.0, 6.0])))
+        if rng.integers(0, 2):
+            vol = (torch.rand(6, 7, 5, generator=torch.Generator().manual_seed(case)) > 0.3).float()
+            vol = torch.nn.functional.interpolate(vol[None, None], size=(20, 22, 18), mode="nearest")[0, 0]
+            f.alphaMask = AlphaGridMask(torch.device(DEV), f.aabb.detach(), vol.to(DEV))
+        rays = make_rays(R, 1000 * seed + 100 + case, pinhole=pin).to(DEV)
+        z = f.z_schedule(False, ns, rays.device)
+        if act != "softplus":
+            continue                                   # the ATen port restates the softplus path only
+        fld = {k: v for k, v in f.state_dict().items()}
+        with torch.no_grad():
+            rgb, depth, w, acc, _ = f.render_weights(rays, N_samples=ns, white_bg=white)
+            rgb_p, depth_p = ot.render_field(fld, rays, z[None], white, 0.0, weight_thres=f.rayMarch_weight_thres)
+        e_rgb = ((rgb - rgb_p).abs() / rgb_p.abs().clamp(min=1e-3)).amax(-1)
+        e_dep = (depth - depth_p).abs() / depth_p.abs().clamp(min=1e-3)
+        assert float(e_dep.max()) < TOL, (case, grid, R, ns, float(e_dep.max()))
+        bad = e_rgb > TOL
+        near = (w - f.rayMarch_weight_thres).abs().amin(-1)
+        assert int(bad.sum()) <= max(1, R // 100) and bool((near[bad] < 1e-6).all()), (case, grid, R, ns, float(e_rgb.max()))
+        assert float((rgb - rgb_p).abs().max()) < 5e-3
+        stats["outlier_rays"] += int(bad.sum())
+        stats["cases"] += 1
+        if R > 200 or f.alphaMask is not None:
+            continue
+        gr = torch.randn(R, 3, device=DEV)
+        gd = torch.randn(R, device=DEV)
+        _, _, mine, rep = _train_grads(f, rays, z, gr, gd, white)
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in f.named_parameters()}
+        r2 = rays.clone().requires_grad_(True)
+        a2, b2 = ot.render_field({**fld, **leaves}, r2, z[None], white, 0.0)
+        ((a2 * gr).sum() + (b2 * gd).sum()).backward()
+        ref = {n: (r2.grad if n == "rays" else leaves[n].grad) for n in mine}
+        if bool((near < 1e-6).any()):
+            continue                                   # a sample on the shading threshold: not a gradient test
+        worst = check_grads_with_flips(mine, ref, rep)
+        stats["grad_cases"] += 1
+        stats["flip_cases"] += rep["n_flips"] > 0
+        stats["flips"] += rep["n_flips"]
+        stats["worst_out"] = max(stats["worst_out"], max(v[0] for v in worst.values()))
+        stats["worst_in"] = max(stats["worst_in"], max(v[1] for v in worst.values()))
+    print("fuzz", seed, stats)
+    assert stats["cases"] >= 6 and stats["grad_cases"] >= 2, stats
