@@ -98,6 +98,7 @@ int         lrf_abi_version(void);
 /* Debug: when set (device buffer of R*S*64 floats), the split-bf16 shade kernel stores 16
  * intermediate values per (compact sample, lane group); NULL (default) disables it. */
 void        lrf_debug_set_dump(float* buf);
+void        lrf_debug_set_mlp_threads(int threads); /* 1024 (default) | 512 | 256: workgroup size of k_mlp (experiments) */
 void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);
 
@@ -152,8 +153,10 @@ int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, con
 
 /* Debug / parity diagnostics: byte offsets inside the training workspace of {activation rows, gradient rows,
  * rowinfo (row -> ray*S+k or ~0), toff} and the row strides / column offsets {ACT_LD, GRD_LD, ACT_H1, ACT_H2}
- * in floats.  Rows are indexed tile*16 + lane; valid after lrf_render_bwd of the same workspace. */
-void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[8]);
+ * in floats, then the byte offset of the density-feature buffer [R,S] (-inf = sample not evaluated: masked,
+ * last, or behind an early termination; overwritten with d(loss)/d(feature) by lrf_render_bwd).  Rows are
+ * indexed tile*16 + lane; rowinfo is valid after lrf_render_bwd of the same workspace. */
+void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[9]);
 
 /* Pieces of the path exposed on their own (unit parity tests; also used by
  * TensorVMSplit.compute_densityfeature / compute_appfeature / compute_alpha):

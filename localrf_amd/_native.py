@@ -58,6 +58,7 @@ SYMBOLS = {
     "lrf_last_error": (C.c_char_p, []),
     "lrf_debug_set_dump": (None, [C.c_void_p]),
     "lrf_debug_set_mlp_policy": (None, [C.c_int]),
+    "lrf_debug_set_mlp_threads": (None, [C.c_int]),
     "lrf_workspace_layout_bwd": (None, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "lrf_cache_bytes": (C.c_size_t, [C.POINTER(C.c_int32)]),
     "lrf_pack_field": (C.c_int, [C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),

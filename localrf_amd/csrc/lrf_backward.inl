@@ -1210,12 +1210,13 @@ extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t gr
 
 // Byte offsets of the pieces of the training workspace a test may want to look at (debug / parity
 // diagnostics only: e.g. comparing the ReLU masks of the saved activation rows with the reference's).
-extern "C" void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[8]) {
+extern "C" void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[9]) {
   using namespace lrf;
   const BwdWorkspace b = carve_bwd(nullptr, R, S, grid);
   auto off = [](const void* p) { return (uint64_t)reinterpret_cast<uintptr_t>(p); };
   out[0] = off(b.act); out[1] = off(b.grd); out[2] = off(b.rowinfo); out[3] = off(b.fw.toff);
   out[4] = (uint64_t)ACT_LD; out[5] = (uint64_t)GRD_LD; out[6] = (uint64_t)ACT_H1; out[7] = (uint64_t)ACT_H2;
+  out[8] = off(b.feat);
 }
 
 extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,

@@ -48,7 +48,12 @@ constexpr int IMGB_TAIL = IMGB_W2 + 8 * 4 * 128;   // uint4 index of the float t
 constexpr int TAIL_W3H = 0;                        // floats [g4][33][4]: 32 features + one pad slot per lane
 constexpr int TAIL_W3H_GS = 132;                   // group, so the groups' float4 reads fall on different banks
 constexpr int TAIL_B1 = 528, TAIL_B2 = 656, TAIL_W3V = 784, TAIL_FLOATS = 800;
-constexpr int IMGB_U4 = IMGB_TAIL + TAIL_FLOATS / 4;   // 6088 uint4 = 97,408 B
+constexpr int IMGB_U4 = IMGB_TAIL + TAIL_FLOATS / 4;   // 6088 uint4 = 97,408 B: what the fused kernels keep in LDS
+// k_mlp only (lrf_shade2.inl): mlp_view.0.weight[:, :128] as four more A fragments [ks4] (rows 0..2 = r,g,b,
+// rows 3..15 zero), same K order as layer 2 -- the 128 -> 3 head as a fourth MFMA layer
+constexpr int IMGB_W3F = IMGB_TAIL + 256;              // fragment-aligned (multiples of 128 uint4), behind the tail
+constexpr int IMGB_ALL = IMGB_W3F + 4 * 128;           // 6656 uint4 = 106,496 B
+static_assert(IMGB_W3F % 128 == 0 && IMGB_W3F >= IMGB_U4 && IMGB_W1 % 128 == 0, "fragments are addressed in units of 128 uint4");
 
 struct Layout {
   size_t dplane[3], dline[3], aplane[3], aline[3], mlp, mlpb, total;   // float offsets
@@ -68,7 +73,7 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
   for (int p = 0; p < 3; ++p) { L.aplane[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CAS); }
   for (int p = 0; p < 3; ++p) { L.aline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CAS); }
   L.mlp = off; off = align64(off + IMG_FLOATS);
-  L.mlpb = off; off = align64(off + (size_t)IMGB_U4 * 4);
+  L.mlpb = off; off = align64(off + (size_t)IMGB_ALL * 4);
   L.total = off;
   return L;
 }
@@ -186,6 +191,47 @@ __device__ __forceinline__ float density_feature(const DField& f, const float u[
     for (int h = 0; h < LRF_CD / 4; ++h) {
       const float4 a = ld4(q00 + 4 * h), b = ld4(q10 + 4 * h), c = ld4(q01 + 4 * h), d = ld4(q11 + 4 * h);
       const float4 e = ld4(r0 + 4 * h), g = ld4(r1 + 4 * h);
+      sp += (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + g.x * wl1);
+      sp += (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + g.y * wl1);
+      sp += (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + g.z * wl1);
+      sp += (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + g.w * wl1);
+    }
+    feat += sp;
+  }
+  return feat;
+}
+
+// ---- gathers with 32-bit byte offsets ---------------------------------------------------------
+// `base` is wave-uniform (an SGPR pair), the byte offset a 32-bit VGPR: the load becomes
+// global_load_dwordx4 v, v_off, s[base:base+1] and the address arithmetic stays 32-bit (the
+// size_t indexing of density_feature / gather_app6_plane costs ~100 64-bit VALU ops per 16-sample
+// tile).  Planes are < 4 GB: 640 x 640 texels x 128 B = 52 MB.
+__device__ __forceinline__ float4 ld4b(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// density_feature with 32-bit offsets (same arithmetic, same order)
+__device__ __forceinline__ float density_feature32(const DField& f, const float u[3]) {
+  float feat = 0.0f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+    const unsigned o00 = (row0 + x0) * (LRF_CD * 4u), o10 = (row0 + x1) * (LRF_CD * 4u);
+    const unsigned o01 = (row1 + x0) * (LRF_CD * 4u), o11 = (row1 + x1) * (LRF_CD * 4u);
+    const unsigned q0 = (unsigned)l0 * (LRF_CD * 4u), q1 = (unsigned)l1 * (LRF_CD * 4u);
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
+    const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
+    const float wl0 = 1.0f - tl, wl1 = tl;
+    float sp = 0.0f;
+#pragma unroll
+    for (int h = 0; h < LRF_CD / 4; ++h) {
+      const float4 a = ld4b(f.dplane[p], o00 + 16 * h), b = ld4b(f.dplane[p], o10 + 16 * h);
+      const float4 c = ld4b(f.dplane[p], o01 + 16 * h), d = ld4b(f.dplane[p], o11 + 16 * h);
+      const float4 e = ld4b(f.dline[p], q0 + 16 * h), g = ld4b(f.dline[p], q1 + 16 * h);
       sp += (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + g.x * wl1);
       sp += (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + g.y * wl1);
       sp += (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + g.z * wl1);

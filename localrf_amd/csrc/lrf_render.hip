@@ -111,7 +111,24 @@ __device__ __forceinline__ float bf16_val(unsigned short b) {
 // 32-bit word (two bf16) of the fragment area, then the fp32 tail.
 __global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= IMGB_U4 * 4) return;
+  if (idx >= IMGB_ALL * 4) return;
+  if (idx >= IMGB_W3F * 4) {                                   // head fragments (k_mlp): frag = ks
+    const int e = idx - IMGB_W3F * 4;
+    const int u4 = e >> 2, wj = e & 3;
+    const int lane = u4 & 63, part = (u4 >> 6) & 1, ks = u4 >> 7;
+    const int i = lane & 15, g = lane >> 4;
+    unsigned short out[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * wj + h;
+      const int col = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);
+      const float v = i < 3 ? p.w3[i * (LRF_FEATC + 3) + col] : 0.0f;
+      const unsigned short hi = bf16_bits(v);
+      out[h] = part ? bf16_bits(v - bf16_val(hi)) : hi;
+    }
+    img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
+    return;
+  }
   if (idx >= IMGB_TAIL * 4) {                                  // fp32 tail
     const int e = idx - IMGB_TAIL * 4;
     float v = 0.0f;
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(256) void k_march(
         bool valid = true;
         if (f.alpha_vol) valid = alpha_mask_sample(f, x[0], x[1], x[2]) > 0.0f;   // :593-598
         if (valid) {
-          fk = density_feature(f, u);
+          fk = density_feature32(f, u);
           const float sigma = feature2density(fk, f.density_shift, relu);            // :603-608
           const float dist = z[k + 1] - zk;                                          // :584-587
           alpha = 1.0f - expf(-sigma * dist * f.distance_scale);                     // :610
@@ -946,7 +963,8 @@ static Workspace carve(void* ws, int R, int S) {
 }
 
 static float* g_dump = nullptr;
-static int g_mlp_policy = 0;       // lrf_debug_set_mlp_policy: MFMA issue policy of k_mlp (lrf_shade2.inl)
+static int g_mlp_policy = 4;
+static int g_mlp_threads = 1024;   // lrf_debug_set_mlp_threads: workgroup size of k_mlp (512 leaves half the register file to other kernels)       // lrf_debug_set_mlp_policy: MFMA issue policy of k_mlp (lrf_shade2.inl)
 
 static int device_cus() {                 // of the current device (one process may drive several)
   static int cache[64] = {};
@@ -975,7 +993,8 @@ extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
-void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = (policy >= 0 && policy <= 3) ? policy : 0; }
+void lrf_debug_set_mlp_threads(int threads) { g_mlp_threads = (threads == 512 || threads == 256) ? threads : 1024; }
+void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = ((policy >= 0 && policy <= 7) || policy == 10 || policy == 14) ? policy : 4; }
 const char* lrf_last_error(void) { return g_err; }
 
 size_t lrf_cache_bytes(const int32_t grid[3]) { return make_layout(grid).total * sizeof(float); }
@@ -993,7 +1012,7 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
     hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CAS + 255) / 256), dim3(256), 0, st, p->app_line[q], base + L.aline[q], LRF_CA, L.ll[q], LRF_CAS, 1);
   }
   hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
-  hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p,
+  hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_ALL * 4 + 255) / 256), dim3(256), 0, st, *p,
                      reinterpret_cast<uint32_t*>(base + L.mlpb));
   LRF_HIP(hipGetLastError());
   return 0;
@@ -1019,11 +1038,21 @@ static int launch_shade_split(const DField& d, const float* rays, const float* z
   }
   hipLaunchKernelGGL(k_app, dim3(cus * occ), dim3(256), lds_app, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.ffrag);
   if (mid) LRF_HIP(hipEventRecord(mid, st));
+  if (g_dump && g_mlp_policy >= 10) {        // debug: phase timing of k_mlp (policy 10 + p), counters -> the dump buffer
+    DField dd = d; dd.dump = g_dump;
+    if (g_mlp_policy == 14) hipLaunchKernelGGL((k_mlp<4, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax);
+    else hipLaunchKernelGGL((k_mlp<0, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax);
+    return 0;
+  }
   switch (g_mlp_policy) {
-    case 1: hipLaunchKernelGGL(k_mlp<1>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 2: hipLaunchKernelGGL(k_mlp<2>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 3: hipLaunchKernelGGL(k_mlp<3>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    default: hipLaunchKernelGGL(k_mlp<0>, dim3(cus), dim3(1024), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 1: hipLaunchKernelGGL(k_mlp<1>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 2: hipLaunchKernelGGL(k_mlp<2>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 3: hipLaunchKernelGGL(k_mlp<3>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 6: hipLaunchKernelGGL((k_mlp<4, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 7: hipLaunchKernelGGL((k_mlp<0, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 5: hipLaunchKernelGGL(k_mlp<5>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 0: hipLaunchKernelGGL(k_mlp<0>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    default: hipLaunchKernelGGL(k_mlp<4>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
   }
   return 0;
 }

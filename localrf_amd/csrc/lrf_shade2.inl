@@ -57,6 +57,11 @@ __device__ __forceinline__ bool tile_walk2_seek(TileWalk2& tw, const int* __rest
   return moved;
 }
 
+// ReLU on the integer pipe: for x >= +0 the bit pattern is a non-negative int, for x < 0 (and -0) a negative
+// one, so max_i32(bits, 0) is relu(x) in ONE instruction (fmaxf(x, 0) costs two: IEEE maxNum first quiets its
+// operand with v_max x, x, x).
+__device__ __forceinline__ float relu_i(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 struct RayGeo { float o[3], dh[3]; };
 __device__ __forceinline__ RayGeo load_ray(const float* __restrict__ rays, int ray) {
   const float* rp = rays + (size_t)ray * 6;
@@ -65,6 +70,33 @@ __device__ __forceinline__ RayGeo load_ray(const float* __restrict__ rays, int r
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);      // tensorBase.py:578-580
   g.dh[0] = rp[3] / dn; g.dh[1] = rp[4] / dn; g.dh[2] = rp[5] / dn;
   return g;
+}
+
+// gather_app6_plane with 32-bit byte offsets (ld4b): same taps, same arithmetic order
+template <int p>
+__device__ __forceinline__ void gather_app6_plane32(const DField& f, const float u[3], int g, float X[8]) {
+  int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+  tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+  tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+  tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+  const unsigned gb = 32u * (unsigned)g;                                   // this lane group's 8 slots of the 128-byte texel
+  const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+  const unsigned o00 = (row0 + x0) * (LRF_CAS * 4u) + gb, o10 = (row0 + x1) * (LRF_CAS * 4u) + gb;
+  const unsigned o01 = (row1 + x0) * (LRF_CAS * 4u) + gb, o11 = (row1 + x1) * (LRF_CAS * 4u) + gb;
+  const unsigned q0 = (unsigned)l0 * (LRF_CAS * 4u) + gb, q1 = (unsigned)l1 * (LRF_CAS * 4u) + gb;
+  const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
+  const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
+  const float wl0 = 1.0f - tl, wl1 = tl;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 a = ld4b(f.aplane[p], o00 + 16 * h), b = ld4b(f.aplane[p], o10 + 16 * h);
+    const float4 c = ld4b(f.aplane[p], o01 + 16 * h), d = ld4b(f.aplane[p], o11 + 16 * h);
+    const float4 e = ld4b(f.aline[p], q0 + 16 * h), q = ld4b(f.aline[p], q1 + 16 * h);
+    X[4 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
+    X[4 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
+    X[4 * h + 2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
+    X[4 * h + 3] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + q.w * wl1);
+  }
 }
 
 // ------------------------------------------------------------------------------- k_app
@@ -108,13 +140,13 @@ __global__ __launch_bounds__(256) void k_app(
     {
       float v[8];
       bf16x8 bh, bl;
-      gather_app6_plane<0>(f, u, g, v);
+      gather_app6_plane32<0>(f, u, g, v);
       split8(v, bh, bl);
       gemm_step<2>(bas, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
-      gather_app6_plane<1>(f, u, g, v);
+      gather_app6_plane32<1>(f, u, g, v);
       split8(v, bh, bl);
       gemm_step<2>(bas, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
-      gather_app6_plane<2>(f, u, g, v);
+      gather_app6_plane32<2>(f, u, g, v);
       split8(v, bh, bl);
       gemm_step<2>(bas, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
@@ -132,15 +164,19 @@ __global__ __launch_bounds__(256) void k_app(
 
 // ------------------------------------------------------------------------------- k_mlp
 // MFMA issue policy of the layer-1 / layer-2 chains (runtime choice for the hazard experiments of
-// DESIGN.md "gfx950 / hipcc findings"; the shipped default is POLICY 0):
+// DESIGN.md "gfx950 / hipcc findings"; the shipped default is POLICY 4, the hand-issued fallback POLICY 0):
 //   0  hand-issued in-place MFMA, 4 wait states behind each, operands held 48 wait states (= k_shade_bf16)
 //   1  hand-issued in-place MFMA, 2 wait states behind each, A fragments held for two further
 //      fragments (>= 6 MFMAs) by register rotation instead of wait states, no tail pad
 //   2  compiler-scheduled builtin, operands kept live the same way (hold), no wait states
 //   3  compiler-scheduled builtin, nothing else (the build that showed run-to-run differences in round 1)
+//   4  as 3, with the A fragments fetched from LDS two fragments ahead of their MFMAs (explicit software
+//      pipeline: the 16 waves of a workgroup run in lockstep phases, so without it every wave sits on the
+//      LDS queue at the same time -- 57 % of wave time parked on s_waitcnt, profiles/r02c)
+//   5  as 1 (hand-issued), with the same two-fragment prefetch
 template <int POLICY>
 __device__ __forceinline__ void mfma_p(bf16x8 a, bf16x8 b, f32x4& acc) {
-  if (POLICY >= 2) {
+  if (POLICY >= 2 && POLICY <= 4) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
   } else {
     const i32x4 ai = __builtin_bit_cast(i32x4, a), bi = __builtin_bit_cast(i32x4, b);
@@ -166,7 +202,7 @@ __device__ __forceinline__ void split8_p(const float v[8], bf16x8& hi, bf16x8& l
 }
 template <int POLICY, int NT>
 __device__ __forceinline__ void settle_p(f32x4* acc) {
-  if (POLICY <= 1) {
+  if (POLICY <= 1 || POLICY == 5) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[t]));
   }
@@ -176,6 +212,25 @@ template <int POLICY, int NT>
 __device__ __forceinline__ void gemm_step_q(const uint4* img, int frag0, int stride, int lane,
                                             bf16x8 bh, bf16x8 bl, f32x4* acc) {
   if (POLICY == 0) { gemm_step<NT>(img, frag0, stride, lane, bh, bl, acc); return; }
+  if (POLICY >= 4) {
+    bf16x8 ah[NT], al[NT];                                      // fully unrolled: only ~3 fragments are live at a time
+    ah[0] = lds_frag(img, frag0, 0, lane); al[0] = lds_frag(img, frag0, 1, lane);
+    if (NT > 1) { ah[1] = lds_frag(img, frag0 + stride, 0, lane); al[1] = lds_frag(img, frag0 + stride, 1, lane); }
+#pragma unroll
+    for (int t1 = 0; t1 < NT; ++t1) {
+      if (t1 + 2 < NT) {
+        ah[t1 + 2] = lds_frag(img, frag0 + (t1 + 2) * stride, 0, lane);
+        al[t1 + 2] = lds_frag(img, frag0 + (t1 + 2) * stride, 1, lane);
+      }
+      if (POLICY == 4) __builtin_amdgcn_sched_barrier(0);       // keep the fetch ahead of this fragment's MFMAs
+      mfma_p<POLICY>(al[t1], bh, acc[t1]);
+      mfma_p<POLICY>(ah[t1], bl, acc[t1]);
+      mfma_p<POLICY>(ah[t1], bh, acc[t1]);
+      if (POLICY == 5 && t1 >= 2) { hold(ah[t1 - 2]); hold(al[t1 - 2]); }
+    }
+    if (POLICY == 5) { hold(ah[NT - 1]); hold(al[NT - 1]); if (NT > 1) { hold(ah[NT - 2]); hold(al[NT - 2]); } }
+    return;
+  }
   bf16x8 p1h = bh, p1l = bl, p2h = bh, p2l = bl;               // the two previous A fragments (dummies at first)
 #pragma unroll
   for (int t1 = 0; t1 < NT; ++t1) {
@@ -190,15 +245,21 @@ __device__ __forceinline__ void gemm_step_q(const uint4* img, int frag0, int str
   if (POLICY <= 2) { hold(p1h); hold(p1l); hold(p2h); hold(p2l); }
 }
 
-template <int POLICY>
+// TIMED (debug, lrf_debug_set_dump): per-wave s_memtime totals of the phases of a tile -> dump[wave][8]
+// {header+prefetch issue, layer 1, layer 2, head+store, tiles}
+// HEADM: the 128 -> 3 head as a fourth split-bf16 MFMA layer (12 MFMAs per tile) instead of 96 fp32 FMAs,
+// 32 LDS weight reads and six cross-row shuffles per lane on the VALU / LDS pipes.
+template <int POLICY, bool TIMED = false, bool HEADM = true>
 __global__ __launch_bounds__(1024) void k_mlp(
     DField f, const float* __restrict__ rays, int S, const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const float* __restrict__ cw, const uint4* __restrict__ ffrag,
     float* __restrict__ part, int pmax) {
-  __shared__ uint4 img[IMGB_U4 - IMGB_W1];                     // W1, W2 fragments + fp32 tail (83 KB)
-  for (int i = threadIdx.x; i < IMGB_U4 - IMGB_W1; i += blockDim.x) img[i] = f.mlpb[IMGB_W1 + i];
+  unsigned long long tk[5] = {0, 0, 0, 0, 0}, tlast = 0;
+#define LRF_TICK(i) do { if (TIMED) { const unsigned long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
+  __shared__ uint4 img[IMGB_ALL - IMGB_W1];                    // W1, W2 fragments, fp32 tail, head fragments (91 KB)
+  for (int i = threadIdx.x; i < IMGB_ALL - IMGB_W1; i += blockDim.x) img[i] = f.mlpb[IMGB_W1 + i];
   __syncthreads();
-  constexpr int F_W1 = 0, F_W2 = (IMGB_W2 - IMGB_W1) / 128;    // fragment indices inside img
+  constexpr int F_W1 = 0, F_W2 = (IMGB_W2 - IMGB_W1) / 128, F_W3 = (IMGB_W3F - IMGB_W1) / 128;   // fragment indices inside img
   const float* tail = reinterpret_cast<const float*>(img + (IMGB_TAIL - IMGB_W1));
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
   int t0, t1;
@@ -212,6 +273,7 @@ __global__ __launch_bounds__(1024) void k_mlp(
   int ray = tw.ray, j0 = (t0 - tw.tile0) * ITEM;
   int cnt = min(ITEM, tw.nc - j0);
   uint4 fh = ffrag[((size_t)t0 * 2 + 0) * 64 + lane], fl = ffrag[((size_t)t0 * 2 + 1) * 64 + lane];
+  if (TIMED) tlast = __builtin_readcyclecounter();
   for (int t = t0; t < t1; ++t) {
     asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
     ray = __builtin_amdgcn_readfirstlane(ray); j0 = __builtin_amdgcn_readfirstlane(j0);
@@ -229,13 +291,14 @@ __global__ __launch_bounds__(1024) void k_mlp(
       fh_n = ffrag[((size_t)(t + 1) * 2 + 0) * 64 + lane];
       fl_n = ffrag[((size_t)(t + 1) * 2 + 1) * 64 + lane];
     }
+    LRF_TICK(0);
     // layer 1 (tensorBase.py:129-130): one k-step, B = the fragment k_app wrote
     f32x4 h1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) h1[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * q + 4 * g]);
     {
       bf16x8 bh = __builtin_bit_cast(bf16x8, fh), bl = __builtin_bit_cast(bf16x8, fl);
-      if (POLICY <= 1) {                                       // loaded operands: settle before the asm MFMAs
+      if (POLICY <= 1 || POLICY == 5) {                        // loaded operands: settle before the asm MFMAs
         uint4 H = __builtin_bit_cast(uint4, bh), L = __builtin_bit_cast(uint4, bl);
         asm volatile("s_nop 1" : "+v"(H.x), "+v"(H.y), "+v"(H.z), "+v"(H.w), "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w),
                                  "+v"(h1[0]), "+v"(h1[1]), "+v"(h1[2]), "+v"(h1[3]), "+v"(h1[4]), "+v"(h1[5]), "+v"(h1[6]), "+v"(h1[7]));
@@ -245,11 +308,12 @@ __global__ __launch_bounds__(1024) void k_mlp(
       gemm_step_q<POLICY, 8>(img, F_W1, 1, lane, bh, bl, h1);
       settle_p<POLICY, 8>(h1);
     }
+    LRF_TICK(1);
     // layer 2: 4 k-steps, k-step ks consumes relu(h1) tiles 2ks and 2ks+1
     f32x4 h2[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) h2[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * q + 4 * g]);
-    if (POLICY <= 1) {
+    if (POLICY <= 1 || POLICY == 5) {
       asm volatile("s_nop 1" : "+v"(h2[0]), "+v"(h2[1]), "+v"(h2[2]), "+v"(h2[3]), "+v"(h2[4]), "+v"(h2[5]), "+v"(h2[6]), "+v"(h2[7]));
     }
     bf16x8 pbh = {}, pbl = {};                                  // previous k-step's B operands
@@ -257,41 +321,62 @@ __global__ __launch_bounds__(1024) void k_mlp(
     for (int ks = 0; ks < 4; ++ks) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[2 * ks + (j >> 2)][j & 3], 0.0f);
+      for (int j = 0; j < 8; ++j) v[j] = relu_i(h1[2 * ks + (j >> 2)][j & 3]);
       bf16x8 bh, bl;
       split8_p<POLICY>(v, bh, bl);
       gemm_step_q<POLICY, 8>(img, F_W2 + ks, 4, lane, bh, bl, h2);
-      if (POLICY == 1 || POLICY == 2) { if (ks) { hold(pbh); hold(pbl); } pbh = bh; pbl = bl; }
+      if (POLICY == 1 || POLICY == 2 || POLICY == 5) { if (ks) { hold(pbh); hold(pbl); } pbh = bh; pbl = bl; }
     }
-    if (POLICY == 1 || POLICY == 2) { hold(pbh); hold(pbl); }
+    if (POLICY == 1 || POLICY == 2 || POLICY == 5) { hold(pbh); hold(pbl); }
     settle_p<POLICY, 8>(h2);
-    // head on the VALU in fp32 (tensorBase.py:131-133)
+    LRF_TICK(2);
+    // head (tensorBase.py:131-133)
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    if (HEADM) {
+      // as a fourth layer: rows 0..2 of D are r,g,b -- lanes of group g = 0 hold them for their sample
+      f32x4 oc = {0, 0, 0, 0};
+      if (POLICY <= 1 || POLICY == 5) asm volatile("" : "+v"(oc));
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+      for (int ks = 0; ks < 4; ++ks) {
+        float v[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float hv = fmaxf(h2[q][r], 0.0f);
-        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (q * 4 + r) * 4]);
-        o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
+        for (int j = 0; j < 8; ++j) v[j] = relu_i(h2[2 * ks + (j >> 2)][j & 3]);
+        bf16x8 bh, bl;
+        split8_p<POLICY>(v, bh, bl);
+        gemm_step_q<POLICY, 1>(img, F_W3 + ks, 1, lane, bh, bl, &oc);
       }
-    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
-    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+      settle_p<POLICY, 1>(&oc);
+      o0 = oc[0]; o1 = oc[1]; o2 = oc[2];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = relu_i(h2[q][r]);
+          const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (q * 4 + r) * 4]);
+          o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
+        }
+      o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+      o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+    }
     // view-direction part of mlp_view.0 + bias: constant per ray (tensorBase.py:131-132; viewdirs
     // detached :628)
     float vb[3];
     {
-      const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);                       // tensorBase.py:578-580
-      const float dh[3] = {d0 / dn, d1 / dn, d2 / dn};
+      // d / |d| (tensorBase.py:578-580) with the hardware reciprocal square root (1 ulp) instead of sqrt + 3 divides
+      const float inv = __frsqrt_rn(d0 * d0 + d1 * d1 + d2 * d2);
+      const float dh[3] = {d0 * inv, d1 * inv, d2 * inv};
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
         vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
       }
     }
-    float cr = w / (1.0f + expf(-(o0 + vb[0])));               // :133, :632
-    float cg = w / (1.0f + expf(-(o1 + vb[1])));
-    float cb = w / (1.0f + expf(-(o2 + vb[2])));
+    // w * sigmoid(x) (:133, :632): hardware exp2 / reciprocal (each ~1 ulp; a 1e-7 relative change of a colour)
+    const float wq = (HEADM && g != 0) ? 0.0f : w;              // MFMA head: only the g = 0 lanes hold a colour
+    float cr = wq * __frcp_rn(1.0f + __expf(-(o0 + vb[0])));
+    float cg = wq * __frcp_rn(1.0f + __expf(-(o1 + vb[1])));
+    float cb = wq * __frcp_rn(1.0f + __expf(-(o2 + vb[2])));
 #pragma unroll
     for (int dd = 1; dd < 16; dd <<= 1) {
       cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
@@ -301,7 +386,14 @@ __global__ __launch_bounds__(1024) void k_mlp(
       pp[0] = cr; pp[1] = cg; pp[2] = cb;
     }
     ray = ray_n; j0 = j0_n; cnt = cnt_n; fh = fh_n; fl = fl_n;
+    LRF_TICK(3);
+    tk[4] += 1;
   }
+  if (TIMED && f.dump && lane == 0) {
+    unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
+    for (int i = 0; i < 5; ++i) dp[i] = tk[i];
+  }
+#undef LRF_TICK
 }
 
 }  // namespace lrf

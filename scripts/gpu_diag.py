@@ -751,7 +751,7 @@ def stage_mfma_policy():
     z = f.z_schedule(False, 1536, rays.device).contiguous()
     lib = N.lib()
     ref = None
-    for pol in (0, 1, 2, 3, 0):
+    for pol in (0, 4, 6, 7, 4):
         lib.lrf_debug_set_mlp_policy(pol)
         with torch.no_grad():
             first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
@@ -769,13 +769,119 @@ def stage_mfma_policy():
         log(f"policy {pol}: renders differing from the first {ndiff}/150 (max rays {nray}, max |diff| {maxd:.2e}) | "
             f"max |rgb - policy0| {float((first - ref).abs().max()):.2e} | k_app {prof['app_ms'] * 1e3:.1f} us "
             f"k_mlp {prof['mlp_ms'] * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
-    lib.lrf_debug_set_mlp_policy(0)
+    lib.lrf_debug_set_mlp_policy(4)
     f.mlp_engine = "bf16x3_fused"
     prof = bench.kernel_profile(f, rays, z, reps=10)
     log(f"fused engine: k_shade {(prof['shade_ms'] - prof['scan_ms']) * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
 
 
-STAGES = [("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_walls():
+    """Trained-like scene of bench.py: per-kernel times with and without early termination."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from util import make_rays
+    f = bench.walls_field(torch.device("cuda:0"))
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    for mask in (False, True):
+        if mask:
+            f.updateAlphaMask((150, 150, 150))
+            log("mask kept fraction", float(f.alphaMask.alpha_volume.mean()))
+        for T in (1e-9, 0.0):
+            f.early_term_T = T
+            with torch.no_grad():
+                for _ in range(3):
+                    f(rays, white_bg=True, is_train=False, N_samples=1536)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(20):
+                    f(rays, white_bg=True, is_train=False, N_samples=1536)
+                torch.cuda.synchronize()
+                dt = (time.time() - t0) / 20
+            p = bench.kernel_profile(f, rays, z, reps=5)
+            log(f"mask {mask} term_T {T}: wall {dt * 1e3:.3f} ms/step | march {p['march_ms'] * 1e3:.1f} scan {p['scan_ms'] * 1e3:.1f} "
+                f"app {p['app_ms'] * 1e3:.1f} mlp {p['mlp_ms'] * 1e3:.1f} fin {p['finalize_ms'] * 1e3:.1f} total {p['total_ms'] * 1e3:.1f} us | shaded {p['n_shaded']}")
+
+
+def stage_mlp_phases():
+    """s_memtime phase totals of k_mlp per wave (debug build of the kernel, lrf_shade2.inl TIMED)."""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    for pol in (10, 14):
+        buf = torch.zeros(256 * 16 * 8, dtype=torch.int64, device="cuda")
+        with torch.no_grad():
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+            lib.lrf_debug_set_dump(buf.data_ptr())
+            lib.lrf_debug_set_mlp_policy(pol)
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+            torch.cuda.synchronize()
+            lib.lrf_debug_set_mlp_policy(4)
+            lib.lrf_debug_set_dump(None)
+        t = buf.view(256 * 16, 8).double()
+        tiles = t[:, 4].sum()
+        names = ["header+prefetch", "layer1", "layer2", "head+store"]
+        log(f"k_mlp policy {pol - 10}: tiles {int(tiles)} | cycles per tile and wave: " +
+            " ".join(f"{n} {float(t[:, i].sum() / tiles):.0f}" for i, n in enumerate(names)) +
+            f" | total {float(t[:, :4].sum() / tiles):.0f} | per-wave total min/max {float(t[:, :4].sum(1).min()):.0f}/{float(t[:, :4].sum(1).max()):.0f}")
+
+
+def stage_overlap():
+    """Do two renders on two streams overlap (k_app of one under k_mlp of the other)?  Two field objects
+    (own workspaces), same batch; 40 renders each, sequential on one stream vs concurrent on two, for
+    k_mlp workgroups of 1024 and 512 threads."""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    fa = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    fb = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    lib = N.lib()
+
+    def run(two):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        with torch.no_grad():
+            for _ in range(40):
+                with torch.cuda.stream(s1):
+                    fa(rays, white_bg=True, is_train=False, N_samples=1536)
+                with torch.cuda.stream(s2 if two else s1):
+                    fb(rays, white_bg=True, is_train=False, N_samples=1536)
+        torch.cuda.synchronize()
+        return (time.time() - t0) / 80 * 1e3
+    for pol in (0, 4):
+        for thr in (1024, 512, 256):
+            lib.lrf_debug_set_mlp_policy(pol)
+            lib.lrf_debug_set_mlp_threads(thr)
+            run(False); run(True)
+            a, b = run(False), run(True)
+            log(f"policy {pol} k_mlp threads {thr}: one stream {a:.4f} ms/render | two streams {b:.4f} ms/render")
+    lib.lrf_debug_set_mlp_threads(1024)
+    lib.lrf_debug_set_mlp_policy(4)
+
+
+def stage_soak():
+    """3000 renders of the config-2 batch with the shipped engine: every one must equal the first bit for bit."""
+    import torch
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    with torch.no_grad():
+        first, d0 = f(rays, white_bg=True, is_train=False, N_samples=1536)
+        bad = 0
+        for i in range(3000):
+            again, d1 = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            if not (torch.equal(first, again) and torch.equal(d0, d1)):
+                bad += 1
+    log(f"soak: 3000 renders, {bad} differ from the first")
+
+
+STAGES = [("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

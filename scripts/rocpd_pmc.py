@@ -5,7 +5,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-KEEP = ("k_march", "k_shade", "k_finalize", "k_scan", "k_bwd", "k_pack", "k_scatter", "k_wgrad", "k_bin", "k_scene")
+KEEP = ("k_march", "k_shade", "k_app", "k_mlp", "k_dense", "k_alpha", "k_finalize", "k_scan", "k_bwd", "k_pack", "k_scatter", "k_wgrad", "k_bin", "k_scene")
 rows = defaultdict(dict)
 dur = {}
 for path in sys.argv[1:]:
@@ -14,7 +14,7 @@ for path in sys.argv[1:]:
          "group by kernel_name, counter_name, dispatch_id")
     acc = defaultdict(list)
     for name, ctr, disp, val, d in db.execute(q):
-        short = name.split("(")[0].replace("lrf::", "")
+        short = name.split("(")[0].replace("lrf::", "").replace("void ", "")
         if not any(k in short for k in KEEP):
             continue
         acc[(short, ctr)].append(val)

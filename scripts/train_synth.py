@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Config-5 driver: the progressive optimisation loop of the reference's train.py:349-474 around
+localrf_amd.LocalTensorfs, on SYNTHETIC data (no dataset, no network): sample -> forward -> losses ->
+optimizer_step -> progressive append_frame / append_rf, the upsample schedule of opt.py:61-70
+(64^3 -> ... -> N_voxel_final), alpha-mask rebuilds, density_L1, FusedAdam.
+
+The targets come from a hidden teacher scene (a TensorVMSplit with solid walls and random appearance)
+rendered by the same HIP path from a camera that moves along a straight line, so the loss really
+can fall and the poses really drift as the camera moves.  Flow / monocular-depth losses need
+precomputed RAFT / DPT maps (train.py:385-423) and are off, exactly as `--loss_flow_weight_inital 0
+--loss_depth_weight_inital 0` would run the reference.
+
+  python scripts/train_synth.py [--frames 24] [--final 300] [--iters-per-frame 60] [--json out.json]
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/train_synth.py ...
+      (data parallel: every rank draws the same batch and renders its share of the views; one
+       gradient all-reduce per iteration through LocalTensorfs.grad_sync)
+
+Prints one JSON object: loss curve summary, ms / iteration at every grid resolution, peak memory,
+checkpoint round trip.  `run()` is also called (tiny settings) by tests/test_gpu_training.py.
+"""
+import argparse
+import contextlib
+import io
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FIELD_KW = dict(density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=27,
+                shadingMode="MLP_Fea_late_view", near_far=[0.1, 1e3], density_shift=-5,
+                alphaMask_thres=1e-4, distance_scale=25, rayMarch_weight_thres=1e-3,
+                pos_pe=0, view_pe=0, fea_pe=0, featureC=128, step_ratio=0.5, fea2denseAct="softplus")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+class SyntheticFrames:
+    """What train.py needs of LocalRFDataset (dataLoader/localrf_dataset.py): a growing window of
+    active frames, `sample()` -> 16 views x batch/16 rays with their target colours, activate /
+    deactivate.  Targets: the teacher field rendered from the true camera of each frame."""
+
+    def __init__(self, n_frames, W, H, n_init, dev, seed=0):
+        from localrf_amd import TensorVMSplit
+        self.W, self.H, self.num_images, self.dev = W, H, n_frames, dev
+        self.active_frames_bounds = [0, n_init]
+        self.rng = np.random.default_rng(seed)
+        torch.manual_seed(1234)
+        aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+        teacher = quiet(TensorVMSplit, torch.device("cpu"), aabb, [96, 96, 96], **FIELD_KW)
+        with torch.no_grad():
+            for p in teacher.density_plane:
+                p.mul_(0.1)
+            c = torch.linspace(-2, 2, 96)
+            for p in range(3):
+                for comp, centre in ((0, 1.2), (1, -1.2)):
+                    teacher.density_plane[p][0, comp].fill_(1.0)
+                    teacher.density_line[p][0, comp, :, 0] = 40.0 * torch.exp(-((c - centre) / 0.1) ** 2)
+            for p in teacher.app_plane:
+                p.mul_(6.0)
+        teacher = teacher.to(dev)
+        focal = W / math.tan(85.6 * math.pi / 180 / 2) / 2
+        jj, ii = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        dirs = torch.stack([(ii.float() + 0.5 - W / 2) / focal, -(jj.float() + 0.5 - H / 2) / focal,
+                            -torch.ones(H, W)], -1).reshape(-1, 3)
+        self.images = []
+        with torch.no_grad():
+            for f in range(n_frames):
+                o = torch.tensor([0.04 * f, 0.01 * math.sin(0.5 * f), 0.0]).expand_as(dirs)     # true camera path
+                rays = torch.cat([o, dirs], -1).to(dev)
+                rgb, _ = teacher(rays, white_bg=True, is_train=False, N_samples=300)
+                self.images.append(rgb.clamp(0, 1))
+        self.images = torch.stack(self.images)                        # [F, H*W, 3] on the device
+        del teacher
+
+    def has_left_frames(self):
+        return self.active_frames_bounds[1] < self.num_images
+
+    def activate_frames(self, n=1):
+        self.active_frames_bounds[1] = min(self.active_frames_bounds[1] + n, self.num_images)
+
+    def deactivate_frames(self, first_kept):
+        self.active_frames_bounds[0] = int(first_kept)
+
+    def sample(self, batch_size, n_views=16):
+        lo, hi = self.active_frames_bounds
+        views = np.sort(self.rng.integers(lo, hi, n_views))
+        per = batch_size // n_views
+        pix = self.rng.integers(0, self.W * self.H, (n_views, per))
+        view_t = torch.from_numpy(views)
+        pix_t = torch.from_numpy(pix)
+        return view_t, pix_t.reshape(-1), (view_t[:, None], pix_t)
+
+
+def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
+        dev="cuda:0", ddp=False, log=None):
+    from localrf_amd import LocalTensorfs
+    from localrf_amd.dist import allreduce_grads, shard_views
+    from localrf_amd.rays import N_to_reso
+    import torch.distributed as dist
+    dev = torch.device(dev)
+    rank = dist.get_rank() if ddp else 0
+    world = dist.get_world_size() if ddp else 1
+    data = SyntheticFrames(frames, W, H, n_init, dev, seed)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).to(dev)
+    # opt.py:61-70 scaled by iters_per_frame / 600
+    sc = iters_per_frame / 600.0
+    upsamp = [max(1, round(u * sc)) for u in (100, 150, 200, 250, 300)]
+    n_init_vox, n_final_vox = 64 ** 3, final ** 3
+    nvox = torch.round(torch.exp(torch.linspace(math.log(n_init_vox), math.log(n_final_vox), len(upsamp) + 1))).long().tolist()[1:]
+    N_voxel_list = {u: round(n ** (1 / 3)) ** 3 for u, n in zip(upsamp, nvox)}
+    mask_list = [max(1, round(u * sc)) for u in (100, 200, 300)]
+    torch.manual_seed(seed)                                           # identical replicas under DDP
+    lt = quiet(LocalTensorfs, camera_prior=None, fov=85.6, n_init_frames=min(n_init, frames), n_overlap=3, WH=(W, H),
+               n_iters_per_frame=iters_per_frame, n_iters_reg=max(1, round(100 * sc)), lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3, lr_decay_target_ratio=0.1,
+               N_voxel_list=N_voxel_list, update_AlphaMask_list=mask_list, lr_upsample_reset=True, device=dev,
+               aabb=aabb, gridSize=N_to_reso(n_init_vox, aabb), **FIELD_KW).to(dev)
+    if ddp:
+        lt.grad_sync = lambda m: allreduce_grads(m, average=True)
+    L1_weight, add_frames_every, n_max_frames, max_drift, n_overlap = 1e-2, max(1, round(100 * sc)), 100, 1.0, 3
+    n_added, last_add, it = 0, 0, 0
+    losses, per_res, events = [], {}, []
+    torch.cuda.reset_peak_memory_stats(dev)
+    mem_marks = []
+    training = True
+    t_mark, it_mark = time.perf_counter(), 0
+    res = int(lt.tensorfs[-1].gridSize[0])
+    while training and (max_iters is None or it < max_iters):
+        view_ids, ray_idx, (vv, pp) = data.sample(batch)
+        target = data.images[vv, pp].reshape(-1, 3)
+        if ddp:                                                        # this rank's views of the common batch
+            per = ray_idx.shape[0] // view_ids.shape[0]
+            ray_idx, v_sh = shard_views(ray_idx, view_ids, rank, world)
+            v0 = rank * v_sh.shape[0]
+            target = target[v0 * per:(v0 + v_sh.shape[0]) * per]
+            view_ids = v_sh
+        rgb_map, depth_map, _, _ = lt(ray_idx, view_ids.tolist(), W, H, is_train=True, test_id=False)
+        loss = (0.25 * torch.abs(rgb_map - target)).mean()             # train.py:369-371, unit loss weights
+        total = loss
+        if lt.regularize:
+            tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)         # train.py:425-429, opt.py:111-113
+            total = total + tv + l1
+        can_add_rf = lt.optimizer_step(total, True)
+        training |= data.active_frames_bounds[1] != data.num_images
+        if not lt.is_refining:                                         # train.py:438-460
+            should_refine = (not data.has_left_frames()) or (n_added > n_overlap and (
+                float(lt.get_dist_to_last_rf()) > max_drift
+                or data.active_frames_bounds[1] - data.active_frames_bounds[0] >= n_max_frames))
+            if should_refine and (it - last_add) >= add_frames_every:
+                lt.is_refining = True
+                events.append((it, "refine"))
+            add = data.has_left_frames() and (it - last_add + 1) % add_frames_every == 0
+            if add and not should_refine and not lt.is_refining:
+                lt.append_frame()
+                data.activate_frames()
+                n_added += 1
+                last_add = it
+        if can_add_rf:                                                 # train.py:462-474
+            if data.has_left_frames():
+                lt.append_rf(n_added)
+                lt.to(dev)
+                n_added = 0
+                keep = (lt.blending_weights[:, -1] > 0)
+                data.deactivate_frames(int(np.argmax(keep.cpu().numpy(), axis=0)))
+                events.append((it, "append_rf"))
+            else:
+                training = False
+        it += 1
+        new_res = int(lt.tensorfs[-1].gridSize[0])
+        if new_res != res or not training or (max_iters is not None and it == max_iters):
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t_mark
+            if it - it_mark > 0:
+                e = per_res.setdefault(res, {"iters": 0, "s": 0.0})
+                e["iters"] += it - it_mark
+                e["s"] += dt
+            mem_marks.append((it, torch.cuda.memory_allocated(dev)))
+            t_mark, it_mark, res = time.perf_counter(), it, new_res
+        if it % 25 == 0:
+            losses.append(float(loss.detach()))
+            if log and rank == 0:
+                log(f"it {it} loss {losses[-1]:.4f} res {res} fields {len(lt.tensorfs)} frames {len(lt.r_c2w)}")
+    torch.cuda.synchronize(dev)
+    # checkpoint round trip into the reference's key set (local_tensorfs.py:326-356)
+    sd = {k: v.detach().clone() for k, v in lt.state_dict().items()}
+    lt2 = quiet(LocalTensorfs, **{**lt.get_kwargs(), "device": dev})
+    quiet(lt2.load, sd)
+    sd2 = lt2.state_dict()
+    same = set(sd) == set(sd2) and all(torch.equal(sd[k].to(dev), sd2[k].to(dev)) for k in sd)
+    import re
+    pat = re.compile(r"^(blending_weights|init_focal|focal_offset|center_rel|(r_c2w|t_c2w|exposure|world2rf)\.\d+|"
+                     r"tensorfs\.\d+\.(aabb|invaabbSize|(density|app)_(plane|line)\.[012]|basis_mat\.weight|"
+                     r"renderModule\.(mlp\.[02]|mlp_view\.0)\.(weight|bias)|alphaMask\.(aabb|invgridSize|alpha_volume)))$")
+    keys_ok = all(pat.match(k) for k in sd)
+    return {"iterations": it, "fields": len(lt.tensorfs), "frames": len(lt.r_c2w), "events": events[:20],
+            "loss_first": float(np.mean(losses[:2])) if losses else None, "loss_last": float(np.mean(losses[-2:])) if losses else None,
+            "loss_curve": losses[:: max(1, len(losses) // 20)], "finite": bool(all(math.isfinite(x) for x in losses)),
+            "ms_per_iteration_by_resolution": {str(r): 1e3 * e["s"] / e["iters"] for r, e in per_res.items()},
+            "iterations_by_resolution": {str(r): e["iters"] for r, e in per_res.items()},
+            "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "memory_marks_GB": [(i, m / 2 ** 30) for i, m in mem_marks],
+            "checkpoint_roundtrip": bool(same), "checkpoint_keys_follow_reference": bool(keys_ok), "world": world,
+            "final_resolution": res}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--final", type=int, default=300, help="N_voxel_final^(1/3) (the reference: 640; BASELINE configs[4]: 500)")
+    ap.add_argument("--iters-per-frame", type=int, default=60, help="the reference: 600 (opt.py:31)")
+    ap.add_argument("--max-iters", type=int, default=None)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    import __graft_entry__ as ge
+    ddp = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if ddp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if local != 0:
+            dist.barrier(device_ids=[local])
+    ge.build()
+    if ddp and local == 0:
+        dist.barrier(device_ids=[local])
+    out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters,
+              dev=f"cuda:{local}", ddp=ddp, log=lambda m: print(m, file=sys.stderr, flush=True))
+    if not ddp or int(os.environ["RANK"]) == 0:
+        print(json.dumps(out))
+        if args.json:
+            json.dump(out, open(args.json, "w"), indent=1)
+    if ddp:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

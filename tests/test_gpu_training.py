@@ -46,8 +46,9 @@ def test_scene_gradients_match_aten_port():
     z = field.z_schedule(False, -1, torch.device(DEV)).clone()        # fixed schedule for both paths
     field.z_override = z
     ray_ids, view_ids = _batch(lt)
-    gr = torch.randn(ray_ids.shape[0], 3, device=DEV)
-    gd = torch.randn(ray_ids.shape[0], device=DEV)
+    _g = torch.Generator().manual_seed(77)
+    gr = torch.randn(ray_ids.shape[0], 3, generator=_g).to(DEV)
+    gd = torch.randn(ray_ids.shape[0], generator=_g).to(DEV)
 
     def run():
         for p in lt.parameters():
@@ -520,8 +521,11 @@ def test_config3_full_size_vs_reference_golden():
     e_rgb = np.abs(rgbs.cpu().numpy() - g["rgbs"]).max(-1)
     e_dep = np.abs(depths.cpu().numpy() - g["depths"]) / np.maximum(np.abs(g["depths"]), 1e-3)
     assert e_dep.max() < 1e-4, e_dep.max()
-    bad = e_rgb > 1e-4                                  # blended colours are in [0,1]: absolute = relative to 1
-    assert bad.sum() <= 8 and e_rgb.max() < 2e-3, (int(bad.sum()), float(e_rgb.max()))
+    # blended colours are in [0,1]: absolute = relative to 1.  Each of the FOUR field renders may flip a
+    # sample on the weight > 1e-3 threshold for <= 0.2 % of its rays (test_config2_all_rays_...); blended
+    # with weights <= 0.4 such a flip moves the colour by < 1e-3
+    bad = e_rgb > 1e-4
+    assert bad.sum() <= 32 and e_rgb.max() < 1e-3, (int(bad.sum()), float(e_rgb.max()))
 
 
 def test_regularisers_vs_reference_golden():

@@ -37,10 +37,12 @@ def _overlap(x, y):
     return not (x[1] < y[0] or y[1] < x[0])
 
 
-# Kernels that ship on the product path (k_mlp<0> is the default policy; k_mlp<1..3> are the hazard
-# experiments of lrf_shade2.inl and are expected to violate these rules) and their bf16 MFMA counts
-# per tile: 18 (basis) + 24 (layer 1) + 96 (layer 2).
-SHIPPED = (("k_shade_bf16E", 138), ("k_bwd_shade_fwdE", 138), ("k_appE", 18), ("k_mlpILi0EE", 120))
+# Kernels whose bf16 MFMAs are HAND-ISSUED (gathers and an MFMA chain in one kernel: the configuration that
+# showed run-to-run differences when hipcc scheduled it) and their bf16 MFMA counts per tile:
+# 18 (basis) + 24 (layer 1) + 96 (layer 2) [+ 12 (head)].  k_mlp has no gathers; its default policy (4) is the
+# compiler-scheduled builtin, pinned by the 200-render determinism test on the GPU; policy 0 is the hand-issued
+# fallback and is held to the rules below.
+SHIPPED = (("k_shade_bf16E", 138), ("k_bwd_shade_fwdE", 138), ("k_appE", 18), ("k_mlpILi0ELb0ELb1EE", 132))
 
 
 def _shipped_text(asm, kern):
@@ -118,7 +120,7 @@ def test_bf16_mfma_sources_are_not_rewritten_close_behind(asm):
 
 
 def test_scratch_use_is_bounded(asm):
-    for kern, limit in (("k_marchE", 0), ("k_shade_bf16E", 128), ("k_appE", 0), ("k_mlpILi0EE", 0)):
+    for kern, limit in (("k_marchE", 0), ("k_shade_bf16E", 128), ("k_appE", 0), ("k_mlpILi0ELb0ELb1EE", 0), ("k_mlpILi4ELb0ELb1EE", 0)):
         m = re.search(r"\.amdhsa_kernel _ZN3lrf\d+%s.*?\.end_amdhsa_kernel" % kern, asm, re.S)
         assert m, kern
         priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m[0])

@@ -200,9 +200,9 @@ def relu_flip_report(f, rays, z, ws):
     from localrf_amd import _native as N
     from oracle import vm_render_torch as ot
     R, S = rays.shape[0], z.numel()
-    out = (C.c_uint64 * 8)()
+    out = (C.c_uint64 * 9)()
     N.lib().lrf_workspace_layout_bwd(R, S, (C.c_int32 * 3)(*f._grid_host), out)
-    act_off, _, ri_off, toff_off, ACT_LD, _, ACT_H1, ACT_H2 = [int(v) for v in out]
+    act_off, _, ri_off, toff_off, ACT_LD, _, ACT_H1, ACT_H2, _ = [int(v) for v in out]
     toff = ws[toff_off:toff_off + 4 * (R + 1)].view(torch.int32)
     rows = int(toff[R]) * 16
     act = ws[act_off:act_off + rows * ACT_LD * 4].view(torch.float32).view(rows, ACT_LD)
@@ -258,7 +258,7 @@ def flip_allowed_mask(name, like, rep):
     if name.startswith("app_plane.") or name.startswith("app_line."):
         p = int(name[-1])
         m = rep["planes"][p][None, None] if "plane" in name else rep["lines"][p][None, None, :, None]
-        return m.expand(like.shape)
+        return m.expand(like.shape).contiguous()
     if name == "rays":
         m = torch.zeros(like.shape, dtype=torch.bool, device=like.device)
         m[rep["rays"]] = True
@@ -268,7 +268,7 @@ def flip_allowed_mask(name, like, rep):
     return torch.full(like.shape, rep["n_flips"] > 0, dtype=torch.bool, device=like.device)
 
 
-def check_grads_with_flips(mine, ref, rep, tol=1e-4, flip_tol=5e-2, dense_flip_tol=5e-3, subset=None, gmax=None):
+def check_grads_with_flips(mine, ref, rep, tol=1e-4, flip_tol=5e-2, dense_flip_tol=2e-2, subset=None, gmax=None):
     """mine / ref: name -> gradient tensor (state-dict names, plus "rays").  Every entry must agree to
     `tol` of the tensor's largest reference magnitude, except what a ReLU flip found by
     relu_flip_report can touch: the flipped samples' texel footprints in the appearance planes / lines
@@ -282,7 +282,7 @@ def check_grads_with_flips(mine, ref, rep, tol=1e-4, flip_tol=5e-2, dense_flip_t
         allowed = flip_allowed_mask(name, gm, rep)
         if subset is not None and name in subset:
             gm, allowed = gm.reshape(-1)[subset[name]], allowed.reshape(-1)[subset[name]]
-            gr = gr.reshape(-1)
+        gm, gr, allowed = gm.reshape(-1), gr.reshape(-1), allowed.reshape(-1)
         den = max(float(gmax[name]) if gmax is not None else float(gr.abs().max()), 1e-12)
         err = (gm - gr).abs() / den
         e_out = float(err[~allowed].max()) if (~allowed).any() else 0.0
