@@ -239,7 +239,7 @@ def committed_traffic():
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            out = {k.replace("k_shade_bf16", "k_shade"): {"traffic_bytes": v["traffic_bytes"],
+            out = {k.replace("k_shade_bf16", "k_shade2"): {"traffic_bytes": v["traffic_bytes"],
                                                            "l2_hit_rate": v["TCC_HIT"] / max(v["TCC_HIT"] + v["TCC_MISS"], 1.0)}
                    for k, v in pmc["kernels"].items()}
             return out, f"NOT measured in this run: committed profiles/{name} ({pmc.get('source', '')[:80]})"
@@ -256,14 +256,14 @@ def roofline_object(prof, S, traffic, traffic_src):
     app_bytes = n_sh * APP_BYTES_PER_SAMPLE
     kern = {"k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes, "bound": "hbm"},
             "k_finalize": {"ms": prof["finalize_ms"]}, "k_scan_tiles": {"ms": prof["scan_ms"]}}
-    if prof["app_ms"] > 0:
+    if prof["app_ms"] > 0:                                 # LRF_FLAG_MLP_SPLIT
         kern["k_app"] = {"ms": prof["app_ms"], "alg_bytes": app_bytes + n_sh * FRAG_BYTES_PER_SLOT, "bound": "hbm",
                          "alg_flop": n_sh * BASIS_FLOP, "issued_mfma_flop": tiles * 18 * MFMA_FLOP}
         kern["k_mlp"] = {"ms": prof["mlp_ms"], "alg_bytes": n_sh * (FRAG_BYTES_PER_SLOT + 4), "bound": "mfma",
                          "alg_flop": n_sh * MLP_FLOP, "issued_mfma_flop": tiles * 120 * MFMA_FLOP}
-    else:
-        kern["k_shade"] = {"ms": prof["shade_ms"] - prof["scan_ms"], "alg_bytes": app_bytes, "bound": "hbm",
-                           "alg_flop": n_sh * (BASIS_FLOP + MLP_FLOP), "issued_mfma_flop": tiles * 138 * MFMA_FLOP}
+    else:                                                  # default engine: one fused colour kernel, 150 MFMAs per tile
+        kern["k_shade2"] = {"ms": prof["shade_ms"] - prof["scan_ms"], "alg_bytes": app_bytes, "bound": "hbm",
+                            "alg_flop": n_sh * (BASIS_FLOP + MLP_FLOP), "issued_mfma_flop": tiles * 150 * MFMA_FLOP}
     for name, k in kern.items():
         t = k["ms"] * 1e-3
         if "alg_bytes" in k and t > 0:
@@ -278,7 +278,7 @@ def roofline_object(prof, S, traffic, traffic_src):
             k["l2_hit_rate"] = tr["l2_hit_rate"]
             if t > 0:
                 k["hbm_frac"] = tr["traffic_bytes"] / t / 1e9 / HBM_PEAK_GBS
-    cands = [n for n in ("k_march", "k_app", "k_mlp", "k_shade") if n in kern]
+    cands = [n for n in ("k_march", "k_app", "k_mlp", "k_shade2") if n in kern]
     dom = max(cands, key=lambda n: kern[n]["ms"])
     d = kern[dom]
     if d["bound"] == "mfma":
@@ -482,11 +482,18 @@ def main():
                 d32 = timed(fwd, 20, 3, sync)
                 field.mlp_engine = "bf16x3_fused"
                 dfu = timed(fwd, 20, 3, sync)
+                field.mlp_engine = "bf16x3_split"
+                dsp = timed(fwd, 20, 3, sync)
+                psp = kernel_profile(field, rays, z)
                 field.mlp_engine = "bf16x3"
             work = {"exact_f32_engine": {"rays_per_s": R_PER_GPU * 20 / d32, "ms_per_step": d32 / 20 * 1e3,
                                          "what": "same batch, colour MLP on v_mfma_f32_16x16x4_f32 (LRF_FLAG_MLP_F32)"},
-                    "fused_bf16x3_engine": {"rays_per_s": R_PER_GPU * 20 / dfu, "ms_per_step": dfu / 20 * 1e3,
-                                            "what": "same batch, round 1's single colour kernel (LRF_FLAG_MLP_FUSED)"}}
+                    "round1_fused_engine": {"rays_per_s": R_PER_GPU * 20 / dfu, "ms_per_step": dfu / 20 * 1e3,
+                                            "what": "same batch, round 1's colour kernel k_shade_bf16 (LRF_FLAG_MLP_FUSED)"},
+                    "split_engine": {"rays_per_s": R_PER_GPU * 20 / dsp, "ms_per_step": dsp / 20 * 1e3,
+                                     "k_app_ms": psp["app_ms"], "k_mlp_ms": psp["mlp_ms"],
+                                     "what": "same batch, colour stage as k_app (gathers + basis) + k_mlp (MFMA chain, no gathers) "
+                                             "(LRF_FLAG_MLP_SPLIT)"}}
             try:
                 wf = walls_field(dev)
                 wf.updateAlphaMask((GRID // 2,) * 3)

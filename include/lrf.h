@@ -38,8 +38,8 @@ extern "C" {
 #define LRF_FLAG_MLP_VALU   4u   /* debug engine: colour MLP on the vector ALU, natural-layout weights */
 #define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
                                     split-bf16 (hi+lo, 3-term) MFMA chain */
-#define LRF_FLAG_MLP_FUSED  32u  /* colour stage as round 1's single fused kernel (k_shade_bf16) instead of the
-                                  * default k_app + k_mlp pair; same arithmetic, bit-identical results */
+#define LRF_FLAG_MLP_FUSED  32u  /* colour stage as round 1's fused kernel (k_shade_bf16) instead of the default k_shade2 */
+#define LRF_FLAG_MLP_SPLIT  64u  /* colour stage as two kernels, k_app (gather + basis) and k_mlp (the MFMA chain) */
 #define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
@@ -99,6 +99,10 @@ int         lrf_abi_version(void);
  * intermediate values per (compact sample, lane group); NULL (default) disables it. */
 void        lrf_debug_set_dump(float* buf);
 void        lrf_debug_set_mlp_threads(int threads); /* 1024 (default) | 512 | 256: workgroup size of k_mlp (experiments) */
+void        lrf_debug_set_app_oversubscribe(int n); /* k_app workgroups per resident slot, 1..16 (default 4) */
+void        lrf_debug_set_subbatches(int q);        /* ray ranges of the sub-batch pipeline of lrf_render_fwd, 1..8 (default 1 = off) */
+void        lrf_debug_set_skew(int n);              /* start skew between the waves of a SIMD in k_shade2, units of 6400 cycles */
+void        lrf_debug_set_lds_lines(int on);        /* k_march: density lines staged in LDS (default on when they fit) */
 void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);
 

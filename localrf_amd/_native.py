@@ -14,6 +14,7 @@ LRF_FLAG_MLP_VALU = 4
 LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
 LRF_FLAG_MLP_FUSED = 32
+LRF_FLAG_MLP_SPLIT = 64
 
 _f = C.c_void_p  # device float*
 
@@ -59,6 +60,10 @@ SYMBOLS = {
     "lrf_debug_set_dump": (None, [C.c_void_p]),
     "lrf_debug_set_mlp_policy": (None, [C.c_int]),
     "lrf_debug_set_mlp_threads": (None, [C.c_int]),
+    "lrf_debug_set_app_oversubscribe": (None, [C.c_int]),
+    "lrf_debug_set_subbatches": (None, [C.c_int]),
+    "lrf_debug_set_skew": (None, [C.c_int]),
+    "lrf_debug_set_lds_lines": (None, [C.c_int]),
     "lrf_workspace_layout_bwd": (None, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "lrf_cache_bytes": (C.c_size_t, [C.POINTER(C.c_int32)]),
     "lrf_pack_field": (C.c_int, [C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),

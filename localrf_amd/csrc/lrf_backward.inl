@@ -1231,8 +1231,7 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   const DField d = make_dfield(f);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
-  hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
-                     d, rays, z, R, S, flags, 0.0f, depth, w.acc, (float*)nullptr, w.ncomp, w.cidx, w.cw, b.feat);
+  launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
                      b.crgb, b.act, w.cw, w.part, w.pmax);
@@ -1276,8 +1275,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
   hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
-    hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
-                       d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, (float*)nullptr, w.ncomp, w.cidx, w.cw, b.feat);
+    launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
     hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
                        b.crgb, b.act, (const float*)nullptr, (float*)nullptr, 0);

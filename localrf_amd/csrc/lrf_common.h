@@ -242,6 +242,48 @@ __device__ __forceinline__ float density_feature32(const DField& f, const float 
   return feat;
 }
 
+// density_feature for the march: 32-bit saddr gathers of the four plane taps, the two line taps from LDS when
+// the caller staged the lines there (LDSL: s_line[p] = the [L][8] line of plane p; 24 texture-path loads per sample
+// instead of 36), and the 8-channel contraction on packed fp32 pairs (v_pk_fma_f32: even / odd channel sums,
+// added at the end -- the summation order differs from density_feature in the last bits only).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool LDSL>
+__device__ __forceinline__ float density_feature_m(const DField& f, const float u[3], const float* const s_line[3]) {
+  f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+    const unsigned o00 = (row0 + x0) * (LRF_CD * 4u), o10 = (row0 + x1) * (LRF_CD * 4u);
+    const unsigned o01 = (row1 + x0) * (LRF_CD * 4u), o11 = (row1 + x1) * (LRF_CD * 4u);
+    const f32x2 w00 = {(1.0f - tx) * (1.0f - ty), (1.0f - tx) * (1.0f - ty)}, w10 = {tx * (1.0f - ty), tx * (1.0f - ty)};
+    const f32x2 w01 = {(1.0f - tx) * ty, (1.0f - tx) * ty}, w11 = {tx * ty, tx * ty};
+    const f32x2 wl0 = {1.0f - tl, 1.0f - tl}, wl1 = {tl, tl};
+#pragma unroll
+    for (int h = 0; h < LRF_CD / 4; ++h) {
+      const float4 a = ld4b(f.dplane[p], o00 + 16 * h), b = ld4b(f.dplane[p], o10 + 16 * h);
+      const float4 c = ld4b(f.dplane[p], o01 + 16 * h), d = ld4b(f.dplane[p], o11 + 16 * h);
+      float4 e, g;
+      if (LDSL) {
+        e = *reinterpret_cast<const float4*>(s_line[p] + l0 * LRF_CD + 4 * h);
+        g = *reinterpret_cast<const float4*>(s_line[p] + l1 * LRF_CD + 4 * h);
+      } else {
+        e = ld4b(f.dline[p], (unsigned)l0 * (LRF_CD * 4u) + 16 * h);
+        g = ld4b(f.dline[p], (unsigned)l1 * (LRF_CD * 4u) + 16 * h);
+      }
+      const f32x2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+      const f32x2 c0 = {c.x, c.y}, c1 = {c.z, c.w}, d0 = {d.x, d.y}, d1 = {d.z, d.w};
+      const f32x2 e0 = {e.x, e.y}, e1 = {e.z, e.w}, g0 = {g.x, g.y}, g1 = {g.z, g.w};
+      acc += (a0 * w00 + b0 * w10 + c0 * w01 + d0 * w11) * (e0 * wl0 + g0 * wl1);
+      acc += (a1 * w00 + b1 * w10 + c1 * w01 + d1 * w11) * (e1 * wl0 + g1 * wl1);
+    }
+  }
+  return acc.x + acc.y;
+}
+
 // Inclusive product scan across the 64 lanes of a wave; returns the exclusive product in
 // `excl` and the wave total in `total`.
 __device__ __forceinline__ void wave_scan_prod(float v, int lane, float& excl, float& total) {

@@ -176,7 +176,10 @@ __global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
 // --------------------------------------------------------------------------- march
 // One wavefront per ray.  tensorBase.py:576-622 (sampling, density, alpha2weights,
 // acc/depth, floater filter, shading mask).
-__global__ __launch_bounds__(256) void k_march(
+// LDSL: the three density lines ([L][8] floats each, 9.6 KB at 300) are staged in LDS behind the per-wave alpha
+// slices, so a sample costs 24 texture-path loads instead of 36 (the march is bound by that path: TA 57 % busy)
+template <bool LDSL>
+__global__ __launch_bounds__(1024) void k_march(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
     uint32_t flags, float floater,
     float* __restrict__ depth, float* __restrict__ acc_ws, float* __restrict__ w_all,
@@ -186,7 +189,22 @@ __global__ __launch_bounds__(256) void k_march(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nb = gridDim.x;                              // XCD-aware block order, see tile_walk_begin
   const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int ray = lb * 4 + wave;
+  const int nw = blockDim.x >> 6;                          // rays per workgroup: 4, 8 or 16 (launch_march)
+  const int ray = lb * nw + wave;
+  const float* s_line[3] = {nullptr, nullptr, nullptr};
+  if (LDSL) {                                              // lines behind the alpha slices (whole block: before any return)
+    float* base = s_alpha_all + (size_t)nw * S;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int n = f.ll[p] * LRF_CD / 4;
+      float4* dst = reinterpret_cast<float4*>(base);
+      const float4* src = reinterpret_cast<const float4*>(f.dline[p]);
+      for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+      s_line[p] = base;
+      base += f.ll[p] * LRF_CD;
+    }
+    __syncthreads();
+  }
   if (ray >= R) return;
   float* s_alpha = s_alpha_all + (size_t)wave * S;
 
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(256) void k_march(
         bool valid = true;
         if (f.alpha_vol) valid = alpha_mask_sample(f, x[0], x[1], x[2]) > 0.0f;   // :593-598
         if (valid) {
-          fk = density_feature32(f, u);
+          fk = density_feature_m<LDSL>(f, u, s_line);
           const float sigma = feature2density(fk, f.density_shift, relu);            // :603-608
           const float dist = z[k + 1] - zk;                                          // :584-587
           alpha = 1.0f - expf(-sigma * dist * f.distance_scale);                     // :610
@@ -943,6 +961,7 @@ static DField make_dfield(const LrfField* f) {
 struct Workspace {
   int* toff; int* ncomp; float* acc; uint16_t* cidx; float* cw; float* part;
   uint4* ffrag;            // k_app -> k_mlp: layer-1 B fragments, 2 KB per 16-sample tile
+  int2* tinfo;             // k_app -> k_mlp: (ray, j0 * 32 + count) per tile
   int pmax; size_t bytes;
 };
 static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -958,12 +977,19 @@ static Workspace carve(void* ws, int R, int S) {
   w.cw    = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
   w.part  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
   w.ffrag = reinterpret_cast<uint4*>(p + off);     off += up256((size_t)R * w.pmax * 2048);
+  w.tinfo = reinterpret_cast<int2*>(p + off);      off += up256((size_t)R * w.pmax * 8);
   w.bytes = off;
   return w;
 }
 
 static float* g_dump = nullptr;
 static int g_mlp_policy = 4;
+constexpr int MAX_SUB = 8;         // sub-batch pipeline of lrf_render_fwd (see render_fwd_impl)
+static int g_subbatches = 1;       // measured on MI355X: a cross-stream event wait costs ~50 us, more than the overlap returns
+static int sub_rays(int R, int Q) { return (((R + Q - 1) / Q) + 3) & ~3; }       // k_march blocks hold 4 rays
+static int g_no_lds_lines = 0;     // lrf_debug_set_lds_lines(0): k_march reads its lines from global memory
+static int g_skew = 0;             // lrf_debug_set_skew: phase skew of k_shade2's waves, units of 6400 cycles
+static int g_app_over = 4;         // lrf_debug_set_app_oversubscribe: k_app workgroups per resident slot
 static int g_mlp_threads = 1024;   // lrf_debug_set_mlp_threads: workgroup size of k_mlp (512 leaves half the register file to other kernels)       // lrf_debug_set_mlp_policy: MFMA issue policy of k_mlp (lrf_shade2.inl)
 
 static int device_cus() {                 // of the current device (one process may drive several)
@@ -977,6 +1003,36 @@ static int device_cus() {                 // of the current device (one process 
     if (cus <= 0) cus = 256;
   }
   return cus;
+}
+
+// k_march launch: lines in LDS when the three of them (+ the alpha slices) leave four workgroups per CU
+static void launch_march(const DField& d, const float* rays, const float* z, int R, int S, uint32_t flags, float floater,
+                         float* depth, float* acc, float* w_all, int* ncomp, uint16_t* cidx, float* cw, float* feat,
+                         hipStream_t st) {
+  // 4 waves per SIMD either way (123 VGPRs): 4 / 2 / 1 workgroups of 4 / 8 / 16 rays per CU, whichever keeps
+  // alpha slices + lines within the CU's 160 KB (300^3: 8 + 29 KB x 4; 500^3: 18 + 48 KB x 2; 640^3: 47 + 61 KB x 1)
+  const size_t lds_l = (size_t)(d.ll[0] + d.ll[1] + d.ll[2]) * LRF_CD * sizeof(float);
+  int nw = 0;
+  if (!g_no_lds_lines) {
+    for (int cand = 4; cand <= 16 && !nw; cand *= 2)
+      if (((size_t)cand * S * sizeof(float) + lds_l) * (16 / cand) <= 156 * 1024) nw = cand;
+  }
+  if (nw) {
+    const size_t lds = (size_t)nw * S * sizeof(float) + lds_l;
+    if (lds > 64 * 1024) {
+      static bool attr_done[64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess && !attr_done[dev & 63]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[dev & 63] = true;
+      }
+    }
+    hipLaunchKernelGGL(k_march<true>, dim3((R + nw - 1) / nw), dim3(64 * nw), lds, st,
+                       d, rays, z, R, S, flags, floater, depth, acc, w_all, ncomp, cidx, cw, feat);
+  } else {
+    hipLaunchKernelGGL(k_march<false>, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
+                       d, rays, z, R, S, flags, floater, depth, acc, w_all, ncomp, cidx, cw, feat);
+  }
 }
 
 }  // namespace lrf
@@ -993,6 +1049,10 @@ extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
+void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
+void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
+void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
+void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
 void lrf_debug_set_mlp_threads(int threads) { g_mlp_threads = (threads == 512 || threads == 256) ? threads : 1024; }
 void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = ((policy >= 0 && policy <= 7) || policy == 10 || policy == 14) ? policy : 4; }
 const char* lrf_last_error(void) { return g_err; }
@@ -1019,10 +1079,12 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
 }
 
 size_t lrf_workspace_bytes(int32_t R, int32_t S) {
-  return carve(nullptr, R, S).bytes;
+  size_t best = carve(nullptr, R, S).bytes;               // sub-batch pipeline: Q separately carved ranges
+  for (int Q = 2; Q <= MAX_SUB; ++Q) best = max(best, (size_t)Q * carve(nullptr, sub_rays(R, Q), S).bytes);
+  return best;
 }
 
-// default colour engine: k_app (gather + basis) then k_mlp (27 -> 128 -> 128 -> 3), lrf_shade2.inl
+// LRF_FLAG_MLP_SPLIT: k_app (gather + basis) then k_mlp (27 -> 128 -> 128 -> 3), lrf_shade2.inl
 static int launch_shade_split(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                               hipStream_t st, hipEvent_t mid) {
   const int cus = device_cus();
@@ -1036,40 +1098,38 @@ static int launch_shade_split(const DField& d, const float* rays, const float* z
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_app, 256, 28 * 1024) != hipSuccess || n <= 0) n = 4;
     occ = n > 8 ? 8 : n;
   }
-  hipLaunchKernelGGL(k_app, dim3(cus * occ), dim3(256), lds_app, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.ffrag);
+  // more workgroups than resident slots: the hardware's workgroup scheduler balances the load (tile ranges of
+  // a static split finish far apart); a k_app workgroup only stages 14 KB, so a fresh one costs little
+  hipLaunchKernelGGL(k_app, dim3(cus * occ * g_app_over), dim3(256), lds_app, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.ffrag, w.tinfo);
   if (mid) LRF_HIP(hipEventRecord(mid, st));
   if (g_dump && g_mlp_policy >= 10) {        // debug: phase timing of k_mlp (policy 10 + p), counters -> the dump buffer
     DField dd = d; dd.dump = g_dump;
-    if (g_mlp_policy == 14) hipLaunchKernelGGL((k_mlp<4, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax);
-    else hipLaunchKernelGGL((k_mlp<0, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax);
+    if (g_mlp_policy == 14) hipLaunchKernelGGL((k_mlp<4, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax);
+    else hipLaunchKernelGGL((k_mlp<0, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax);
     return 0;
   }
   switch (g_mlp_policy) {
-    case 1: hipLaunchKernelGGL(k_mlp<1>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 2: hipLaunchKernelGGL(k_mlp<2>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 3: hipLaunchKernelGGL(k_mlp<3>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 6: hipLaunchKernelGGL((k_mlp<4, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 7: hipLaunchKernelGGL((k_mlp<0, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 5: hipLaunchKernelGGL(k_mlp<5>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    case 0: hipLaunchKernelGGL(k_mlp<0>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
-    default: hipLaunchKernelGGL(k_mlp<4>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.part, w.pmax); break;
+    case 1: hipLaunchKernelGGL(k_mlp<1>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    case 2: hipLaunchKernelGGL(k_mlp<2>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    case 3: hipLaunchKernelGGL(k_mlp<3>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    case 6: hipLaunchKernelGGL((k_mlp<4, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    case 7: hipLaunchKernelGGL((k_mlp<0, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    case 5: hipLaunchKernelGGL(k_mlp<5>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    case 0: hipLaunchKernelGGL(k_mlp<0>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
+    default: hipLaunchKernelGGL(k_mlp<4>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
   }
   return 0;
 }
 
-static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
-                           uint32_t flags, float floater_thresh, float* rgb, float* depth,
-                           float* weight_out, float* acc_out, void* workspace, hipStream_t st,
-                           hipEvent_t* ev /* 6 events or null: start, after march, after shade, end, between k_app and k_mlp, after k_scan_tiles */) {
-  if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
-  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
-  DField d = make_dfield(f);
-  d.dump = g_dump;
+// One batch (or sub-batch) of rays through the four stages on `st`.  app_done (optional) is recorded right
+// after k_app: the point from which only matrix-pipe / VALU work (k_mlp) is left.
+static int render_fwd_one(const DField& d, const float* rays, const float* z, int32_t R, int32_t S,
+                          uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                          float* weight_out, float* acc_out, void* workspace, hipStream_t st,
+                          hipEvent_t* ev, hipEvent_t app_done) {
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
-  hipLaunchKernelGGL(k_march, dim3((R + 3) / 4), dim3(256), (size_t)4 * S * sizeof(float), st,
-                     d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out,
-                     w.ncomp, w.cidx, w.cw, (float*)nullptr);
+  launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (flags & LRF_FLAG_MLP_VALU) {
     hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st,
@@ -1083,14 +1143,89 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
     else if (flags & LRF_FLAG_MLP_FUSED)
       hipLaunchKernelGGL(k_shade_bf16, dim3(device_cus()), dim3(1024), 0, st,
                          d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
-    else {
-      if (int rc = launch_shade_split(d, rays, z, S, R, w, st, ev ? ev[4] : nullptr)) return rc;
+    else if (!(flags & LRF_FLAG_MLP_SPLIT)) {                 // default engine: k_shade2
+      const size_t lds2 = (size_t)IMGB_ALL * sizeof(uint4) + (size_t)S * sizeof(float);
+      static bool attr_done[64] = {};
+      int dev = 0;
+      LRF_HIP(hipGetDevice(&dev));
+      if (!attr_done[dev & 63]) {
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done[dev & 63] = true;
+      }
+      if (g_dump && g_mlp_policy >= 10)
+        hipLaunchKernelGGL(k_shade2<true>, dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      else
+        hipLaunchKernelGGL(k_shade2<false>, dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+    } else {
+      if (int rc = launch_shade_split(d, rays, z, S, R, w, st, ev ? ev[4] : app_done)) return rc;
     }
   }
   if (ev) LRF_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
                      R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, acc_out);
   if (ev) LRF_HIP(hipEventRecord(ev[3], st));
+  return 0;
+}
+
+// Sub-batch pipeline of the default engine.  k_march and k_app are bound by the texture path (TA 57-65 %
+// busy, matrix pipe idle), k_mlp by the matrix pipe / VALU (no gathers): a batch is cut into g_subbatches ray
+// ranges that alternate between the caller's stream and a side stream, and sub-batch q starts marching when
+// sub-batch q-1 has finished its k_app -- so the gathers of one range run under the MFMA chain of the
+// previous one.  Results are those of the single-range launch (rays are independent).
+struct SideStream { hipStream_t s; hipEvent_t fork, join, app[MAX_SUB]; bool ok; };
+static SideStream* side_stream() {
+  static SideStream tab[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  SideStream& x = tab[dev & 63];
+  if (!x.ok) {
+    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    bool good = hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < MAX_SUB && good; ++i) good = hipEventCreateWithFlags(&x.app[i], hipEventDisableTiming) == hipSuccess;
+    if (!good) return nullptr;
+    x.ok = true;
+  }
+  return &x;
+}
+static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                           uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                           float* weight_out, float* acc_out, void* workspace, hipStream_t st,
+                           hipEvent_t* ev /* 6 events or null: start, after march, after shade, end, between k_app and k_mlp, after k_scan_tiles */) {
+  if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
+  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
+  DField d = make_dfield(f);
+  d.dump = g_dump;
+  const bool split_engine = (flags & LRF_FLAG_MLP_SPLIT) && !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED));
+  int Q = (split_engine && !ev && !g_dump) ? g_subbatches : 1;
+  while (Q > 1 && R / Q < 512) --Q;                       // not worth splitting small batches
+  SideStream* ss = Q > 1 ? side_stream() : nullptr;
+  if (!ss) Q = 1;
+  if (Q == 1) {
+    if (int rc = render_fwd_one(d, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out, workspace, st, ev, nullptr))
+      return rc;
+    LRF_HIP(hipGetLastError());
+    return 0;
+  }
+  const int Rq = sub_rays(R, Q);
+  const size_t wsq = carve(nullptr, Rq, S).bytes;
+  LRF_HIP(hipEventRecord(ss->fork, st));                  // the side stream starts behind the caller's earlier work
+  LRF_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+  for (int q = 0; q < Q; ++q) {
+    const int r0 = q * Rq, n = min(Rq, R - r0);
+    if (n <= 0) break;
+    hipStream_t sq = (q & 1) ? ss->s : st;
+    if (q) LRF_HIP(hipStreamWaitEvent(sq, ss->app[q - 1], 0));
+    if (int rc = render_fwd_one(d, rays + (size_t)r0 * 6, z, n, S, flags, floater_thresh, rgb + (size_t)r0 * 3, depth + r0,
+                                weight_out ? weight_out + (size_t)r0 * S : nullptr, acc_out ? acc_out + r0 : nullptr,
+                                reinterpret_cast<char*>(workspace) + (size_t)q * wsq, sq, nullptr, ss->app[q]))
+      return rc;
+  }
+  LRF_HIP(hipEventRecord(ss->join, ss->s));               // the caller's stream continues behind both
+  LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1121,7 +1256,7 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
     (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
     ms_out[4] = ms_out[5] = 0.0f;          // shade = k_scan_tiles [4] + k_app [5] + k_mlp (default engine)
     if (!(flags & LRF_FLAG_MLP_VALU)) (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[5]);
-    if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED)))
+    if ((flags & LRF_FLAG_MLP_SPLIT) && !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED)))
       (void)hipEventElapsedTime(&ms_out[5], ev[5], ev[4]);
     if (n_shaded_out) {
       // shaded-sample count of this batch = sum of ncomp (host copy; measurement only)

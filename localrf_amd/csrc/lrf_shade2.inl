@@ -103,7 +103,7 @@ __device__ __forceinline__ void gather_app6_plane32(const DField& f, const float
 __global__ __launch_bounds__(256) void k_app(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
-    uint4* __restrict__ ffrag /* [tile][hi, lo][lane] */) {
+    uint4* __restrict__ ffrag /* [tile][hi, lo][lane] */, int2* __restrict__ tinfo /* [tile] (ray, j0 * 32 + count) */) {
   extern __shared__ uint4 s_dyn[];                             // basis fragments, then z[S]
   uint4* bas = s_dyn;
   float* s_z = reinterpret_cast<float*>(s_dyn + IMGB_W1);
@@ -120,16 +120,18 @@ __global__ __launch_bounds__(256) void k_app(
   int j0 = (t0 - tw.tile0) * ITEM;
   int cnt = min(ITEM, tw.nc - j0);
   int k = cidx[(size_t)tw.ray * S + j0 + (s < cnt ? s : 0)];
+  int ray_c = tw.ray;
   for (int t = t0; t < t1; ++t) {
     asm volatile("" ::: "memory");     // keep the LDS fragment reads inside the loop
     float x[3], u[3];
     sample_point(f, rg.o, rg.dh, s_z[k], x, u);
     // header of the next tile: one dependent load, issued before this tile's gathers and consumed
     // after them
-    int k_n = 0, j0_n = 0, cnt_n = 0;
+    int k_n = 0, j0_n = 0, cnt_n = 0, ray_n = ray_c;
     RayGeo rg_n = rg;
     if (t + 1 < t1) {
       if (tile_walk2_seek(tw, toff, ncomp, t + 1)) rg_n = load_ray(rays, tw.ray);
+      ray_n = tw.ray;
       j0_n = (t + 1 - tw.tile0) * ITEM;
       cnt_n = min(ITEM, tw.nc - j0_n);
       k_n = cidx[(size_t)tw.ray * S + j0_n + (s < cnt_n ? s : 0)];
@@ -157,8 +159,9 @@ __global__ __launch_bounds__(256) void k_app(
       split8(v, bh, bl);
       ffrag[((size_t)t * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, bh);
       ffrag[((size_t)t * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, bl);
+      if (lane == 0) tinfo[t] = make_int2(ray_c, j0 * 32 + cnt);
     }
-    k = k_n; j0 = j0_n; cnt = cnt_n; rg = rg_n;
+    k = k_n; j0 = j0_n; cnt = cnt_n; rg = rg_n; ray_c = ray_n;
   }
 }
 
@@ -215,20 +218,20 @@ __device__ __forceinline__ void gemm_step_q(const uint4* img, int frag0, int str
   if (POLICY >= 4) {
     bf16x8 ah[NT], al[NT];                                      // fully unrolled: only ~3 fragments are live at a time
     ah[0] = lds_frag(img, frag0, 0, lane); al[0] = lds_frag(img, frag0, 1, lane);
-    if (NT > 1) { ah[1] = lds_frag(img, frag0 + stride, 0, lane); al[1] = lds_frag(img, frag0 + stride, 1, lane); }
+    if constexpr (NT > 1) { ah[1] = lds_frag(img, frag0 + stride, 0, lane); al[1] = lds_frag(img, frag0 + stride, 1, lane); }
 #pragma unroll
     for (int t1 = 0; t1 < NT; ++t1) {
       if (t1 + 2 < NT) {
-        ah[t1 + 2] = lds_frag(img, frag0 + (t1 + 2) * stride, 0, lane);
-        al[t1 + 2] = lds_frag(img, frag0 + (t1 + 2) * stride, 1, lane);
+        ah[(t1 + 2) % NT] = lds_frag(img, frag0 + (t1 + 2) * stride, 0, lane);
+        al[(t1 + 2) % NT] = lds_frag(img, frag0 + (t1 + 2) * stride, 1, lane);
       }
       if (POLICY == 4) __builtin_amdgcn_sched_barrier(0);       // keep the fetch ahead of this fragment's MFMAs
       mfma_p<POLICY>(al[t1], bh, acc[t1]);
       mfma_p<POLICY>(ah[t1], bl, acc[t1]);
       mfma_p<POLICY>(ah[t1], bh, acc[t1]);
-      if (POLICY == 5 && t1 >= 2) { hold(ah[t1 - 2]); hold(al[t1 - 2]); }
+      if (POLICY == 5 && t1 >= 2) { hold(ah[(t1 - 2) % NT]); hold(al[(t1 - 2) % NT]); }
     }
-    if (POLICY == 5) { hold(ah[NT - 1]); hold(al[NT - 1]); if (NT > 1) { hold(ah[NT - 2]); hold(al[NT - 2]); } }
+    if (POLICY == 5) { hold(ah[NT - 1]); hold(al[NT - 1]); if constexpr (NT > 1) { hold(ah[NT - 2]); hold(al[NT - 2]); } }
     return;
   }
   bf16x8 p1h = bh, p1l = bl, p2h = bh, p2l = bl;               // the two previous A fragments (dummies at first)
@@ -253,7 +256,7 @@ template <int POLICY, bool TIMED = false, bool HEADM = true>
 __global__ __launch_bounds__(1024) void k_mlp(
     DField f, const float* __restrict__ rays, int S, const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const float* __restrict__ cw, const uint4* __restrict__ ffrag,
-    float* __restrict__ part, int pmax) {
+    const int2* __restrict__ tinfo, float* __restrict__ part, int pmax) {
   unsigned long long tk[5] = {0, 0, 0, 0, 0}, tlast = 0;
 #define LRF_TICK(i) do { if (TIMED) { const unsigned long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
   __shared__ uint4 img[IMGB_ALL - IMGB_W1];                    // W1, W2 fragments, fp32 tail, head fragments (91 KB)
@@ -262,34 +265,41 @@ __global__ __launch_bounds__(1024) void k_mlp(
   constexpr int F_W1 = 0, F_W2 = (IMGB_W2 - IMGB_W1) / 128, F_W3 = (IMGB_W3F - IMGB_W1) / 128;   // fragment indices inside img
   const float* tail = reinterpret_cast<const float*>(img + (IMGB_TAIL - IMGB_W1));
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
-  int t0, t1;
-  tile_range(toff, R, t0, t1);
-  if (t0 >= t1) return;
-  TileWalk2 tw = tile_walk2_begin(toff, ncomp, R, t0);
-  tile_walk2_seek(tw, toff, ncomp, t0);
-  // state of the current tile: (ray, j0, cnt) are wave-uniform and were found one tile ahead; the
-  // fragment is prefetched one tile ahead; weight and view direction are only needed at the end of a
-  // tile and are loaded at its top
-  int ray = tw.ray, j0 = (t0 - tw.tile0) * ITEM;
-  int cnt = min(ITEM, tw.nc - j0);
-  uint4 fh = ffrag[((size_t)t0 * 2 + 0) * 64 + lane], fl = ffrag[((size_t)t0 * 2 + 1) * 64 + lane];
+  // Tiles: this workgroup owns one contiguous range (XCD-aware block order); its waves pull tiles from
+  // an LDS counter.  With a static split per wave the waves of a SIMD finished up to 2x apart (the oldest
+  // wave wins every arbitration; s_memtime totals 85K..175K cycles per wave, scripts/gpu_diag.py mlp_phases),
+  // and the kernel lasts as long as its slowest wave.
+  __shared__ int s_next;
+  const int T = toff[R];
+  const int nb = gridDim.x, nw = blockDim.x >> 6;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int T0 = (int)((long long)lb * T / nb), T1 = (int)((long long)(lb + 1) * T / nb);
+  if (threadIdx.x == 0) s_next = T0 + nw;
+  __syncthreads();
+  int t = __builtin_amdgcn_readfirstlane(T0 + (int)(threadIdx.x >> 6));
+  if (t >= T1) return;
+  // state of the current tile: its header (k_app wrote (ray, j0 * 32 + count) per tile) and its fragment are
+  // fetched one tile ahead; weight and view direction are only needed at the end of a tile and are loaded at
+  // its top
+  int2 hdr = tinfo[t];
+  uint4 fh = ffrag[((size_t)t * 2 + 0) * 64 + lane], fl = ffrag[((size_t)t * 2 + 1) * 64 + lane];
   if (TIMED) tlast = __builtin_readcyclecounter();
-  for (int t = t0; t < t1; ++t) {
+  while (t < T1) {
     asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
-    ray = __builtin_amdgcn_readfirstlane(ray); j0 = __builtin_amdgcn_readfirstlane(j0);
-    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    const int ray = __builtin_amdgcn_readfirstlane(hdr.x);
+    const int j0 = __builtin_amdgcn_readfirstlane(hdr.y) >> 5, cnt = __builtin_amdgcn_readfirstlane(hdr.y) & 31;
     const float w = s < cnt ? cw[(size_t)ray * S + j0 + s] : 0.0f;
     const float* rp = rays + (size_t)ray * 6;
     const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
-    int ray_n = ray, j0_n = 0, cnt_n = 0;
+    int t_n = 0;
+    if (lane == 0) t_n = atomicAdd(&s_next, 1);
+    t_n = __builtin_amdgcn_readfirstlane(t_n);
+    int2 hdr_n = hdr;
     uint4 fh_n = fh, fl_n = fl;
-    if (t + 1 < t1) {
-      tile_walk2_seek(tw, toff, ncomp, t + 1);
-      ray_n = tw.ray;
-      j0_n = (t + 1 - tw.tile0) * ITEM;
-      cnt_n = min(ITEM, tw.nc - j0_n);
-      fh_n = ffrag[((size_t)(t + 1) * 2 + 0) * 64 + lane];
-      fl_n = ffrag[((size_t)(t + 1) * 2 + 1) * 64 + lane];
+    if (t_n < T1) {
+      hdr_n = tinfo[t_n];
+      fh_n = ffrag[((size_t)t_n * 2 + 0) * 64 + lane];
+      fl_n = ffrag[((size_t)t_n * 2 + 1) * 64 + lane];
     }
     LRF_TICK(0);
     // layer 1 (tensorBase.py:129-130): one k-step, B = the fragment k_app wrote
@@ -385,13 +395,150 @@ __global__ __launch_bounds__(1024) void k_mlp(
       float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
       pp[0] = cr; pp[1] = cg; pp[2] = cb;
     }
-    ray = ray_n; j0 = j0_n; cnt = cnt_n; fh = fh_n; fl = fl_n;
+    t = t_n; hdr = hdr_n; fh = fh_n; fl = fl_n;
     LRF_TICK(3);
     tk[4] += 1;
   }
   if (TIMED && f.dump && lane == 0) {
     unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
     for (int i = 0; i < 5; ++i) dp[i] = tk[i];
+  }
+#undef LRF_TICK
+}
+
+// ------------------------------------------------------------------------------- k_shade2
+// The fused colour kernel again (gather -> basis -> 128 -> 128 -> head per tile, one persistent 1024-thread
+// workgroup per CU), rebuilt from what the split taught: the tile header is prefetched one tile ahead and the
+// sample distances sit in LDS (k_shade_bf16 walks four dependent loads before its first gather), 32-bit saddr
+// gathers, integer ReLU, hardware rsqrt / exp2 / rcp, the head as a fourth MFMA layer.  Gathers and an MFMA
+// chain share this kernel, so every MFMA is hand-issued (policy 0: mfma_bf16_acc / hold / settle).
+template <bool TIMED>
+__global__ __launch_bounds__(1024) void k_shade2(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    const float* __restrict__ cw, float* __restrict__ part, int pmax, int skew) {
+  extern __shared__ uint4 s_dyn[];                             // whole image (basis, W1, W2, tail, head), then z[S]
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define LRF_TICK(i) do { if (TIMED) { const unsigned long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
+  uint4* img = s_dyn;
+  float* s_z = reinterpret_cast<float*>(s_dyn + IMGB_ALL);
+  for (int i = threadIdx.x; i < IMGB_ALL; i += blockDim.x) img[i] = f.mlpb[i];
+  for (int i = threadIdx.x; i < S; i += blockDim.x) s_z[i] = z[i];
+  __syncthreads();
+  const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
+  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
+  // Phase skew: the four waves of a SIMD (waves w, w+4, w+8, w+12 of the workgroup) start `skew` x 6400 cycles
+  // apart.  All waves run the same code on same-sized tiles, so without it they stay in lockstep -- all in the
+  // gather phases (texture path) at once, then all in the MFMA phases at once -- and the kernel's time is the SUM
+  // of the phases (s_memtime: 9.0K gather + 14.6K MLP cycles per tile and wave) instead of their overlap.
+  for (int i = 0, n = (int)(threadIdx.x >> 8) * skew; i < n; ++i) __builtin_amdgcn_s_sleep(100);
+  int t0, t1;
+  tile_range(toff, R, t0, t1);
+  if (t0 >= t1) return;
+  TileWalk2 tw = tile_walk2_begin(toff, ncomp, R, t0);
+  tile_walk2_seek(tw, toff, ncomp, t0);
+  RayGeo rg = load_ray(rays, tw.ray);
+  int ray_c = tw.ray;
+  int j0 = (t0 - tw.tile0) * ITEM;
+  int cnt = min(ITEM, tw.nc - j0);
+  int k = cidx[(size_t)tw.ray * S + j0 + (s < cnt ? s : 0)];
+  if (TIMED) tlast = __builtin_readcyclecounter();
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("" ::: "memory");     // keep the LDS fragment reads inside the loop
+    float x[3], u[3];
+    sample_point(f, rg.o, rg.dh, s_z[k], x, u);
+    const float w = s < cnt ? cw[(size_t)ray_c * S + j0 + s] : 0.0f;          // needed at the end of the tile
+    int k_n = 0, j0_n = 0, cnt_n = 0, ray_n = ray_c;
+    RayGeo rg_n = rg;
+    if (t + 1 < t1) {                  // header of the next tile: consumed after this tile's gathers
+      if (tile_walk2_seek(tw, toff, ncomp, t + 1)) rg_n = load_ray(rays, tw.ray);
+      ray_n = tw.ray;
+      j0_n = (t + 1 - tw.tile0) * ITEM;
+      cnt_n = min(ITEM, tw.nc - j0_n);
+      k_n = cidx[(size_t)tw.ray * S + j0_n + (s < cnt_n ? s : 0)];
+    }
+    LRF_TICK(0);
+    f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
+    {
+      float v[8];
+      bf16x8 bh, bl;
+      gather_app6_plane32<0>(f, u, g, v);
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
+      LRF_TICK(1);
+      gather_app6_plane32<1>(f, u, g, v);
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
+      LRF_TICK(2);
+      gather_app6_plane32<2>(f, u, g, v);
+      split8(v, bh, bl);
+      gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
+      settle<2>(fe);
+      LRF_TICK(3);
+    }
+    f32x4 h1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h1[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * q + 4 * g]);
+    {
+      const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
+      settle<8>(h1);
+    }
+    LRF_TICK(4);
+    f32x4 h2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h2[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * q + 4 * g]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = relu_i(h1[2 * ks + (j >> 2)][j & 3]);
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
+    }
+    settle<8>(h2);
+    LRF_TICK(5);
+    f32x4 oc = {0, 0, 0, 0};
+    asm volatile("" : "+v"(oc));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = relu_i(h2[2 * ks + (j >> 2)][j & 3]);
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<1>(img, IMGB_W3F / 128 + ks, 1, lane, bh, bl, &oc);
+    }
+    settle<1>(&oc);
+    float vb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
+      vb[c] = wv.w + wv.x * rg.dh[0] + wv.y * rg.dh[1] + wv.z * rg.dh[2];
+    }
+    const float wq = g != 0 ? 0.0f : w;                        // only the g = 0 lanes hold a colour
+    float cr = wq * __frcp_rn(1.0f + __expf(-(oc[0] + vb[0])));
+    float cg = wq * __frcp_rn(1.0f + __expf(-(oc[1] + vb[1])));
+    float cb = wq * __frcp_rn(1.0f + __expf(-(oc[2] + vb[2])));
+#pragma unroll
+    for (int dd = 1; dd < 16; dd <<= 1) {
+      cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
+    }
+    if (lane == 0) {
+      float* pp = part + ((size_t)ray_c * pmax + j0 / ITEM) * 3;
+      pp[0] = cr; pp[1] = cg; pp[2] = cb;
+    }
+    k = k_n; j0 = j0_n; cnt = cnt_n; rg = rg_n; ray_c = ray_n;
+    LRF_TICK(6);
+    tk[7] += 1;
+  }
+  if (TIMED && f.dump && lane == 0) {
+    unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
+    for (int i = 0; i < 8; ++i) dp[i] = tk[i];
   }
 #undef LRF_TICK
 }

@@ -80,7 +80,8 @@ class _RenderFn(torch.autograd.Function):
         # shaded-sample lists, per-sample colours, activation rows) in a workspace owned by this
         # graph node -- a 6.5 GB worst-case reservation at 4096 x 512, 288 GB of HBM -- instead of recomputing it.
         if not flags & (N.LRF_FLAG_MLP_VALU | N.LRF_FLAG_MLP_F32):
-            rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, flags)
+            tflags = flags & ~(N.LRF_FLAG_MLP_FUSED | N.LRF_FLAG_MLP_SPLIT)     # one row-saving forward for all bf16x3 engines
+            rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, tflags)
         else:
             rgb, depth = field._native_forward(rays, z, flags, floater)
             ctx.ws, ctx.versions = None, field._param_versions()
@@ -223,9 +224,10 @@ class TensorVMSplit(torch.nn.Module):
         self._cache = None
         self._cache_key = None
         self._ws = None
-        # colour-MLP engine: "bf16x3" split-bf16 MFMA chain as k_app + k_mlp (default) |
-        # "bf16x3_fused" the same arithmetic in round 1's single kernel (LRF_FLAG_MLP_FUSED) | "f32"
-        # exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
+        # colour-MLP engine: "bf16x3" split-bf16 (hi + lo, 3-term) MFMA chain in k_shade2 (default) |
+        # "bf16x3_split" the same chain as two kernels, k_app + k_mlp (LRF_FLAG_MLP_SPLIT) | "bf16x3_fused"
+        # round 1's kernel (LRF_FLAG_MLP_FUSED) | "f32" exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu"
+        # plain-loop debug engine (LRF_FLAG_MLP_VALU)
         self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
         # early termination of the march (LrfField.term_T in include/lrf.h): 0 = evaluate every sample
@@ -423,6 +425,8 @@ class TensorVMSplit(torch.nn.Module):
             fl |= N.LRF_FLAG_MLP_F32
         elif self.mlp_engine == "bf16x3_fused":
             fl |= N.LRF_FLAG_MLP_FUSED
+        elif self.mlp_engine == "bf16x3_split":
+            fl |= N.LRF_FLAG_MLP_SPLIT
         elif self.mlp_engine != "bf16x3":
             raise ValueError(f"unknown mlp_engine {self.mlp_engine!r}")
         return fl

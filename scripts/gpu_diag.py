@@ -747,11 +747,12 @@ def stage_mfma_policy():
     from localrf_amd import _native as N
     from util import make_field, make_rays, quiet
     f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    f.mlp_engine = "bf16x3_split"
     rays = make_rays(4096, 1).cuda()
     z = f.z_schedule(False, 1536, rays.device).contiguous()
     lib = N.lib()
     ref = None
-    for pol in (0, 4, 6, 7, 4):
+    for pol in [int(v) for v in os.environ.get("DIAG_POLICIES", "0,4").split(",")]:
         lib.lrf_debug_set_mlp_policy(pol)
         with torch.no_grad():
             first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
@@ -770,9 +771,14 @@ def stage_mfma_policy():
             f"max |rgb - policy0| {float((first - ref).abs().max()):.2e} | k_app {prof['app_ms'] * 1e3:.1f} us "
             f"k_mlp {prof['mlp_ms'] * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
     lib.lrf_debug_set_mlp_policy(4)
-    f.mlp_engine = "bf16x3_fused"
-    prof = bench.kernel_profile(f, rays, z, reps=10)
-    log(f"fused engine: k_shade {(prof['shade_ms'] - prof['scan_ms']) * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
+    for eng in ("bf16x3_fused", "bf16x3"):
+        f.mlp_engine = eng
+        with torch.no_grad():
+            first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            nd = sum(0 if torch.equal(first, f(rays, white_bg=True, is_train=False, N_samples=1536)[0]) else 1 for _ in range(150))
+        prof = bench.kernel_profile(f, rays, z, reps=10)
+        log(f"{eng}: k_shade {(prof['shade_ms'] - prof['scan_ms']) * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us | "
+            f"max |rgb - split| {float((first - ref).abs().max()):.2e} | renders differing {nd}/150")
 
 
 def stage_walls():
@@ -810,6 +816,7 @@ def stage_mlp_phases():
     from localrf_amd import _native as N
     from util import make_field, make_rays, quiet
     f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    f.mlp_engine = "bf16x3_split"
     rays = make_rays(4096, 1).cuda()
     lib = N.lib()
     for pol in (10, 14):
@@ -881,7 +888,126 @@ def stage_soak():
     log(f"soak: 3000 renders, {bad} differ from the first")
 
 
-STAGES = [("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_app_over():
+    """k_app oversubscription sweep + k_mlp time with the dynamic tile queue."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    f.mlp_engine = "bf16x3_split"
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+    for over in (1, 2, 4, 8, 16):
+        lib.lrf_debug_set_app_oversubscribe(over)
+        p = bench.kernel_profile(f, rays, z, reps=10)
+        log(f"k_app oversubscribe {over}: k_app {p['app_ms'] * 1e3:.1f} us k_mlp {p['mlp_ms'] * 1e3:.1f} us k_march {p['march_ms'] * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us")
+    lib.lrf_debug_set_app_oversubscribe(4)
+
+
+def stage_subbatch():
+    """Sub-batch pipeline sweep: ranges x k_mlp workgroup size; wall time per render (40 renders, no sync between)."""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    f.mlp_engine = "bf16x3_split"
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    with torch.no_grad():
+        lib.lrf_debug_set_subbatches(1)
+        ref, dref = f(rays, white_bg=True, is_train=False, N_samples=1536)
+        for thr in (1024, 512):
+            for q in (1, 2, 3, 4, 6, 8):
+                lib.lrf_debug_set_subbatches(q)
+                lib.lrf_debug_set_mlp_threads(thr)
+                for _ in range(10):
+                    out, dep = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(100):
+                    out, dep = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                torch.cuda.synchronize()
+                dt = (time.time() - t0) / 100 * 1e3
+                same = torch.equal(out, ref) and torch.equal(dep, dref)
+                log(f"k_mlp threads {thr} sub-batches {q}: {dt:.4f} ms/render ({4096 / dt / 1e3:.2f} M rays/s) bit-identical to 1 range: {same}")
+    lib.lrf_debug_set_subbatches(4)
+    lib.lrf_debug_set_mlp_threads(1024)
+
+
+def stage_shade2_phases():
+    """s_memtime phase totals of k_shade2 per wave (TIMED build)."""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    buf = torch.zeros(256 * 16 * 8, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        f(rays, white_bg=True, is_train=False, N_samples=1536)
+        lib.lrf_debug_set_dump(buf.data_ptr())
+        lib.lrf_debug_set_mlp_policy(10)
+        f(rays, white_bg=True, is_train=False, N_samples=1536)
+        torch.cuda.synchronize()
+        lib.lrf_debug_set_mlp_policy(4)
+        lib.lrf_debug_set_dump(None)
+    t = buf.view(256 * 16, 8).double()
+    tiles = t[:, 7].sum()
+    names = ["header", "plane0", "plane1", "plane2", "layer1", "layer2", "head+store"]
+    log(f"k_shade2: tiles {int(tiles)} | cycles per tile and wave: " + " ".join(f"{n} {float(t[:, i].sum() / tiles):.0f}" for i, n in enumerate(names)) +
+        f" | total {float(t[:, :7].sum() / tiles):.0f} | per-wave total min/max {float(t[:, :7].sum(1).min()):.0f}/{float(t[:, :7].sum(1).max()):.0f}")
+
+
+def stage_skew():
+    """k_shade2 with the waves of a SIMD started out of phase."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+    with torch.no_grad():
+        for _ in range(300):                                  # clock ramp
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+    for sk in (0, 1, 2, 3, 4, 6, 0):
+        lib.lrf_debug_set_skew(sk)
+        with torch.no_grad():
+            for _ in range(50):
+                f(rays, white_bg=True, is_train=False, N_samples=1536)
+        p = bench.kernel_profile(f, rays, z, reps=10)
+        log(f"skew {sk} x 6400 cycles: k_shade2 {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us")
+    lib.lrf_debug_set_skew(0)
+
+
+def stage_march():
+    """k_march with its density lines in LDS vs in global memory (300^3 and 500^3)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    lib = N.lib()
+    rays = make_rays(4096, 1).cuda()
+    for grid, ns in ((300, 1536), (340, -1), (500, -1)):
+        f = quiet(make_field, [grid] * 3, "cpu", seed=0).to("cuda:0")
+        z = f.z_schedule(False, ns, rays.device).contiguous()
+        with torch.no_grad():
+            for _ in range(200):
+                f(rays, white_bg=True, is_train=False, N_samples=ns)
+        for on in (1, 0, 1):
+            lib.lrf_debug_set_lds_lines(on)
+            p = bench.kernel_profile(f, rays, z, reps=10)
+            log(f"grid {grid} S {z.numel()} lds lines {on}: k_march {p['march_ms'] * 1e3:.1f} us shade {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us")
+    lib.lrf_debug_set_lds_lines(1)
+
+
+STAGES = [("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -120,7 +120,7 @@ def test_bf16_mfma_sources_are_not_rewritten_close_behind(asm):
 
 
 def test_scratch_use_is_bounded(asm):
-    for kern, limit in (("k_marchE", 0), ("k_shade_bf16E", 128), ("k_appE", 0), ("k_mlpILi0ELb0ELb1EE", 0), ("k_mlpILi4ELb0ELb1EE", 0)):
+    for kern, limit in (("k_marchILb1EE", 0), ("k_marchILb0EE", 0), ("k_shade_bf16E", 128), ("k_appE", 0), ("k_mlpILi0ELb0ELb1EE", 0), ("k_mlpILi4ELb0ELb1EE", 0)):
         m = re.search(r"\.amdhsa_kernel _ZN3lrf\d+%s.*?\.end_amdhsa_kernel" % kern, asm, re.S)
         assert m, kern
         priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m[0])
