@@ -67,6 +67,7 @@ class SyntheticFrames:
                     teacher.density_line[p][0, comp, :, 0] = 40.0 * torch.exp(-((c - centre) / 0.1) ** 2)
             for p in teacher.app_plane:
                 p.mul_(6.0)
+            teacher.renderModule.mlp_view[0].weight.mul_(25.0)          # saturated, textured colours (image std ~0.2)
         teacher = teacher.to(dev)
         focal = W / math.tan(85.6 * math.pi / 180 / 2) / 2
         jj, ii = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
@@ -80,6 +81,8 @@ class SyntheticFrames:
                 rgb, _ = teacher(rays, white_bg=True, is_train=False, N_samples=300)
                 self.images.append(rgb.clamp(0, 1))
         self.images = torch.stack(self.images)                        # [F, H*W, 3] on the device
+        self.stats = {"mean": float(self.images.mean()), "std": float(self.images.std()),
+                      "frame_to_frame": float((self.images[1:] - self.images[:-1]).abs().mean())}
         del teacher
 
     def has_left_frames(self):
@@ -102,7 +105,7 @@ class SyntheticFrames:
 
 
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12):
     from localrf_amd import LocalTensorfs
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -127,7 +130,10 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                aabb=aabb, gridSize=N_to_reso(n_init_vox, aabb), **FIELD_KW).to(dev)
     if ddp:
         lt.grad_sync = lambda m: allreduce_grads(m, average=True)
-    L1_weight, add_frames_every, n_max_frames, max_drift, n_overlap = 1e-2, max(1, round(100 * sc)), 100, 1.0, 3
+    # train.py defaults: add_frames_every 100, n_max_frames 100, max_drift 1 (opt.py); the synthetic camera moves 0.04 per
+    # frame and short runs do not recover that motion, so the frame-count criterion (n_max_frames) is what starts a
+    # refinement / a new field here
+    L1_weight, add_frames_every, n_overlap = 1e-2, max(1, round(100 * sc)), 3
     n_added, last_add, it = 0, 0, 0
     losses, per_res, events = [], {}, []
     torch.cuda.reset_peak_memory_stats(dev)
@@ -162,6 +168,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             add = data.has_left_frames() and (it - last_add + 1) % add_frames_every == 0
             if add and not should_refine and not lt.is_refining:
                 lt.append_frame()
+                lt.to(dev)
                 data.activate_frames()
                 n_added += 1
                 last_add = it
@@ -202,7 +209,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                      r"tensorfs\.\d+\.(aabb|invaabbSize|(density|app)_(plane|line)\.[012]|basis_mat\.weight|"
                      r"renderModule\.(mlp\.[02]|mlp_view\.0)\.(weight|bias)|alphaMask\.(aabb|invgridSize|alpha_volume)))$")
     keys_ok = all(pat.match(k) for k in sd)
-    return {"iterations": it, "fields": len(lt.tensorfs), "frames": len(lt.r_c2w), "events": events[:20],
+    return {"target_image_stats": data.stats, "iterations": it, "fields": len(lt.tensorfs), "frames": len(lt.r_c2w), "events": events[:20],
             "loss_first": float(np.mean(losses[:2])) if losses else None, "loss_last": float(np.mean(losses[-2:])) if losses else None,
             "loss_curve": losses[:: max(1, len(losses) // 20)], "finite": bool(all(math.isfinite(x) for x in losses)),
             "ms_per_iteration_by_resolution": {str(r): 1e3 * e["s"] / e["iters"] for r, e in per_res.items()},
@@ -218,6 +225,7 @@ def main():
     ap.add_argument("--final", type=int, default=300, help="N_voxel_final^(1/3) (the reference: 640; BASELINE configs[4]: 500)")
     ap.add_argument("--iters-per-frame", type=int, default=60, help="the reference: 600 (opt.py:31)")
     ap.add_argument("--max-iters", type=int, default=None)
+    ap.add_argument("--n-max-frames", type=int, default=12, help="frames per field before refinement (the reference: 100)")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -233,7 +241,7 @@ def main():
     ge.build()
     if ddp and local == 0:
         dist.barrier(device_ids=[local])
-    out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters,
+    out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
               dev=f"cuda:{local}", ddp=ddp, log=lambda m: print(m, file=sys.stderr, flush=True))
     if not ddp or int(os.environ["RANK"]) == 0:
         print(json.dumps(out))

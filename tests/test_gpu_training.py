@@ -631,3 +631,21 @@ def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
         n += 1
     assert n >= 19 + 3 * 4
     assert got[0]["bytes"] >= 4 * sum(p.numel() for p in lt.tensorfs[-1].parameters() if p.requires_grad)
+
+
+def test_progressive_training_driver_on_synthetic_frames():
+    """scripts/train_synth.py: the loop of the reference's train.py:349-474 (sample -> forward -> loss + density_L1 ->
+    optimizer_step -> progressive append_frame / append_rf, upsample schedule, alpha-mask rebuilds) around
+    LocalTensorfs on synthetic frames -- a short run must visit several resolutions and fields, keep the loss
+    finite and falling, and round-trip its checkpoint through the reference's key set."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import train_synth
+    out = train_synth.run(frames=16, final=96, iters_per_frame=12, n_max_frames=6, dev=DEV)
+    assert out["finite"] and out["iterations"] > 100, out
+    assert out["loss_last"] < 0.7 * out["loss_first"], (out["loss_first"], out["loss_last"])
+    assert out["fields"] >= 2 and out["frames"] == 16, (out["fields"], out["frames"], out["events"])
+    assert len(out["ms_per_iteration_by_resolution"]) >= 3 and out["final_resolution"] >= 90, out["ms_per_iteration_by_resolution"]
+    assert out["checkpoint_roundtrip"] and out["checkpoint_keys_follow_reference"]
+    assert out["target_image_stats"]["std"] > 0.05, out["target_image_stats"]       # the teacher scene is not blank
