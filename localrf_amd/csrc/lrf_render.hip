@@ -988,6 +988,7 @@ constexpr int MAX_SUB = 8;         // sub-batch pipeline of lrf_render_fwd (see 
 static int g_subbatches = 1;       // measured on MI355X: a cross-stream event wait costs ~50 us, more than the overlap returns
 static int sub_rays(int R, int Q) { return (((R + Q - 1) / Q) + 3) & ~3; }       // k_march blocks hold 4 rays
 static int g_no_lds_lines = 0;     // lrf_debug_set_lds_lines(0): k_march reads its lines from global memory
+static int g_shade_pipe = 0;       // lrf_debug_set_shade_pipe: k_shade2 with the next tile's plane-0 gather issued under the head phase
 static int g_skew = 0;             // lrf_debug_set_skew: phase skew of k_shade2's waves, units of 6400 cycles
 static int g_app_over = 4;         // lrf_debug_set_app_oversubscribe: k_app workgroups per resident slot
 static int g_mlp_threads = 1024;   // lrf_debug_set_mlp_threads: workgroup size of k_mlp (512 leaves half the register file to other kernels)       // lrf_debug_set_mlp_policy: MFMA issue policy of k_mlp (lrf_shade2.inl)
@@ -1005,6 +1006,23 @@ static int device_cus() {                 // of the current device (one process 
   return cus;
 }
 
+static int g_bwd_overlap = 1;      // lrf_debug_set_bwd_overlap: weight-gradient GEMMs on a side stream, beside the scatter kernels
+struct SideStream { hipStream_t s; hipEvent_t fork, join, app[MAX_SUB]; bool ok; };
+static SideStream* side_stream() {
+  static SideStream tab[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  SideStream& x = tab[dev & 63];
+  if (!x.ok) {
+    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    bool good = hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < MAX_SUB && good; ++i) good = hipEventCreateWithFlags(&x.app[i], hipEventDisableTiming) == hipSuccess;
+    if (!good) return nullptr;
+    x.ok = true;
+  }
+  return &x;
+}
 // k_march launch: lines in LDS when the three of them (+ the alpha slices) leave four workgroups per CU
 static void launch_march(const DField& d, const float* rays, const float* z, int R, int S, uint32_t flags, float floater,
                          float* depth, float* acc, float* w_all, int* ncomp, uint16_t* cidx, float* cw, float* feat,
@@ -1049,7 +1067,9 @@ extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
+void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = on ? 1 : 0; }
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
+void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 7) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
 void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
 void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
@@ -1150,14 +1170,36 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
       LRF_HIP(hipGetDevice(&dev));
       if (!attr_done[dev & 63]) {
         LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<true, false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev & 63] = true;
       }
       if (g_dump && g_mlp_policy >= 10)
-        hipLaunchKernelGGL(k_shade2<true>, dim3(device_cus()), dim3(1024), lds2, st,
+        hipLaunchKernelGGL((k_shade2<true, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st,
                            d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
-      else
+      else if (g_shade_pipe >= 4 && g_shade_pipe <= 6) {
+        if (g_shade_pipe == 4) hipLaunchKernelGGL((k_shade2<false, false, 0, 1>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+        if (g_shade_pipe == 5) hipLaunchKernelGGL((k_shade2<false, false, 0, 2>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+        if (g_shade_pipe == 6) hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      } else if (g_shade_pipe == 2)
+        hipLaunchKernelGGL((k_shade2<false, false, 1>), dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      else if (g_shade_pipe == 3)
+        hipLaunchKernelGGL((k_shade2<false, false, 3>), dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      else if (g_shade_pipe == 1)
+        hipLaunchKernelGGL((k_shade2<false, true>), dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      else if (g_shade_pipe == 7)       // MFMA head, header loads in flight under the chain (experiment; rare run-to-run differences seen)
         hipLaunchKernelGGL(k_shade2<false>, dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      else                              // shipped: VALU head, no global load in flight under the MFMA chain
+        hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st,
                            d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
     } else {
       if (int rc = launch_shade_split(d, rays, z, S, R, w, st, ev ? ev[4] : app_done)) return rc;
@@ -1175,22 +1217,6 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
 // ranges that alternate between the caller's stream and a side stream, and sub-batch q starts marching when
 // sub-batch q-1 has finished its k_app -- so the gathers of one range run under the MFMA chain of the
 // previous one.  Results are those of the single-range launch (rays are independent).
-struct SideStream { hipStream_t s; hipEvent_t fork, join, app[MAX_SUB]; bool ok; };
-static SideStream* side_stream() {
-  static SideStream tab[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  SideStream& x = tab[dev & 63];
-  if (!x.ok) {
-    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    bool good = hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < MAX_SUB && good; ++i) good = hipEventCreateWithFlags(&x.app[i], hipEventDisableTiming) == hipSuccess;
-    if (!good) return nullptr;
-    x.ok = true;
-  }
-  return &x;
-}
 static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                            uint32_t flags, float floater_thresh, float* rgb, float* depth,
                            float* weight_out, float* acc_out, void* workspace, hipStream_t st,

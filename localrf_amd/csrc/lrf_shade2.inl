@@ -406,13 +406,79 @@ __global__ __launch_bounds__(1024) void k_mlp(
 #undef LRF_TICK
 }
 
+// gather_app6_plane32 in two halves: issue the twelve 16-byte loads of a plane (kept in registers), combine later
+struct PlaneRaw { float4 a[2], b[2], c[2], d[2], e[2], q[2]; float tx, ty, tl; };
+template <int p>
+__device__ __forceinline__ PlaneRaw plane_issue(const DField& f, const float u[3], int g) {
+  PlaneRaw r;
+  int x0, x1, y0, y1, l0, l1;
+  tap1d(u[MAT0[p]], f.pw[p], x0, x1, r.tx);
+  tap1d(u[MAT1[p]], f.ph[p], y0, y1, r.ty);
+  tap1d(u[VEC[p]],  f.ll[p], l0, l1, r.tl);
+  const unsigned gb = 32u * (unsigned)g;
+  const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+  const unsigned o00 = (row0 + x0) * (LRF_CAS * 4u) + gb, o10 = (row0 + x1) * (LRF_CAS * 4u) + gb;
+  const unsigned o01 = (row1 + x0) * (LRF_CAS * 4u) + gb, o11 = (row1 + x1) * (LRF_CAS * 4u) + gb;
+  const unsigned q0 = (unsigned)l0 * (LRF_CAS * 4u) + gb, q1 = (unsigned)l1 * (LRF_CAS * 4u) + gb;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    r.a[h] = ld4b(f.aplane[p], o00 + 16 * h); r.b[h] = ld4b(f.aplane[p], o10 + 16 * h);
+    r.c[h] = ld4b(f.aplane[p], o01 + 16 * h); r.d[h] = ld4b(f.aplane[p], o11 + 16 * h);
+    r.e[h] = ld4b(f.aline[p], q0 + 16 * h);   r.q[h] = ld4b(f.aline[p], q1 + 16 * h);
+  }
+  return r;
+}
+__device__ __forceinline__ void plane_combine(const PlaneRaw& r, float X[8]) {
+  const float w00 = (1.0f - r.tx) * (1.0f - r.ty), w10 = r.tx * (1.0f - r.ty);
+  const float w01 = (1.0f - r.tx) * r.ty,          w11 = r.tx * r.ty;
+  const float wl0 = 1.0f - r.tl, wl1 = r.tl;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 a = r.a[h], b = r.b[h], c = r.c[h], d = r.d[h], e = r.e[h], q = r.q[h];
+    X[4 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
+    X[4 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
+    X[4 * h + 2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
+    X[4 * h + 3] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + q.w * wl1);
+  }
+}
+
+// Cache prefetch of a plane's six taps: one dword per lane and tap (the four lanes of a sample touch the four
+// 32-byte pieces of the 128-byte texel, so every line the real 16-byte loads will read is requested), results
+// summed into `sink` by the caller one iteration later.  A quarter of the texture-path cycles of a real load.
+template <int p>
+__device__ __forceinline__ void plane_touch(const DField& f, const float u[3], int g, float t[6]) {
+  int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+  tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+  tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+  tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+  const unsigned gb = 32u * (unsigned)g;
+  const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+  const char* pl = reinterpret_cast<const char*>(f.aplane[p]);
+  const char* ln = reinterpret_cast<const char*>(f.aline[p]);
+  t[0] = *reinterpret_cast<const float*>(pl + ((row0 + x0) * (LRF_CAS * 4u) + gb));
+  t[1] = *reinterpret_cast<const float*>(pl + ((row0 + x1) * (LRF_CAS * 4u) + gb));
+  t[2] = *reinterpret_cast<const float*>(pl + ((row1 + x0) * (LRF_CAS * 4u) + gb));
+  t[3] = *reinterpret_cast<const float*>(pl + ((row1 + x1) * (LRF_CAS * 4u) + gb));
+  t[4] = *reinterpret_cast<const float*>(ln + ((unsigned)l0 * (LRF_CAS * 4u) + gb));
+  t[5] = *reinterpret_cast<const float*>(ln + ((unsigned)l1 * (LRF_CAS * 4u) + gb));
+}
+
 // ------------------------------------------------------------------------------- k_shade2
 // The fused colour kernel again (gather -> basis -> 128 -> 128 -> head per tile, one persistent 1024-thread
 // workgroup per CU), rebuilt from what the split taught: the tile header is prefetched one tile ahead and the
 // sample distances sit in LDS (k_shade_bf16 walks four dependent loads before its first gather), 32-bit saddr
-// gathers, integer ReLU, hardware rsqrt / exp2 / rcp, the head as a fourth MFMA layer.  Gathers and an MFMA
-// chain share this kernel, so every MFMA is hand-issued (policy 0: mfma_bf16_acc / hold / settle).
-template <bool TIMED>
+// gathers, integer ReLU, hardware exp2 / rcp.  Gathers and an MFMA chain share this kernel, so every MFMA is
+// hand-issued (policy 0: mfma_bf16_acc / hold / settle) and -- shipped variant VAR = 3 -- the prefetched header
+// loads are drained before the first MFMA of a tile, so that no global load is in flight under the chain (free:
+// 158.5 vs 158.4 us), and the head runs on the VALU (155.5 us; the 12 hand-padded head MFMAs cost more than the
+// 96 FMAs they replace here).  The variant with the MFMA head and loads in flight showed 3 renders with 1e-6-scale
+// differences in ~5000 on two of six boxes, none in 24000 on a third (scripts/gpu_diag.py flake / coldstart).
+// PIPE: the next tile's plane-0 gather is issued before the head phase of the current tile (h1 is dead by then) and
+// consumed at the top of the next iteration -- one of the three gather round trips per tile leaves the critical path.
+// TOUCH = n: the lines of the next tile's first n planes are requested (plane_touch) before the head phase.
+// VAR (experiments on the rare run-to-run difference): bit 0 = wait for the prefetched header loads before the
+// first MFMA (no global load in flight under the MFMA chain), bit 1 = head on the VALU as in k_shade_bf16.
+template <bool TIMED, bool PIPE = false, int TOUCH = 0, int VAR = 0>
 __global__ __launch_bounds__(1024) void k_shade2(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
@@ -442,11 +508,22 @@ __global__ __launch_bounds__(1024) void k_shade2(
   int j0 = (t0 - tw.tile0) * ITEM;
   int cnt = min(ITEM, tw.nc - j0);
   int k = cidx[(size_t)tw.ray * S + j0 + (s < cnt ? s : 0)];
+  float x[3], u[3];
+  PlaneRaw raw0;
+  if (PIPE) {
+    sample_point(f, rg.o, rg.dh, s_z[k], x, u);
+    raw0 = plane_issue<0>(f, u, g);
+  }
+  float touch[TOUCH > 0 ? 6 * TOUCH : 1] = {};
+  float sink = 0.0f;
   if (TIMED) tlast = __builtin_readcyclecounter();
   for (int t = t0; t < t1; ++t) {
     asm volatile("" ::: "memory");     // keep the LDS fragment reads inside the loop
-    float x[3], u[3];
-    sample_point(f, rg.o, rg.dh, s_z[k], x, u);
+    if (TOUCH > 0) {
+#pragma unroll
+      for (int i = 0; i < 6 * TOUCH; ++i) sink += touch[i];
+    }
+    if (!PIPE) sample_point(f, rg.o, rg.dh, s_z[k], x, u);
     const float w = s < cnt ? cw[(size_t)ray_c * S + j0 + s] : 0.0f;          // needed at the end of the tile
     int k_n = 0, j0_n = 0, cnt_n = 0, ray_n = ray_c;
     RayGeo rg_n = rg;
@@ -457,13 +534,14 @@ __global__ __launch_bounds__(1024) void k_shade2(
       cnt_n = min(ITEM, tw.nc - j0_n);
       k_n = cidx[(size_t)tw.ray * S + j0_n + (s < cnt_n ? s : 0)];
     }
+    if (VAR & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LRF_TICK(0);
     f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
     {
       float v[8];
       bf16x8 bh, bl;
-      gather_app6_plane32<0>(f, u, g, v);
+      if (PIPE) plane_combine(raw0, v); else gather_app6_plane32<0>(f, u, g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       LRF_TICK(1);
@@ -502,18 +580,44 @@ __global__ __launch_bounds__(1024) void k_shade2(
     }
     settle<8>(h2);
     LRF_TICK(5);
-    f32x4 oc = {0, 0, 0, 0};
-    asm volatile("" : "+v"(oc));
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = relu_i(h2[2 * ks + (j >> 2)][j & 3]);
-      bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<1>(img, IMGB_W3F / 128 + ks, 1, lane, bh, bl, &oc);
+    if (PIPE && t + 1 < t1) {          // next tile: position, then its plane-0 loads go out under the head phase
+      sample_point(f, rg_n.o, rg_n.dh, s_z[k_n], x, u);
+      raw0 = plane_issue<0>(f, u, g);
     }
-    settle<1>(&oc);
+    if (TOUCH > 0 && t + 1 < t1) {     // next tile: request its lines now, read them after the head phase
+      float xn[3], un[3];
+      sample_point(f, rg_n.o, rg_n.dh, s_z[k_n], xn, un);
+      plane_touch<0>(f, un, g, touch);
+      if (TOUCH > 1) plane_touch<1>(f, un, g, touch + 6 * (TOUCH > 1 ? 1 : 0));
+      if (TOUCH > 2) plane_touch<2>(f, un, g, touch + 6 * (TOUCH > 2 ? 2 : 0));
+    }
+    f32x4 oc = {0, 0, 0, 0};
+    if (VAR & 2) {
+      float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float hv = relu_i(h2[q][r]);
+          const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (q * 4 + r) * 4]);
+          o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
+        }
+      o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+      o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+      oc[0] = o0; oc[1] = o1; oc[2] = o2;
+    } else {
+      asm volatile("" : "+v"(oc));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = relu_i(h2[2 * ks + (j >> 2)][j & 3]);
+        bf16x8 bh, bl;
+        split8(v, bh, bl);
+        gemm_step<1>(img, IMGB_W3F / 128 + ks, 1, lane, bh, bl, &oc);
+      }
+      settle<1>(&oc);
+    }
     float vb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -540,6 +644,7 @@ __global__ __launch_bounds__(1024) void k_shade2(
     unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
     for (int i = 0; i < 8; ++i) dp[i] = tk[i];
   }
+  if (TOUCH > 0 && sink == 1.2345678e30f) part[0] = sink;      // keeps the touch loads alive; never true
 #undef LRF_TICK
 }
 

@@ -1007,7 +1007,135 @@ def stage_march():
     lib.lrf_debug_set_lds_lines(1)
 
 
-STAGES = [("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_bwd_overlap():
+    """Training step (forward with a graph + backward) with the weight-gradient GEMMs on a side stream vs in line."""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    g = torch.Generator().manual_seed(3)
+    gr, gd = torch.randn(4096, 3, generator=g).cuda(), torch.randn(4096, generator=g).cuda()
+    lib = N.lib()
+
+    def step():
+        for p in f.parameters():
+            p.grad = None
+        rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=1536)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    f.z_override = None
+    for r in rays, :
+        r.requires_grad_(False)
+    for p in f.parameters():
+        p.requires_grad_(True)
+    ref = None
+    for on in (1, 0, 1, 0):
+        lib.lrf_debug_set_bwd_overlap(on)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / 20 * 1e3
+        gsum = {n: p.grad.double().abs().sum().item() for n, p in f.named_parameters() if p.grad is not None}
+        if ref is None:
+            ref = gsum
+        worst = max(abs(gsum[k] - ref[k]) / max(ref[k], 1e-30) for k in ref)
+        log(f"bwd overlap {on}: fwd+bwd {dt:.3f} ms | max relative change of a gradient's |sum| vs first run {worst:.2e}")
+    lib.lrf_debug_set_bwd_overlap(1)
+
+
+def stage_shade_pipe():
+    """k_shade2 with / without the software-pipelined plane-0 gather: time, agreement, determinism."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+    with torch.no_grad():
+        for _ in range(300):
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+        ref, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+        for on in (0, 4, 5, 6, 0):
+            lib.lrf_debug_set_shade_pipe(on)
+            first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            nd = sum(0 if torch.equal(first, f(rays, white_bg=True, is_train=False, N_samples=1536)[0]) else 1 for _ in range(200))
+            p = bench.kernel_profile(f, rays, z, reps=10)
+            log(f"shade pipe {on}: k_shade2 {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us | "
+                f"max |rgb - unpiped| {float((first - ref).abs().max()):.2e} | renders differing {nd}/200")
+    lib.lrf_debug_set_shade_pipe(0)
+
+
+def stage_flake():
+    """Which part of k_shade2 produces the rare run-to-run differences?  DIAG_RENDERS renders per configuration;
+    colour and depth (depth comes from k_march alone) compared with the first render.
+    modes: 0 shipped (VALU head, no global load in flight under the MFMA chain) | 7 MFMA head, loads in flight"""
+    import torch
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    n = int(os.environ.get("DIAG_RENDERS", "12000"))
+    cfgs = [("bf16x3", 0), ("bf16x3", 7), ("bf16x3_split", 0), ("bf16x3_fused", 0), ("bf16x3", 0)]
+    for eng, mode in cfgs:
+        f.mlp_engine = eng
+        lib.lrf_debug_set_shade_pipe(mode)
+        t0 = time.time()
+        with torch.no_grad():
+            first, d0 = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            bad_rgb = bad_dep = 0
+            worst = 0.0
+            nrays = 0
+            for _ in range(n):
+                again, d1 = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                if not torch.equal(first, again):
+                    bad_rgb += 1
+                    dd = (first - again).abs().amax(-1)
+                    worst = max(worst, float(dd.max()))
+                    nrays = max(nrays, int((dd > 0).sum()))
+                if not torch.equal(d0, d1):
+                    bad_dep += 1
+        log(f"engine {eng} mode {mode}: {n} renders in {time.time() - t0:.1f} s | colour differs {bad_rgb} (max {worst:.2e}, up to {nrays} rays) | depth differs {bad_dep}")
+    lib.lrf_debug_set_shade_pipe(0)
+
+
+def stage_coldstart():
+    """Are the rare run-to-run differences a cold-start effect?  Fresh process per trial, 400 renders right after
+    start-up (no clock ramp), per engine; counts renders that differ from the majority result."""
+    import subprocess as sp
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from util import make_field, make_rays, quiet
+f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+f.mlp_engine = sys.argv[1]
+rays = make_rays(4096, 1).cuda()
+outs = []
+with torch.no_grad():
+    for i in range(400):
+        rgb, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+        outs.append(rgb)
+torch.cuda.synchronize()
+ref = outs[-1]
+bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+print(len(bad), bad[:8], max([float((o - ref).abs().max()) for o in outs]) )
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    for eng in ("bf16x3", "bf16x3_fused", "bf16x3_split"):
+        res = []
+        for trial in range(int(os.environ.get("DIAG_TRIALS", "12"))):
+            r = sp.run([sys.executable, "-c", code, eng], capture_output=True, text=True, timeout=120)
+            res.append(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "ERR " + r.stderr[-200:])
+        log(f"engine {eng}: per fresh process (differing renders of 400, first indices, max |diff|): {res}")
+
+
+STAGES = [("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
