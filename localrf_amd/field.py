@@ -328,11 +328,20 @@ class TensorVMSplit(torch.nn.Module):
 
     # ------------------------------------------------------------------ native plumbing
     def _param_list(self):
-        rm = self.renderModule
-        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane)
-                + list(self.app_line)
-                + [self.basis_mat.weight, rm.mlp[0].weight, rm.mlp[0].bias, rm.mlp[2].weight,
-                   rm.mlp[2].bias, rm.mlp_view[0].weight, rm.mlp_view[0].bias])
+        """The 19 parameter tensors in the order of LrfParams.  Read through the modules' parameter dicts:
+        ParameterList.__getitem__ / Module.__getattr__ cost ~4 us per tensor, which at 16 field calls per
+        scene forward (4 fields x 4 chunks, BASELINE configs[2]) was half of the host time."""
+        out = []
+        for pl in (self.density_plane, self.density_line, self.app_plane, self.app_line):
+            d = pl._parameters
+            out += [d["0"], d["1"], d["2"]]
+        mods = self._modules
+        rm = mods["renderModule"]._modules
+        mlp, view = rm["mlp"]._modules, rm["mlp_view"]._modules
+        out.append(mods["basis_mat"]._parameters["weight"])
+        for lin in (mlp["0"], mlp["2"], view["0"]):
+            out += [lin._parameters["weight"], lin._parameters["bias"]]
+        return out
 
     def _require_gpu(self, t):
         if not t.is_cuda:

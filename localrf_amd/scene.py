@@ -69,6 +69,8 @@ class LocalTensorfs(torch.nn.Module):
         # data-parallel hook (localrf_amd/dist.py): called between backward and the optimiser steps of
         # optimizer_step with this module; None = single process, as the reference
         self.grad_sync = None
+        # lower bound of the rays per field call in forward (see there); 1 = chunk exactly as the reference
+        self.min_chunk = 65536
 
         self.lr_factor = 1
         self.regularize = True
@@ -362,9 +364,19 @@ class LocalTensorfs(torch.nn.Module):
                 host = self._blending_host()[view_list]         # host mirror: no device round trip
                 active = torch.nonzero(host.sum(0))[:, 0].tolist()
                 blending_weights = self.blending_weights[view_ids]
-            else:
+            elif blending_weights.is_cuda:                      # :405-410; reading the active set back is a device sync
                 active = torch.nonzero(torch.sum(blending_weights, dim=0))[:, 0].tolist()
-            bw = blending_weights[:, active]
+            else:                                               # host weights (extension): no sync, pinned upload
+                active = torch.nonzero(torch.sum(blending_weights, dim=0))[:, 0].tolist()
+                stage = torch.empty(blending_weights.shape, dtype=torch.float32, pin_memory=True)
+                stage.copy_(blending_weights)
+                blending_weights = stage.to(dev, non_blocking=True)
+            # blending_weights[:, active] with a Python list uploads the index with a pageable copy, which blocks the
+            # host until the stream drains (DESIGN.md finding 7): slice when the active fields are contiguous
+            if active == list(range(active[0], active[-1] + 1)) if active else False:
+                bw = blending_weights[:, active[0]:active[-1] + 1]
+            else:
+                bw = blending_weights.index_select(1, _upload_ids(active, dev)) if active else blending_weights[:, :0]
 
         pinhole = self.fov != 360
         focal = self.focal(W) if pinhole else None
@@ -385,7 +397,11 @@ class LocalTensorfs(torch.nn.Module):
             if self.tensorfs[rf].device != dev:
                 self.tensorfs[rf].to(dev)                       # stays there (no shuttle back)
 
-        chunk = max(1, chunk // len(active))
+        # `chunk` bounds the reference's peak memory (:440: chunk // n_active rays per field call).  Rays are
+        # independent, so the result does not depend on it; with 288 GB of HBM a field renders up to
+        # self.min_chunk rays per call whatever the caller's chunk (4 fields x 4096 rays, chunk 4096: 4 calls
+        # instead of 16 -- the forward was host-bound on those launches)
+        chunk = max(1, chunk // len(active), self.min_chunk)
         taped = torch.is_grad_enabled() and (rays.requires_grad or any(
             p.requires_grad for rf in active for p in self.tensorfs[rf].parameters()))
         if taped:

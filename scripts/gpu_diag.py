@@ -1135,7 +1135,45 @@ print(len(bad), bad[:8], max([float((o - ref).abs().max()) for o in outs]) )
         log(f"engine {eng}: per fresh process (differing renders of 400, first indices, max |diff|): {res}")
 
 
-STAGES = [("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+def stage_scene_profile():
+    """Host-side profile of LocalTensorfs.forward at BASELINE configs[2] (4 blended 300^3 fields, 4096 rays)."""
+    import cProfile
+    import pstats
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    lt, ray_ids, view_ids, bw = bench.config3_scene(torch.device("cuda:0"))
+
+    def step():
+        return lt(ray_ids, view_ids, 64, 48, is_train=False, blending_weights=bw, chunk=4096)
+    with torch.no_grad():
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(100):
+            step()
+        torch.cuda.synchronize()
+        log(f"config3 forward: {(time.time() - t0) * 10:.3f} ms/step (host + GPU, no sync inside)")
+        t0 = time.time()
+        for _ in range(100):
+            step()
+        host = (time.time() - t0) * 10
+        torch.cuda.synchronize()
+        log(f"config3 forward: host time to enqueue {host:.3f} ms/step")
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(100):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+    import io
+    buf = io.StringIO()
+    pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(28)
+    log(buf.getvalue()[-4500:])
+
+
+STAGES = [("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

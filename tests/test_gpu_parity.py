@@ -136,6 +136,7 @@ def test_local_tensorfs_blend_vs_reference_golden(built_lib):
     with torch.no_grad():
         rgbs, depths, dirs, ij = lt(ray_ids, view_ids, 32, 24, is_train=False,
                                     blending_weights=torch.from_numpy(g["bw"]).to(DEV), chunk=4096)
+        lt.min_chunk = 1                                 # chunk as the reference does: 64 // 4 = 16 rays per field call
         rgbs_t, depths_t, _, _ = lt(ray_ids, view_ids, 32, 24, is_train=False, chunk=64, test_id=True)
     assert np.abs(_np(dirs) - g["dirs"]).max() < 1e-6
     assert (ij.cpu().numpy() == g["ij"]).all()
