@@ -1069,7 +1069,7 @@ int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = on ? 1 : 0; }
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
-void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 7) ? mode : 0; }
+void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 8) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
 void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
 void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
@@ -1176,6 +1176,7 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
         LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev & 63] = true;
       }
@@ -1194,6 +1195,9 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
                            d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
       else if (g_shade_pipe == 1)
         hipLaunchKernelGGL((k_shade2<false, true>), dim3(device_cus()), dim3(1024), lds2, st,
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+      else if (g_shade_pipe == 8)       // layers 1-2 on the compiler-scheduled builtin (experiment)
+        hipLaunchKernelGGL((k_shade2<false, false, 0, 7>), dim3(device_cus()), dim3(1024), lds2, st,
                            d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
       else if (g_shade_pipe == 7)       // MFMA head, header loads in flight under the chain (experiment; rare run-to-run differences seen)
         hipLaunchKernelGGL(k_shade2<false>, dim3(device_cus()), dim3(1024), lds2, st,

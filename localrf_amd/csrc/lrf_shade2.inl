@@ -476,6 +476,8 @@ __device__ __forceinline__ void plane_touch(const DField& f, const float u[3], i
 // PIPE: the next tile's plane-0 gather is issued before the head phase of the current tile (h1 is dead by then) and
 // consumed at the top of the next iteration -- one of the three gather round trips per tile leaves the critical path.
 // TOUCH = n: the lines of the next tile's first n planes are requested (plane_touch) before the head phase.
+// VAR bit 2 (experiment): layers 1 and 2 on the compiler-scheduled builtin with LDS prefetch (policy 4 of k_mlp), fenced
+// by scheduling barriers from the hand-issued basis phase -- no global load of this wave is in flight then.
 // VAR (experiments on the rare run-to-run difference): bit 0 = wait for the prefetched header loads before the
 // first MFMA (no global load in flight under the MFMA chain), bit 1 = head on the VALU as in k_shade_bf16.
 template <bool TIMED, bool PIPE = false, int TOUCH = 0, int VAR = 0>
@@ -558,12 +560,21 @@ __global__ __launch_bounds__(1024) void k_shade2(
     f32x4 h1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) h1[q] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * q + 4 * g]);
+    if (VAR & 4) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
     {
       const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
       bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
-      settle<8>(h1);
+      if (VAR & 4) {
+        split8_p<4>(v, bh, bl);
+        gemm_step_q<4, 8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
+      } else {
+        split8(v, bh, bl);
+        gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
+        settle<8>(h1);
+      }
     }
     LRF_TICK(4);
     f32x4 h2[8];
@@ -575,10 +586,20 @@ __global__ __launch_bounds__(1024) void k_shade2(
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = relu_i(h1[2 * ks + (j >> 2)][j & 3]);
       bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
+      if (VAR & 4) {
+        split8_p<4>(v, bh, bl);
+        gemm_step_q<4, 8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
+      } else {
+        split8(v, bh, bl);
+        gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
+      }
     }
-    settle<8>(h2);
+    if (VAR & 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+    } else {
+      settle<8>(h2);
+    }
     LRF_TICK(5);
     if (PIPE && t + 1 < t1) {          // next tile: position, then its plane-0 loads go out under the head phase
       sample_point(f, rg_n.o, rg_n.dh, s_z[k_n], x, u);

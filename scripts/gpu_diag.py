@@ -1062,7 +1062,7 @@ def stage_shade_pipe():
         for _ in range(300):
             f(rays, white_bg=True, is_train=False, N_samples=1536)
         ref, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-        for on in (0, 4, 5, 6, 0):
+        for on in (0, 8, 0):
             lib.lrf_debug_set_shade_pipe(on)
             first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
             nd = sum(0 if torch.equal(first, f(rays, white_bg=True, is_train=False, N_samples=1536)[0]) else 1 for _ in range(200))
@@ -1075,7 +1075,8 @@ def stage_shade_pipe():
 def stage_flake():
     """Which part of k_shade2 produces the rare run-to-run differences?  DIAG_RENDERS renders per configuration;
     colour and depth (depth comes from k_march alone) compared with the first render.
-    modes: 0 shipped (VALU head, no global load in flight under the MFMA chain) | 7 MFMA head, loads in flight"""
+    modes: 0 shipped (VALU head, no global load in flight under the MFMA chain) | 7 MFMA head, loads in flight |
+    8 layers 1-2 on the compiler-scheduled builtin (fenced, loads drained)"""
     import torch
     from localrf_amd import _native as N
     from util import make_field, make_rays, quiet
@@ -1083,7 +1084,7 @@ def stage_flake():
     rays = make_rays(4096, 1).cuda()
     lib = N.lib()
     n = int(os.environ.get("DIAG_RENDERS", "12000"))
-    cfgs = [("bf16x3", 0), ("bf16x3", 7), ("bf16x3_split", 0), ("bf16x3_fused", 0), ("bf16x3", 0)]
+    cfgs = [("bf16x3", 0), ("bf16x3", 8), ("bf16x3", 7), ("bf16x3_split", 0), ("bf16x3_fused", 0), ("bf16x3", 0)]
     for eng, mode in cfgs:
         f.mlp_engine = eng
         lib.lrf_debug_set_shade_pipe(mode)
