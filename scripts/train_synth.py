@@ -227,20 +227,27 @@ def main():
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--n-max-frames", type=int, default=12, help="frames per field before refinement (the reference: 100)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--backend", default="nccl", help="under torchrun: nccl (= RCCL, one rank per GPU) or gloo (ranks may share a GPU)")
     args = ap.parse_args()
     import __graft_entry__ as ge
     ddp = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if local != 0:
-            dist.barrier(device_ids=[local])
+        first = int(os.environ.get("LOCAL_RANK", "0")) == 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            bar = lambda: dist.barrier(device_ids=[local])
+        else:
+            dist.init_process_group(args.backend)
+            bar = dist.barrier
+        if not first:
+            bar()
     ge.build()
-    if ddp and local == 0:
-        dist.barrier(device_ids=[local])
+    if ddp and first:
+        bar()
     out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
               dev=f"cuda:{local}", ddp=ddp, log=lambda m: print(m, file=sys.stderr, flush=True))
     if not ddp or int(os.environ["RANK"]) == 0:
