@@ -254,8 +254,10 @@ def roofline_object(prof, S, traffic, traffic_src):
     tiles = (n_sh + 15) // 16                              # lower bound (rays pad their last tile)
     dens_bytes = R_PER_GPU * S * DENS_BYTES_PER_SAMPLE
     app_bytes = n_sh * APP_BYTES_PER_SAMPLE
-    kern = {"k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes, "bound": "hbm"},
-            "k_finalize": {"ms": prof["finalize_ms"]}, "k_scan_tiles": {"ms": prof["scan_ms"]}}
+    kern = {"k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes, "bound": "hbm"}}
+    if prof["finalize_ms"] > 1e-3:                         # four-launch sequence (the default engine folds the tile
+        kern["k_finalize"] = {"ms": prof["finalize_ms"]}   # scan and the per-ray sum into k_shade2: two launches)
+        kern["k_scan_tiles"] = {"ms": prof["scan_ms"]}
     if prof["app_ms"] > 0:                                 # LRF_FLAG_MLP_SPLIT
         kern["k_app"] = {"ms": prof["app_ms"], "alg_bytes": app_bytes + n_sh * FRAG_BYTES_PER_SLOT, "bound": "hbm",
                          "alg_flop": n_sh * BASIS_FLOP, "issued_mfma_flop": tiles * 18 * MFMA_FLOP}

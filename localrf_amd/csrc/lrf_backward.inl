@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
     float* __restrict__ crgb, float* __restrict__ act,
     const float* __restrict__ cw /* with part: also emit the per-tile weighted colours of k_shade_bf16 */,
-    float* __restrict__ part, int pmax) {
+    float* __restrict__ part, int pmax, uint32_t* __restrict__ relu_bits) {
   __shared__ uint4 img[IMGB_U4];
   for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
   __syncthreads();
@@ -219,12 +219,19 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
       settle<8>(h1);
     }
+    // ReLU masks for the data-gradient kernel: bit 4 t1 + r of this lane's word = unit 16 t1 + 4 g + r of sample s is
+    // active.  One dword per lane and layer (512 B per tile) instead of re-reading the 16 KB of h1 / h2 rows there.
+    uint32_t m1 = 0, m2 = 0;
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
+      for (int r = 0; r < 4; ++r) {
+        h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
+        m1 |= min(__float_as_uint(h1[t1][r]), 1u) << (4 * t1 + r);        // relu output: +0 or positive
+      }
       *reinterpret_cast<f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g) = h1[t1];
     }
+    relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane] = m1;
     *reinterpret_cast<float4*>(arow + ACT_H1 + 128 + 4 * g) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
     f32x4 h2[8];
 #pragma unroll
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         h2[t1][r] = fmaxf(h2[t1][r], 0.0f);
+        m2 |= min(__float_as_uint(h2[t1][r]), 1u) << (4 * t1 + r);
         const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
         o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
       }
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     }
     *reinterpret_cast<float4*>(arow + ACT_H2 + 128 + 4 * g) =
         g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane] = m2;
     o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
     if (valid && g == 0) {
@@ -288,13 +297,18 @@ __device__ __forceinline__ void ld4g(const float* p, float* out) {
 #endif
   out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
 }
+// x where bit k of the saved ReLU mask is set, else +0: sign-extended one-bit field (0 / ~0) ANDed into the value
+__device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
+  return __uint_as_float(__float_as_uint(x) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, k, 1));
+}
 struct AppGeo { const float* pl[3]; const float* ln[3]; int pw[3], ph[3], ll[3]; float lo[3], inv[3]; };
 __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     DField f, const float* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
-    float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax) {
+    float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax,
+    const uint32_t* __restrict__ relu_bits) {
   __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
   // Geometry of the appearance lookups, read back from LDS next to its use: as kernel arguments
   // these 30 uniform values stayed live across the MFMA phases, overflowed the SGPR file and were
@@ -331,8 +345,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     const int k = cidx[ci];
     const float zk = z[k];
     const size_t row = (size_t)tw.t * 16 + s;
-    const float* arow = act + row * ACT_LD;
     float* grow = grd + row * GRD_LD;
+    const uint32_t m1 = relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane];       // ReLU masks saved by k_bwd_shade_fwd
+    const uint32_t m2 = relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane];
 
     // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k  (tensorBase.py:632-633)
     float go[3] = {0.0f, 0.0f, 0.0f};
@@ -351,12 +366,11 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     f32x4 dz[8];
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) {
-      const f32x4 h2 = *reinterpret_cast<const f32x4*>(arow + ACT_H2 + 16 * t1 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float4 wv = *reinterpret_cast<const float4*>(&img[IMT_W3H + (g * 32 + t1 * 4 + r) * 4]);
         const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
-        dz[t1][r] = h2[r] > 0.0f ? d : 0.0f;
+        dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);
       }
       *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];
     }
@@ -375,9 +389,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
 #pragma unroll
         for (int r = 0; r < 4; ++r) d1 = mfma4(a[r], dz[t0][r], d1);
       }
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d1[r] = h1[r] > 0.0f ? d1[r] : 0.0f;
+      for (int r = 0; r < 4; ++r) d1[r] = relu_gate(d1[r], m1, 4 * t1 + r);
       *reinterpret_cast<f32x4*>(grow + GRD_DZ1 + 16 * t1 + 4 * g) = d1;
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
@@ -758,8 +771,9 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
 #pragma unroll
     for (int a = 0; a < 3; ++a) { go3[a] += gx3[a]; gdh[a] += gx3[a] * zk; }
   }
-  // appearance partials of this ray's tiles (written by k_bwd_shade_dgrad)
-  const int nt = (nsh + ITEM - 1) / ITEM;
+  // appearance partials of this ray's tiles (written by k_bwd_shade_dgrad); with rpart == null they are added
+  // afterwards by k_rays_add_rpart, so that this kernel does not have to wait for the data-gradient kernel
+  const int nt = rpart ? (nsh + ITEM - 1) / ITEM : 0;
   for (int t = lane; t < nt; t += 64) {
     const float* rpp = rpart + ((size_t)ray * pmax + t) * 8;
 #pragma unroll
@@ -777,6 +791,32 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       gp[a] = go3[a];
       gp[3 + a] = (gdh[a] - dh[a] * dot) / dn - gd * depth / dn * dh[a];
     }
+  }
+}
+
+// d(loss)/d(rays) += the appearance lookups' position gradients (per-tile partials of k_bwd_shade_dgrad): the tail of
+// k_bwd_ray as its own launch, linear in the partial sums: g_o += sum go, g_d += (I - dhat dhat^T) sum gdh / |d|.
+__global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict__ rays, int R, const int* __restrict__ ncomp,
+                                                        const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= R) return;
+  const int nt = (ncomp[ray] + ITEM - 1) / ITEM;
+  float go3[3] = {0.0f, 0.0f, 0.0f}, gdh[3] = {0.0f, 0.0f, 0.0f};
+  for (int t = 0; t < nt; ++t) {
+    const float4* rpp = reinterpret_cast<const float4*>(rpart + ((size_t)ray * pmax + t) * 8);
+    const float4 a = rpp[0], b = rpp[1];
+    go3[0] += a.x; go3[1] += a.y; go3[2] += a.z;
+    gdh[0] += a.w; gdh[1] += b.x; gdh[2] += b.y;
+  }
+  const float* rp = rays + (size_t)ray * 6;
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+  const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+  const float dot = dh[0] * gdh[0] + dh[1] * gdh[1] + dh[2] * gdh[2];
+  float* gp = g_rays + (size_t)ray * 6;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gp[a] += go3[a];
+    gp[3 + a] += (gdh[a] - dh[a] * dot) / dn;
   }
 }
 
@@ -1168,6 +1208,8 @@ struct BwdWorkspace {
   float* feat; float* crgb; float* gcache; float* imt; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
+  uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_bwd_shade_fwd -> k_bwd_shade_dgrad
+  uint16_t* tid2; int* hist2; int* offs2; int* cursor2; uint32_t* list2;   // bins of the appearance scatter (runs beside the density scatter)
   uint32_t nmax;
   size_t gcache_floats, bytes;
 };
@@ -1198,6 +1240,12 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   b.offs = reinterpret_cast<int*>(take(BIN_MAX + 1));
   b.cursor = reinterpret_cast<int*>(take(BIN_MAX));
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
+  b.relu_bits = reinterpret_cast<uint32_t*>(take(rows / 16 * 128));
+  b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
+  b.hist2 = reinterpret_cast<int*>(take(BIN_MAX));
+  b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
+  b.cursor2 = reinterpret_cast<int*>(take(BIN_MAX));
+  b.list2 = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.bytes = off;
   return b;
 }
@@ -1234,7 +1282,7 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                     b.crgb, b.act, w.cw, w.part, w.pmax);
+                     b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits);
   hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
                      R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
   LRF_HIP(hipGetLastError());
@@ -1278,28 +1326,59 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
     hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                       b.crgb, b.act, (const float*)nullptr, (float*)nullptr, 0);
+                       b.crgb, b.act, (const float*)nullptr, (float*)nullptr, 0, b.relu_bits);
   }
-  hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax);
-  // After the data gradient the backward forks: the weight-gradient GEMMs (row reads, matrix pipe) go to a side
-  // stream, the per-ray backward + binned scatter (LDS atomics) stay on the caller's; they share no outputs.
-  // Measured: 3.23 -> 3.08..3.15 ms per forward+backward at configs[1] (the two groups mostly fill the chip alone).
+  // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
+  //   caller's stream: k_bwd_shade_dgrad -> k_wgrad (dW2) -> appearance bins + scatter     [-> join] -> ray partials, unpack
+  //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) 3 x k_wgrad -> (dW2 done) reduce
+  // k_bwd_ray and the density scatter need nothing from the data-gradient kernel (the appearance lookups' position
+  // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
+  // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
   SideStream* ss = g_bwd_overlap ? side_stream() : nullptr;
-  hipStream_t sw = st;
+  hipStream_t sb = st;
   if (ss) {
     LRF_HIP(hipEventRecord(ss->fork, st));
     LRF_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-    sw = ss->s;
+    sb = ss->s;
   }
+  const BinGeom bg = make_bins(L);
+  if (bg.total > BIN_MAX) return set_err("lrf_render_bwd: grid too large for the tile binning (BIN_MAX)");
+  const int nblk = (int)((b.nmax + BIN_CHUNK - 1) / BIN_CHUNK);
+  for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
+
+  // ---- caller's stream: data gradient of the colour network
+  hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
+                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits);
+  if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));
+
+  // ---- side stream: per-ray backward, density scatter
+  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), sb,
+                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
+                     (const float*)nullptr, w.pmax, g_rays);
+  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * bg.total, sb));
+  hipLaunchKernelGGL((k_bin_hist<false>), dim3(nblk), dim3(256), 0, sb, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, sb, b.hist, bg.total, b.offs, b.cursor);
+  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.cursor, b.list);
+  hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * 4), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, sb,
+                     d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
+  hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024),
+                     sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), sb,
+                     d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
+
+  // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
+  // (the largest one, dW2, stays on the caller's stream behind the data gradient: it balances the two branches)
   const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
-  hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, sw, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
                      w.toff, R, b.wpart, WP_W2);
-  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, sw, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
+  if (ss) {
+    LRF_HIP(hipEventRecord(ss->app[1], st));
+    LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
+  }
+  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
                      w.toff, R, b.wpart, WP_W1);
-  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, sw, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
-  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, sw, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
                      w.toff, R, b.wpart, WP_W3);
   {
     WgradSegs segs;
@@ -1316,37 +1395,25 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
     seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
     segs.total_elems = elems;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, sw, b.wpart, w.toff, R, segs);
+    if (ss) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));      // dW2's partials come from the caller's stream
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, sb, b.wpart, w.toff, R, segs);
   }
-  if (ss) LRF_HIP(hipEventRecord(ss->join, ss->s));
-  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), st,
-                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
-                     b.rpart, w.pmax, g_rays);
-  // binned scatter of the plane/line gradients: density entries (all samples), then appearance rows
-  const BinGeom bg = make_bins(L);
-  if (bg.total > BIN_MAX) return set_err("lrf_render_bwd: grid too large for the tile binning (BIN_MAX)");
-  const int nblk = (int)((b.nmax + BIN_CHUNK - 1) / BIN_CHUNK);
-  for (int app = 0; app < 2; ++app) {
-    LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * bg.total, st));
-    if (app) hipLaunchKernelGGL((k_bin_hist<true>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
-    else     hipLaunchKernelGGL((k_bin_hist<false>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist, bg.total, b.offs, b.cursor);
-    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, app, b.tid, b.cursor, b.list);
-    if (app) {
-      hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024>), dim3(cus), dim3(1024), sizeof(float) * BCELL * BCELL * LRF_CA, st,
-                         d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
-      for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
-      hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024),
-                         sizeof(float) * LRF_CA * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
-                         d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
-    } else {
-      hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * 4), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, st,
-                         d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
-      hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024),
-                         sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
-                         d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
-    }
-  }
+  if (ss) LRF_HIP(hipEventRecord(ss->join, sb));
+
+  // ---- caller's stream: appearance scatter (its own bin buffers: the density scatter may still be running)
+  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * bg.total, st));
+  hipLaunchKernelGGL((k_bin_hist<true>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid2, b.hist2);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist2, bg.total, b.offs2, b.cursor2);
+  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.cursor2, b.list2);
+  hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024>), dim3(cus), dim3(1024), sizeof(float) * BCELL * BCELL * LRF_CA, st,
+                     d, bg, L, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, b.gcache);
+  hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024),
+                     sizeof(float) * LRF_CA * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
+                     d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
+
+  // ---- join: both branches done
+  if (ss) LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
+  hipLaunchKernelGGL(k_rays_add_rpart, dim3((R + 255) / 256), dim3(256), 0, st, rays, R, w.ncomp, b.rpart, w.pmax, g_rays);
   {
     UnpackTab tab;
     int wmax = 1, hmax = 1;
@@ -1360,7 +1427,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     }
     hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 12), dim3(128), 0, st, tab);
   }
-  if (ss) LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));     // the caller's stream continues behind both branches
   LRF_HIP(hipGetLastError());
   return 0;
 }

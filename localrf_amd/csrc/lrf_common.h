@@ -94,6 +94,7 @@ struct DField {
   const float* basis; const float* w1; const float* b1; const float* w2; const float* b2;
   const float* w3; const float* b3;
   float* dump;                 // debug: per-sample stage values (lrf_debug_set_dump), else null
+  int* ctr;                    // fused launch sequence: workgroups-done counter of k_shade2 (zeroed by k_march), else null
 };
 
 // ------------------------------------------------------------------ geometry

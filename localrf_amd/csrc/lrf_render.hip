@@ -187,6 +187,7 @@ __global__ __launch_bounds__(1024) void k_march(
     float* __restrict__ feat_out /* [R,S] density feature, -inf where not evaluated; or null */) {
   extern __shared__ float s_alpha_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (f.ctr && blockIdx.x == 0 && threadIdx.x == 0) *f.ctr = 0;      // workgroups-done counter of the k_shade2 that follows
   const int nb = gridDim.x;                              // XCD-aware block order, see tile_walk_begin
   const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int nw = blockDim.x >> 6;                          // rays per workgroup: 4, 8 or 16 (launch_march)
@@ -954,6 +955,7 @@ static DField make_dfield(const LrfField* f) {
   d.density_shift = f->density_shift; d.distance_scale = f->distance_scale; d.weight_thres = f->weight_thres;
   d.term_T = f->term_T > 0.0f ? f->term_T : 0.0f;
   d.dump = nullptr;
+  d.ctr = nullptr;
   d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
   return d;
 }
@@ -962,6 +964,7 @@ struct Workspace {
   int* toff; int* ncomp; float* acc; uint16_t* cidx; float* cw; float* part;
   uint4* ffrag;            // k_app -> k_mlp: layer-1 B fragments, 2 KB per 16-sample tile
   int2* tinfo;             // k_app -> k_mlp: (ray, j0 * 32 + count) per tile
+  int* ctr;                // fused sequence: workgroups-done counter of k_shade2
   int pmax; size_t bytes;
 };
 static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -978,6 +981,7 @@ static Workspace carve(void* ws, int R, int S) {
   w.part  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
   w.ffrag = reinterpret_cast<uint4*>(p + off);     off += up256((size_t)R * w.pmax * 2048);
   w.tinfo = reinterpret_cast<int2*>(p + off);      off += up256((size_t)R * w.pmax * 8);
+  w.ctr   = reinterpret_cast<int*>(p + off);       off += 256;
   w.bytes = off;
   return w;
 }
@@ -1069,7 +1073,7 @@ int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = on ? 1 : 0; }
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
-void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 8) ? mode : 0; }
+void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 11) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
 void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
 void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
@@ -1149,6 +1153,37 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
                           hipEvent_t* ev, hipEvent_t app_done) {
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
+  // Default engine, batches whose tile offsets fit in LDS beside the image: two launches, k_march -> k_shade2<FUSE>
+  // (scan and finalize folded into the colour kernel, lrf_shade2.inl).  lrf_debug_set_shade_pipe(9) = four launches.
+  const size_t lds_fused = (size_t)IMGB_U4 * sizeof(uint4) + (size_t)S * sizeof(float) + (size_t)(R + 1) * sizeof(int);
+  const bool fuse = !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED | LRF_FLAG_MLP_SPLIT)) &&
+                    (g_shade_pipe == 0 || g_shade_pipe >= 10) && !(g_dump && g_mlp_policy >= 10) && lds_fused + 256 <= 160 * 1024;
+  if (fuse) {
+    DField dd = d;
+    dd.ctr = w.ctr;
+    launch_march(dd, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
+    if (ev) { LRF_HIP(hipEventRecord(ev[1], st)); LRF_HIP(hipEventRecord(ev[5], st)); }
+    static bool attr_done[64] = {};
+    int dev = 0;
+    LRF_HIP(hipGetDevice(&dev));
+    if (!attr_done[dev & 63]) {                                // 80 B of static LDS (scan scratch) come on top
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      attr_done[dev & 63] = true;
+    }
+    if (g_shade_pipe == 10)          // experiment: release / acquire fences instead of write-through partials
+      hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 2>), dim3(device_cus()), dim3(1024), lds_fused, st,
+                         dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
+    else if (g_shade_pipe == 11)     // experiment: __threadfence() on both sides
+      hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 3>), dim3(device_cus()), dim3(1024), lds_fused, st,
+                         dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
+    else
+      hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 1>), dim3(device_cus()), dim3(1024), lds_fused, st,
+                         dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
+    if (ev) { LRF_HIP(hipEventRecord(ev[2], st)); LRF_HIP(hipEventRecord(ev[3], st)); }
+    return 0;
+  }
   launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (flags & LRF_FLAG_MLP_VALU) {
@@ -1182,29 +1217,29 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
       }
       if (g_dump && g_mlp_policy >= 10)
         hipLaunchKernelGGL((k_shade2<true, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       else if (g_shade_pipe >= 4 && g_shade_pipe <= 6) {
-        if (g_shade_pipe == 4) hipLaunchKernelGGL((k_shade2<false, false, 0, 1>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
-        if (g_shade_pipe == 5) hipLaunchKernelGGL((k_shade2<false, false, 0, 2>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
-        if (g_shade_pipe == 6) hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+        if (g_shade_pipe == 4) hipLaunchKernelGGL((k_shade2<false, false, 0, 1>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
+        if (g_shade_pipe == 5) hipLaunchKernelGGL((k_shade2<false, false, 0, 2>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
+        if (g_shade_pipe == 6) hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       } else if (g_shade_pipe == 2)
         hipLaunchKernelGGL((k_shade2<false, false, 1>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       else if (g_shade_pipe == 3)
         hipLaunchKernelGGL((k_shade2<false, false, 3>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       else if (g_shade_pipe == 1)
         hipLaunchKernelGGL((k_shade2<false, true>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       else if (g_shade_pipe == 8)       // layers 1-2 on the compiler-scheduled builtin (experiment)
         hipLaunchKernelGGL((k_shade2<false, false, 0, 7>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       else if (g_shade_pipe == 7)       // MFMA head, header loads in flight under the chain (experiment; rare run-to-run differences seen)
         hipLaunchKernelGGL(k_shade2<false>, dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
       else                              // shipped: VALU head, no global load in flight under the MFMA chain
         hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew);
+                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
     } else {
       if (int rc = launch_shade_split(d, rays, z, S, R, w, st, ev ? ev[4] : app_done)) return rc;
     }

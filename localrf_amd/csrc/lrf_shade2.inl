@@ -20,6 +20,7 @@
 // Arithmetic is identical to k_shade_bf16 (same fragments, same MFMA order, same head): the two
 // engines agree bit for bit, which tests/test_gpu_parity.py checks.
 #pragma once
+#include <type_traits>
 
 namespace lrf {
 
@@ -28,7 +29,9 @@ namespace lrf {
 struct TileWalk2 {
   int ray, tile0, next_off, nc;     // current ray, its first tile, first tile of the next ray, ncomp[ray]
 };
-__device__ __forceinline__ void tile_range(const int* __restrict__ toff, int R, int& t0, int& t1) {
+typedef __attribute__((address_space(3))) int lds_int;       // tile offsets held in LDS by the fused k_shade2
+template <class P>
+__device__ __forceinline__ void tile_range(P toff, int R, int& t0, int& t1) {
   const int T = toff[R];
   const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
   const int nb = gridDim.x;                                    // XCD-aware block order, see tile_walk_begin
@@ -37,7 +40,8 @@ __device__ __forceinline__ void tile_range(const int* __restrict__ toff, int R, 
   t0 = __builtin_amdgcn_readfirstlane((int)(wid * T / waves));
   t1 = __builtin_amdgcn_readfirstlane((int)((wid + 1) * T / waves));
 }
-__device__ __forceinline__ TileWalk2 tile_walk2_begin(const int* __restrict__ toff, const int* __restrict__ ncomp,
+template <class P>
+__device__ __forceinline__ TileWalk2 tile_walk2_begin(P toff, const int* __restrict__ ncomp,
                                                       int R, int t) {
   int lo = 0, hi = R;                                          // largest ray with toff[ray] <= t
   while (hi - lo > 1) {
@@ -49,7 +53,8 @@ __device__ __forceinline__ TileWalk2 tile_walk2_begin(const int* __restrict__ to
   return tw;
 }
 // advance to the ray owning tile t (skips rays without shaded samples); true if the ray changed
-__device__ __forceinline__ bool tile_walk2_seek(TileWalk2& tw, const int* __restrict__ toff,
+template <class P>
+__device__ __forceinline__ bool tile_walk2_seek(TileWalk2& tw, P toff,
                                                 const int* __restrict__ ncomp, int t) {
   bool moved = false;
   while (tw.next_off <= t) { ++tw.ray; tw.tile0 = tw.next_off; tw.next_off = toff[tw.ray + 1]; moved = true; }
@@ -480,18 +485,89 @@ __device__ __forceinline__ void plane_touch(const DField& f, const float u[3], i
 // by scheduling barriers from the hand-issued basis phase -- no global load of this wave is in flight then.
 // VAR (experiments on the rare run-to-run difference): bit 0 = wait for the prefetched header loads before the
 // first MFMA (no global load in flight under the MFMA chain), bit 1 = head on the VALU as in k_shade_bf16.
-template <bool TIMED, bool PIPE = false, int TOUCH = 0, int VAR = 0>
+// FUSE: the launch sequence of the default engine is k_march -> k_shade2<FUSE> (two launches instead of four).
+//  * k_scan_tiles is gone: every workgroup scans the R per-ray tile counts itself into LDS (1024 threads, ~1 us,
+//    under the image load) -- and the tile walk then reads its offsets from LDS instead of from L2;
+//  * k_finalize is gone: a workgroup's waves own one contiguous tile range, so after its tile loop the workgroup
+//    sums (in tile order, as k_finalize does: same bits) the partials of every ray whose tiles all lie inside
+//    that range; the <= gridDim.x - 1 rays that straddle a workgroup boundary are summed by whichever workgroup
+//    finishes last (release fence + counter f.ctr, zeroed by the k_march of the same call; agent-scope loads).
+// No float atomics, no spinning: results do not depend on the order in which workgroups finish.
+template <bool COHERENT>
+__device__ __forceinline__ void finalize_ray(int ray, int nit, int pmax, uint32_t flags, const float* __restrict__ acc,
+                                             const float* part, float* __restrict__ rgb, float* __restrict__ acc_out) {
+  const float* pp = part + (size_t)ray * pmax * 3;
+  float r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int i0 = 0; i0 < nit; i0 += 8) {                         // 8 tiles' partials in flight, summed in tile order
+    float v[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+      v[j] = 0.0f;
+      if (i0 + j / 3 < nit)
+        v[j] = COHERENT ? __hip_atomic_load(pp + i0 * 3 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pp[i0 * 3 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + j < nit) { r += v[3 * j]; g += v[3 * j + 1]; b += v[3 * j + 2]; }
+  }
+  const float a = acc[ray];
+  if (flags & LRF_FLAG_WHITE_BG) {
+    const float bg = 1.0f - a;
+    r += bg; g += bg; b += bg;
+  }
+  rgb[(size_t)ray * 3 + 0] = r; rgb[(size_t)ray * 3 + 1] = g; rgb[(size_t)ray * 3 + 2] = b;
+  if (acc_out) acc_out[ray] = a;
+}
+// first index r in [0, n] with toff[r] >= v (toff non-decreasing, n + 1 entries)
+__device__ __forceinline__ int toff_lower_bound(const lds_int* toff, int n, int v) {
+  int lo = 0, hi = n + 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (toff[mid] >= v) hi = mid; else lo = mid + 1;
+  }
+  return lo < n ? lo : n;
+}
+
+template <bool TIMED, bool PIPE = false, int TOUCH = 0, int VAR = 0, int FUSE = 0>
 __global__ __launch_bounds__(1024) void k_shade2(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int* __restrict__ toff, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
-    const float* __restrict__ cw, float* __restrict__ part, int pmax, int skew) {
-  extern __shared__ uint4 s_dyn[];                             // whole image (basis, W1, W2, tail, head), then z[S]
+    const int* __restrict__ toff_g, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    const float* __restrict__ cw, float* __restrict__ part, int pmax, int skew,
+    uint32_t flags, const float* __restrict__ acc, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+  static_assert(!FUSE || (VAR & 2), "the fused variant stages the image without the head fragments (VALU head)");
+  extern __shared__ uint4 s_dyn[];                             // image (basis, W1, W2, tail[, head]), z[S][, toff[R + 1]]
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define LRF_TICK(i) do { if (TIMED) { const unsigned long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
+  constexpr int NIMG = FUSE ? IMGB_U4 : IMGB_ALL;
   uint4* img = s_dyn;
-  float* s_z = reinterpret_cast<float*>(s_dyn + IMGB_ALL);
-  for (int i = threadIdx.x; i < IMGB_ALL; i += blockDim.x) img[i] = f.mlpb[i];
+  float* s_z = reinterpret_cast<float*>(s_dyn + NIMG);
+  for (int i = threadIdx.x; i < NIMG; i += blockDim.x) img[i] = f.mlpb[i];
   for (int i = threadIdx.x; i < S; i += blockDim.x) s_z[i] = z[i];
+  lds_int* s_toff = (lds_int*)(s_z + S);
+  if (FUSE) {                                                  // k_scan_tiles, per workgroup, into LDS
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < R; base += 1024) {
+      const int r = base + tid;
+      const int v = r < R ? (ncomp[r] + ITEM - 1) / ITEM : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (ln >= d) incl += t;
+      }
+      __syncthreads();                                         // s_wave of the previous round has been read
+      if (ln == 63) s_wave[wv] = incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { const int x = s_wave[q]; woff += q < wv ? x : 0; tot += x; }
+      if (r < R) s_toff[r] = carry + woff + incl - v;
+      carry += tot;
+    }
+    if (tid == 0) s_toff[R] = carry;
+  }
   __syncthreads();
   const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
@@ -501,18 +577,26 @@ __global__ __launch_bounds__(1024) void k_shade2(
   // of the phases (s_memtime: 9.0K gather + 14.6K MLP cycles per tile and wave) instead of their overlap.
   for (int i = 0, n = (int)(threadIdx.x >> 8) * skew; i < n; ++i) __builtin_amdgcn_s_sleep(100);
   int t0, t1;
+  typedef typename std::conditional<FUSE != 0, const lds_int*, const int*>::type ToffP;
+  ToffP toff;
+  if constexpr (FUSE) toff = s_toff; else toff = toff_g;
   tile_range(toff, R, t0, t1);
-  if (t0 >= t1) return;
-  TileWalk2 tw = tile_walk2_begin(toff, ncomp, R, t0);
-  tile_walk2_seek(tw, toff, ncomp, t0);
-  RayGeo rg = load_ray(rays, tw.ray);
-  int ray_c = tw.ray;
-  int j0 = (t0 - tw.tile0) * ITEM;
-  int cnt = min(ITEM, tw.nc - j0);
-  int k = cidx[(size_t)tw.ray * S + j0 + (s < cnt ? s : 0)];
+  if (!FUSE && t0 >= t1) return;
+  TileWalk2 tw = {0, 0, 0, 0};
+  RayGeo rg = {{0, 0, 0}, {0, 0, 0}};
+  int ray_c = 0, j0 = 0, cnt = 0, k = 0;
+  if (t0 < t1) {
+    tw = tile_walk2_begin(toff, ncomp, R, t0);
+    tile_walk2_seek(tw, toff, ncomp, t0);
+    rg = load_ray(rays, tw.ray);
+    ray_c = tw.ray;
+    j0 = (t0 - tw.tile0) * ITEM;
+    cnt = min(ITEM, tw.nc - j0);
+    k = cidx[(size_t)tw.ray * S + j0 + (s < cnt ? s : 0)];
+  }
   float x[3], u[3];
   PlaneRaw raw0;
-  if (PIPE) {
+  if (PIPE && t0 < t1) {
     sample_point(f, rg.o, rg.dh, s_z[k], x, u);
     raw0 = plane_issue<0>(f, u, g);
   }
@@ -655,7 +739,13 @@ __global__ __launch_bounds__(1024) void k_shade2(
     }
     if (lane == 0) {
       float* pp = part + ((size_t)ray_c * pmax + j0 / ITEM) * 3;
-      pp[0] = cr; pp[1] = cg; pp[2] = cb;
+      if (FUSE == 1) {                 // written through to the agent's coherence point: a boundary ray's partials are read from another XCD
+        __hip_atomic_store(pp + 0, cr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 2, cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        pp[0] = cr; pp[1] = cg; pp[2] = cb;
+      }
     }
     k = k_n; j0 = j0_n; cnt = cnt_n; rg = rg_n; ray_c = ray_n;
     LRF_TICK(6);
@@ -666,6 +756,43 @@ __global__ __launch_bounds__(1024) void k_shade2(
     for (int i = 0; i < 8; ++i) dp[i] = tk[i];
   }
   if (TOUCH > 0 && sink == 1.2345678e30f) part[0] = sink;      // keeps the touch loads alive; never true
+  if (FUSE) {                                                  // k_finalize, see above
+    __shared__ int s_last;
+    // Release of this workgroup's partials to the workgroup that finishes last (possibly on another XCD, whose L2 is
+    // not coherent with this one's).  FUSE 1: the partials were stored write-through (agent scope) and the barrier
+    // waits for their acknowledgements (s_waitcnt vmcnt(0)) -- no cache-wide operation.  FUSE 2: release fence
+    // (L2 write-back).  FUSE 3: __threadfence(), which also INVALIDATES this XCD's L2 under the workgroups still
+    // rendering (measured: colour kernel 160 -> 235 us).
+    if (FUSE == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (FUSE == 3) __threadfence();
+    __syncthreads();
+    const int nb = gridDim.x, tid = threadIdx.x;
+    const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int T = s_toff[R];
+    const long long waves = (long long)nb * (blockDim.x >> 6);
+    const int wpb = blockDim.x >> 6;
+    const int B0 = (int)((long long)lb * wpb * T / waves), B1 = (int)((long long)(lb + 1) * wpb * T / waves);
+    const int ra = toff_lower_bound(s_toff, R, B0);
+    const int rb = lb == nb - 1 ? R : toff_lower_bound(s_toff, R, B1);
+    for (int r = ra + tid; r < rb; r += blockDim.x) {
+      const int a = s_toff[r], b = s_toff[r + 1];
+      if (b <= B1) finalize_ray<false>(r, b - a, pmax, flags, acc, part, rgb_out, acc_out);
+    }
+    if (tid == 0) s_last = __hip_atomic_fetch_add(f.ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+    __syncthreads();
+    if (s_last) {                                              // every other workgroup has released its partials
+      if (FUSE == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (FUSE == 3) __threadfence();
+      for (int ob = tid; ob < nb - 1; ob += blockDim.x) {      // the ray owned by logical block ob that crosses its upper boundary
+        const int C0 = (int)((long long)ob * wpb * T / waves), C1 = (int)((long long)(ob + 1) * wpb * T / waves);
+        const int r = toff_lower_bound(s_toff, R, C1) - 1;
+        if (r >= 0) {
+          const int a = s_toff[r], b = s_toff[r + 1];
+          if (a >= C0 && b > C1) finalize_ray<true>(r, b - a, pmax, flags, acc, part, rgb_out, acc_out);
+        }
+      }
+    }
+  }
 #undef LRF_TICK
 }
 

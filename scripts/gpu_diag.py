@@ -985,6 +985,47 @@ def stage_skew():
     lib.lrf_debug_set_skew(0)
 
 
+def stage_fuse():
+    """Default engine as two launches (k_march -> k_shade2<FUSE>) vs four (k_scan_tiles and k_finalize as kernels):
+    wall time per 4096-ray render, 2000 renders each, alternating; kernel times through the profile entry; repeatability."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+
+    def fwd():
+        return f(rays, white_bg=True, is_train=False, N_samples=1536)
+    with torch.no_grad():
+        for _ in range(500):
+            fwd()
+        torch.cuda.synchronize()
+        for pipe in (0, 9, 10, 11, 0, 9, 10, 0):
+            lib.lrf_debug_set_shade_pipe(pipe)
+            for _ in range(50):
+                fwd()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2000):
+                fwd()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2000
+            p = bench.kernel_profile(f, rays, z, reps=10)
+            log(f"shade_pipe {pipe} ({ {0: 'two launches, write-through partials', 9: 'four launches', 10: 'two launches, release/acquire fences', 11: 'two launches, __threadfence'}[pipe] }): {dt * 1e3:.4f} ms/step = {4096 / dt / 1e6:.2f} M rays/s | "
+                f"march {p['march_ms'] * 1e3:.1f} scan {p['scan_ms'] * 1e3:.1f} colour {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} fin {p['finalize_ms'] * 1e3:.1f} total {p['total_ms'] * 1e3:.1f} us")
+        lib.lrf_debug_set_shade_pipe(0)
+        ref = fwd()
+        ndiff = 0
+        for _ in range(6000):
+            o = fwd()
+            ndiff += int(not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1])))
+        log(f"two-launch sequence: renders differing from the first: {ndiff} of 6000")
+
+
 def stage_march():
     """k_march with its density lines in LDS vs in global memory (300^3 and 500^3)."""
     import torch
@@ -1174,7 +1215,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

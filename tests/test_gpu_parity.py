@@ -309,6 +309,52 @@ def test_split_and_fused_colour_engines_are_bit_identical(big):
         assert torch.equal(outs["bf16x3"][1], outs[eng][1])
 
 
+def test_two_launch_sequence_equals_four_launch_sequence(big):
+    """Default engine: k_march -> k_shade2<FUSE> (tile scan and per-ray sum folded into the colour kernel: the scan
+    per workgroup in LDS, the sum by the workgroup owning all of a ray's tiles, boundary rays by the workgroup that
+    finishes last) against k_march -> k_scan_tiles -> k_shade2 -> k_finalize: same sums in the same order.  Ragged batch sizes, a batch
+    too large for the LDS copy of the offsets (falls back to four launches), rays that leave the box at once, and an
+    empty field (one tile per ray: the forced last sample)."""
+    import localrf_amd._native as N
+    f, rays = big
+    lib = N.lib()
+
+    def both(field, r, **kw):
+        outs = []
+        for pipe in (0, 9):
+            lib.lrf_debug_set_shade_pipe(pipe)
+            try:
+                with torch.no_grad():
+                    outs.append(field(r, white_bg=kw.get("white_bg", True), is_train=False, N_samples=kw.get("N", 1536)))
+            finally:
+                lib.lrf_debug_set_shade_pipe(0)
+        d = (outs[0][0] - outs[1][0]).abs()
+        print("two vs four launches: R", r.shape[0], "rays differing", int((d.amax(-1) > 0).sum()), "max |diff|", float(d.max()))
+        assert torch.equal(outs[0][1], outs[1][1])               # depth: the same k_march
+        assert float(d.max()) < 5e-7                             # colours: the two template instances round alike up to fp contraction
+        return outs[0]
+
+    both(f, rays)
+    both(f, rays, white_bg=False)
+    for R in (1, 63, 1000, 4095):
+        both(f, rays[:R])
+    both(f, rays, N=1032)                                    # S = 344
+    many = make_rays(20000, 5).to(DEV)                       # offsets do not fit in LDS: four launches either way
+    both(f, many)
+    far = rays.clone()
+    far[::3, :3] = 50.0                                      # every third ray starts far outside and points away:
+    far[::3, 3:] = torch.tensor([1.0, 0.2, 0.1], device=DEV)  # only the forced last sample can be shaded
+    both(f, far)
+    empty = quiet(make_field, [64, 64, 64], "cpu", seed=3)
+    with torch.no_grad():
+        for p in empty.density_plane:
+            p.zero_()
+    empty = empty.to(DEV)
+    empty.density_shift = -30.0                              # alpha ~ 0 everywhere
+    rgb, _ = both(empty, rays, N=192)
+    assert rgb.shape == (4096, 3)
+
+
 def test_full_size_properties(big):
     f, rays = big
     with torch.no_grad():
