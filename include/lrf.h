@@ -271,6 +271,45 @@ int lrf_tv_loss_fwd(const LrfTvSeg* segs, int32_t count, float weight, void* wor
 int lrf_tv_loss_bwd(const LrfTvSeg* segs, int32_t count, float weight, const float* g_out /* device [1] */,
                     void* stream);
 
+/* ---- grid upsample and the geometric losses around the path ------------------------------
+ * lrf_upsample_bilinear: TensorVMSplit.up_sampling_VM (models/tensoRF.py:198-221) = F.interpolate(mode="bilinear",
+ * align_corners=True) of one plane [C,H,W] -> [C,H2,W2] (a line is [C,L,1] -> [C,L2,1]). */
+int lrf_upsample_bilinear(const float* src, int32_t C, int32_t H, int32_t W, float* dst, int32_t H2, int32_t W2, void* stream);
+
+/* Optical-flow loss of train.py:385-412 with utils/utils.py:15-48 (pts2px, inverse_pose, get_cam2cams,
+ * get_pred_flow).  V views of n rays each (rays of a view contiguous, as LocalTensorfs.forward returns them):
+ * arr[v][j] = sum|pred_bwd - bwd_flow| * bwd_mask + sum|pred_fwd - fwd_flow| * fwd_mask (fwd_mask counts as 0 for the
+ * views flagged in fwd_off: train.py:396 flags `view_ids == len(cam2world) - 1`, absolute id against slice length),
+ * entries above the view's `quantile` (0.9) zeroed (train.py:408).
+ * fwd: arr_out [V*n] (after zeroing), view_sum [V] (sum of a view's kept entries; flow_loss_arr.mean() =
+ * sum(view_sum) / (V n)).  bwd: gradients of scale * g_loss[0] * sum(arr) with respect to depth [V*n], dirs [V*n,3],
+ * cam2world [F,3,4] and (focal, cx, cy) per view [V,3]; workspace = V * 36 floats. */
+#define LRF_LOSS_MAX_PER_VIEW 4096
+typedef struct LrfFlowLoss {
+  const float* cam2world;   /* [F,3,4]: LocalTensorfs.get_cam2world(starting_id) */
+  const int32_t* frame;     /* [V]: view id - starting frame id */
+  const int32_t* fwd_off;   /* [V]: != 0 -> this view's forward mask is zeroed (train.py:396) */
+  const float* dirs;        /* [V*n,3] */
+  const float* depth;       /* [V*n] */
+  const int64_t* ij;        /* [V*n,2] (col, row) */
+  const float* fwd_flow; const float* fwd_mask; const float* bwd_flow; const float* bwd_mask;   /* [V*n,2], [V*n] */
+  const float* focal;       /* device [1] */
+  const float* center;      /* device [2] */
+  int32_t F, V, n;
+  float quantile;
+} LrfFlowLoss;
+int lrf_flow_loss_fwd(const LrfFlowLoss* a, float* arr_out, float* view_sum, void* stream);
+int lrf_flow_loss_bwd(const LrfFlowLoss* a, const float* arr_out, const float* g_loss /* device [1] */, float scale,
+                      float* g_depth, float* g_dirs, float* g_cam2world, float* g_intr /* [V,3] */, float* workspace,
+                      void* stream);
+/* Monocular-depth loss of train.py:414-423 with compute_depth_loss (utils/utils.py:50-59) on x = 1 / clamp(depth, 1e-6)
+ * and the target inverse depths gt: per view median / mean-abs-deviation normalisation of both, squared difference,
+ * entries above the view's `quantile` (0.8) zeroed.  stats [V,6] carries the per-view statistics to the backward. */
+int lrf_depth_loss_fwd(const float* depth, const float* gt, int32_t V, int32_t n, float quantile, float* arr_out,
+                       float* stats, float* view_sum, void* stream);
+int lrf_depth_loss_bwd(const float* depth, const float* gt, int32_t V, int32_t n, const float* arr_out, const float* stats,
+                       const float* g_loss /* device [1] */, float scale, float* g_depth, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,14 @@ class LrfTvSeg(C.Structure):
     _fields_ = [("x", _f), ("g", _f), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("scale", C.c_float)]
 
 
+class LrfFlowLoss(C.Structure):
+    _fields_ = [("cam2world", _f), ("frame", C.c_void_p), ("fwd_off", C.c_void_p), ("dirs", _f), ("depth", _f), ("ij", C.c_void_p),
+                ("fwd_flow", _f), ("fwd_mask", _f), ("bwd_flow", _f), ("bwd_mask", _f), ("focal", _f), ("center", _f),
+                ("F", C.c_int32), ("V", C.c_int32), ("n", C.c_int32), ("quantile", C.c_float)]
+
+
+LRF_LOSS_MAX_PER_VIEW = 4096
+
 # every symbol include/lrf.h declares: (restype, argtypes)
 SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
@@ -98,6 +106,11 @@ SYMBOLS = {
     "lrf_tv_workspace": (C.c_size_t, [C.POINTER(LrfTvSeg), C.c_int32]),
     "lrf_tv_loss_fwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, C.c_void_p, _f, C.c_void_p]),
     "lrf_tv_loss_bwd": (C.c_int, [C.POINTER(LrfTvSeg), C.c_int32, C.c_float, _f, C.c_void_p]),
+    "lrf_upsample_bilinear": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, C.c_int32, C.c_void_p]),
+    "lrf_flow_loss_fwd": (C.c_int, [C.POINTER(LrfFlowLoss), _f, _f, C.c_void_p]),
+    "lrf_flow_loss_bwd": (C.c_int, [C.POINTER(LrfFlowLoss), _f, _f, C.c_float, _f, _f, _f, _f, _f, C.c_void_p]),
+    "lrf_depth_loss_fwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_float, _f, _f, _f, C.c_void_p]),
+    "lrf_depth_loss_bwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, _f, _f, _f, C.c_float, _f, C.c_void_p]),
     "lrf_scene_rays": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32,
                                  C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
     "lrf_scene_rays_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int32, _f, _f, C.c_int32,

@@ -1062,6 +1062,7 @@ static void launch_march(const DField& d, const float* rays, const float* z, int
 #include "lrf_backward.inl"
 #include "lrf_scene.inl"
 #include "lrf_adam.inl"
+#include "lrf_losses.inl"
 #include "lrf_reg.inl"
 #include "lrf_mask.inl"
 

@@ -704,15 +704,20 @@ class TensorVMSplit(torch.nn.Module):
 
     @torch.no_grad()
     def up_sampling_VM(self, plane_coef, line_coef, res_target):
-        """tensoRF.py:198-221: bilinear, align_corners=True; new Parameter objects."""
+        """tensoRF.py:198-221: bilinear, align_corners=True (lrf_upsample_bilinear); new Parameter objects."""
+        def resize(t, h2, w2):
+            src = t.data.detach().contiguous().float()
+            if src.device.type != "cuda":
+                raise N.NativeError("localrf_amd: upsample_volume_grid needs the field on the GPU (no CPU fallback)")
+            _, c, h, w = src.shape
+            dst = torch.empty(1, c, int(h2), int(w2), dtype=torch.float32, device=src.device)
+            N.check(N.lib().lrf_upsample_bilinear(N.ptr(src), c, h, w, N.ptr(dst), int(h2), int(w2),
+                                                  torch.cuda.current_stream(src.device).cuda_stream), "lrf_upsample_bilinear")
+            return torch.nn.Parameter(dst)
         for i in range(3):
             m0, m1 = self.matMode[i]
-            plane_coef[i] = torch.nn.Parameter(F.interpolate(
-                plane_coef[i].data, size=(res_target[m1], res_target[m0]), mode="bilinear",
-                align_corners=True))
-            line_coef[i] = torch.nn.Parameter(F.interpolate(
-                line_coef[i].data, size=(res_target[self.vecMode[i]], 1), mode="bilinear",
-                align_corners=True))
+            plane_coef[i] = resize(plane_coef[i], res_target[m1], res_target[m0])
+            line_coef[i] = resize(line_coef[i], res_target[self.vecMode[i]], 1)
         return plane_coef, line_coef
 
     @torch.no_grad()

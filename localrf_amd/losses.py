@@ -1,0 +1,129 @@
+"""Geometric losses around the render path, as HIP kernels behind the reference's expressions.
+
+  flow_loss(...)   train.py:385-412 with utils/utils.py:15-48 (pts2px, inverse_pose, get_cam2cams, get_fwd_bwd_cam2cams,
+                   get_pred_flow): returns `flow_loss_arr.mean()` after the 0.9-quantile clipping, i.e. the value
+                   train.py multiplies by loss_flow_weight * reg_loss_weight / ((W + H) / 2)
+  depth_loss(...)  train.py:414-423 with compute_depth_loss (utils/utils.py:50-59): returns `depth_loss_arr.mean()`
+                   after the 0.8-quantile clipping
+
+Both take what `LocalTensorfs.forward` returns (depth_map, directions, ij) and are differentiable with respect to
+depth_map (-> field and poses), directions, cam2world (-> poses) and focal / center.  One workgroup per view; the
+per-view torch.median / torch.quantile come from an LDS sort (csrc/lrf_losses.inl).  No torch fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from .scene_ops import _f32c, _stream
+
+
+def _i32(t, dev):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.to(device=dev, dtype=torch.int32).contiguous()
+
+
+class _FlowLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, dirs, cam2world, focal, center, ij, frame, fwd_off, fwd_flow, fwd_mask, bwd_flow, bwd_mask, q):
+        dev = depth.device
+        V, n = depth.shape
+        a = N.LrfFlowLoss()
+        keep = [_f32c(cam2world), frame, _f32c(dirs), _f32c(depth), ij.contiguous(), _f32c(fwd_flow), _f32c(fwd_mask),
+                _f32c(bwd_flow), _f32c(bwd_mask), _f32c(focal).reshape(-1), _f32c(center).reshape(-1), fwd_off]
+        if keep[0].dim() != 3 or keep[0].shape[1:] != (3, 4):
+            raise ValueError("cam2world must be [F,3,4]")
+        if keep[4].dtype != torch.int64:
+            raise ValueError("ij must be int64 (LocalTensorfs.forward's fourth output)")
+        for name, t in zip(("cam2world", "frame", "dirs", "depth", "ij", "fwd_flow", "fwd_mask", "bwd_flow", "bwd_mask",
+                            "focal", "center", "fwd_off"), keep):
+            setattr(a, name, t.data_ptr())
+        a.F, a.V, a.n, a.quantile = keep[0].shape[0], V, n, float(q)
+        arr = torch.empty(V, n, dtype=torch.float32, device=dev)
+        vsum = torch.empty(V, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_flow_loss_fwd(C.byref(a), N.ptr(arr), N.ptr(vsum), _stream(dev)), "lrf_flow_loss_fwd")
+        ctx.args, ctx.keep, ctx.arr = a, keep, arr
+        ctx.focal_shape = focal.shape
+        ctx.mark_non_differentiable(arr)
+        return vsum.sum() / float(V * n), arr
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_arr):
+        a, keep, arr = ctx.args, ctx.keep, ctx.arr
+        dev = arr.device
+        V, n = arr.shape
+        g_depth = torch.empty(V, n, dtype=torch.float32, device=dev)
+        g_dirs = torch.empty(V, n, 3, dtype=torch.float32, device=dev)
+        g_c2w = torch.empty(a.F, 3, 4, dtype=torch.float32, device=dev)
+        g_intr = torch.empty(V, 3, dtype=torch.float32, device=dev)
+        ws = torch.empty(V * 36, dtype=torch.float32, device=dev)
+        g = _f32c(g_loss).reshape(1)
+        N.check(N.lib().lrf_flow_loss_bwd(C.byref(a), N.ptr(arr), N.ptr(g), 1.0 / float(V * n), N.ptr(g_depth), N.ptr(g_dirs),
+                                          N.ptr(g_c2w), N.ptr(g_intr), N.ptr(ws), _stream(dev)), "lrf_flow_loss_bwd")
+        s = g_intr.sum(0)
+        return g_depth, g_dirs, g_c2w, s[0:1].reshape(ctx.focal_shape), s[1:3], None, None, None, None, None, None, None, None
+
+
+def flow_loss(depth_map, directions, ij, cam2world, view_ids, starting_frame_id, fwd_flow, fwd_mask, bwd_flow, bwd_mask,
+              focal, center, quantile=0.9, return_arr=False):
+    """`flow_loss_arr.mean()` of train.py:385-410.  depth_map [V*n] or [V,n]; directions [V*n,3]; ij [V*n,2] int64;
+    cam2world = local_tensorfs.get_cam2world(starting_id=starting_frame_id) [F,3,4]; view_ids [V]; flows [V*n,2],
+    masks [V*n]; focal = local_tensorfs.focal(W) (tensor [1] or float), center = local_tensorfs.center(W, H) [2]."""
+    dev = depth_map.device
+    if dev.type != "cuda":
+        raise N.NativeError("localrf_amd.losses: tensors must be on the GPU (there is no CPU fallback)")
+    view_ids = torch.as_tensor(view_ids)
+    V = int(view_ids.shape[0])
+    depth = depth_map.reshape(V, -1)
+    n = depth.shape[1]
+    if n > N.LRF_LOSS_MAX_PER_VIEW:
+        raise ValueError(f"at most {N.LRF_LOSS_MAX_PER_VIEW} rays per view")
+    frame = _i32(view_ids, dev) - int(starting_frame_id)
+    # train.py:396 compares the ABSOLUTE view id with the length of the cam2world slice; reproduced as is
+    fwd_off = (_i32(view_ids, dev) == int(cam2world.shape[0]) - 1).to(torch.int32).contiguous()
+    if not torch.is_tensor(focal):
+        focal = torch.tensor([float(focal)], device=dev)
+    loss, arr = _FlowLossFn.apply(depth, directions.reshape(V, n, 3), cam2world, focal, center, ij.reshape(V, n, 2), frame.contiguous(), fwd_off,
+                                  fwd_flow.reshape(V, n, 2), fwd_mask.reshape(V, n).float(), bwd_flow.reshape(V, n, 2),
+                                  bwd_mask.reshape(V, n).float(), quantile)
+    return (loss, arr) if return_arr else loss
+
+
+class _DepthLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, gt, q):
+        dev = depth.device
+        V, n = depth.shape
+        d, g = _f32c(depth), _f32c(gt)
+        arr = torch.empty(V, n, dtype=torch.float32, device=dev)
+        stats = torch.empty(V, 6, dtype=torch.float32, device=dev)
+        vsum = torch.empty(V, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_depth_loss_fwd(N.ptr(d), N.ptr(g), V, n, float(q), N.ptr(arr), N.ptr(stats), N.ptr(vsum), _stream(dev)),
+                "lrf_depth_loss_fwd")
+        ctx.keep = (d, g, arr, stats)
+        ctx.mark_non_differentiable(arr)
+        return vsum.sum() / float(V * n), arr
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_arr):
+        d, g, arr, stats = ctx.keep
+        V, n = arr.shape
+        g_depth = torch.empty_like(d)
+        gl = _f32c(g_loss).reshape(1)
+        N.check(N.lib().lrf_depth_loss_bwd(N.ptr(d), N.ptr(g), V, n, N.ptr(arr), N.ptr(stats), N.ptr(gl), 1.0 / float(V * n),
+                                           N.ptr(g_depth), _stream(d.device)), "lrf_depth_loss_bwd")
+        return g_depth, None, None
+
+
+def depth_loss(depth_map, invdepths, n_views, quantile=0.8, return_arr=False):
+    """`depth_loss_arr.mean()` of train.py:414-421: compute_depth_loss(1 / depth_map.clamp(1e-6), invdepths) per view,
+    entries above the view's 0.8-quantile zeroed."""
+    dev = depth_map.device
+    if dev.type != "cuda":
+        raise N.NativeError("localrf_amd.losses: tensors must be on the GPU (there is no CPU fallback)")
+    depth = depth_map.reshape(int(n_views), -1)
+    if depth.shape[1] > N.LRF_LOSS_MAX_PER_VIEW:
+        raise ValueError(f"at most {N.LRF_LOSS_MAX_PER_VIEW} rays per view")
+    loss, arr = _DepthLossFn.apply(depth, invdepths.reshape(depth.shape), quantile)
+    return (loss, arr) if return_arr else loss

@@ -200,3 +200,64 @@ def update_alpha_mask(fld, grid_size, step_size, alpha_mask_thres=1e-4, density_
     alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
     alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(tuple(int(g) for g in grid_size)[::-1])
     return (alpha >= alpha_mask_thres).float()
+
+
+def upsample_vm(fld, res_target, mat_mode=((0, 1), (0, 2), (1, 2)), vec_mode=(2, 1, 0)):
+    """models/tensoRF.py:198-221 (up_sampling_VM for the density and the appearance tensors): bilinear,
+    align_corners=True.  Returns a dict of the 12 resized tensors."""
+    out = {}
+    for kind in ("density", "app"):
+        for i in range(3):
+            m0, m1 = mat_mode[i]
+            out[f"{kind}_plane.{i}"] = F.interpolate(fld[f"{kind}_plane.{i}"], size=(int(res_target[m1]), int(res_target[m0])),
+                                                     mode="bilinear", align_corners=True)
+            out[f"{kind}_line.{i}"] = F.interpolate(fld[f"{kind}_line.{i}"], size=(int(res_target[vec_mode[i]]), 1),
+                                                    mode="bilinear", align_corners=True)
+    return out
+
+
+def _cam2cams(cam2worlds, indices, offset):
+    """utils/utils.py:22-35 (inverse_pose + get_cam2cams)."""
+    idx = torch.clamp(indices + offset, 0, len(cam2worlds) - 1)
+    a = cam2worlds[idx]
+    w = a[:, :3, :3].transpose(1, 2)
+    tw = -torch.bmm(w, a[:, :3, 3:])[..., 0]
+    b = cam2worlds[indices]
+    rot = torch.bmm(w, b[:, :3, :3])
+    t = torch.bmm(w, b[:, :3, 3:])[..., 0] + tw
+    return rot, t
+
+
+def _pred_flow(pts, ij, rot, t, focal, center):
+    """utils/utils.py:15-21,43-48 (pts2px + get_pred_flow)."""
+    q = torch.bmm(rot, pts.transpose(1, 2)).transpose(1, 2) + t[:, None]
+    x, y, zc = q[..., 0], -q[..., 1], torch.clip(-q[..., 2], min=1e-6)
+    px = torch.stack([x / zc * focal + center[0] - 0.5, y / zc * focal + center[1] - 0.5], -1)
+    return px - ij.float()
+
+
+def flow_loss(depth_map, directions, ij, cam2world, view_ids, starting_frame_id, fwd_flow, fwd_mask, bwd_flow, bwd_mask,
+              focal, center, quantile=0.9):
+    """train.py:385-410: reprojection flow loss per view, entries above the view's 0.9-quantile zeroed.
+    Shapes [V,n,...]; returns (flow_loss_arr.mean(), flow_loss_arr)."""
+    fm = fwd_mask.clone()
+    fm[view_ids == len(cam2world) - 1] = 0
+    idx = view_ids - starting_frame_id
+    pts = directions * depth_map[..., None]
+    arr = torch.sum(torch.abs(_pred_flow(pts, ij, *_cam2cams(cam2world, idx, -1), focal, center) - bwd_flow), -1) * bwd_mask
+    arr = arr + torch.sum(torch.abs(_pred_flow(pts, ij, *_cam2cams(cam2world, idx, 1), focal, center) - fwd_flow), -1) * fm
+    keep = ~(arr > torch.quantile(arr.detach(), quantile, dim=1)[..., None])
+    arr = arr * keep
+    return arr.mean(), arr
+
+
+def depth_loss(depth_map, invdepths, quantile=0.8):
+    """train.py:414-421 with compute_depth_loss (utils/utils.py:50-59): returns (depth_loss_arr.mean(), arr)."""
+    def norm(x):
+        t = torch.median(x, dim=-1, keepdim=True).values
+        s = torch.mean(torch.abs(x - t), dim=-1, keepdim=True)
+        return (x - t) / s
+    arr = (norm(1 / depth_map.clamp(1e-6)) - norm(invdepths)) ** 2
+    keep = ~(arr > torch.quantile(arr.detach(), quantile, dim=1)[..., None])
+    arr = arr * keep
+    return arr.mean(), arr

@@ -1026,6 +1026,65 @@ def stage_fuse():
         log(f"two-launch sequence: renders differing from the first: {ndiff} of 6000")
 
 
+def stage_geo():
+    """Geometric losses (train.py:385-423): HIP kernels vs the ATen op chain on the same GPU, forward + backward,
+    4096 rays over 16 views; and the grid upsample 300^3 -> 380^3 vs F.interpolate."""
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N, losses
+    from oracle import vm_render_torch as ot
+    dev = "cuda:0"
+    V, n, Fr, W, H = 16, 256, 20, 640, 480
+    gen = torch.Generator().manual_seed(7)
+    rot = torch.linalg.qr(torch.eye(3)[None] + 0.05 * torch.randn(Fr, 3, 3, generator=gen))[0]
+    c2w = torch.cat([rot, 0.2 * torch.randn(Fr, 3, 1, generator=gen)], -1).to(dev)
+    col, row = torch.randint(0, W, (V, n), generator=gen), torch.randint(0, H, (V, n), generator=gen)
+    kw = dict(ij=torch.stack([col, row], -1).to(dev), view_ids=(torch.randperm(Fr, generator=gen)[:V]).to(dev), starting_frame_id=0,
+              fwd_flow=(4 * torch.randn(V, n, 2, generator=gen)).to(dev), bwd_flow=(4 * torch.randn(V, n, 2, generator=gen)).to(dev),
+              fwd_mask=(torch.rand(V, n, generator=gen) > 0.2).float().to(dev), bwd_mask=(torch.rand(V, n, generator=gen) > 0.2).float().to(dev))
+    dirs = torch.stack([(col + 0.5 - W / 2) / 500.0, -(row + 0.5 - H / 2) / 500.0, -torch.ones(V, n)], -1).to(dev)
+    depth0 = (0.5 + 5 * torch.rand(V, n, generator=gen)).to(dev)
+    inv = (0.1 + torch.rand(V, n, generator=gen)).to(dev)
+
+    def step(impl):
+        leaves = dict(depth_map=depth0.clone().requires_grad_(True), directions=dirs.clone().requires_grad_(True),
+                      cam2world=c2w.clone().requires_grad_(True), focal=torch.tensor([500.0], device=dev, requires_grad=True),
+                      center=torch.tensor([W / 2.0, H / 2.0], device=dev, requires_grad=True))
+        if impl == "hip":
+            total = losses.flow_loss(**leaves, **kw) + 0.1 * losses.depth_loss(leaves["depth_map"], inv, V)
+        else:
+            total = ot.flow_loss(**leaves, **kw)[0] + 0.1 * ot.depth_loss(leaves["depth_map"], inv)[0]
+        total.backward()
+        return float(total.detach()) if False else total.detach()
+    for impl in ("hip", "aten", "hip", "aten"):
+        for _ in range(20):
+            step(impl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            v = step(impl)
+        torch.cuda.synchronize()
+        log(f"geometric losses ({impl}): {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms per forward+backward (4096 rays, 16 views) | value {float(v):.6f}")
+    lib = N.lib()
+    src = torch.randn(1, 24, 300, 300, device=dev)
+    dst = torch.empty(1, 24, 380, 380, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for name, fn in (("lrf_upsample_bilinear", lambda: N.check(lib.lrf_upsample_bilinear(N.ptr(src), 24, 300, 300, N.ptr(dst), 380, 380, st), "up")),
+                     ("F.interpolate", lambda: F.interpolate(src, size=(380, 380), mode="bilinear", align_corners=True))):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        log(f"upsample 24 x 300^2 -> 380^2 ({name}): {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms")
+    ref = F.interpolate(src, size=(380, 380), mode="bilinear", align_corners=True)
+    N.check(lib.lrf_upsample_bilinear(N.ptr(src), 24, 300, 300, N.ptr(dst), 380, 380, st), "up")
+    log(f"upsample max |kernel - ATen| {float((dst - ref).abs().max()):.2e}")
+
+
 def stage_march():
     """k_march with its density lines in LDS vs in global memory (300^3 and 500^3)."""
     import torch
@@ -1215,7 +1274,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

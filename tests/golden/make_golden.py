@@ -398,6 +398,85 @@ def case_sixd(name):
     save(name, **arrs)
 
 
+def case_upsample(TensorVMSplit, name, grid=(16, 20, 12), target=(24, 27, 30), seed=71):
+    """TensorVMSplit.upsample_volume_grid (tensoRF.py:198-233): F.interpolate(bilinear, align_corners=True) of the 6
+    planes and 6 lines + update_stepSize."""
+    f = make_field(TensorVMSplit, grid, seed)
+    fsum = field_checksum(f.state_dict())
+    quiet(f.upsample_volume_grid, list(target))
+    arrs = dict(grid=np.array(grid), target=np.array(target), seed=np.array(seed), field_sum=fsum,
+                nSamples=np.array(int(f.nSamples)), stepSize=np.array(float(f.stepSize), np.float32))
+    for k, v in f.state_dict().items():
+        if "plane" in k or "line" in k:
+            arrs[f"up.{k}"] = v.detach().numpy().copy()
+    save(name, **arrs)
+
+
+def case_geo_losses(name, seed=81, F=6, V=4, n=96, W=64, H=48):
+    """The optical-flow and monocular-depth losses of train.py:385-423, computed with the reference's own
+    utils/utils.py functions (get_fwd_bwd_cam2cams, get_pred_flow, compute_depth_loss); the lines of train.py that
+    combine them are inline code there and are repeated here verbatim in meaning (masks, quantile clipping, mean)."""
+    from utils.utils import compute_depth_loss, get_fwd_bwd_cam2cams, get_pred_flow, sixD_to_mtx
+    g = torch.Generator().manual_seed(seed)
+    r6 = torch.eye(3)[:, :2][None].repeat(F, 1, 1) + 0.08 * torch.randn(F, 3, 2, generator=g)
+    r6[4] = torch.tensor([[0.36, 0.0], [0.0, 1.0], [-0.93, 0.05]])        # frame 4 is turned by ~1.2 rad: a few rays reproject behind it (z clip in pts2px)
+    rot = torch.stack([sixD_to_mtx(r6[i:i + 1])[0] for i in range(F)])   # one view at a time (no dim-less cross quirk)
+    trans = 0.2 * torch.randn(F, 3, 1, generator=g)
+    cam2world = torch.cat([rot, trans], -1).detach().clone().requires_grad_(True)          # [F,3,4]
+    # absolute view ids with a non-zero starting frame: train.py:396 compares the ABSOLUTE id with the length of the
+    # cam2world slice, so here view 5 (relative 4, not the last) loses its forward mask and view 6 (the last) keeps it
+    view_ids = torch.tensor([1, 3, 6, 5])
+    starting_frame_id = 1
+    focal = torch.tensor([60.0], requires_grad=True)
+    center = torch.tensor([W * 0.5, H * 0.48], requires_grad=True)
+    col = torch.randint(0, W, (V, n), generator=g)
+    row = torch.randint(0, H, (V, n), generator=g)
+    ij = torch.stack([col, row], -1)                                                       # [V,n,2] int64
+    with torch.no_grad():
+        dirs0 = torch.stack([(col + 0.5 - center[0]) / focal, -(row + 0.5 - center[1]) / focal, -torch.ones(V, n)], -1)
+    directions = dirs0.clone().requires_grad_(True)
+    depth_map = (0.5 + 3.5 * torch.rand(V, n, generator=g)).requires_grad_(True)
+    fwd_flow = 3.0 * torch.randn(V, n, 2, generator=g)
+    bwd_flow = 3.0 * torch.randn(V, n, 2, generator=g)
+    fwd_mask = (torch.rand(V, n, generator=g) > 0.3).float()
+    bwd_mask = (torch.rand(V, n, generator=g) > 0.3).float()
+    invdepths = 0.2 + torch.rand(V, n, generator=g)
+
+    # train.py:389-410
+    fm = fwd_mask.clone()
+    fm[view_ids == len(cam2world) - 1] = 0
+    fwd_cam2cams, bwd_cam2cams = get_fwd_bwd_cam2cams(cam2world, view_ids - starting_frame_id)
+    pts = directions * depth_map[..., None]
+    pred_fwd_flow = get_pred_flow(pts, ij, fwd_cam2cams, focal, center)
+    pred_bwd_flow = get_pred_flow(pts, ij, bwd_cam2cams, focal, center)
+    flow_loss_arr = torch.sum(torch.abs(pred_bwd_flow - bwd_flow), dim=-1) * bwd_mask
+    flow_loss_arr += torch.sum(torch.abs(pred_fwd_flow - fwd_flow), dim=-1) * fm
+    flow_loss_arr[flow_loss_arr > torch.quantile(flow_loss_arr, 0.9, dim=1)[..., None]] = 0
+    flow_mean = flow_loss_arr.mean()
+    flow_mean.backward()
+    arrs = dict(seed=np.array(seed), WH=np.array([W, H]), view_ids=view_ids.numpy(), starting_frame_id=np.array(starting_frame_id),
+                cam2world=cam2world.detach().numpy(), focal=focal.detach().numpy(), center=center.detach().numpy(), ij=ij.numpy(),
+                directions=directions.detach().numpy(), depth=depth_map.detach().numpy(), fwd_flow=fwd_flow.numpy(),
+                bwd_flow=bwd_flow.numpy(), fwd_mask=fwd_mask.numpy(), bwd_mask=bwd_mask.numpy(), invdepths=invdepths.numpy())
+    arrs.update({"flow.arr": flow_loss_arr.detach().numpy(), "flow.mean": np.array(float(flow_mean)),
+                 "flow.fwd_cam2cams": fwd_cam2cams.detach().numpy(), "flow.bwd_cam2cams": bwd_cam2cams.detach().numpy(),
+                 "flow.g_depth": depth_map.grad.numpy().copy(), "flow.g_dirs": directions.grad.numpy().copy(),
+                 "flow.g_cam2world": cam2world.grad.numpy().copy(), "flow.g_focal": focal.grad.numpy().copy(),
+                 "flow.g_center": center.grad.numpy().copy()})
+    print("flow: mean", float(flow_mean), "zeroed", int((flow_loss_arr == 0).sum()), "of", V * n)
+
+    # train.py:417-421
+    depth_map.grad = None
+    _, _, depth_loss_arr = compute_depth_loss(1 / depth_map.clamp(1e-6), invdepths)
+    depth_loss_arr[depth_loss_arr > torch.quantile(depth_loss_arr, 0.8, dim=1)[..., None]] = 0
+    depth_mean = depth_loss_arr.mean()
+    depth_mean.backward()
+    arrs.update({"depth.arr": depth_loss_arr.detach().numpy(), "depth.mean": np.array(float(depth_mean)),
+                 "depth.g_depth": depth_map.grad.numpy().copy()})
+    print("depth: mean", float(depth_mean))
+    save(name, **arrs)
+
+
 def build_local(LocalTensorfs, grid, seed, WH, camera_prior=None, lr_i=1e-3):
     torch.manual_seed(seed)
     aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
@@ -512,7 +591,9 @@ def main():
               "sixd": lambda: case_sixd("sixd_to_mtx.npz"),
               "local3": lambda: case_local_train_views(LocalTensorfs, "local_train_3views.npz", (20, 24, 28), 43, [0, 2, 4]),
               "prior": lambda: case_local_train_views(LocalTensorfs, "local_train_prior.npz", (20, 24, 28), 45, [0, 1, 3, 4], camera_prior=True),
-              "config3": lambda: case_config3(LocalTensorfs, "config3_4x300.npz")}
+              "config3": lambda: case_config3(LocalTensorfs, "config3_4x300.npz"),
+              "upsample": lambda: case_upsample(TensorVMSplit, "upsample_grid.npz"),
+              "geo": lambda: case_geo_losses("geo_losses.npz")}
         for k in only:
             r2[k]()
         return
@@ -540,6 +621,8 @@ def main():
     case_local_train_views(LocalTensorfs, "local_train_3views.npz", (20, 24, 28), 43, [0, 2, 4])
     case_local_train_views(LocalTensorfs, "local_train_prior.npz", (20, 24, 28), 45, [0, 1, 3, 4], camera_prior=True)
     case_config3(LocalTensorfs, "config3_4x300.npz")
+    case_upsample(TensorVMSplit, "upsample_grid.npz")
+    case_geo_losses("geo_losses.npz")
 
 
 if __name__ == "__main__":

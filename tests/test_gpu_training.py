@@ -649,3 +649,118 @@ def test_progressive_training_driver_on_synthetic_frames():
     assert len(out["ms_per_iteration_by_resolution"]) >= 3 and out["final_resolution"] >= 90, out["ms_per_iteration_by_resolution"]
     assert out["checkpoint_roundtrip"] and out["checkpoint_keys_follow_reference"]
     assert out["target_image_stats"]["std"] > 0.05, out["target_image_stats"]       # the teacher scene is not blank
+
+
+def test_upsample_vs_reference_golden(built_lib):
+    """upsample_volume_grid through lrf_upsample_bilinear against the 12 tensors the reference's
+    F.interpolate(bilinear, align_corners=True) produced (tensoRF.py:198-233), then a render on the new grid."""
+    from util import field_from_seed, load_golden, make_rays
+    g = load_golden("upsample_grid")
+    f = field_from_seed(g, DEV)
+    f.upsample_volume_grid([int(v) for v in g["target"]])
+    n = 0
+    for k, v in f.state_dict().items():
+        if "plane" in k or "line" in k:
+            ref = g["up." + k]
+            assert tuple(v.shape) == ref.shape, k
+            assert np.abs(v.cpu().numpy() - ref).max() <= 1e-6, k
+            n += 1
+    assert n == 12
+    assert int(f.nSamples) == int(g["nSamples"]) and abs(float(f.stepSize) - float(g["stepSize"])) < 1e-6
+    with torch.no_grad():
+        rgb, depth = f(make_rays(64, 3).to(DEV), white_bg=True, is_train=False, N_samples=96)
+    assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+
+
+def _geo_inputs(g, grad=True):
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    leaf = lambda k: t(k).clone().requires_grad_(grad)
+    return dict(depth_map=leaf("depth"), directions=leaf("directions"), ij=t("ij"), cam2world=leaf("cam2world"),
+                view_ids=t("view_ids"), starting_frame_id=int(g["starting_frame_id"]), fwd_flow=t("fwd_flow"),
+                fwd_mask=t("fwd_mask"), bwd_flow=t("bwd_flow"), bwd_mask=t("bwd_mask"), focal=leaf("focal"), center=leaf("center"))
+
+
+def test_geometric_losses_vs_reference_golden(built_lib):
+    """lrf_flow_loss_* / lrf_depth_loss_* against values, clipped per-ray arrays and gradients recorded from the
+    reference's utils/utils.py functions combined as train.py:385-423 does (first frame, last frame, a frame turned
+    far enough that some rays reproject behind it)."""
+    from localrf_amd import losses
+    from util import load_golden
+    g = load_golden("geo_losses")
+    a = _geo_inputs(g)
+    mean, arr = losses.flow_loss(return_arr=True, **a)
+    mean.backward()
+    ref = g["flow.arr"]
+    assert abs(float(mean) - float(g["flow.mean"])) <= 1e-5 * abs(float(g["flow.mean"]))
+    assert ((arr.cpu().numpy() == 0) == (ref == 0)).all()
+    assert np.abs(arr.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    for key, v in (("g_depth", a["depth_map"]), ("g_dirs", a["directions"]), ("g_cam2world", a["cam2world"]),
+                   ("g_focal", a["focal"]), ("g_center", a["center"])):
+        r = g["flow." + key]
+        err = np.abs(v.grad.cpu().numpy().reshape(r.shape) - r).max() / np.abs(r).max()
+        print("flow", key, err)
+        assert err <= 1e-4, key
+    d = torch.from_numpy(g["depth"]).to(DEV).requires_grad_(True)
+    mean, arr = losses.depth_loss(d, torch.from_numpy(g["invdepths"]).to(DEV), d.shape[0], return_arr=True)
+    mean.backward()
+    ref = g["depth.arr"]
+    assert abs(float(mean) - float(g["depth.mean"])) <= 1e-5 * abs(float(g["depth.mean"]))
+    assert ((arr.cpu().numpy() == 0) == (ref == 0)).all()
+    assert np.abs(arr.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    err = np.abs(d.grad.cpu().numpy() - g["depth.g_depth"]).max() / np.abs(g["depth.g_depth"]).max()
+    print("depth g_depth", err)
+    assert err <= 1e-4
+
+
+@pytest.mark.parametrize("V,n", [(16, 256), (3, 1000), (1, 4096), (5, 7)])
+def test_geometric_losses_vs_aten_chain_at_batch_sizes(built_lib, V, n):
+    """The same losses at train.py's batch shapes (4096 rays over V views; ragged and tiny cases) against the ATen
+    restatement (oracle/vm_render_torch.py, pinned to the reference golden above) on the same GPU."""
+    from localrf_amd import losses
+    from oracle import vm_render_torch as ot
+    gen = torch.Generator().manual_seed(100 + V)
+    F_ = V + 3
+    r6 = torch.eye(3)[:, :2][None].repeat(F_, 1, 1) + 0.05 * torch.randn(F_, 3, 2, generator=gen)
+    b1 = torch.nn.functional.normalize(r6[..., 0], dim=-1)
+    b2 = torch.nn.functional.normalize(r6[..., 1] - (b1 * r6[..., 1]).sum(-1, keepdim=True) * b1, dim=-1)
+    rot = torch.stack([b1, b2, torch.cross(b1, b2, dim=-1)], -1)
+    c2w = torch.cat([rot, 0.2 * torch.randn(F_, 3, 1, generator=gen)], -1)
+    W, H = 640, 480
+    col, row = torch.randint(0, W, (V, n), generator=gen), torch.randint(0, H, (V, n), generator=gen)
+    start = 2
+    frames = torch.randperm(F_, generator=gen)[:V]
+    frames[0] = 0                                                                    # first frame: its backward neighbour is itself
+    if V > 1:
+        frames[1] = F_ - 1                                                           # last frame: forward mask off
+    view_ids = frames + start
+    base = dict(ij=torch.stack([col, row], -1), view_ids=view_ids, starting_frame_id=start,
+                fwd_flow=4 * torch.randn(V, n, 2, generator=gen), bwd_flow=4 * torch.randn(V, n, 2, generator=gen),
+                fwd_mask=(torch.rand(V, n, generator=gen) > 0.2).float(), bwd_mask=(torch.rand(V, n, generator=gen) > 0.2).float())
+    focal0, center0 = torch.tensor([500.0]), torch.tensor([W * 0.5, H * 0.5])
+    dirs0 = torch.stack([(col + 0.5 - center0[0]) / focal0, -(row + 0.5 - center0[1]) / focal0, -torch.ones(V, n)], -1)
+    depth0 = 0.5 + 5 * torch.rand(V, n, generator=gen)
+    inv0 = 0.1 + torch.rand(V, n, generator=gen)
+    res = {}
+    for impl in ("hip", "aten"):
+        leaves = dict(depth_map=depth0.to(DEV).requires_grad_(True), directions=dirs0.to(DEV).requires_grad_(True),
+                      cam2world=c2w.to(DEV).requires_grad_(True), focal=focal0.to(DEV).requires_grad_(True),
+                      center=center0.to(DEV).requires_grad_(True))
+        kw = {k: v.to(DEV) if torch.is_tensor(v) else v for k, v in base.items()}
+        if impl == "hip":
+            fl, farr = losses.flow_loss(return_arr=True, **leaves, **kw)
+            dl, darr = losses.depth_loss(leaves["depth_map"], inv0.to(DEV), V, return_arr=True)
+        else:
+            fl, farr = ot.flow_loss(**leaves, **kw)
+            dl, darr = ot.depth_loss(leaves["depth_map"], inv0.to(DEV))
+        gf = torch.autograd.grad(fl, list(leaves.values()), retain_graph=True)
+        gd = torch.autograd.grad(dl, [leaves["depth_map"]])
+        res[impl] = (float(fl), farr.detach(), float(dl), darr.detach(), [x.detach() for x in gf], gd[0].detach())
+    h, a = res["hip"], res["aten"]
+    assert abs(h[0] - a[0]) <= 1e-5 * abs(a[0]) and abs(h[2] - a[2]) <= 1e-5 * abs(a[2]), (h[0], a[0], h[2], a[2])
+    flips = int(((h[1] == 0) != (a[1] == 0)).sum()) + int(((h[3] == 0) != (a[3] == 0)).sum())
+    assert flips == 0, flips
+    for name, x, y in zip(("depth", "dirs", "cam2world", "focal", "center"), h[4], a[4]):
+        err = float((x.reshape(y.shape) - y).abs().max() / y.abs().max().clamp(min=1e-20))
+        assert err <= 1e-4, (name, err)
+    err = float((h[5] - a[5]).abs().max() / a[5].abs().max())
+    assert err <= 1e-4, ("depth loss g_depth", err)

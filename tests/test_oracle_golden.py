@@ -411,3 +411,51 @@ def test_config3_seeded_scene_regenerates():
     lt = local_from_golden_seed(g, lr_i=0, n_grow=3)
     assert len(lt.tensorfs) == int(g["n_fields"]) == 4
     assert [f.nSamples for f in lt.tensorfs] == [int(v) for v in g["nSamples"]]
+
+
+def _geo_inputs(g, device="cpu", grad=True):
+    import torch
+    t = lambda k: torch.from_numpy(g[k]).to(device)
+    leaf = lambda k: t(k).clone().requires_grad_(grad)
+    return dict(depth_map=leaf("depth"), directions=leaf("directions"), ij=t("ij"), cam2world=leaf("cam2world"),
+                view_ids=t("view_ids"), starting_frame_id=int(g["starting_frame_id"]), fwd_flow=t("fwd_flow"),
+                fwd_mask=t("fwd_mask"), bwd_flow=t("bwd_flow"), bwd_mask=t("bwd_mask"), focal=leaf("focal"), center=leaf("center"))
+
+
+def test_geometric_losses_match_reference():
+    """Optical-flow and monocular-depth losses (train.py:385-423 on utils/utils.py:15-59): values, the clipped
+    per-ray arrays and every gradient recorded from the reference's own functions."""
+    import torch
+    from oracle import vm_render_torch as ot
+    g = load_golden("geo_losses")
+    a = _geo_inputs(g)
+    mean, arr = ot.flow_loss(**a)
+    mean.backward()
+    assert abs(float(mean) - float(g["flow.mean"])) <= 2e-6 * abs(float(g["flow.mean"]))
+    assert np.abs(arr.detach().numpy() - g["flow.arr"]).max() <= 1e-5 * np.abs(g["flow.arr"]).max()
+    assert ((arr.detach().numpy() == 0) == (g["flow.arr"] == 0)).all()
+    for key, v in (("g_depth", a["depth_map"]), ("g_dirs", a["directions"]), ("g_cam2world", a["cam2world"]),
+                   ("g_focal", a["focal"]), ("g_center", a["center"])):
+        ref = g["flow." + key]
+        assert np.abs(v.grad.numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), key
+    d = torch.from_numpy(g["depth"]).clone().requires_grad_(True)
+    mean, arr = ot.depth_loss(d, torch.from_numpy(g["invdepths"]))
+    mean.backward()
+    assert abs(float(mean) - float(g["depth.mean"])) <= 2e-6 * abs(float(g["depth.mean"]))
+    assert np.abs(arr.detach().numpy() - g["depth.arr"]).max() <= 1e-5 * np.abs(g["depth.arr"]).max()
+    assert np.abs(d.grad.numpy() - g["depth.g_depth"]).max() <= 1e-5 * np.abs(g["depth.g_depth"]).max()
+
+
+def test_upsample_matches_reference():
+    """upsample_volume_grid (tensoRF.py:198-233): the 12 resized tensors recorded from the reference."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import field_from_seed
+    g = load_golden("upsample_grid")
+    f = field_from_seed(g)
+    up = ot.upsample_vm({k: v.detach() for k, v in f.state_dict().items()}, g["target"])
+    n = 0
+    for k, v in up.items():
+        assert np.abs(v.numpy() - g["up." + k]).max() <= 1e-6, k
+        n += 1
+    assert n == 12
