@@ -6,9 +6,10 @@ optimizer_step -> progressive append_frame / append_rf, the upsample schedule of
 
 The targets come from a hidden teacher scene (a TensorVMSplit with solid walls and random appearance)
 rendered by the same HIP path from a camera that moves along a straight line, so the loss really
-can fall and the poses really drift as the camera moves.  Flow / monocular-depth losses need
-precomputed RAFT / DPT maps (train.py:385-423) and are off, exactly as `--loss_flow_weight_inital 0
---loss_depth_weight_inital 0` would run the reference.
+can fall and the poses really drift as the camera moves.  The optical-flow and monocular-depth
+losses (train.py:385-423, weights 1 and 0.1 as opt.py sets them) are on while the field regularises:
+their targets -- what RAFT / DPT provide to the reference -- are the teacher's exact flow between
+neighbouring frames and its inverse depth (localrf_amd.losses kernels).  `--no-geo` switches them off.
 
   python scripts/train_synth.py [--frames 24] [--final 300] [--iters-per-frame 60] [--json out.json]
   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/train_synth.py ...
@@ -73,14 +74,29 @@ class SyntheticFrames:
         jj, ii = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
         dirs = torch.stack([(ii.float() + 0.5 - W / 2) / focal, -(jj.float() + 0.5 - H / 2) / focal,
                             -torch.ones(H, W)], -1).reshape(-1, 3)
-        self.images = []
+        self.images, depths = [], []
+        cam_t = torch.tensor([[0.04 * f, 0.01 * math.sin(0.5 * f), 0.0] for f in range(n_frames)])   # true camera path
         with torch.no_grad():
             for f in range(n_frames):
-                o = torch.tensor([0.04 * f, 0.01 * math.sin(0.5 * f), 0.0]).expand_as(dirs)     # true camera path
-                rays = torch.cat([o, dirs], -1).to(dev)
-                rgb, _ = teacher(rays, white_bg=True, is_train=False, N_samples=300)
+                rays = torch.cat([cam_t[f].expand_as(dirs), dirs], -1).to(dev)
+                rgb, dep = teacher(rays, white_bg=True, is_train=False, N_samples=300)
                 self.images.append(rgb.clamp(0, 1))
+                depths.append(dep)
         self.images = torch.stack(self.images)                        # [F, H*W, 3] on the device
+        # what RAFT / DPT give the reference (dataLoader/localrf_dataset.py): flow to the next / previous frame and an
+        # inverse depth per pixel -- here exact, from the teacher's depth and the true (rotation-free) camera path
+        depths = torch.stack(depths)                                  # [F, H*W]
+        pix = torch.stack([ii.reshape(-1), jj.reshape(-1)], -1).float().to(dev)
+        dirs_d = dirs.to(dev)
+
+        def flow_to(f, g):
+            q = dirs_d * depths[f][:, None] + (cam_t[f] - cam_t[g]).to(dev)        # point in frame g's camera (utils.py:43-46)
+            zc = (-q[:, 2]).clamp(min=1e-6)
+            px = torch.stack([q[:, 0] / zc * focal + W / 2 - 0.5, -q[:, 1] / zc * focal + H / 2 - 0.5], -1)
+            return px - pix
+        self.fwd_flow = torch.stack([flow_to(f, min(f + 1, n_frames - 1)) for f in range(n_frames)])
+        self.bwd_flow = torch.stack([flow_to(f, max(f - 1, 0)) for f in range(n_frames)])
+        self.invdepths = 1.0 / depths.clamp(min=1e-6)
         self.stats = {"mean": float(self.images.mean()), "std": float(self.images.std()),
                       "frame_to_frame": float((self.images[1:] - self.images[:-1]).abs().mean())}
         del teacher
@@ -105,8 +121,8 @@ class SyntheticFrames:
 
 
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12):
-    from localrf_amd import LocalTensorfs
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True):
+    from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
     import torch.distributed as dist
@@ -135,7 +151,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     # refinement / a new field here
     L1_weight, add_frames_every, n_overlap = 1e-2, max(1, round(100 * sc)), 3
     n_added, last_add, it = 0, 0, 0
-    losses, per_res, events = [], {}, []
+    losses, per_res, events, geo_vals = [], {}, [], []
     torch.cuda.reset_peak_memory_stats(dev)
     mem_marks = []
     training = True
@@ -150,9 +166,22 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             v0 = rank * v_sh.shape[0]
             target = target[v0 * per:(v0 + v_sh.shape[0]) * per]
             view_ids = v_sh
-        rgb_map, depth_map, _, _ = lt(ray_idx, view_ids.tolist(), W, H, is_train=True, test_id=False)
+        rgb_map, depth_map, directions, ij = lt(ray_idx, view_ids.tolist(), W, H, is_train=True, test_id=False)
         loss = (0.25 * torch.abs(rgb_map - target)).mean()             # train.py:369-371, unit loss weights
         total = loss
+        if lt.regularize and geo:                                      # train.py:357,385-423; opt.py: weights 1 and 0.1
+            reg_w = lt.lr_factor ** lt.rf_iter[-1]
+            start = max(data.active_frames_bounds[0] - 1, 0)
+            vsel = view_ids.pin_memory().to(dev, non_blocking=True)                # pageable copies would block the host (DESIGN finding 7)
+            psel = ray_idx.reshape(view_ids.shape[0], -1).pin_memory().to(dev, non_blocking=True)
+            last = data.num_images - 1
+            fl = geo_losses.flow_loss(depth_map, directions, ij, lt.get_cam2world(starting_id=start), view_ids, start,
+                                      data.fwd_flow[vsel[:, None], psel], (vsel < last).float()[:, None].expand(psel.shape),
+                                      data.bwd_flow[vsel[:, None], psel], (vsel > 0).float()[:, None].expand(psel.shape),
+                                      lt.focal(W), lt.center(W, H))
+            dl = geo_losses.depth_loss(depth_map, data.invdepths[vsel[:, None], psel], view_ids.shape[0])
+            total = total + fl * 1.0 * reg_w / ((W + H) / 2) + dl * 0.1 * reg_w
+            geo_vals.append((float(fl.detach()), float(dl.detach())) if it % 25 == 0 else None)
         if lt.regularize:
             tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)         # train.py:425-429, opt.py:111-113
             total = total + tv + l1
@@ -215,6 +244,8 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             "ms_per_iteration_by_resolution": {str(r): 1e3 * e["s"] / e["iters"] for r, e in per_res.items()},
             "iterations_by_resolution": {str(r): e["iters"] for r, e in per_res.items()},
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "memory_marks_GB": [(i, m / 2 ** 30) for i, m in mem_marks],
+            "geometric_losses": {"iterations_with_them": len(geo_vals), "flow_first_last": [v[0] for v in geo_vals if v][:1] + [v[0] for v in geo_vals if v][-1:],
+                                 "depth_first_last": [v[1] for v in geo_vals if v][:1] + [v[1] for v in geo_vals if v][-1:]},
             "checkpoint_roundtrip": bool(same), "checkpoint_keys_follow_reference": bool(keys_ok), "world": world,
             "final_resolution": res}
 
@@ -227,6 +258,7 @@ def main():
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--n-max-frames", type=int, default=12, help="frames per field before refinement (the reference: 100)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--no-geo", action="store_true", help="without the optical-flow / monocular-depth losses")
     ap.add_argument("--backend", default="nccl", help="under torchrun: nccl (= RCCL, one rank per GPU) or gloo (ranks may share a GPU)")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -249,7 +281,7 @@ def main():
     if ddp and first:
         bar()
     out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
-              dev=f"cuda:{local}", ddp=ddp, log=lambda m: print(m, file=sys.stderr, flush=True))
+              dev=f"cuda:{local}", ddp=ddp, geo=not args.no_geo, log=lambda m: print(m, file=sys.stderr, flush=True))
     if not ddp or int(os.environ["RANK"]) == 0:
         print(json.dumps(out))
         if args.json:
