@@ -103,7 +103,8 @@ void        lrf_debug_set_app_oversubscribe(int n); /* k_app workgroups per resi
 void        lrf_debug_set_subbatches(int q);        /* ray ranges of the sub-batch pipeline of lrf_render_fwd, 1..8 (default 1 = off) */
 void        lrf_debug_set_skew(int n);              /* start skew between the waves of a SIMD in k_shade2, units of 6400 cycles */
 void        lrf_debug_set_lds_lines(int on);        /* k_march: density lines staged in LDS (default on when they fit) */
-void        lrf_debug_set_bwd_overlap(int on);      /* lrf_render_bwd: weight-gradient GEMMs on a side stream (default on) */
+void        lrf_debug_set_bwd_overlap(int on);      /* lrf_render_bwd: two branches on two streams (default on) */
+void        lrf_debug_set_train_fwd_engine(int engine);   /* row-saving forward: 1 = k_bwd_shade_fwd (default), 0 = k_shade2<SAVE> in two launches (slower: DESIGN.md s4b) */
 void        lrf_debug_set_shade_pipe(int on);       /* k_shade2: software-pipelined plane-0 gather (experiment) */
 void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);

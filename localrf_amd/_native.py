@@ -74,6 +74,7 @@ SYMBOLS = {
     "lrf_debug_set_lds_lines": (None, [C.c_int]),
     "lrf_debug_set_shade_pipe": (None, [C.c_int]),
     "lrf_debug_set_bwd_overlap": (None, [C.c_int]),
+    "lrf_debug_set_train_fwd_engine": (None, [C.c_int]),
     "lrf_workspace_layout_bwd": (None, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "lrf_cache_bytes": (C.c_size_t, [C.POINTER(C.c_int32)]),
     "lrf_pack_field": (C.c_int, [C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),

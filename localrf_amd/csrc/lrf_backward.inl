@@ -31,9 +31,7 @@
 
 namespace lrf {
 
-// ---- saved rows (floats) -------------------------------------------------------------
-constexpr int ACT_X = 0, ACT_FEAT = 80, ACT_H1 = 112, ACT_H2 = 256, ACT_LD = 400;
-constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DZ1 = 48, GRD_DZ2 = 176, GRD_DX = 304, GRD_LD = 384;
+// ---- saved rows (floats): ACT_* / GRD_* column offsets are in lrf_common.h (the row-saving forward is k_shade2<SAVE>)
 // transposed fp32 fragment image for the dgrad chain
 constexpr int IMT_W2T = 0;                          // [t'8][t8][lane64][4]  W2[16t+4g+r][16t'+i]
 constexpr int IMT_W1T = IMT_W2T + 8 * 8 * 256;      // [t'2][t8][lane64][4]  W1[16t+4g+r][16t'+i]
@@ -1250,7 +1248,39 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   return b;
 }
 
+// The row-saving colour kernel: k_bwd_shade_fwd behind k_scan_tiles (default), or k_shade2<SAVE> as two launches
+// (lrf_debug_set_train_fwd_engine(0)).  Measured at configs[1] (scripts/gpu_diag.py bwd_overlap): row-saving forward
+// 0.69 ms with k_bwd_shade_fwd, 0.83 ms with k_shade2<SAVE> (its prefetched tile header + the row pointers push it to
+// 268 B of scratch per lane, in a kernel that is bound by its 1.5 KB of row stores per sample, not by the gathers the
+// prefetch hides): fwd+bwd 2.82 vs 2.93 ms.  The eval kernel's structure does not carry over.
+static int g_train_fwd_engine = 1;
+static int shade_save_attrs() {
+  static bool done[64] = {};
+  int dev = 0;
+  LRF_HIP(hipGetDevice(&dev));
+  if (!done[dev & 63]) {
+    LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    done[dev & 63] = true;
+  }
+  return 0;
+}
+static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
+                              const BwdWorkspace& b, hipStream_t st) {
+  if (g_train_fwd_engine == 1) {
+    hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
+                       b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits);
+    return;
+  }
+  const size_t lds = (size_t)IMGB_ALL * sizeof(uint4) + (size_t)S * sizeof(float);
+  hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 0, true>), dim3(device_cus()), dim3(1024), lds, st,
+                     d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, 0, 0u, (const float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, b.crgb, b.act, b.relu_bits, (int*)nullptr);
+}
+
 }  // namespace lrf
+
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_train_fwd_engine = e == 0 ? 0 : 1; }
 
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
@@ -1279,12 +1309,22 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   const DField d = make_dfield(f);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
-  launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-  hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                     b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits);
-  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
-                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
+  if (int rc = shade_save_attrs()) return rc;
+  const size_t lds_fused = (size_t)IMGB_U4 * sizeof(uint4) + (size_t)S * sizeof(float) + (size_t)(R + 1) * sizeof(int);
+  if (g_train_fwd_engine == 0 && lds_fused + 256 <= 160 * 1024) {       // two launches, as the eval forward (lrf_shade2.inl)
+    DField dd = d;
+    dd.ctr = w.ctr;
+    launch_march(dd, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
+    hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 1, true>), dim3(device_cus()), dim3(1024), lds_fused, st,
+                       dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, 0, flags, w.acc, rgb, (float*)nullptr,
+                       b.crgb, b.act, b.relu_bits, w.toff);
+  } else {
+    launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+    launch_shade_save(d, rays, z, S, R, w, b, st);
+    hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
+                       R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
+  }
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1325,8 +1365,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-    hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(cus), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                       b.crgb, b.act, (const float*)nullptr, (float*)nullptr, 0, b.relu_bits);
+    if (int rc = shade_save_attrs()) return rc;
+    launch_shade_save(d, rays, z, S, R, w, b, st);
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
   //   caller's stream: k_bwd_shade_dgrad -> k_wgrad (dW2) -> appearance bins + scatter     [-> join] -> ray partials, unpack

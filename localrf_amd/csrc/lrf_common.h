@@ -79,6 +79,12 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
 }
 
 // Device-side view of a field, passed by value to kernels.
+// ---- rows the training forward saves per shaded sample for the backward (floats; lrf_backward.inl) --------------
+//   ACT row: X[72] (+8 pad) | feat[27], 1 | relu(h1)[128], 1 (+pad) | relu(h2)[128], dhat[3], 1 (+pad)
+//   GRD row: go[3] | dfeat | dz1 | dz2 | dX
+constexpr int ACT_X = 0, ACT_FEAT = 80, ACT_H1 = 112, ACT_H2 = 256, ACT_LD = 400;
+constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DZ1 = 48, GRD_DZ2 = 176, GRD_DX = 304, GRD_LD = 384;
+
 struct DField {
   const float* dplane[3]; const float* dline[3];
   const float* aplane[3]; const float* aline[3];

@@ -493,6 +493,11 @@ __device__ __forceinline__ void plane_touch(const DField& f, const float u[3], i
 //    that range; the <= gridDim.x - 1 rays that straddle a workgroup boundary are summed by whichever workgroup
 //    finishes last (release fence + counter f.ctr, zeroed by the k_march of the same call; agent-scope loads).
 // No float atomics, no spinning: results do not depend on the order in which workgroups finish.
+// the lane's 6 gathered products of one plane into the ACT row (natural channel order)
+__device__ __forceinline__ void save_x6(float* dst, const float v[8]) {
+#pragma unroll
+  for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(dst + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+}
 template <bool COHERENT>
 __device__ __forceinline__ void finalize_ray(int ray, int nit, int pmax, uint32_t flags, const float* __restrict__ acc,
                                              const float* part, float* __restrict__ rgb, float* __restrict__ acc_out) {
@@ -528,12 +533,19 @@ __device__ __forceinline__ int toff_lower_bound(const lds_int* toff, int n, int 
   return lo < n ? lo : n;
 }
 
-template <bool TIMED, bool PIPE = false, int TOUCH = 0, int VAR = 0, int FUSE = 0>
+// SAVE: the row-saving forward of training (lrf_render_fwd_train, and the recompute path of lrf_render_bwd): besides
+// the tile partials it leaves, per shaded sample, the colour (crgb), the ACT row [X | feat, 1 | relu(h1), 1 |
+// relu(h2), dhat, 1] (the 1 columns turn bias gradients into GEMM columns of k_wgrad) and the two layers' ReLU
+// masks as one dword per lane and layer (bit 4 q + r = unit 16 q + 4 g + r of sample s) for k_bwd_shade_dgrad.
+// With FUSE the tile offsets (needed by the backward kernels) are also written to global memory by workgroup 0.
+template <bool TIMED, bool PIPE = false, int TOUCH = 0, int VAR = 0, int FUSE = 0, bool SAVE = false>
 __global__ __launch_bounds__(1024) void k_shade2(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff_g, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
     const float* __restrict__ cw, float* __restrict__ part, int pmax, int skew,
-    uint32_t flags, const float* __restrict__ acc, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+    uint32_t flags, const float* __restrict__ acc, float* __restrict__ rgb_out, float* __restrict__ acc_out,
+    float* __restrict__ crgb = nullptr, float* __restrict__ act = nullptr, uint32_t* __restrict__ relu_bits = nullptr,
+    int* __restrict__ toff_out = nullptr) {
   static_assert(!FUSE || (VAR & 2), "the fused variant stages the image without the head fragments (VALU head)");
   extern __shared__ uint4 s_dyn[];                             // image (basis, W1, W2, tail[, head]), z[S][, toff[R + 1]]
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -569,6 +581,8 @@ __global__ __launch_bounds__(1024) void k_shade2(
     if (tid == 0) s_toff[R] = carry;
   }
   __syncthreads();
+  if (FUSE && SAVE && blockIdx.x == 0)
+    for (int i = threadIdx.x; i <= R; i += blockDim.x) toff_out[i] = s_toff[i];
   const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
   const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
   // Phase skew: the four waves of a SIMD (waves w, w+4, w+8, w+12 of the workgroup) start `skew` x 6400 cycles
@@ -610,6 +624,7 @@ __global__ __launch_bounds__(1024) void k_shade2(
       for (int i = 0; i < 6 * TOUCH; ++i) sink += touch[i];
     }
     if (!PIPE) sample_point(f, rg.o, rg.dh, s_z[k], x, u);
+    float* arow = SAVE ? act + ((size_t)t * 16 + s) * ACT_LD : nullptr;
     const float w = s < cnt ? cw[(size_t)ray_c * S + j0 + s] : 0.0f;          // needed at the end of the tile
     int k_n = 0, j0_n = 0, cnt_n = 0, ray_n = ray_c;
     RayGeo rg_n = rg;
@@ -628,18 +643,30 @@ __global__ __launch_bounds__(1024) void k_shade2(
       float v[8];
       bf16x8 bh, bl;
       if (PIPE) plane_combine(raw0, v); else gather_app6_plane32<0>(f, u, g, v);
+      if (SAVE) save_x6(arow + ACT_X + 0 * LRF_CA + 6 * g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       LRF_TICK(1);
       gather_app6_plane32<1>(f, u, g, v);
+      if (SAVE) save_x6(arow + ACT_X + 1 * LRF_CA + 6 * g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
       LRF_TICK(2);
       gather_app6_plane32<2>(f, u, g, v);
+      if (SAVE) save_x6(arow + ACT_X + 2 * LRF_CA + 6 * g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
       LRF_TICK(3);
+    }
+    if (SAVE) {                        // feat (27) | 1 | 0 0 0 0 ; pad columns 72..79 of the X block
+      float4 a4 = make_float4(fe[0][0], fe[0][1], fe[0][2], fe[0][3]);
+      float4 b4 = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
+      if (g == 2) b4.w = 1.0f;                       // column 27 = bias column of the dW1 GEMM
+      if (g == 3) b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(arow + ACT_FEAT + 4 * g) = a4;
+      *reinterpret_cast<float4*>(arow + ACT_FEAT + 16 + 4 * g) = b4;
+      if (g < 2) *reinterpret_cast<float4*>(arow + 72 + 4 * g) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     f32x4 h1[8];
 #pragma unroll
@@ -659,6 +686,20 @@ __global__ __launch_bounds__(1024) void k_shade2(
         gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
         settle<8>(h1);
       }
+    }
+    if (SAVE) {
+      uint32_t m1 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h1[q][r] = relu_i(h1[q][r]);
+          m1 |= min(__float_as_uint(h1[q][r]), 1u) << (4 * q + r);         // relu output: +0 or positive
+        }
+        *reinterpret_cast<f32x4*>(arow + ACT_H1 + 16 * q + 4 * g) = h1[q];
+      }
+      *reinterpret_cast<float4*>(arow + ACT_H1 + 128 + 4 * g) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+      relu_bits[((size_t)t * 2 + 0) * 64 + lane] = m1;
     }
     LRF_TICK(4);
     f32x4 h2[8];
@@ -683,6 +724,21 @@ __global__ __launch_bounds__(1024) void k_shade2(
       asm volatile("" ::: "memory");
     } else {
       settle<8>(h2);
+    }
+    if (SAVE) {
+      uint32_t m2 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h2[q][r] = relu_i(h2[q][r]);
+          m2 |= min(__float_as_uint(h2[q][r]), 1u) << (4 * q + r);
+        }
+        *reinterpret_cast<f32x4*>(arow + ACT_H2 + 16 * q + 4 * g) = h2[q];
+      }
+      *reinterpret_cast<float4*>(arow + ACT_H2 + 128 + 4 * g) =
+          g == 0 ? make_float4(rg.dh[0], rg.dh[1], rg.dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      relu_bits[((size_t)t * 2 + 1) * 64 + lane] = m2;
     }
     LRF_TICK(5);
     if (PIPE && t + 1 < t1) {          // next tile: position, then its plane-0 loads go out under the head phase
@@ -730,9 +786,14 @@ __global__ __launch_bounds__(1024) void k_shade2(
       vb[c] = wv.w + wv.x * rg.dh[0] + wv.y * rg.dh[1] + wv.z * rg.dh[2];
     }
     const float wq = g != 0 ? 0.0f : w;                        // only the g = 0 lanes hold a colour
-    float cr = wq * __frcp_rn(1.0f + __expf(-(oc[0] + vb[0])));
-    float cg = wq * __frcp_rn(1.0f + __expf(-(oc[1] + vb[1])));
-    float cb = wq * __frcp_rn(1.0f + __expf(-(oc[2] + vb[2])));
+    const float sr = __frcp_rn(1.0f + __expf(-(oc[0] + vb[0])));
+    const float sg = __frcp_rn(1.0f + __expf(-(oc[1] + vb[1])));
+    const float sb = __frcp_rn(1.0f + __expf(-(oc[2] + vb[2])));
+    if (SAVE && g == 0 && s < cnt) {                           // the sample's colour: d sigmoid = c (1 - c) in the backward
+      float* cp = crgb + ((size_t)ray_c * S + j0 + s) * 3;
+      cp[0] = sr; cp[1] = sg; cp[2] = sb;
+    }
+    float cr = wq * sr, cg = wq * sg, cb = wq * sb;
 #pragma unroll
     for (int dd = 1; dd < 16; dd <<= 1) {
       cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);

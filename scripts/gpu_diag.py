@@ -1129,22 +1129,33 @@ def stage_bwd_overlap():
     for p in f.parameters():
         p.requires_grad_(True)
     ref = None
-    for on in (1, 0, 1, 0):
+    for on, eng in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 0), (1, 1)):
         lib.lrf_debug_set_bwd_overlap(on)
-        for _ in range(5):
+        lib.lrf_debug_set_train_fwd_engine(eng)
+        for _ in range(10):
             step()
         torch.cuda.synchronize()
         t0 = time.time()
-        for _ in range(20):
+        for _ in range(40):
             step()
         torch.cuda.synchronize()
-        dt = (time.time() - t0) / 20 * 1e3
+        dt = (time.time() - t0) / 40 * 1e3
+        with torch.no_grad():                                 # the row-saving forward alone
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for _ in range(40):
+                with torch.enable_grad():
+                    f(rays, white_bg=True, is_train=False, N_samples=1536)
+            torch.cuda.synchronize()
+            dtf = (time.time() - t1) / 40 * 1e3
         gsum = {n: p.grad.double().abs().sum().item() for n, p in f.named_parameters() if p.grad is not None}
         if ref is None:
             ref = gsum
         worst = max(abs(gsum[k] - ref[k]) / max(ref[k], 1e-30) for k in ref)
-        log(f"bwd overlap {on}: fwd+bwd {dt:.3f} ms | max relative change of a gradient's |sum| vs first run {worst:.2e}")
+        log(f"bwd overlap {on}, row-saving forward {'k_shade2<SAVE>' if eng == 0 else 'k_bwd_shade_fwd'}: fwd+bwd {dt:.3f} ms (forward alone {dtf:.3f} ms) | "
+            f"max relative change of a gradient's |sum| vs first run {worst:.2e}")
     lib.lrf_debug_set_bwd_overlap(1)
+    lib.lrf_debug_set_train_fwd_engine(1)
 
 
 def stage_shade_pipe():

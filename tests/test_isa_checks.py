@@ -43,7 +43,8 @@ def _overlap(x, y):
 # compiler-scheduled builtin, pinned by the 200-render determinism test on the GPU; policy 0 is the hand-issued
 # fallback and is held to the rules below.
 SHIPPED = (("k_shade_bf16E", 138), ("k_bwd_shade_fwdE", 138), ("k_appE", 18), ("k_mlpILi0ELb0ELb1EE", 132),
-           ("k_shade2ILb0ELb0ELi0ELi3ELi0EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1EE", 138))
+           ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE", 138),
+           ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", 138))
 
 
 def _shipped_text(asm, kern):
@@ -122,7 +123,8 @@ def test_bf16_mfma_sources_are_not_rewritten_close_behind(asm):
 
 def test_scratch_use_is_bounded(asm):
     for kern, limit in (("k_marchILb1EE", 0), ("k_marchILb0EE", 0), ("k_shade_bf16E", 128), ("k_appE", 0), ("k_mlpILi0ELb0ELb1EE", 0), ("k_mlpILi4ELb0ELb1EE", 0),
-                        ("k_shade2ILb0ELb0ELi0ELi3ELi0EE", 0), ("k_shade2ILb0ELb0ELi0ELi3ELi1EE", 0)):
+                        ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", 0), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE", 0),
+                        ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", 320), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", 320)):
         m = re.search(r"\.amdhsa_kernel _ZN3lrf\d+%s.*?\.end_amdhsa_kernel" % kern, asm, re.S)
         assert m, kern
         priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m[0])
