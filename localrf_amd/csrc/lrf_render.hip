@@ -992,6 +992,7 @@ constexpr int MAX_SUB = 8;         // sub-batch pipeline of lrf_render_fwd (see 
 static int g_subbatches = 1;       // measured on MI355X: a cross-stream event wait costs ~50 us, more than the overlap returns
 static int sub_rays(int R, int Q) { return (((R + Q - 1) / Q) + 3) & ~3; }       // k_march blocks hold 4 rays
 static int g_no_lds_lines = 0;     // lrf_debug_set_lds_lines(0): k_march reads its lines from global memory
+static bool g_last_fused = false;   // the last render_fwd_one ran the two-launch sequence (read by lrf_render_fwd_profile)
 static int g_shade_pipe = 0;       // lrf_debug_set_shade_pipe: k_shade2 with the next tile's plane-0 gather issued under the head phase
 static int g_skew = 0;             // lrf_debug_set_skew: phase skew of k_shade2's waves, units of 6400 cycles
 static int g_app_over = 4;         // lrf_debug_set_app_oversubscribe: k_app workgroups per resident slot
@@ -1163,7 +1164,8 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
     DField dd = d;
     dd.ctr = w.ctr;
     launch_march(dd, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
-    if (ev) { LRF_HIP(hipEventRecord(ev[1], st)); LRF_HIP(hipEventRecord(ev[5], st)); }
+    if (ev) LRF_HIP(hipEventRecord(ev[1], st));
+    g_last_fused = true;
     static bool attr_done[64] = {};
     int dev = 0;
     LRF_HIP(hipGetDevice(&dev));
@@ -1182,9 +1184,10 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
     else
       hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 1>), dim3(device_cus()), dim3(1024), lds_fused, st,
                          dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-    if (ev) { LRF_HIP(hipEventRecord(ev[2], st)); LRF_HIP(hipEventRecord(ev[3], st)); }
+    if (ev) LRF_HIP(hipEventRecord(ev[2], st));
     return 0;
   }
+  g_last_fused = false;
   launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (flags & LRF_FLAG_MLP_VALU) {
@@ -1314,14 +1317,20 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
   LRF_HIP(hipEventRecord(ev[5], st));      // re-recorded after k_scan_tiles by the MFMA engines
   int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, nullptr, nullptr, workspace, st, ev);
   if (rc == 0) {
-    hipError_t e = hipEventSynchronize(ev[3]);
-    if (e != hipSuccess) rc = set_err("hipEventSynchronize", e);
+    hipError_t e = hipStreamSynchronize(st);             // (the two-launch sequence records ev[0..2] only)
+    if (e != hipSuccess) rc = set_err("hipStreamSynchronize", e);
   }
   if (rc == 0) {
-    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
-    (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
-    ms_out[4] = ms_out[5] = 0.0f;          // shade = k_scan_tiles [4] + k_app [5] + k_mlp (default engine)
-    if (!(flags & LRF_FLAG_MLP_VALU)) (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[5]);
+    ms_out[2] = ms_out[4] = ms_out[5] = 0.0f;          // shade = k_scan_tiles [4] + k_app [5] + k_mlp (default engine)
+    if (g_last_fused) {                    // two launches: k_march, k_shade2 (scan and finalize inside)
+      (void)hipEventElapsedTime(&ms_out[0], ev[0], ev[1]);
+      (void)hipEventElapsedTime(&ms_out[1], ev[1], ev[2]);
+      (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[2]);
+    } else {
+      for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+      (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
+    }
+    if (!g_last_fused && !(flags & LRF_FLAG_MLP_VALU)) (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[5]);
     if ((flags & LRF_FLAG_MLP_SPLIT) && !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED)))
       (void)hipEventElapsedTime(&ms_out[5], ev[5], ev[4]);
     if (n_shaded_out) {
