@@ -1129,7 +1129,7 @@ def stage_bwd_overlap():
     for p in f.parameters():
         p.requires_grad_(True)
     ref = None
-    for on, eng in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 0), (1, 1)):
+    for on, eng in ((1, 1), (0, 1), (1, 0), (0, 0), (1, 1), (1, 0)):
         lib.lrf_debug_set_bwd_overlap(on)
         lib.lrf_debug_set_train_fwd_engine(eng)
         for _ in range(10):
