@@ -153,6 +153,46 @@ def torch_rocm_baseline(field_sd, rays, iters=5):
     return out
 
 
+def geometric_losses_workload(dev, V=16, n=256, Fr=20, W=640, H=480, iters=100):
+    """the flow + depth losses of train.py:385-423 on a 4096-ray batch (16 views), forward + backward:
+    localrf_amd.losses (HIP) and, beside it, the ATen op chain (oracle/vm_render_torch.py: baseline leg only)."""
+    from localrf_amd import losses
+    from oracle import vm_render_torch as ot
+    gen = torch.Generator().manual_seed(7)
+    rot = torch.linalg.qr(torch.eye(3)[None] + 0.05 * torch.randn(Fr, 3, 3, generator=gen))[0]
+    c2w = torch.cat([rot, 0.2 * torch.randn(Fr, 3, 1, generator=gen)], -1).to(dev)
+    col, row = torch.randint(0, W, (V, n), generator=gen), torch.randint(0, H, (V, n), generator=gen)
+    kw = dict(ij=torch.stack([col, row], -1).to(dev), view_ids=torch.randperm(Fr, generator=gen)[:V].to(dev), starting_frame_id=0,
+              fwd_flow=(4 * torch.randn(V, n, 2, generator=gen)).to(dev), bwd_flow=(4 * torch.randn(V, n, 2, generator=gen)).to(dev),
+              fwd_mask=(torch.rand(V, n, generator=gen) > 0.2).float().to(dev), bwd_mask=(torch.rand(V, n, generator=gen) > 0.2).float().to(dev))
+    dirs = torch.stack([(col + 0.5 - W / 2) / 500.0, -(row + 0.5 - H / 2) / 500.0, -torch.ones(V, n)], -1).to(dev)
+    depth0 = (0.5 + 5 * torch.rand(V, n, generator=gen)).to(dev)
+    inv = (0.1 + torch.rand(V, n, generator=gen)).to(dev)
+
+    def step(impl):
+        lv = dict(depth_map=depth0.clone().requires_grad_(True), directions=dirs.clone().requires_grad_(True),
+                  cam2world=c2w.clone().requires_grad_(True), focal=torch.tensor([500.0], device=dev, requires_grad=True),
+                  center=torch.tensor([W / 2.0, H / 2.0], device=dev, requires_grad=True))
+        if impl == "hip":
+            total = losses.flow_loss(**lv, **kw) + 0.1 * losses.depth_loss(lv["depth_map"], inv, V)
+        else:
+            total = ot.flow_loss(**lv, **kw)[0] + 0.1 * ot.depth_loss(lv["depth_map"], inv)[0]
+        total.backward()
+        return total.detach()
+    out = {"what": "flow + depth losses of train.py:385-423, forward + backward, 4096 rays over 16 views"}
+    for impl in ("hip", "aten"):
+        for _ in range(10):
+            step(impl)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            v = step(impl)
+        torch.cuda.synchronize(dev)
+        out[impl + "_ms"] = (time.perf_counter() - t0) / iters * 1e3
+        out[impl + "_value"] = float(v)
+    return out
+
+
 # ------------------------------------------------------------------------------ measurement helpers
 def timed(fn, steps, warmup, sync):
     for _ in range(warmup):
@@ -454,11 +494,11 @@ def main():
         n_sh = prof["n_shaded"]
         rows = ((n_sh + 15) // 16) * 16
         # bytes the training step moves through HBM-side memory by construction: the saved activation /
-        # gradient rows (ACT 400 + GRD 384 floats per row: written once; wgrad reads both, dgrad re-reads
-        # h1/h2), the density features (R*S floats, written + read twice), gradient images + reference-layout
+        # gradient rows (ACT 400 + GRD 384 floats per row: written once, read once by the weight-gradient GEMMs; the
+        # data gradient takes its ReLU masks from 32 B per sample), the density features (R*S floats, written + read twice), gradient images + reference-layout
         # gradients (3 x 35 MB) + Adam (param, m, v read+write) -- cache-served gathers not counted
         n_par = sum(p.numel() for p in field.parameters() if p.requires_grad)
-        train_bytes = rows * 4 * (400 * 2 + 256 + 384 * 2) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
+        train_bytes = rows * (4 * (400 * 2 + 384 * 2) + 32 * 2) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
         train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
                  "what": "lrf_render_fwd_train + lrf_render_bwd + "
                          + (f"allreduce_grads over RCCL ({reduced[0] / 1e6:.1f} MB in place) + " if ddp else "")
@@ -525,6 +565,10 @@ def main():
                 del lt
             except Exception as e:                           # noqa: BLE001
                 work["config3_4x300"] = {"error": repr(e)}
+            try:
+                work["geometric_losses"] = geometric_losses_workload(dev)
+            except Exception as e:                           # noqa: BLE001
+                work["geometric_losses"] = {"error": repr(e)}
             out["workloads"] = work
             sd = field.state_dict()
             out["torch_rocm_baseline"] = torch_rocm_baseline(sd, rays)
