@@ -341,6 +341,8 @@ def test_two_launch_sequence_equals_four_launch_sequence(big):
     both(f, rays, N=1032)                                    # S = 344
     many = make_rays(20000, 5).to(DEV)                       # offsets do not fit in LDS: four launches either way
     both(f, many)
+    both(f, many[:12000])                                    # 12 rounds of the in-kernel scan, ~47 rays per workgroup
+    both(f, many[:5000], N=6144)                             # S = 2048
     far = rays.clone()
     far[::3, :3] = 50.0                                      # every third ray starts far outside and points away:
     far[::3, 3:] = torch.tensor([1.0, 0.2, 0.1], device=DEV)  # only the forced last sample can be shaded
