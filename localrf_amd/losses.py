@@ -79,6 +79,11 @@ def flow_loss(depth_map, directions, ij, cam2world, view_ids, starting_frame_id,
     n = depth.shape[1]
     if n > N.LRF_LOSS_MAX_PER_VIEW:
         raise ValueError(f"at most {N.LRF_LOSS_MAX_PER_VIEW} rays per view")
+    if view_ids.device.type == "cpu" and V:                       # (ids on the device are not checked: that would synchronise)
+        lo, hi = int(view_ids.min()) - int(starting_frame_id), int(view_ids.max()) - int(starting_frame_id)
+        if lo < 0 or hi >= int(cam2world.shape[0]):
+            raise IndexError(f"view ids {int(view_ids.min())}..{int(view_ids.max())} outside cam2world[{starting_frame_id}:"
+                             f"{starting_frame_id + int(cam2world.shape[0])}]")
     frame = _i32(view_ids, dev) - int(starting_frame_id)
     # train.py:396 compares the ABSOLUTE view id with the length of the cam2world slice; reproduced as is
     fwd_off = (_i32(view_ids, dev) == int(cam2world.shape[0]) - 1).to(torch.int32).contiguous()
