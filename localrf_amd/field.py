@@ -350,7 +350,7 @@ class TensorVMSplit(torch.nn.Module):
                 f"{t.device} tensor. There is no CPU fallback.")
 
     def _c_params(self):
-        ps = [p.detach() for p in self._param_list()]
+        ps = self._param_list()                              # only data_ptr() is taken: no detach()
         for p in ps:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise N.NativeError("localrf_amd: parameters must be contiguous fp32")

@@ -19,9 +19,15 @@ from .scene_ops import _f32c, _stream
 
 
 def _i32(t, dev):
+    """int32 on the device.  Host ids are staged through pinned memory: a pageable host->device copy blocks the host
+    until the stream has drained (DESIGN.md finding 7), which would serialise the iteration."""
     if not torch.is_tensor(t):
         t = torch.as_tensor(t)
-    return t.to(device=dev, dtype=torch.int32).contiguous()
+    if t.is_cuda:
+        return t.to(dtype=torch.int32).contiguous()
+    stage = torch.empty(t.shape, dtype=torch.int32, pin_memory=True)
+    stage.copy_(t)
+    return stage.to(dev, non_blocking=True)
 
 
 class _FlowLossFn(torch.autograd.Function):
@@ -43,7 +49,7 @@ class _FlowLossFn(torch.autograd.Function):
         arr = torch.empty(V, n, dtype=torch.float32, device=dev)
         vsum = torch.empty(V, dtype=torch.float32, device=dev)
         N.check(N.lib().lrf_flow_loss_fwd(C.byref(a), N.ptr(arr), N.ptr(vsum), _stream(dev)), "lrf_flow_loss_fwd")
-        ctx.args, ctx.keep, ctx.arr = a, keep, arr
+        ctx.args, ctx.keep, ctx.arr = a, [t.detach() for t in keep], arr     # (kept alive for the raw pointers in `a`)
         ctx.focal_shape = focal.shape
         ctx.mark_non_differentiable(arr)
         return vsum.sum() / float(V * n), arr
@@ -84,12 +90,18 @@ def flow_loss(depth_map, directions, ij, cam2world, view_ids, starting_frame_id,
         if lo < 0 or hi >= int(cam2world.shape[0]):
             raise IndexError(f"view ids {int(view_ids.min())}..{int(view_ids.max())} outside cam2world[{starting_frame_id}:"
                              f"{starting_frame_id + int(cam2world.shape[0])}]")
-    frame = _i32(view_ids, dev) - int(starting_frame_id)
     # train.py:396 compares the ABSOLUTE view id with the length of the cam2world slice; reproduced as is
-    fwd_off = (_i32(view_ids, dev) == int(cam2world.shape[0]) - 1).to(torch.int32).contiguous()
+    if view_ids.device.type == "cpu":                              # one staged upload: [frame index | forward-mask-off flag]
+        both = _i32(torch.stack([view_ids.to(torch.int64) - int(starting_frame_id),
+                                 (view_ids == int(cam2world.shape[0]) - 1).to(torch.int64)]), dev)
+        frame, fwd_off = both[0], both[1]
+    else:
+        ids = _i32(view_ids, dev)
+        frame = ids - int(starting_frame_id)
+        fwd_off = (ids == int(cam2world.shape[0]) - 1).to(torch.int32)
     if not torch.is_tensor(focal):
         focal = torch.tensor([float(focal)], device=dev)
-    loss, arr = _FlowLossFn.apply(depth, directions.reshape(V, n, 3), cam2world, focal, center, ij.reshape(V, n, 2), frame.contiguous(), fwd_off,
+    loss, arr = _FlowLossFn.apply(depth, directions.reshape(V, n, 3), cam2world, focal, center, ij.reshape(V, n, 2), frame.contiguous(), fwd_off.contiguous(),
                                   fwd_flow.reshape(V, n, 2), fwd_mask.reshape(V, n).float(), bwd_flow.reshape(V, n, 2),
                                   bwd_mask.reshape(V, n).float(), quantile)
     return (loss, arr) if return_arr else loss
@@ -106,7 +118,7 @@ class _DepthLossFn(torch.autograd.Function):
         vsum = torch.empty(V, dtype=torch.float32, device=dev)
         N.check(N.lib().lrf_depth_loss_fwd(N.ptr(d), N.ptr(g), V, n, float(q), N.ptr(arr), N.ptr(stats), N.ptr(vsum), _stream(dev)),
                 "lrf_depth_loss_fwd")
-        ctx.keep = (d, g, arr, stats)
+        ctx.keep = (d.detach(), g.detach(), arr, stats)
         ctx.mark_non_differentiable(arr)
         return vsum.sum() / float(V * n), arr
 

@@ -246,8 +246,11 @@ class LocalTensorfs(torch.nn.Module):
         """[V,3,4] camera-to-world from the 6D rotation + translation params (:292-299)."""
         if view_ids is not None:
             ids = view_ids.tolist() if torch.is_tensor(view_ids) else list(view_ids)   # one sync, not one per view
-            r = [self.r_c2w[v] for v in ids]
-            t = [self.t_c2w[v] for v in ids]
+            rp, tp = self.r_c2w._parameters, self.t_c2w._parameters      # ParameterList.__getitem__ costs ~3 us a piece
+            n = len(rp)
+            keys = [str(v if v >= 0 else v + n) for v in ids]
+            r = [rp[k] for k in keys]
+            t = [tp[k] for k in keys]
         else:
             r = list(self.r_c2w[starting_id:])
             t = list(self.t_c2w[starting_id:])

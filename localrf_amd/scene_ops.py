@@ -19,6 +19,10 @@ def _stream(dev):
 
 
 def _f32c(t):
+    """Contiguous fp32 view of t for a native call (only data_ptr() is taken, so an already conforming tensor is
+    passed through as is: detach() alone costs ~4 us, 70 of them per training iteration)."""
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
     return t.detach().contiguous().float()
 
 

@@ -1085,6 +1085,30 @@ def stage_geo():
     log(f"upsample max |kernel - ATen| {float((dst - ref).abs().max()):.2e}")
 
 
+def stage_train_host():
+    """Host-side profile of the progressive training iteration (scripts/train_synth.py at a small resolution, where
+    the GPU work is short and the iteration time is what Python spends)."""
+    import cProfile, pstats, io as _io
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import train_synth
+    train_synth.run(frames=6, final=80, iters_per_frame=20, max_iters=60, dev="cuda:0")          # warm everything
+    for geo in (True, False):
+        out = train_synth.run(frames=8, final=100, iters_per_frame=30, max_iters=300, dev="cuda:0", geo=geo)
+        log(f"plain run (geometric losses {'on' if geo else 'off'}): ms/iteration by resolution {({k: round(v, 3) for k, v in out['ms_per_iteration_by_resolution'].items()})}")
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pr.enable()
+    out = train_synth.run(frames=8, final=100, iters_per_frame=30, max_iters=300, dev="cuda:0")
+    pr.disable()
+    torch.cuda.synchronize()
+    log(f"300 iterations in {time.perf_counter() - t0:.2f} s under cProfile; ms/iteration by resolution {out['ms_per_iteration_by_resolution']}")
+    buf = _io.StringIO()
+    pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(45)
+    log(buf.getvalue()[-7000:])
+
+
 def stage_march():
     """k_march with its density lines in LDS vs in global memory (300^3 and 500^3)."""
     import torch
@@ -1285,7 +1309,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -159,7 +159,11 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     res = int(lt.tensorfs[-1].gridSize[0])
     while training and (max_iters is None or it < max_iters):
         view_ids, ray_idx, (vv, pp) = data.sample(batch)
-        target = data.images[vv, pp].reshape(-1, 3)
+        # indices go up through pinned memory: indexing a device tensor with host indices (or any pageable
+        # host->device copy, as train.py:352-358 does) blocks the host until the stream has drained
+        vv_d = vv.pin_memory().to(dev, non_blocking=True)
+        pp_d = pp.pin_memory().to(dev, non_blocking=True)
+        target = data.images[vv_d, pp_d].reshape(-1, 3)
         if ddp:                                                        # this rank's views of the common batch
             per = ray_idx.shape[0] // view_ids.shape[0]
             ray_idx, v_sh = shard_views(ray_idx, view_ids, rank, world)
@@ -172,8 +176,11 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
         if lt.regularize and geo:                                      # train.py:357,385-423; opt.py: weights 1 and 0.1
             reg_w = lt.lr_factor ** lt.rf_iter[-1]
             start = max(data.active_frames_bounds[0] - 1, 0)
-            vsel = view_ids.pin_memory().to(dev, non_blocking=True)                # pageable copies would block the host (DESIGN finding 7)
-            psel = ray_idx.reshape(view_ids.shape[0], -1).pin_memory().to(dev, non_blocking=True)
+            if ddp:
+                vsel = view_ids.pin_memory().to(dev, non_blocking=True)
+                psel = ray_idx.reshape(view_ids.shape[0], -1).pin_memory().to(dev, non_blocking=True)
+            else:
+                vsel, psel = vv_d[:, 0], pp_d
             last = data.num_images - 1
             fl = geo_losses.flow_loss(depth_map, directions, ij, lt.get_cam2world(starting_id=start), view_ids, start,
                                       data.fwd_flow[vsel[:, None], psel], (vsel < last).float()[:, None].expand(psel.shape),
