@@ -180,17 +180,18 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     {
       float v[8];
       bf16x8 bh, bl;
-      gather_app6_plane<0>(f, u, g, v);
+      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);   // 32-bit gathers, taps once per axis (as k_shade2)
+      gather_app6_plane32<0>(f, at, g, v);
 #pragma unroll
       for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 0 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
-      gather_app6_plane<1>(f, u, g, v);
+      gather_app6_plane32<1>(f, at, g, v);
 #pragma unroll
       for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 1 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
-      gather_app6_plane<2>(f, u, g, v);
+      gather_app6_plane32<2>(f, at, g, v);
 #pragma unroll
       for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 2 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
       split8(v, bh, bl);

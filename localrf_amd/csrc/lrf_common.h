@@ -126,6 +126,19 @@ __device__ __forceinline__ void tap1d(float u, int size, int& i0, int& i1, float
   i1 = min(i0 + 1, size - 1);
 }
 
+// The interpolation taps of a sample along the three axes, computed once: plane p samples axes MAT0[p] / MAT1[p] and its
+// line axis VEC[p], and make_layout gives every plane / line the grid size of the axis it lies along
+// (pw[p] = grid[MAT0[p]], ph[p] = grid[MAT1[p]], ll[p] = grid[VEC[p]]), so the nine tap1d calls of a three-plane lookup
+// are three distinct ones.  Same arithmetic, same values.
+struct AxisTaps { int i0[3], i1[3]; float t[3]; };
+__device__ __forceinline__ AxisTaps axis_taps(const int pw0, const int ph0, const int ll0, const float u[3]) {
+  AxisTaps a;
+  tap1d(u[0], pw0, a.i0[0], a.i1[0], a.t[0]);        // grid[0] = pw[0]
+  tap1d(u[1], ph0, a.i0[1], a.i1[1], a.t[1]);        // grid[1] = ph[0]
+  tap1d(u[2], ll0, a.i0[2], a.i1[2], a.t[2]);        // grid[2] = ll[0]
+  return a;
+}
+
 // tensorBase.py:495-499 (torch softplus: beta=1, threshold=20)
 __device__ __forceinline__ float feature2density(float f, float shift, bool relu) {
   if (relu) return fmaxf(f, 0.0f);
@@ -257,12 +270,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool LDSL>
 __device__ __forceinline__ float density_feature_m(const DField& f, const float u[3], const float* const s_line[3]) {
   f32x2 acc = {0.0f, 0.0f};
+  const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
-    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    const int x0 = at.i0[MAT0[p]], x1 = at.i1[MAT0[p]], y0 = at.i0[MAT1[p]], y1 = at.i1[MAT1[p]];
+    const int l0 = at.i0[VEC[p]], l1 = at.i1[VEC[p]];
+    const float tx = at.t[MAT0[p]], ty = at.t[MAT1[p]], tl = at.t[VEC[p]];
     const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
     const unsigned o00 = (row0 + x0) * (LRF_CD * 4u), o10 = (row0 + x1) * (LRF_CD * 4u);
     const unsigned o01 = (row1 + x0) * (LRF_CD * 4u), o11 = (row1 + x1) * (LRF_CD * 4u);

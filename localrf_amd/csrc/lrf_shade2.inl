@@ -79,11 +79,10 @@ __device__ __forceinline__ RayGeo load_ray(const float* __restrict__ rays, int r
 
 // gather_app6_plane with 32-bit byte offsets (ld4b): same taps, same arithmetic order
 template <int p>
-__device__ __forceinline__ void gather_app6_plane32(const DField& f, const float u[3], int g, float X[8]) {
-  int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-  tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-  tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-  tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+__device__ __forceinline__ void gather_app6_plane32(const DField& f, const AxisTaps& at, int g, float X[8]) {
+  const int x0 = at.i0[MAT0[p]], x1 = at.i1[MAT0[p]], y0 = at.i0[MAT1[p]], y1 = at.i1[MAT1[p]];
+  const int l0 = at.i0[VEC[p]], l1 = at.i1[VEC[p]];
+  const float tx = at.t[MAT0[p]], ty = at.t[MAT1[p]], tl = at.t[VEC[p]];
   const unsigned gb = 32u * (unsigned)g;                                   // this lane group's 8 slots of the 128-byte texel
   const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
   const unsigned o00 = (row0 + x0) * (LRF_CAS * 4u) + gb, o10 = (row0 + x1) * (LRF_CAS * 4u) + gb;
@@ -99,9 +98,12 @@ __device__ __forceinline__ void gather_app6_plane32(const DField& f, const float
     const float4 e = ld4b(f.aline[p], q0 + 16 * h), q = ld4b(f.aline[p], q1 + 16 * h);
     X[4 * h]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
     X[4 * h + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
-    X[4 * h + 2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
-    X[4 * h + 3] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + q.w * wl1);
+    if (h == 0) {
+      X[2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
+      X[3] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + q.w * wl1);
+    }
   }
+  X[6] = 0.0f; X[7] = 0.0f;            // slots 6, 7 of a lane group are the texel's zero pads (app_pc): +0 x weights = +0
 }
 
 // ------------------------------------------------------------------------------- k_app
@@ -147,13 +149,14 @@ __global__ __launch_bounds__(256) void k_app(
     {
       float v[8];
       bf16x8 bh, bl;
-      gather_app6_plane32<0>(f, u, g, v);
+      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);
+      gather_app6_plane32<0>(f, at, g, v);
       split8(v, bh, bl);
       gemm_step<2>(bas, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
-      gather_app6_plane32<1>(f, u, g, v);
+      gather_app6_plane32<1>(f, at, g, v);
       split8(v, bh, bl);
       gemm_step<2>(bas, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
-      gather_app6_plane32<2>(f, u, g, v);
+      gather_app6_plane32<2>(f, at, g, v);
       split8(v, bh, bl);
       gemm_step<2>(bas, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
@@ -642,17 +645,18 @@ __global__ __launch_bounds__(1024) void k_shade2(
     {
       float v[8];
       bf16x8 bh, bl;
-      if (PIPE) plane_combine(raw0, v); else gather_app6_plane32<0>(f, u, g, v);
+      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);
+      if (PIPE) plane_combine(raw0, v); else gather_app6_plane32<0>(f, at, g, v);
       if (SAVE) save_x6(arow + ACT_X + 0 * LRF_CA + 6 * g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       LRF_TICK(1);
-      gather_app6_plane32<1>(f, u, g, v);
+      gather_app6_plane32<1>(f, at, g, v);
       if (SAVE) save_x6(arow + ACT_X + 1 * LRF_CA + 6 * g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
       LRF_TICK(2);
-      gather_app6_plane32<2>(f, u, g, v);
+      gather_app6_plane32<2>(f, at, g, v);
       if (SAVE) save_x6(arow + ACT_X + 2 * LRF_CA + 6 * g, v);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
