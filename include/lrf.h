@@ -108,6 +108,7 @@ void        lrf_debug_set_train_fwd_engine(int engine);   /* row-saving forward:
 void        lrf_debug_set_shade_pipe(int on);       /* k_shade2: software-pipelined plane-0 gather (experiment) */
 void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);
+char*       lrf_error_slot(void);                   /* internal: the calling thread's 512-byte error text (shared by the library's translation units) */
 
 /* Bytes of the layout cache for a grid (x,y,z). */
 size_t lrf_cache_bytes(const int32_t grid[3]);

@@ -65,6 +65,7 @@ LRF_LOSS_MAX_PER_VIEW = 4096
 SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
     "lrf_last_error": (C.c_char_p, []),
+    "lrf_error_slot": (C.c_void_p, []),
     "lrf_debug_set_dump": (None, [C.c_void_p]),
     "lrf_debug_set_mlp_policy": (None, [C.c_int]),
     "lrf_debug_set_mlp_threads": (None, [C.c_int]),

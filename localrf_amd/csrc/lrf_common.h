@@ -2,6 +2,7 @@
 // gfx950 kernels.  Geometry helpers restate, per sample, what the reference does with
 // whole-tensor ATen ops (file:line relative to /root/reference/localTensoRF).
 #pragma once
+#include "lrf_tu.h"          // first: which translation unit this is (renames, see there)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/lrf.h"

@@ -31,10 +31,13 @@ namespace lrf {
 
 constexpr int ITEM = 16;          // compact samples per shade work item = one 16-column MFMA tile
 
-thread_local char g_err[512] = "";
+#if LRF_TU != 2
+thread_local char g_err[512] = "";       // one error text per thread for the whole library (lrf_error_slot)
+#endif
 static int set_err(const char* msg, hipError_t e = hipSuccess) {
-  if (e != hipSuccess) snprintf(g_err, sizeof(g_err), "%s: %s", msg, hipGetErrorString(e));
-  else snprintf(g_err, sizeof(g_err), "%s", msg);
+  char* slot = lrf_error_slot();
+  if (e != hipSuccess) snprintf(slot, 512, "%s: %s", msg, hipGetErrorString(e));
+  else snprintf(slot, 512, "%s", msg);
   return 1;
 }
 #define LRF_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(#call, e_); } while (0)
@@ -1081,7 +1084,10 @@ void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ?
 void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
 void lrf_debug_set_mlp_threads(int threads) { g_mlp_threads = (threads == 512 || threads == 256) ? threads : 1024; }
 void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = ((policy >= 0 && policy <= 7) || policy == 10 || policy == 14) ? policy : 4; }
-const char* lrf_last_error(void) { return g_err; }
+const char* lrf_last_error(void) { return lrf_error_slot(); }
+#if LRF_TU != 2
+char* lrf_error_slot(void) { return g_err; }
+#endif
 
 size_t lrf_cache_bytes(const int32_t grid[3]) { return make_layout(grid).total * sizeof(float); }
 

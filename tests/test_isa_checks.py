@@ -20,17 +20,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "localrf_amd", "csrc", "lrf_render.hip")
 
 
-@pytest.fixture(scope="module")
-def asm():
+def _device_asm(extra):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I",
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17"] + extra + ["-I",
                                os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, SRC],
                               stderr=subprocess.DEVNULL)
         return open(out).read()
+
+
+@pytest.fixture(scope="module")
+def asm():
+    """The library is linked from two translation units of the same source (csrc/lrf_tu.h, __graft_entry__.build):
+    default flags for everything but the training entry points, -fno-slp-vectorize for those.  The text checked here is
+    each shipped kernel as the unit it ships from compiles it (the namespace rename of unit 2 does not change code)."""
+    fwd, bwd = _device_asm([]), _device_asm(["-fno-slp-vectorize"])
+
+    def kernel(text, name):
+        m = re.search(r"(^|\n)(_ZN3lrf\d+%s[^\n:]*:[^\n]*\n.*?\.end_amdhsa_kernel)" % name, text, re.S)
+        assert m, name
+        return m[2]
+    parts = [kernel(bwd if k in FROM_TRAINING_UNIT else fwd, k) for k in ALL_CHECKED]
+    return "\n".join(parts)
 
 
 def _overlap(x, y):
@@ -42,6 +56,10 @@ def _overlap(x, y):
 # 18 (basis) + 24 (layer 1) + 96 (layer 2) [+ 12 (head)].  k_mlp has no gathers; its default policy (4) is the
 # compiler-scheduled builtin, pinned by the 200-render determinism test on the GPU; policy 0 is the hand-issued
 # fallback and is held to the rules below.
+FROM_TRAINING_UNIT = ("k_bwd_shade_fwdE",)
+ALL_CHECKED = ("k_shade_bf16E", "k_bwd_shade_fwdE", "k_appE", "k_mlpILi0ELb0ELb1EE", "k_mlpILi4ELb0ELb1EE",
+               "k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE",
+               "k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", "k_marchILb1EE", "k_marchILb0EE")
 SHIPPED = (("k_shade_bf16E", 138), ("k_bwd_shade_fwdE", 138), ("k_appE", 18), ("k_mlpILi0ELb0ELb1EE", 132),
            ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE", 138),
            ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", 138))
