@@ -498,7 +498,7 @@ def main():
         # data gradient takes its ReLU masks from 32 B per sample), the density features (R*S floats, written + read twice), gradient images + reference-layout
         # gradients (3 x 35 MB) + Adam (param, m, v read+write) -- cache-served gathers not counted
         n_par = sum(p.numel() for p in field.parameters() if p.requires_grad)
-        train_bytes = rows * (4 * (400 * 2 + 384 * 2) + 32 * 2) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
+        train_bytes = rows * (4 * (400 * 2 + (384 - 128) * 2) + 32 * 3) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)   # dz2 (128 floats) is never materialised
         train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
                  "what": "lrf_render_fwd_train + lrf_render_bwd + "
                          + (f"allreduce_grads over RCCL ({reduced[0] / 1e6:.1f} MB in place) + " if ddp else "")

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
     float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax,
-    const uint32_t* __restrict__ relu_bits) {
+    const uint32_t* __restrict__ relu_bits, int store_dz2) {
   __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
   // Geometry of the appearance lookups, read back from LDS next to its use: as kernel arguments
   // these 30 uniform values stayed live across the MFMA phases, overflowed the SGPR file and were
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
         dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);
       }
-      *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];
+      if (store_dz2) *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];   // (k_wgrad_w2 rebuilds dz2 from go + mask bits)
     }
     // dz1 = (W2^T dz2) * [h1 > 0]      (exact fp32 MFMA, transposed fragments), one output tile at
     // a time; each finished tile is masked, stored and consumed at once as k-step t1 of
@@ -645,6 +645,117 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * (NT * 16) + 16 * n + i] = acc[m][n][r];
     }
+  }
+}
+
+// dW2 (and db2) = dz2^T [relu(h1) | 1] without dz2 rows: dz2[u] = [h2_u > 0] * sum_c W3[c][u] go[c] is rank 3 plus a
+// mask, so the kernel rebuilds its A operand from 16 B of go and 16 B of ReLU mask bits per sample (and W3 in
+// registers) instead of reading 512 B of dz2 that k_bwd_shade_dgrad would have had to write first.  Otherwise
+// k_wgrad<8, 9, false, true>: M-tiles w, w + 4 per wave, 9 N-tiles of the h1 row, split-bf16 MFMAs.
+__global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /* grd + GRD_GO */, int ldg,
+                                                  const uint32_t* __restrict__ relu_bits, const float* __restrict__ w3 /* [3][131] */,
+                                                  const float* __restrict__ B, int ldb, const int* __restrict__ toff, int R,
+                                                  float* __restrict__ wpart, int wp_off) {
+  constexpr int KT = 32, NT = 9, WB = NT * 16, LD = WB + 16;     // LD = 16 (mod 32)
+  __shared__ __attribute__((aligned(16))) float s_t[KT * LD];
+  __shared__ float s_go[KT][4];
+  __shared__ uint32_t s_m[KT][4];
+  const int rows = toff[R] * 16;
+  const int r0 = blockIdx.x * WGRAD_CH;
+  if (r0 >= rows) return;
+  const int r1 = min(r0 + WGRAD_CH, rows);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  float wr[2], wg[2], wb[2];                               // W3[:, unit] of this lane's unit in its two M-tiles
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int u = 16 * (wave + 4 * m) + i;
+    wr[m] = w3[u]; wg[m] = w3[131 + u]; wb[m] = w3[262 + u];
+  }
+  constexpr int QB = WB / 4;
+  constexpr int NQ = (KT * QB + 255) / 256;
+  float4 pre[NQ];
+  float4 pre_go = make_float4(0, 0, 0, 0);
+  uint32_t pre_m = 0;
+  auto fetch = [&](int rb) {
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      const int q = threadIdx.x + 256 * t;
+      const int row = rb + q / QB;
+      pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (q < KT * QB && row < r1) pre[t] = *reinterpret_cast<const float4*>(B + (size_t)row * ldb + 4 * (q % QB));
+    }
+    if (threadIdx.x < KT) {                                // go of row rb + tid (0 for rows behind the chunk)
+      const int row = rb + threadIdx.x;
+      pre_go = row < r1 ? *reinterpret_cast<const float4*>(go + (size_t)row * ldg) : make_float4(0, 0, 0, 0);
+    } else if (threadIdx.x < 5 * KT) {                     // mask dword (row, lane group gg): tile row/16, layer 2, lane (row%16) + 16 gg
+      const int k = (threadIdx.x - KT) >> 2, gg = (threadIdx.x - KT) & 3;
+      const int row = rb + k;
+      pre_m = row < r1 ? relu_bits[((size_t)(row >> 4) * 2 + 1) * 64 + (row & 15) + 16 * gg] : 0u;
+    }
+  };
+  fetch(r0);
+  for (int rb = r0; rb < r1; rb += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      const int q = threadIdx.x + 256 * t;
+      if (q < KT * QB) *reinterpret_cast<float4*>(&s_t[(q / QB) * LD + 4 * (q % QB)]) = pre[t];
+    }
+    if (threadIdx.x < KT) *reinterpret_cast<float4*>(&s_go[threadIdx.x][0]) = pre_go;
+    else if (threadIdx.x < 5 * KT) s_m[(threadIdx.x - KT) >> 2][(threadIdx.x - KT) & 3] = pre_m;
+    __syncthreads();
+    if (rb + KT < r1) fetch(rb + KT);
+#pragma unroll
+    for (int ks = 0; ks < KT / 16; ++ks) {
+      s16x4 bh[NT], bl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = s_t[(16 * ks + 4 * j + g) * LD + 16 * n + i];
+        split4_bf16(v, bh[n], bl[n]);
+      }
+      float gr[4], gg_[4], gb[4];
+      uint32_t md[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * ks + 4 * j + g;
+        gr[j] = s_go[k][0]; gg_[j] = s_go[k][1]; gb[j] = s_go[k][2];
+        md[j] = s_m[k][i >> 2];
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int mt = wave + 4 * m;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = wr[m] * gr[j] + wg[m] * gg_[j] + wb[m] * gb[j];
+          v[j] = relu_gate(d, md[j], 4 * mt + (i & 3));
+        }
+        s16x4 ah, al;
+        split4_bf16(v, ah, al);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int mt = wave + 4 * m;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * (NT * 16) + 16 * n + i] = acc[m][n][r];
   }
 }
 
@@ -1316,7 +1427,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 // 268 B of scratch per lane, in a kernel that is bound by its 1.5 KB of row stores per sample, not by the gathers the
 // prefetch hides): fwd+bwd 2.82 vs 2.93 ms.  The eval kernel's structure does not carry over.
 static int g_train_fwd_engine = 1;
-static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 GEMM on the fp32 matrix path (measurement)
+static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 = k_wgrad<8,9> over stored dz2 rows on fp32 MFMAs (measurement)
 static int shade_save_attrs() {
   static bool done[64] = {};
   int dev = 0;
@@ -1432,8 +1543,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     launch_shade_save(d, rays, z, S, R, w, b, st);
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
-  //   caller's stream: k_bwd_shade_dgrad -> k_wgrad (dW2) -> appearance bins + scatter     [-> join] -> ray partials, unpack
-  //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) 3 x k_wgrad -> (dW2 done) reduce
+  //   caller's stream: k_bwd_shade_dgrad -> k_wgrad_w2 (dW2), k_wgrad (dW1) -> appearance bins + scatter  [-> join] -> ray partials, unpack
+  //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) k_wgrad (dbasis, dW3) -> (dW2, dW1 done) reduce
   // k_bwd_ray and the density scatter need nothing from the data-gradient kernel (the appearance lookups' position
   // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
   // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
@@ -1451,7 +1562,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
 
   // ---- caller's stream: data gradient of the colour network
   hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits);
+                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, g_wgrad_bf16 ? 0 : 1);
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));
 
   // ---- side stream: per-ray backward, density scatter
@@ -1469,20 +1580,20 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                      d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
 
   // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
-  // (the largest one, dW2, stays on the caller's stream behind the data gradient: it balances the two branches)
+  // (dW2 and dW1 stay on the caller's stream behind the data gradient: that balances the two branches)
   const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
   if (g_wgrad_bf16)
-    hipLaunchKernelGGL((k_wgrad<8, 9, false, true>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
-                       w.toff, R, b.wpart, WP_W2);
+    hipLaunchKernelGGL(k_wgrad_w2, dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.relu_bits, p->w3,
+                       b.act + ACT_H1, ACT_LD, w.toff, R, b.wpart, WP_W2);
   else
     hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
                        w.toff, R, b.wpart, WP_W2);
+  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
+                     w.toff, R, b.wpart, WP_W1);
   if (ss) {
     LRF_HIP(hipEventRecord(ss->app[1], st));
     LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
   }
-  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
-                     w.toff, R, b.wpart, WP_W1);
   hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
   hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
