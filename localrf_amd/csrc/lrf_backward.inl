@@ -137,6 +137,19 @@ __device__ __forceinline__ void lds_add4_f32(float* p0, float v0, float* p1, flo
   if (r3 != o3) lds_add_retry(q3, r3, v3);
 }
 
+// 16-byte store into a saved row.  Rows are written once and read once by a later kernel: a non-temporal store keeps
+// them from displacing the field's texels in L2 (LRF_ROW_NT, default on; measured in DESIGN.md s4b).
+#ifndef LRF_ROW_NT
+#define LRF_ROW_NT 1
+#endif
+__device__ __forceinline__ void row_store(float* p, f32x4 v) {
+#if LRF_ROW_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 // ---------------------------------------------------------------- colour chain, saving rows
 // Same arithmetic as k_shade_bf16; additionally writes rgb per shaded sample and the ACT row.
 __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
         h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
         m1 |= min(__float_as_uint(h1[t1][r]), 1u) << (4 * t1 + r);        // relu output: +0 or positive
       }
-      *reinterpret_cast<f32x4*>(arow + ACT_H1 + 16 * t1 + 4 * g) = h1[t1];
+      row_store(arow + ACT_H1 + 16 * t1 + 4 * g, h1[t1]);
     }
     relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane] = m1;
     *reinterpret_cast<float4*>(arow + ACT_H1 + 128 + 4 * g) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
         const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
         o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
       }
-      *reinterpret_cast<f32x4*>(arow + ACT_H2 + 16 * t1 + 4 * g) = h2[t1];
+      row_store(arow + ACT_H2 + 16 * t1 + 4 * g, h2[t1]);
     }
     *reinterpret_cast<float4*>(arow + ACT_H2 + 128 + 4 * g) =
         g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) d1[r] = relu_gate(d1[r], m1, 4 * t1 + r);
-      *reinterpret_cast<f32x4*>(grow + GRD_DZ1 + 16 * t1 + 4 * g) = d1;
+      row_store(grow + GRD_DZ1 + 16 * t1 + 4 * g, d1);
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W1T + ((t2 * 8 + t1) * 64 + lane) * 4]);

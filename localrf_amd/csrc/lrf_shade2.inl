@@ -830,6 +830,11 @@ __global__ __launch_bounds__(1024) void k_shade2(
     // rendering (measured: colour kernel 160 -> 235 us).
     if (FUSE == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (FUSE == 3) __threadfence();
+    // every wave's partial stores acknowledged BEFORE the barrier: __syncthreads() alone emits s_waitcnt lgkmcnt(0)
+    // only (a workgroup-scope release does not wait for vector stores when the workgroup shares one L1), and a
+    // partial still in flight when the counter is bumped -- or when another wave of this workgroup sums the ray --
+    // is a stale read: seen as 1-2 differing renders in 6000 on one (faster) box of the pool, none on six others
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int nb = gridDim.x, tid = threadIdx.x;
     const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;

@@ -1109,6 +1109,49 @@ def stage_train_host():
     log(buf.getvalue()[-7000:])
 
 
+def stage_flake2():
+    """Rare run-to-run differences of the default forward, localised: two-launch (fused scan / finalize) vs four-launch
+    sequence, 20000 renders each; for every differing render the rays that differ, their |diff|, and whether the ray
+    straddles a workgroup boundary of k_shade2's tile partition (those are summed by the last workgroup to finish)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+
+    def fwd():
+        return f(rays, white_bg=True, is_train=False, N_samples=1536)
+    with torch.no_grad():
+        for _ in range(300):
+            fwd()
+        rgb0, dep0, w, acc, z = f.render_weights(rays, N_samples=1536)
+        ntile = ((w > f.rayMarch_weight_thres).sum(-1) + 15) // 16            # tiles per ray (floater filter off)
+        toff = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), ntile.cumsum(0)])
+        T = int(toff[-1])
+        nb = torch.cuda.get_device_properties(0).multi_processor_count
+        bounds = torch.tensor([(b * 16) * T // (nb * 16) for b in range(1, nb)], device="cuda")
+        strad = ((toff[:-1, None] < bounds[None]) & (toff[1:, None] > bounds[None])).any(-1)
+        log(f"tiles {T}, workgroups {nb}, rays straddling a workgroup boundary: {int(strad.sum())}")
+        for pipe in (0, 9, 0, 9):
+            lib.lrf_debug_set_shade_pipe(pipe)
+            ref = fwd()
+            ref = (ref[0].clone(), ref[1].clone())
+            nd, found = 0, []
+            for it in range(20000):
+                o = fwd()
+                if not torch.equal(o[0], ref[0]):
+                    nd += 1
+                    d = (o[0] - ref[0]).abs().amax(-1)
+                    idx = torch.nonzero(d > 0).flatten()
+                    found.append([(int(i), float(d[i]), bool(strad[i]), int(ntile[i])) for i in idx[:6]])
+            log(f"shade_pipe {pipe} ({'two' if pipe == 0 else 'four'} launches): {nd} of 20000 renders differ from the first; "
+                f"(ray, |diff|, straddles a boundary, tiles): {found[:8]}")
+        lib.lrf_debug_set_shade_pipe(0)
+
+
 def stage_march():
     """k_march with its density lines in LDS vs in global memory (300^3 and 500^3)."""
     import torch
@@ -1309,7 +1352,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("flake2", 300), ("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
