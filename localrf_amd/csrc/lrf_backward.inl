@@ -137,16 +137,37 @@ __device__ __forceinline__ void lds_add4_f32(float* p0, float v0, float* p1, flo
   if (r3 != o3) lds_add_retry(q3, r3, v3);
 }
 
-// 16-byte store into a saved row.  Rows are written once and read once by a later kernel: a non-temporal store keeps
-// them from displacing the field's texels in L2 (LRF_ROW_NT, default on; measured in DESIGN.md s4b).
+// Stores into / loads from the saved rows.  Rows are written once and read once by a later kernel: with the `nt` hint
+// they do not displace the field's texels in L2 under the gathers running beside them.  LRF_ROW_NT bits: 1 = 16-byte row
+// stores (h1, h2, dz1), 2 = the X row's 8-byte stores, 4 = the weight-gradient GEMMs' row loads, 8 = the dX row's
+// stores.  Default 13: measured on one box (scripts/ab_libs.sh) forward+backward 2.65 (bit 1 only) / 2.41 (13) /
+// 2.57 ms (15: the X row stores cost the row-saving forward 0.59 -> 0.64 ms).
 #ifndef LRF_ROW_NT
-#define LRF_ROW_NT 1
+#define LRF_ROW_NT 13
 #endif
 __device__ __forceinline__ void row_store(float* p, f32x4 v) {
-#if LRF_ROW_NT
+#if LRF_ROW_NT & 1
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 #else
   *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void row_store(float* p, float4 v) { row_store(p, f32x4{v.x, v.y, v.z, v.w}); }
+template <int BIT = 2>
+__device__ __forceinline__ void row_store2(float* p, float a, float b) {
+  if constexpr ((LRF_ROW_NT & BIT) != 0) {
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(f32x2s{a, b}, reinterpret_cast<f32x2s*>(p));
+  } else {
+    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+  }
+}
+__device__ __forceinline__ float4 row_load4(const float* p) {
+#if LRF_ROW_NT & 4
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
 #endif
 }
 
@@ -196,17 +217,17 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);   // 32-bit gathers, taps once per axis (as k_shade2)
       gather_app6_plane32<0>(f, at, g, v);
 #pragma unroll
-      for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 0 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+      for (int h = 0; h < 3; ++h) row_store2(arow + ACT_X + 0 * LRF_CA + 6 * g + 2 * h, v[2 * h], v[2 * h + 1]);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       gather_app6_plane32<1>(f, at, g, v);
 #pragma unroll
-      for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 1 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+      for (int h = 0; h < 3; ++h) row_store2(arow + ACT_X + 1 * LRF_CA + 6 * g + 2 * h, v[2 * h], v[2 * h + 1]);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
       gather_app6_plane32<2>(f, at, g, v);
 #pragma unroll
-      for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(arow + ACT_X + 2 * LRF_CA + 6 * g + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
+      for (int h = 0; h < 3; ++h) row_store2(arow + ACT_X + 2 * LRF_CA + 6 * g + 2 * h, v[2 * h], v[2 * h + 1]);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     for (int pq = 0; pq < 3; ++pq)
 #pragma unroll
       for (int h = 0; h < 3; ++h)
-        *reinterpret_cast<float2*>(grow + GRD_DX + pq * LRF_CA + 6 * g + 2 * h) = make_float2(dX[pq * 6 + 2 * h], dX[pq * 6 + 2 * h + 1]);
+        row_store2<8>(grow + GRD_DX + pq * LRF_CA + 6 * g + 2 * h, dX[pq * 6 + 2 * h], dX[pq * 6 + 2 * h + 1]);
     if (g == 0) rowinfo[row] = valid ? (uint32_t)((size_t)ray * S + k) : 0xffffffffu;
 
     // d/d(position) from the appearance lookups
@@ -564,8 +585,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
       const int row = rb + rr;
       pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (q < KT * (QA + QB) && row < r1)
-        pre[t] = cq < QA ? *reinterpret_cast<const float4*>(A + (size_t)row * lda + 4 * cq)
-                         : *reinterpret_cast<const float4*>(B + (size_t)row * ldb + 4 * (cq - QA));
+        pre[t] = cq < QA ? row_load4(A + (size_t)row * lda + 4 * cq) : row_load4(B + (size_t)row * ldb + 4 * (cq - QA));
     }
   };
   fetch(r0);
@@ -700,7 +720,7 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
       const int q = threadIdx.x + 256 * t;
       const int row = rb + q / QB;
       pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (q < KT * QB && row < r1) pre[t] = *reinterpret_cast<const float4*>(B + (size_t)row * ldb + 4 * (q % QB));
+      if (q < KT * QB && row < r1) pre[t] = row_load4(B + (size_t)row * ldb + 4 * (q % QB));
     }
     if (threadIdx.x < KT) {                                // go of row rb + tid (0 for rows behind the chunk)
       const int row = rb + threadIdx.x;
