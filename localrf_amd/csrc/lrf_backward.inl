@@ -1460,6 +1460,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 // 268 B of scratch per lane, in a kernel that is bound by its 1.5 KB of row stores per sample, not by the gathers the
 // prefetch hides): fwd+bwd 2.82 vs 2.93 ms.  The eval kernel's structure does not carry over.
 static int g_train_fwd_engine = 1;
+static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * n): n weight-gradient GEMMs on the caller's stream
 static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 = k_wgrad<8,9> over stored dz2 rows on fp32 MFMAs (measurement)
 static int shade_save_attrs() {
   static bool done[64] = {};
@@ -1576,8 +1577,9 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     launch_shade_save(d, rays, z, S, R, w, b, st);
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
-  //   caller's stream: k_bwd_shade_dgrad -> k_wgrad_w2 (dW2), k_wgrad (dW1) -> appearance bins + scatter  [-> join] -> ray partials, unpack
-  //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) k_wgrad (dbasis, dW3) -> (dW2, dW1 done) reduce
+  //   caller's stream: k_bwd_shade_dgrad -> k_wgrad_w2 (dW2) -> appearance bins + scatter                  [-> join] -> ray partials, unpack
+  //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) k_wgrad (dW1, dbasis, dW3) -> (dW2 done) reduce
+  // (how many of the four GEMMs stay on the caller's stream is g_wgrad_split: 0..4 measured 2.53 / 2.45 / 2.53 / 2.57 / 2.59 ms)
   // k_bwd_ray and the density scatter need nothing from the data-gradient kernel (the appearance lookups' position
   // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
   // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
@@ -1613,24 +1615,25 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                      d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
 
   // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
-  // (dW2 and dW1 stay on the caller's stream behind the data gradient: that balances the two branches)
+  // weight gradients: the first g_wgrad_split of the four GEMMs (dW2, dW1, dbasis, dW3) stay on the caller's stream
+  // behind the data gradient, the rest run on the side stream behind the density scatter once the data gradient is done
   const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
+  const int on_a = ss ? g_wgrad_split : 4;
+  if (ss && on_a < 4) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
+  auto wst = [&](int idx) { return idx < on_a ? st : sb; };
   if (g_wgrad_bf16)
-    hipLaunchKernelGGL(k_wgrad_w2, dim3(nch_max), dim3(256), 0, st, b.grd + GRD_GO, GRD_LD, b.relu_bits, p->w3,
+    hipLaunchKernelGGL(k_wgrad_w2, dim3(nch_max), dim3(256), 0, wst(0), b.grd + GRD_GO, GRD_LD, b.relu_bits, p->w3,
                        b.act + ACT_H1, ACT_LD, w.toff, R, b.wpart, WP_W2);
   else
-    hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
+    hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, wst(0), b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
                        w.toff, R, b.wpart, WP_W2);
-  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, st, b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
                      w.toff, R, b.wpart, WP_W1);
-  if (ss) {
-    LRF_HIP(hipEventRecord(ss->app[1], st));
-    LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
-  }
-  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(2), b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
-  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, sb, b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, wst(3), b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
                      w.toff, R, b.wpart, WP_W3);
+  if (ss && on_a > 0) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream GEMMs are done behind this
   {
     WgradSegs segs;
     int nseg = 0, elems = 0;
@@ -1646,7 +1649,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
     seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
     segs.total_elems = elems;
-    if (ss) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));      // dW2's partials come from the caller's stream
+    if (ss && on_a > 0) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));      // partials of the caller's-stream GEMMs
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, sb, b.wpart, w.toff, R, segs);
   }
   if (ss) LRF_HIP(hipEventRecord(ss->join, sb));

@@ -1076,7 +1076,7 @@ extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
-void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = on ? 1 : 0; }
+void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): n GEMMs on the caller's stream
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
 void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 11) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }

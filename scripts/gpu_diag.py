@@ -1196,7 +1196,7 @@ def stage_bwd_overlap():
     for p in f.parameters():
         p.requires_grad_(True)
     ref = None
-    for on, eng in ((1, 1), (1, 3), (0, 1), (0, 3), (1, 1), (1, 3), (1, 0)):
+    for on, eng in ((5, 1), (3, 1), (7, 1), (9, 1), (11, 1), (0, 1), (5, 1), (3, 1), (7, 1), (5, 3), (5, 0)):
         lib.lrf_debug_set_bwd_overlap(on)
         lib.lrf_debug_set_train_fwd_engine(eng)
         for _ in range(10):
@@ -1219,9 +1219,9 @@ def stage_bwd_overlap():
         if ref is None:
             ref = gsum
         worst = max(abs(gsum[k] - ref[k]) / max(ref[k], 1e-30) for k in ref)
-        log(f"bwd overlap {on}, row-saving forward {'k_shade2<SAVE>' if (eng & 1) == 0 else 'k_bwd_shade_fwd'}, dW2 on {'fp32' if eng & 2 else 'split-bf16'} MFMA: fwd+bwd {dt:.3f} ms (forward alone {dtf:.3f} ms) | "
+        log(f"bwd overlap {on & 1}{'' if on < 2 else f' ({(on >> 1) - 1} GEMMs on the caller stream)'}, row-saving forward {'k_shade2<SAVE>' if (eng & 1) == 0 else 'k_bwd_shade_fwd'}, dW2 on {'fp32' if eng & 2 else 'split-bf16'} MFMA: fwd+bwd {dt:.3f} ms (forward alone {dtf:.3f} ms) | "
             f"max relative change of a gradient's |sum| vs first run {worst:.2e}")
-    lib.lrf_debug_set_bwd_overlap(1)
+    lib.lrf_debug_set_bwd_overlap(5)
     lib.lrf_debug_set_train_fwd_engine(1)
 
 
