@@ -153,6 +153,21 @@ __device__ __forceinline__ void row_store(float* p, f32x4 v) {
 #endif
 }
 __device__ __forceinline__ void row_store(float* p, float4 v) { row_store(p, f32x4{v.x, v.y, v.z, v.w}); }
+template <int BIT>
+__device__ __forceinline__ void row_store_b(float* p, float4 v) {
+  if constexpr ((LRF_ROW_NT & BIT) != 0) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<float4*>(p) = v;
+}
+template <int BIT>
+__device__ __forceinline__ float2 row_load2_b(const float2* p) {
+  if constexpr ((LRF_ROW_NT & BIT) != 0) {
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    const f32x2s v = __builtin_nontemporal_load(reinterpret_cast<const f32x2s*>(p));
+    return make_float2(v[0], v[1]);
+  } else {
+    return *p;
+  }
+}
 template <int BIT = 2>
 __device__ __forceinline__ void row_store2(float* p, float a, float b) {
   if constexpr ((LRF_ROW_NT & BIT) != 0) {
@@ -238,9 +253,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       float4 b = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
       if (g == 2) b.w = 1.0f;                        // column 27 = bias column of the dW1 GEMM
       if (g == 3) b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      *reinterpret_cast<float4*>(arow + ACT_FEAT + 4 * g) = a;
-      *reinterpret_cast<float4*>(arow + ACT_FEAT + 16 + 4 * g) = b;
-      if (g < 2) *reinterpret_cast<float4*>(arow + 72 + 4 * g) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      row_store_b<32>(arow + ACT_FEAT + 4 * g, a);
+      row_store_b<32>(arow + ACT_FEAT + 16 + 4 * g, b);
+      if (g < 2) row_store_b<32>(arow + 72 + 4 * g, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     }
     f32x4 h1[8];
 #pragma unroll
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       row_store(arow + ACT_H1 + 16 * t1 + 4 * g, h1[t1]);
     }
     relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane] = m1;
-    *reinterpret_cast<float4*>(arow + ACT_H1 + 128 + 4 * g) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+    row_store_b<32>(arow + ACT_H1 + 128 + 4 * g, make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f));
     f32x4 h2[8];
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
@@ -291,8 +306,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       }
       row_store(arow + ACT_H2 + 16 * t1 + 4 * g, h2[t1]);
     }
-    *reinterpret_cast<float4*>(arow + ACT_H2 + 128 + 4 * g) =
-        g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    row_store_b<32>(arow + ACT_H2 + 128 + 4 * g, g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane] = m2;
     o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
@@ -392,8 +406,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         go[c] = g_rgb[(size_t)ray * 3 + c] * w * r * (1.0f - r);
       }
     }
-    *reinterpret_cast<float4*>(grow + GRD_GO + 4 * g) =
-        g == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    row_store_b<32>(grow + GRD_GO + 4 * g, g == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 
     // dz2 = (W3[:, :128]^T go) * [h2 > 0]
     f32x4 dz[8];
@@ -432,8 +445,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         for (int r = 0; r < 4; ++r) df[t2] = mfma4(a[r], d1[r], df[t2]);
       }
     }
-    *reinterpret_cast<f32x4*>(grow + GRD_DFEAT + 4 * g) = df[0];
-    *reinterpret_cast<f32x4*>(grow + GRD_DFEAT + 16 + 4 * g) = df[1];
+    row_store_b<32>(grow + GRD_DFEAT + 4 * g, make_float4(df[0][0], df[0][1], df[0][2], df[0][3]));
+    row_store_b<32>(grow + GRD_DFEAT + 16 + 4 * g, make_float4(df[1][0], df[1][1], df[1][2], df[1][3]));
     // dX = basis^T dfeat, delivered in the gather layout: slot q = 4t'+r of lane (s,g) is
     // channel (p = q/6, 6g + q%6)
     f32x4 dxs[5];
@@ -1262,7 +1275,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
           ld4g(r1 + 8 * sub, e1v); ld4g(r1 + 8 * sub + 4, e1v + 4);
           const float2* dx2 = reinterpret_cast<const float2*>(grd + (size_t)ir * GRD_LD + GRD_DX + p * LRF_CA + 6 * sub);
 #pragma unroll
-          for (int h = 0; h < 3; ++h) { const float2 t2 = dx2[h]; dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
+          for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
         } else {
           e0v[0] = r0[sub]; e1v[0] = r1[sub]; dv[0] = gf[ir];
         }
@@ -1371,7 +1384,7 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
         }
         const float2* dx2 = reinterpret_cast<const float2*>(grd + (size_t)ie * GRD_LD + GRD_DX + p * LRF_CA + 6 * sub);
 #pragma unroll
-        for (int h = 0; h < 3; ++h) { const float2 t2 = dx2[h]; dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
+        for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
       } else {
         v00[0] = q00[sub]; v10[0] = q10[sub]; v01[0] = q01[sub]; v11[0] = q11[sub]; dv[0] = gf[ie];
       }

@@ -1135,20 +1135,62 @@ def stage_flake2():
         bounds = torch.tensor([(b * 16) * T // (nb * 16) for b in range(1, nb)], device="cuda")
         strad = ((toff[:-1, None] < bounds[None]) & (toff[1:, None] > bounds[None])).any(-1)
         log(f"tiles {T}, workgroups {nb}, rays straddling a workgroup boundary: {int(strad.sum())}")
-        for pipe in (0, 9, 0, 9):
+        for pipe in [int(v) for v in os.environ.get("FLAKE2_PIPES", "0,9,0,9").split(",")]:
             lib.lrf_debug_set_shade_pipe(pipe)
             ref = fwd()
             ref = (ref[0].clone(), ref[1].clone())
             nd, found = 0, []
-            for it in range(20000):
+            for it in range(int(os.environ.get("FLAKE2_N", "20000"))):
                 o = fwd()
-                if not torch.equal(o[0], ref[0]):
+                if not torch.equal(o[0], ref[0]) or not torch.equal(o[1], ref[1]):
                     nd += 1
                     d = (o[0] - ref[0]).abs().amax(-1)
-                    idx = torch.nonzero(d > 0).flatten()
-                    found.append([(int(i), float(d[i]), bool(strad[i]), int(ntile[i])) for i in idx[:6]])
-            log(f"shade_pipe {pipe} ({'two' if pipe == 0 else 'four'} launches): {nd} of 20000 renders differ from the first; "
-                f"(ray, |diff|, straddles a boundary, tiles): {found[:8]}")
+                    dd = (o[1] - ref[1]).abs()
+                    idx = torch.nonzero((d > 0) | (dd > 0)).flatten()
+                    if len(found) < 40:
+                        found.append([(int(i), float(d[i]), float(dd[i]), bool(strad[i]), int(ntile[i])) for i in idx[:6]])
+            log(f"shade_pipe {pipe} ({'two' if pipe == 0 else 'four'} launches): {nd} renders differ from the first; "
+                f"(ray, |d rgb|, |d depth|, straddles a boundary, tiles): {found[:6]}")
+        lib.lrf_debug_set_shade_pipe(0)
+
+
+def stage_flake3():
+    """Which kernel do rare run-to-run differences come from?  Same 4096-ray render, every colour engine (they share
+    k_march): renders differing from the first in colour / in depth, largest difference, rays affected."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    n = int(os.environ.get("FLAKE3_N", "4000"))
+    with torch.no_grad():
+        for _ in range(300):
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+        for rep in range(2):
+            for eng, pipe in (("bf16x3", 0), ("bf16x3", 9), ("bf16x3_split", 0), ("bf16x3_fused", 0), ("f32", 0), ("valu", 0)):
+                f.mlp_engine = eng
+                lib.lrf_debug_set_shade_pipe(pipe)
+                m = n if eng != "valu" else max(50, n // 40)
+                ref = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                ref = (ref[0].clone(), ref[1].clone())
+                nc = nd = 0
+                mc = md = 0.0
+                rays_c = set()
+                for _ in range(m):
+                    o = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                    if not torch.equal(o[0], ref[0]):
+                        nc += 1
+                        d = (o[0] - ref[0]).abs().amax(-1)
+                        mc = max(mc, float(d.max()))
+                        if len(rays_c) < 64:
+                            rays_c.update(int(i) for i in torch.nonzero(d > 0).flatten()[:8])
+                    if not torch.equal(o[1], ref[1]):
+                        nd += 1
+                        md = max(md, float((o[1] - ref[1]).abs().max()))
+                log(f"{eng} (shade_pipe {pipe}): {m} renders | colour differs in {nc} (max {mc:.2e}, rays {sorted(rays_c)[:10]}) | depth differs in {nd} (max {md:.2e})")
+        f.mlp_engine = "bf16x3"
         lib.lrf_debug_set_shade_pipe(0)
 
 
@@ -1352,7 +1394,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("flake2", 300), ("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("flake3", 300), ("flake2", 300), ("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
