@@ -1412,12 +1412,28 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
 struct UnpackSeg { const float* src; float* dst; int C, H, W, CS, app; };
 struct UnpackTab { UnpackSeg s[12]; };
 __global__ __launch_bounds__(128) void k_unpack_grads(UnpackTab tab) {
+  // a block takes 128 consecutive texels of one row: their CS-float records are one contiguous span of the image, read
+  // as float4 into LDS (the per-texel reads of the straightforward loop were 4 bytes at a 32- or 128-byte stride), then
+  // written out channel by channel, 128 consecutive floats each
+  __shared__ __attribute__((aligned(16))) float s_t[128 * (LRF_CAS + 1)];
   const UnpackSeg sg = tab.s[blockIdx.z];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
-  if (x >= sg.W || y >= sg.H) return;
+  const int x0 = blockIdx.x * 128, y = blockIdx.y;
+  if (x0 >= sg.W || y >= sg.H) return;
+  const int nx = min(128, sg.W - x0);
+  const int ld = sg.CS + 1;                                 // odd stride: the channel reads below hit distinct banks
+  const float4* src = reinterpret_cast<const float4*>(sg.src + ((size_t)y * sg.W + x0) * sg.CS);
+  const int n4 = nx * sg.CS / 4;
+  for (int i = threadIdx.x; i < n4; i += 128) {
+    const float4 v = src[i];
+    const int t = (4 * i) / sg.CS, c = (4 * i) % sg.CS;
+    float* d = &s_t[t * ld + c];
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t >= nx) return;
   for (int c = 0; c < sg.C; ++c)
-    sg.dst[((size_t)c * sg.H + y) * sg.W + x] += sg.src[((size_t)y * sg.W + x) * sg.CS + (sg.app ? app_pc(c) : c)];
+    sg.dst[((size_t)c * sg.H + y) * sg.W + x0 + t] += s_t[t * ld + (sg.app ? app_pc(c) : c)];
 }
 
 struct BwdWorkspace {
