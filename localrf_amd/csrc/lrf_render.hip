@@ -44,13 +44,24 @@ static int set_err(const char* msg, hipError_t e = hipSuccess) {
 
 // ---------------------------------------------------------------------------- pack
 // [C,H,W] -> [H,W,CS] channel-last; app=1: padded appearance layout (slot app_pc(c), zero pads)
-__global__ void k_pack_plane(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int CS, int app) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
-  if (x >= W) return;
-  float* d = dst + ((size_t)y * W + x) * CS;
-  if (app) for (int q = 0; q < 4; ++q) { d[8 * q + 6] = 0.0f; d[8 * q + 7] = 0.0f; }
-  for (int c = 0; c < C; ++c) d[app ? app_pc(c) : c] = src[((size_t)c * H + y) * W + x];
+__global__ __launch_bounds__(128) void k_pack_plane(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int CS, int app) {
+  // a block packs 128 consecutive texels of one row: channel rows are read 128 floats at a time into LDS, the
+  // CS-float records of those texels are one contiguous span of the destination and leave as float4 (a thread writing
+  // its own record dword by dword stored 4 bytes at a 32- or 128-byte stride)
+  __shared__ __attribute__((aligned(16))) float s_t[128 * (LRF_CAS + 4)];
+  const int x0 = blockIdx.x * 128, y = blockIdx.y, t = threadIdx.x;
+  if (x0 >= W) return;
+  const int nx = min(128, W - x0);
+  const int ld = CS + 4;                                    // records stay 16-byte aligned in LDS
+  if (t < nx) {
+    float* d = &s_t[t * ld];
+    if (app) for (int q = 0; q < 4; ++q) { d[8 * q + 6] = 0.0f; d[8 * q + 7] = 0.0f; }
+    for (int c = 0; c < C; ++c) d[app ? app_pc(c) : c] = src[((size_t)c * H + y) * W + x0 + t];
+  }
+  __syncthreads();
+  float4* out = reinterpret_cast<float4*>(dst + ((size_t)y * W + x0) * CS);
+  const int q4 = CS / 4, n4 = nx * q4;
+  for (int i = t; i < n4; i += 128) out[i] = *reinterpret_cast<const float4*>(&s_t[(i / q4) * ld + 4 * (i % q4)]);
 }
 // [C,L] -> [L,CS]
 __global__ void k_pack_line(const float* __restrict__ src, float* __restrict__ dst, int C, int L, int CS, int app) {
