@@ -44,7 +44,15 @@ static int set_err(const char* msg, hipError_t e = hipSuccess) {
 
 // ---------------------------------------------------------------------------- pack
 // [C,H,W] -> [H,W,CS] channel-last; app=1: padded appearance layout (slot app_pc(c), zero pads)
-__global__ __launch_bounds__(128) void k_pack_plane(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W, int CS, int app) {
+struct PackSeg { const float* src; float* dst; int C, H, W, CS, app; };
+struct PackTab { PackSeg s[12]; };
+// all twelve plane / line tensors of a field in one launch (blockIdx.z selects; a line [C,L,1] is a plane with H = 1)
+__global__ __launch_bounds__(128) void k_pack_planes(PackTab tab) {
+  const PackSeg sg = tab.s[blockIdx.z];
+  const float* __restrict__ src = sg.src;
+  float* __restrict__ dst = sg.dst;
+  const int C = sg.C, H = sg.H, W = sg.W, CS = sg.CS, app = sg.app;
+  if ((int)blockIdx.y >= H) return;
   // a block packs 128 consecutive texels of one row: channel rows are read 128 floats at a time into LDS, the
   // CS-float records of those texels are one contiguous span of the destination and leave as float4 (a thread writing
   // its own record dword by dword stored 4 bytes at a 32- or 128-byte stride)
@@ -62,16 +70,6 @@ __global__ __launch_bounds__(128) void k_pack_plane(const float* __restrict__ sr
   float4* out = reinterpret_cast<float4*>(dst + ((size_t)y * W + x0) * CS);
   const int q4 = CS / 4, n4 = nx * q4;
   for (int i = t; i < n4; i += 128) out[i] = *reinterpret_cast<const float4*>(&s_t[(i / q4) * ld + 4 * (i % q4)]);
-}
-// [C,L] -> [L,CS]
-__global__ void k_pack_line(const float* __restrict__ src, float* __restrict__ dst, int C, int L, int CS, int app) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= CS * L) return;
-  const int l = i / CS, slot = i % CS;
-  float v = 0.0f;
-  if (app) { if ((slot & 7) < 6) v = src[(size_t)(6 * (slot >> 3) + (slot & 7)) * L + l]; }
-  else v = src[(size_t)slot * L + l];
-  dst[i] = v;
 }
 // colour network -> MFMA-fragment-ordered image (see lrf_common.h IMG_*).
 // Fragment lane l = (i = l & 15, g = l >> 4): A operand row 16t'+i, K-slot g.
@@ -1107,13 +1105,17 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const Layout L = make_layout(p->grid);
   float* base = reinterpret_cast<float*>(cache);
+  PackTab tab;
+  int wmax = 1, hmax = 1;
   for (int q = 0; q < 3; ++q) {
-    dim3 grid((L.pw[q] + 127) / 128, L.ph[q]);
-    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->density_plane[q], base + L.dplane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0);
-    hipLaunchKernelGGL(k_pack_plane, grid, dim3(128), 0, st, p->app_plane[q], base + L.aplane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1);
-    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CD + 255) / 256), dim3(256), 0, st, p->density_line[q], base + L.dline[q], LRF_CD, L.ll[q], LRF_CD, 0);
-    hipLaunchKernelGGL(k_pack_line, dim3((L.ll[q] * LRF_CAS + 255) / 256), dim3(256), 0, st, p->app_line[q], base + L.aline[q], LRF_CA, L.ll[q], LRF_CAS, 1);
+    tab.s[4 * q + 0] = PackSeg{p->density_plane[q], base + L.dplane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0};
+    tab.s[4 * q + 1] = PackSeg{p->app_plane[q], base + L.aplane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1};
+    tab.s[4 * q + 2] = PackSeg{p->density_line[q], base + L.dline[q], LRF_CD, 1, L.ll[q], LRF_CD, 0};
+    tab.s[4 * q + 3] = PackSeg{p->app_line[q], base + L.aline[q], LRF_CA, 1, L.ll[q], LRF_CAS, 1};
+    wmax = max(wmax, max(L.pw[q], L.ll[q]));
+    hmax = max(hmax, L.ph[q]);
   }
+  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 12), dim3(128), 0, st, tab);
   hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
   hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_ALL * 4 + 255) / 256), dim3(256), 0, st, *p,
                      reinterpret_cast<uint32_t*>(base + L.mlpb));
