@@ -44,7 +44,14 @@ constexpr int WP_W1 = WP_W2 + 128 * 144;            // [128][32]   dz1^T [feat |
 constexpr int WP_BAS = WP_W1 + 128 * 32;            // [32][80]    dfeat^T X
 constexpr int WP_W3 = WP_BAS + 32 * 80;             // [16][144]   go^T [h2r | dhat | 1]
 constexpr int WP_FLOATS = WP_W3 + 16 * 144;
-constexpr int WGRAD_CH = 1024;                      // rows per K-chunk
+// rows per K-chunk of the weight-gradient GEMMs: about one chunk per CU (a multiple of 256 rows, at least 512), from
+// the number of rows the forward actually produced -- at configs[1] 768 K rows -> 3072: fixed chunk sizes measured
+// 2.38 (1024) / 2.35 (2048) / 2.30 (3072) / 2.41 ms (4096) forward+backward.  At most WGRAD_MAXCH chunks exist.
+constexpr int WGRAD_MAXCH = 264;
+__host__ __device__ inline int wgrad_chunk_rows(int rows) {
+  const int per = (rows + 255) / 256;                      // rows / 256 chunks
+  return max(512, (per + 255) / 256 * 256);
+}
 
 __global__ void k_pack_mlp_t(LrfParams p, float* __restrict__ img) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,6 +584,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   static_assert(!KSPLIT || MT * NT * 256 <= KT * LD, "cross-wave reduction reuses the staging tile");
   __shared__ __attribute__((aligned(16))) float s_t[KT * LD];
   const int rows = toff[R] * 16;
+  const int WGRAD_CH = wgrad_chunk_rows(rows);
   const int r0 = blockIdx.x * WGRAD_CH;
   if (r0 >= rows) return;
   const int r1 = min(r0 + WGRAD_CH, rows);
@@ -707,6 +715,7 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
   __shared__ float s_go[KT][4];
   __shared__ uint32_t s_m[KT][4];
   const int rows = toff[R] * 16;
+  const int WGRAD_CH = wgrad_chunk_rows(rows);
   const int r0 = blockIdx.x * WGRAD_CH;
   if (r0 >= rows) return;
   const int r1 = min(r0 + WGRAD_CH, rows);
@@ -819,6 +828,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   const WgradSeg sg = segs.s[k];
   const int e = ok ? idx - sg.first_elem : 0;
   const int m = e / sg.n_count, n = e % sg.n_count;
+  const int WGRAD_CH = wgrad_chunk_rows(toff[R] * 16);
   const int nch = (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
   float acc = 0.0f;
   for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + sg.off + m * sg.ld + sg.n_off + n];
@@ -1453,7 +1463,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   size_t off = b.fw.bytes;
   const Layout L = make_layout(grid);
   const size_t rows = (size_t)R * b.fw.pmax * 16;
-  const size_t nch = (rows + WGRAD_CH - 1) / WGRAD_CH;
+  const size_t nch = WGRAD_MAXCH;
   b.gcache_floats = L.mlp;
   auto take = [&](size_t nfloat) { float* q = reinterpret_cast<float*>(p + off); off += up256(nfloat * 4); return q; };
   b.feat = take((size_t)R * S);
@@ -1646,7 +1656,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
   // weight gradients: the first g_wgrad_split of the four GEMMs (dW2, dW1, dbasis, dW3) stay on the caller's stream
   // behind the data gradient, the rest run on the side stream behind the density scatter once the data gradient is done
-  const int nch_max = (int)(((size_t)R * w.pmax * 16 + WGRAD_CH - 1) / WGRAD_CH);
+  const int nch_max = WGRAD_MAXCH;      // (blocks behind the last chunk of the actual row count return at once)
   const int on_a = ss ? g_wgrad_split : 4;
   if (ss && on_a < 4) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
   auto wst = [&](int idx) { return idx < on_a ? st : sb; };
