@@ -1058,7 +1058,13 @@ __global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict_
 constexpr int BTILE = 32, BCELL = BTILE + 1;
 constexpr int BIN_CHUNK = 4096;          // entries per block in the hist/fill passes
 constexpr int BIN_MAX = 2048;            // max tiles over the three planes (640^3 -> 1200)
-constexpr int LINE_WGS = 256;            // workgroups per line
+#ifndef LRF_LINE_WGS
+#define LRF_LINE_WGS 256
+#endif
+#ifndef LRF_DPLANE_MULT
+#define LRF_DPLANE_MULT 4
+#endif
+constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
 
 struct BinGeom { int tx[3], ty[3], base[3], total; };
 __host__ __device__ inline BinGeom make_bins(const Layout& L) {
@@ -1647,7 +1653,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL((k_bin_hist<false>), dim3(nblk), dim3(256), 0, sb, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, sb, b.hist, bg.total, b.offs, b.cursor);
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.cursor, b.list);
-  hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * 4), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, sb,
+  hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * LRF_DPLANE_MULT), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, sb,
                      d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
   hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024),
                      sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), sb,
