@@ -104,7 +104,7 @@ void        lrf_debug_set_subbatches(int q);        /* ray ranges of the sub-bat
 void        lrf_debug_set_skew(int n);              /* start skew between the waves of a SIMD in k_shade2, units of 6400 cycles */
 void        lrf_debug_set_lds_lines(int on);        /* k_march: density lines staged in LDS (default on when they fit) */
 void        lrf_debug_set_bwd_overlap(int on);      /* lrf_render_bwd: two branches on two streams (default on) */
-void        lrf_debug_set_train_fwd_engine(int engine);   /* bit 0: row-saving forward 1 = k_bwd_shade_fwd (default), 0 = k_shade2<SAVE> (slower); bit 1: dW2 GEMM on fp32 MFMAs instead of split-bf16 */
+void        lrf_debug_set_train_fwd_engine(int engine);   /* bit 0: row-saving forward 1 = k_bwd_shade_fwd (default), 0 = k_shade2<SAVE> (slower); bit 1: dW2 GEMM on fp32 MFMAs over stored dz2 rows; bit 2: data-gradient chain on fp32 MFMAs */
 void        lrf_debug_set_shade_pipe(int on);       /* k_shade2: software-pipelined plane-0 gather (experiment) */
 void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);

@@ -53,6 +53,56 @@ __host__ __device__ inline int wgrad_chunk_rows(int rows) {
   return max(512, (per + 255) / 256 * 256);
 }
 
+// Split-bf16 image of the TRANSPOSED colour network for the data-gradient chain (same fragment format as IMGB_* in
+// lrf_common.h: [frag][hi, lo][lane 64][8 bf16], A operand row 16 t' + i, K slot (g, j) = feature 16 (2 ks + (j >> 2)) +
+// 4 g + (j & 3) of the previous layer's D registers), then the fp32 W3 block the dz2 step reads:
+//   W2^T  frags [t' 8][ks 4]   A[v][u] = W2[u][v]
+//   W1^T  frags [t' 2][ks 4]   A[f][v] = W1[v][f]   (f < 27)
+//   B^T   frags [t' 5][ks 1]   A[rho][f] = basis[f][ch(rho)]: row rho = 16 t' + 4 gp + r is slot q = 4 t' + r of lane
+//                              group gp = channel (q / 6) * 24 + 6 gp + q % 6 (the gather layout), q < 18
+constexpr int IMTB_W2T = 0;
+constexpr int IMTB_W1T = IMTB_W2T + 32 * 128;
+constexpr int IMTB_BT = IMTB_W1T + 8 * 128;
+constexpr int IMTB_TAIL = IMTB_BT + 5 * 128;          // uint4 index of the fp32 W3H block ([g4][f32][4] floats, as IMT_W3H)
+constexpr int IMTB_U4 = IMTB_TAIL + 128;              // 5888 uint4 = 94,208 B (= IMT_FLOATS floats)
+static_assert(IMTB_U4 * 4 == IMT_FLOATS, "the two transposed images share one buffer and one LDS array");
+__global__ void k_pack_mlp_bf16_t(LrfParams p, uint32_t* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= IMTB_U4 * 4) return;
+  if (idx >= IMTB_TAIL * 4) {
+    const int e = idx - IMTB_TAIL * 4, o = e & 3, fidx = (e >> 2) & 31, g = e >> 7;
+    const int feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3);
+    img[idx] = __float_as_uint(o < 3 ? p.w3[o * (LRF_FEATC + 3) + feat] : 0.0f);
+    return;
+  }
+  const int u4 = idx >> 2, wj = idx & 3;
+  const int lane = u4 & 63, part = (u4 >> 6) & 1, frag = u4 >> 7;
+  const int i = lane & 15, g = lane >> 4;
+  unsigned short out[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = 2 * wj + h;
+    float v = 0.0f;
+    if (frag < 32) {                                           // W2^T: frag = t' * 4 + ks
+      const int t1 = frag >> 2, ks = frag & 3;
+      const int u = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);
+      v = p.w2[u * LRF_FEATC + 16 * t1 + i];
+    } else if (frag < 40) {                                    // W1^T: frag - 32 = t' * 4 + ks
+      const int t1 = (frag - 32) >> 2, ks = (frag - 32) & 3;
+      const int vv = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3), f = 16 * t1 + i;
+      if (f < LRF_APP_DIM) v = p.w1[vv * LRF_APP_DIM + f];
+    } else {                                                   // basis^T: frag - 40 = t'
+      const int t1 = frag - 40;
+      const int f = 16 * (j >> 2) + 4 * g + (j & 3);           // dfeat feature of this K slot
+      const int q = 4 * t1 + (i & 3), gp = i >> 2;             // output slot q of lane group gp
+      if (f < LRF_APP_DIM && q < 18) v = p.basis[f * 72 + (q / 6) * LRF_CA + 6 * gp + (q % 6)];
+    }
+    const unsigned short hi = bf16_bits(v);
+    out[h] = part ? bf16_bits(v - bf16_val(hi)) : hi;
+  }
+  img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
+}
+
 __global__ void k_pack_mlp_t(LrfParams p, float* __restrict__ img) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= IMT_FLOATS) return;
@@ -356,6 +406,10 @@ __device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
   return __uint_as_float(__float_as_uint(x) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, k, 1));
 }
 struct AppGeo { const float* pl[3]; const float* ln[3]; int pw[3], ph[3], ll[3]; float lo[3], inv[3]; };
+// BF16: the chain dz2 -> dz1 -> dfeat -> dX on split-bf16 MFMAs (IMTB_* image, hand-issued as in the forward: the
+// kernel also gathers) instead of v_mfma_f32_16x16x4_f32 on the fp32 image: 135 instead of 360 MFMAs per tile at
+// half the cycles each (the fp32 chain kept the matrix pipe 51 % busy in a 441 us kernel).
+template <bool BF16>
 __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     DField f, const float* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R,
@@ -421,17 +475,65 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     for (int t1 = 0; t1 < 8; ++t1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 wv = *reinterpret_cast<const float4*>(&img[IMT_W3H + (g * 32 + t1 * 4 + r) * 4]);
+        const float4 wv = *reinterpret_cast<const float4*>(&img[(BF16 ? IMTB_TAIL * 4 : IMT_W3H) + (g * 32 + t1 * 4 + r) * 4]);
         const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
         dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);
       }
       if (store_dz2) *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];   // (k_wgrad_w2 rebuilds dz2 from go + mask bits)
     }
+    f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    f32x4 dxs[5];
+#pragma unroll
+    for (int t1 = 0; t1 < 5; ++t1) dxs[t1] = f32x4{0, 0, 0, 0};
+    if constexpr (BF16) {
+      const uint4* imgb = reinterpret_cast<const uint4*>(img);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no global load in flight under the hand-issued chain
+      f32x4 d1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d1[q] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(d1[q]));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                       // dz1 = W2^T dz2
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dz[2 * ks + (j >> 2)][j & 3];
+        bf16x8 bh, bl;
+        split8(v, bh, bl);
+        gemm_step<8>(imgb, IMTB_W2T / 128 + ks, 4, lane, bh, bl, d1);
+      }
+      settle<8>(d1);
+#pragma unroll
+      for (int t1 = 0; t1 < 8; ++t1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[t1][r] = relu_gate(d1[t1][r], m1, 4 * t1 + r);
+        row_store(grow + GRD_DZ1 + 16 * t1 + 4 * g, d1[t1]);
+      }
+      asm volatile("" : "+v"(df[0]), "+v"(df[1]));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                       // dfeat = W1^T dz1
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = d1[2 * ks + (j >> 2)][j & 3];
+        bf16x8 bh, bl;
+        split8(v, bh, bl);
+        gemm_step<2>(imgb, IMTB_W1T / 128 + ks, 4, lane, bh, bl, df);
+      }
+      settle<2>(df);
+      {                                                      // dX = basis^T dfeat
+        const float v[8] = {df[0][0], df[0][1], df[0][2], df[0][3], df[1][0], df[1][1], df[1][2], df[1][3]};
+        bf16x8 bh, bl;
+        split8(v, bh, bl);
+#pragma unroll
+        for (int t1 = 0; t1 < 5; ++t1) asm volatile("" : "+v"(dxs[t1]));
+        gemm_step<5>(imgb, IMTB_BT / 128, 1, lane, bh, bl, dxs);
+        settle<5>(dxs);
+      }
+    } else {
     // dz1 = (W2^T dz2) * [h1 > 0]      (exact fp32 MFMA, transposed fragments), one output tile at
     // a time; each finished tile is masked, stored and consumed at once as k-step t1 of
     // dfeat = W1^T dz1, so only dz2 (32 registers) stays live across the loop -- the 8x8 loop nest with
     // all of dz1 live spilled 544 B per lane.  Summation order is unchanged.
-    f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) {
       asm volatile("" ::: "memory");             // keep each tile's row / fragment loads next to their use
@@ -452,13 +554,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         for (int r = 0; r < 4; ++r) df[t2] = mfma4(a[r], d1[r], df[t2]);
       }
     }
-    row_store_b<32>(grow + GRD_DFEAT + 4 * g, make_float4(df[0][0], df[0][1], df[0][2], df[0][3]));
-    row_store_b<32>(grow + GRD_DFEAT + 16 + 4 * g, make_float4(df[1][0], df[1][1], df[1][2], df[1][3]));
     // dX = basis^T dfeat, delivered in the gather layout: slot q = 4t'+r of lane (s,g) is
     // channel (p = q/6, 6g + q%6)
-    f32x4 dxs[5];
-#pragma unroll
-    for (int t1 = 0; t1 < 5; ++t1) dxs[t1] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int t0 = 0; t0 < 2; ++t0) {
 #pragma unroll
@@ -468,6 +565,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         for (int r = 0; r < 4; ++r) dxs[t1] = mfma4(a[r], df[t0][r], dxs[t1]);
       }
     }
+    }
+    row_store_b<32>(grow + GRD_DFEAT + 4 * g, make_float4(df[0][0], df[0][1], df[0][2], df[0][3]));
+    row_store_b<32>(grow + GRD_DFEAT + 16 + 4 * g, make_float4(df[1][0], df[1][1], df[1][2], df[1][3]));
     float dX[18];
 #pragma unroll
     for (int q = 0; q < 18; ++q) dX[q] = dxs[q >> 2][q & 3];
@@ -1505,6 +1605,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 // 268 B of scratch per lane, in a kernel that is bound by its 1.5 KB of row stores per sample, not by the gathers the
 // prefetch hides): fwd+bwd 2.82 vs 2.93 ms.  The eval kernel's structure does not carry over.
 static int g_train_fwd_engine = 1;
+static int g_dgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(4 | ...): data-gradient chain on the exact-fp32 MFMA path
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * n): n weight-gradient GEMMs on the caller's stream
 static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 = k_wgrad<8,9> over stored dz2 rows on fp32 MFMAs (measurement)
 static int shade_save_attrs() {
@@ -1533,7 +1634,7 @@ static void launch_shade_save(const DField& d, const float* rays, const float* z
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_train_fwd_engine = (e & 1) ? 1 : 0; lrf::g_wgrad_bf16 = (e & 2) ? 0 : 1; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_train_fwd_engine = (e & 1) ? 1 : 0; lrf::g_wgrad_bf16 = (e & 2) ? 0 : 1; lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; }
 
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
@@ -1614,7 +1715,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     }
   }
   LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
-  hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
+  if (g_dgrad_bf16) hipLaunchKernelGGL(k_pack_mlp_bf16_t, dim3((IMTB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
+  else hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
@@ -1641,8 +1743,12 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
 
   // ---- caller's stream: data gradient of the colour network
-  hipLaunchKernelGGL(k_bwd_shade_dgrad, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                     w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, g_wgrad_bf16 ? 0 : 1);
+  if (g_dgrad_bf16)
+    hipLaunchKernelGGL(k_bwd_shade_dgrad<true>, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
+                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, g_wgrad_bf16 ? 0 : 1);
+  else
+    hipLaunchKernelGGL(k_bwd_shade_dgrad<false>, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
+                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, g_wgrad_bf16 ? 0 : 1);
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));
 
   // ---- side stream: per-ray backward, density scatter
