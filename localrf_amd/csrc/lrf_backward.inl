@@ -196,11 +196,13 @@ __device__ __forceinline__ void lds_add4_f32(float* p0, float v0, float* p1, flo
 
 // Stores into / loads from the saved rows.  Rows are written once and read once by a later kernel: with the `nt` hint
 // they do not displace the field's texels in L2 under the gathers running beside them.  LRF_ROW_NT bits: 1 = 16-byte row
-// stores (h1, h2, dz1), 2 = the X row's 8-byte stores, 4 = the weight-gradient GEMMs' row loads, 8 = the dX row's
-// stores.  Default 13: measured on one box (scripts/ab_libs.sh) forward+backward 2.65 (bit 1 only) / 2.41 (13) /
-// 2.57 ms (15: the X row stores cost the row-saving forward 0.59 -> 0.64 ms).
+// stores (h1, h2, dz1), 2 = the X block's stores, 4 = the weight-gradient GEMMs' row loads, 8 = the dX row's
+// stores, 16 = the scatter kernels' dX loads, 32 = the small blocks (feat, go, dfeat, bias columns).  Default 15.
+// Measured on one box each (scripts/ab_libs.sh), forward+backward: row-major rows 2.65 (bit 1 only) / 2.41 (13) /
+// 2.57 ms (15: 8-byte X stores); fragment-order rows (lrf_common.h) 1.93-2.00 (13) / 1.89 ms (15: the X block is five
+// coalesced float4 per lane now, the row-saving forward 0.39 -> 0.35 ms).
 #ifndef LRF_ROW_NT
-#define LRF_ROW_NT 13
+#define LRF_ROW_NT 15
 #endif
 __device__ __forceinline__ void row_store(float* p, f32x4 v) {
 #if LRF_ROW_NT & 1
@@ -242,6 +244,10 @@ __device__ __forceinline__ float4 row_load4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 #endif
 }
+template <int P>
+__device__ __forceinline__ void save_x_plane(float* afr, const float v[8], float xc[2]) {
+  save_x_plane_with<P>(afr, v, xc, [](float* p, float4 q) { row_store_b<2>(p, q); });
+}
 
 // ---------------------------------------------------------------- colour chain, saving rows
 // Same arithmetic as k_shade_bf16; additionally writes rgb per shaded sample and the ACT row.
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     const int k = cidx[ci];
     float x[3], u[3];
     sample_point(f, o, dh, z[k], x, u);
-    float* arow = act + ((size_t)tw.t * 16 + s) * ACT_LD;
+    float* afr = frag_lane_base(act, (size_t)tw.t, ACT_LD, s, g);      // + 16 * COL: this lane's float4 of block column COL
 
     f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
@@ -287,32 +293,29 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       float v[8];
       bf16x8 bh, bl;
       const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);   // 32-bit gathers, taps once per axis (as k_shade2)
+      float xc[2];
       gather_app6_plane32<0>(f, at, g, v);
-#pragma unroll
-      for (int h = 0; h < 3; ++h) row_store2(arow + ACT_X + 0 * LRF_CA + 6 * g + 2 * h, v[2 * h], v[2 * h + 1]);
+      save_x_plane<0>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       gather_app6_plane32<1>(f, at, g, v);
-#pragma unroll
-      for (int h = 0; h < 3; ++h) row_store2(arow + ACT_X + 1 * LRF_CA + 6 * g + 2 * h, v[2 * h], v[2 * h + 1]);
+      save_x_plane<1>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
       gather_app6_plane32<2>(f, at, g, v);
-#pragma unroll
-      for (int h = 0; h < 3; ++h) row_store2(arow + ACT_X + 2 * LRF_CA + 6 * g + 2 * h, v[2 * h], v[2 * h + 1]);
+      save_x_plane<2>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
     }
-    // feat (27) | 1 | 0 0 0 0 ; pad columns 72..79 of the X block
+    // feat (27) | 1 | 0 0 0 0
     {
       float4 a = make_float4(fe[0][0], fe[0][1], fe[0][2], fe[0][3]);
       float4 b = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
       if (g == 2) b.w = 1.0f;                        // column 27 = bias column of the dW1 GEMM
       if (g == 3) b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      row_store_b<32>(arow + ACT_FEAT + 4 * g, a);
-      row_store_b<32>(arow + ACT_FEAT + 16 + 4 * g, b);
-      if (g < 2) row_store_b<32>(arow + 72 + 4 * g, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+      row_store_b<32>(afr + 16 * ACT_FEAT, a);
+      row_store_b<32>(afr + 16 * (ACT_FEAT + 16), b);
     }
     f32x4 h1[8];
 #pragma unroll
@@ -334,10 +337,10 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
         h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
         m1 |= min(__float_as_uint(h1[t1][r]), 1u) << (4 * t1 + r);        // relu output: +0 or positive
       }
-      row_store(arow + ACT_H1 + 16 * t1 + 4 * g, h1[t1]);
+      row_store(afr + 16 * (ACT_H1 + 16 * t1), h1[t1]);
     }
     relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane] = m1;
-    row_store_b<32>(arow + ACT_H1 + 128 + 4 * g, make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f));
+    row_store_b<32>(afr + 16 * (ACT_H1 + 128), make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f));
     f32x4 h2[8];
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
@@ -361,9 +364,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
         const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
         o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
       }
-      row_store(arow + ACT_H2 + 16 * t1 + 4 * g, h2[t1]);
+      row_store(afr + 16 * (ACT_H2 + 16 * t1), h2[t1]);
     }
-    row_store_b<32>(arow + ACT_H2 + 128 + 4 * g, g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    row_store_b<32>(afr + 16 * (ACT_H2 + 128), g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane] = m2;
     o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
@@ -404,6 +407,23 @@ __device__ __forceinline__ void ld4g(const float* p, float* out) {
 // x where bit k of the saved ReLU mask is set, else +0: sign-extended one-bit field (0 / ~0) ANDed into the value
 __device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
   return __uint_as_float(__float_as_uint(x) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, k, 1));
+}
+// the lane's 6 live channels of a padded texel: one 16-byte and one 8-byte load at a 32-bit byte offset from a
+// wave-uniform base.  The base comes out of LDS here, so the loads are pinned to the global address space by hand
+// (a generic pointer would make them flat_load).
+__device__ __forceinline__ void ld6b(const float* base, unsigned off, float out[6]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef char __attribute__((address_space(1))) gchar;
+  typedef f32x4 __attribute__((address_space(1))) gf32x4;
+  typedef f32x2 __attribute__((address_space(1))) gf32x2;
+  const gchar* b = (const gchar*)base + off;
+  const f32x4 a = *(const gf32x4*)b;
+  const f32x2 c = *(const gf32x2*)(b + 16);
+#else
+  const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
+  const f32x2 c = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(base) + off + 16);
+#endif
+  out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3]; out[4] = c[0]; out[5] = c[1];
 }
 struct AppGeo { const float* pl[3]; const float* ln[3]; int pw[3], ph[3], ll[3]; float lo[3], inv[3]; };
 // BF16: the chain dz2 -> dz1 -> dfeat -> dX on split-bf16 MFMAs (IMTB_* image, hand-issued as in the forward: the
@@ -453,7 +473,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     const int k = cidx[ci];
     const float zk = z[k];
     const size_t row = (size_t)tw.t * 16 + s;
-    float* grow = grd + row * GRD_LD;
+    float* gfr = frag_lane_base(grd, (size_t)tw.t, GRD_LD, s, g);
+    float* gdx = grd + (size_t)tw.t * (16 * GRD_LD) + GRD_DX * 16 + s * (GRD_LD - GRD_DX);   // row-major dX block (grd_dx_row)
     const uint32_t m1 = relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane];       // ReLU masks saved by k_bwd_shade_fwd
     const uint32_t m2 = relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane];
 
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         go[c] = g_rgb[(size_t)ray * 3 + c] * w * r * (1.0f - r);
       }
     }
-    row_store_b<32>(grow + GRD_GO + 4 * g, g == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    row_store_b<32>(gfr + 16 * GRD_GO, g == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 
     // dz2 = (W3[:, :128]^T go) * [h2 > 0]
     f32x4 dz[8];
@@ -479,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
         dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);
       }
-      if (store_dz2) *reinterpret_cast<f32x4*>(grow + GRD_DZ2 + 16 * t1 + 4 * g) = dz[t1];   // (k_wgrad_w2 rebuilds dz2 from go + mask bits)
+      if (store_dz2) *reinterpret_cast<f32x4*>(gfr + 16 * (GRD_DZ2 + 16 * t1)) = dz[t1];   // (k_wgrad_w2 rebuilds dz2 from go + mask bits)
     }
     f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     f32x4 dxs[5];
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       for (int t1 = 0; t1 < 8; ++t1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) d1[t1][r] = relu_gate(d1[t1][r], m1, 4 * t1 + r);
-        row_store(grow + GRD_DZ1 + 16 * t1 + 4 * g, d1[t1]);
+        row_store(gfr + 16 * (GRD_DZ1 + 16 * t1), d1[t1]);
       }
       asm volatile("" : "+v"(df[0]), "+v"(df[1]));
 #pragma unroll
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) d1[r] = relu_gate(d1[r], m1, 4 * t1 + r);
-      row_store(grow + GRD_DZ1 + 16 * t1 + 4 * g, d1);
+      row_store(gfr + 16 * (GRD_DZ1 + 16 * t1), d1);
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W1T + ((t2 * 8 + t1) * 64 + lane) * 4]);
@@ -566,8 +587,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       }
     }
     }
-    row_store_b<32>(grow + GRD_DFEAT + 4 * g, make_float4(df[0][0], df[0][1], df[0][2], df[0][3]));
-    row_store_b<32>(grow + GRD_DFEAT + 16 + 4 * g, make_float4(df[1][0], df[1][1], df[1][2], df[1][3]));
+    row_store_b<32>(gfr + 16 * GRD_DFEAT, make_float4(df[0][0], df[0][1], df[0][2], df[0][3]));
+    row_store_b<32>(gfr + 16 * (GRD_DFEAT + 16), make_float4(df[1][0], df[1][1], df[1][2], df[1][3]));
     float dX[18];
 #pragma unroll
     for (int q = 0; q < 18; ++q) dX[q] = dxs[q >> 2][q & 3];
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     for (int pq = 0; pq < 3; ++pq)
 #pragma unroll
       for (int h = 0; h < 3; ++h)
-        row_store2<8>(grow + GRD_DX + pq * LRF_CA + 6 * g + 2 * h, dX[pq * 6 + 2 * h], dX[pq * 6 + 2 * h + 1]);
+        row_store2<8>(gdx + pq * LRF_CA + 6 * g + 2 * h, dX[pq * 6 + 2 * h], dX[pq * 6 + 2 * h + 1]);
     if (g == 0) rowinfo[row] = valid ? (uint32_t)((size_t)ray * S + k) : 0xffffffffu;
 
     // d/d(position) from the appearance lookups
@@ -587,31 +608,30 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
 #pragma unroll
     for (int a = 0; a < 3; ++a) u[a] = (xc[a] - geo.lo[a]) * geo.inv[a] - 1.0f;
     if (valid) {
+      // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps, lrf_common.h): three tap computations serve the
+      // nine lookups; byte offsets are 32-bit (ld4b / ld2b), the pad slots 6, 7 of the lane's 8 are not fetched
+      int ai0[3], ai1[3]; float at[3], ag[3];
+      tap1d_g(u[0], geo.pw[0], ai0[0], ai1[0], at[0], ag[0]);
+      tap1d_g(u[1], geo.ph[0], ai0[1], ai1[1], at[1], ag[1]);
+      tap1d_g(u[2], geo.ll[0], ai0[2], ai1[2], at[2], ag[2]);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         asm volatile("" ::: "memory");           // one plane's 12 gathers in flight at a time
-        int x0, x1, y0, y1, l0, l1; float tx, ty, tl, gx, gy, gl;
-        tap1d_g(u[MAT0[p]], geo.pw[p], x0, x1, tx, gx);
-        tap1d_g(u[MAT1[p]], geo.ph[p], y0, y1, ty, gy);
-        tap1d_g(u[VEC[p]],  geo.ll[p], l0, l1, tl, gl);
-        // the lane's 6 channels of every tap as two aligned float4 of the padded texel (slots 6,7
-        // are zero pads); the pointers come out of LDS, so the loads are pinned to the global
-        // address space by hand (a generic pointer would make them flat_load)
-        const float* pl = geo.pl[p] + 8 * g;
-        const float* ln = geo.ln[p] + 8 * g;
-        const float* q00 = pl + ((size_t)y0 * geo.pw[p] + x0) * LRF_CAS;
-        const float* q10 = pl + ((size_t)y0 * geo.pw[p] + x1) * LRF_CAS;
-        const float* q01 = pl + ((size_t)y1 * geo.pw[p] + x0) * LRF_CAS;
-        const float* q11 = pl + ((size_t)y1 * geo.pw[p] + x1) * LRF_CAS;
-        const float* r0 = ln + (size_t)l0 * LRF_CAS;
-        const float* r1 = ln + (size_t)l1 * LRF_CAS;
-        float v00[8], v10[8], v01[8], v11[8], e0[8], e1[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          ld4g(q00 + 4 * h, v00 + 4 * h); ld4g(q10 + 4 * h, v10 + 4 * h);
-          ld4g(q01 + 4 * h, v01 + 4 * h); ld4g(q11 + 4 * h, v11 + 4 * h);
-          ld4g(r0 + 4 * h, e0 + 4 * h);   ld4g(r1 + 4 * h, e1 + 4 * h);
-        }
+        const int x0 = ai0[MAT0[p]], x1 = ai1[MAT0[p]], y0 = ai0[MAT1[p]], y1 = ai1[MAT1[p]];
+        const int l0 = ai0[VEC[p]], l1 = ai1[VEC[p]];
+        const float tx = at[MAT0[p]], ty = at[MAT1[p]], tl = at[VEC[p]];
+        const float gx = ag[MAT0[p]], gy = ag[MAT1[p]], gl = ag[VEC[p]];
+        const unsigned gb = 32u * (unsigned)g;
+        const unsigned pw = (unsigned)geo.pw[p];
+        const unsigned row0 = (unsigned)y0 * pw, row1 = (unsigned)y1 * pw;
+        const unsigned o00 = (row0 + x0) * (LRF_CAS * 4u) + gb, o10 = (row0 + x1) * (LRF_CAS * 4u) + gb;
+        const unsigned o01 = (row1 + x0) * (LRF_CAS * 4u) + gb, o11 = (row1 + x1) * (LRF_CAS * 4u) + gb;
+        const unsigned q0 = (unsigned)l0 * (LRF_CAS * 4u) + gb, q1 = (unsigned)l1 * (LRF_CAS * 4u) + gb;
+        const float* pl = geo.pl[p];
+        const float* ln = geo.ln[p];
+        float v00[6], v10[6], v01[6], v11[6], e0[6], e1[6];
+        ld6b(pl, o00, v00); ld6b(pl, o10, v10); ld6b(pl, o01, v01); ld6b(pl, o11, v11);
+        ld6b(ln, q0, e0);   ld6b(ln, q1, e1);
         float gix = 0.0f, giy = 0.0f, gil = 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -695,18 +715,27 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   for (int m = 0; m < MW; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
-  constexpr int QA = WA / 4, QB = WB / 4;                    // float4 per row
-  constexpr int NQ = (KT * (QA + QB) + 255) / 256;           // float4 per thread and tile
+  // Operands arrive in fragment order (lrf_common.h): A / B point at their first block of tile 0, a tile is 16 * ld
+  // floats further.  One float4 per thread and step: wave-instruction = one whole 1 KB block; inside it the lanes are
+  // dealt (s & 1, lane group, s >> 1) so that the eight lanes of an LDS write cycle land in eight different bank quads of
+  // the row-major staging tile (rows 2 apart share banks: LD = 16 mod 32).
+  constexpr int NBLK = MT + NT;                              // 16-column blocks per tile (A then B)
+  constexpr int NF4 = (KT / 16) * NBLK * 64;                 // float4 per K-step of 32 rows
+  constexpr int NQ = (NF4 + 255) / 256;                      // float4 per thread and tile
   float4 pre[NQ];
   auto fetch = [&](int rb) {                                  // global -> registers (next tile)
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
-      const int rr = q / (QA + QB), cq = q % (QA + QB);
-      const int row = rb + rr;
+      const int l = q & 63, bt = q >> 6, blk = bt % NBLK, th = bt / NBLK;
+      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
+      const int row = rb + 16 * th + sr;
       pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (q < KT * (QA + QB) && row < r1)
-        pre[t] = cq < QA ? row_load4(A + (size_t)row * lda + 4 * cq) : row_load4(B + (size_t)row * ldb + 4 * (cq - QA));
+      if (q < NF4 && row < r1) {
+        const size_t tile = (size_t)(row >> 4);
+        const float* src = blk < MT ? A + tile * (size_t)(16 * lda) + blk * 256 : B + tile * (size_t)(16 * ldb) + (blk - MT) * 256;
+        pre[t] = row_load4(src + ((gq * 16 + sr) << 2));
+      }
     }
   };
   fetch(r0);
@@ -715,7 +744,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
-      if (q < KT * (QA + QB)) *reinterpret_cast<float4*>(&s_t[(q / (QA + QB)) * LD + 4 * (q % (QA + QB))]) = pre[t];
+      const int l = q & 63, bt = q >> 6, blk = bt % NBLK, th = bt / NBLK;
+      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
+      if (q < NF4) *reinterpret_cast<float4*>(&s_t[(16 * th + sr) * LD + 16 * blk + 4 * gq]) = pre[t];
     }
     __syncthreads();
     if (rb + KT < r1) fetch(rb + KT);                        // overlaps the MFMAs below
@@ -831,8 +862,8 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
     const int u = 16 * (wave + 4 * m) + i;
     wr[m] = w3[u]; wg[m] = w3[131 + u]; wb[m] = w3[262 + u];
   }
-  constexpr int QB = WB / 4;
-  constexpr int NQ = (KT * QB + 255) / 256;
+  constexpr int NF4 = (KT / 16) * NT * 64;                 // B in fragment order, staged as in k_wgrad
+  constexpr int NQ = (NF4 + 255) / 256;
   float4 pre[NQ];
   float4 pre_go = make_float4(0, 0, 0, 0);
   uint32_t pre_m = 0;
@@ -840,13 +871,15 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
-      const int row = rb + q / QB;
+      const int l = q & 63, bt = q >> 6, blk = bt % NT, th = bt / NT;
+      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
+      const int row = rb + 16 * th + sr;
       pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (q < KT * QB && row < r1) pre[t] = row_load4(B + (size_t)row * ldb + 4 * (q % QB));
+      if (q < NF4 && row < r1) pre[t] = row_load4(B + (size_t)(row >> 4) * (size_t)(16 * ldb) + blk * 256 + ((gq * 16 + sr) << 2));
     }
-    if (threadIdx.x < KT) {                                // go of row rb + tid (0 for rows behind the chunk)
+    if (threadIdx.x < KT) {                                // go of row rb + tid (0 for rows behind the chunk): block 0, lane group 0
       const int row = rb + threadIdx.x;
-      pre_go = row < r1 ? *reinterpret_cast<const float4*>(go + (size_t)row * ldg) : make_float4(0, 0, 0, 0);
+      pre_go = row < r1 ? *reinterpret_cast<const float4*>(go + (size_t)(row >> 4) * (size_t)(16 * ldg) + ((row & 15) << 2)) : make_float4(0, 0, 0, 0);
     } else if (threadIdx.x < 5 * KT) {                     // mask dword (row, lane group gg): tile row/16, layer 2, lane (row%16) + 16 gg
       const int k = (threadIdx.x - KT) >> 2, gg = (threadIdx.x - KT) & 3;
       const int row = rb + k;
@@ -859,7 +892,9 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
-      if (q < KT * QB) *reinterpret_cast<float4*>(&s_t[(q / QB) * LD + 4 * (q % QB)]) = pre[t];
+      const int l = q & 63, bt = q >> 6, blk = bt % NT, th = bt / NT;
+      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
+      if (q < NF4) *reinterpret_cast<float4*>(&s_t[(16 * th + sr) * LD + 16 * blk + 4 * gq]) = pre[t];
     }
     if (threadIdx.x < KT) *reinterpret_cast<float4*>(&s_go[threadIdx.x][0]) = pre_go;
     else if (threadIdx.x < 5 * KT) s_m[(threadIdx.x - KT) >> 2][(threadIdx.x - KT) & 3] = pre_m;
@@ -916,7 +951,7 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
 
 // dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in a fixed order) for
 // the seven weight / bias tensors in one launch: 16 lanes per output element.
-struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem; float* dst; };
+struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem, x_slots; float* dst; };   // x_slots: source column of n is x_slot_col(n)
 struct WgradSegs { WgradSeg s[7]; int total_elems; };
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
                                                       WgradSegs segs) {
@@ -931,7 +966,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   const int WGRAD_CH = wgrad_chunk_rows(toff[R] * 16);
   const int nch = (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
   float acc = 0.0f;
-  for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + sg.off + m * sg.ld + sg.n_off + n];
+  const int src = sg.off + m * sg.ld + sg.n_off + (sg.x_slots ? x_slot_col(n) : n);
+  for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + src];
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);          // fixed tree: deterministic
   if (ok && sub == 0) sg.dst[m * sg.dst_ld + n] += acc;
@@ -1389,7 +1425,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
         if (APP) {
           ld4g(r0 + 8 * sub, e0v); ld4g(r0 + 8 * sub + 4, e0v + 4);
           ld4g(r1 + 8 * sub, e1v); ld4g(r1 + 8 * sub + 4, e1v + 4);
-          const float2* dx2 = reinterpret_cast<const float2*>(grd + (size_t)ir * GRD_LD + GRD_DX + p * LRF_CA + 6 * sub);
+          const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, (size_t)ir) + p * LRF_CA + 6 * sub);
 #pragma unroll
           for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
         } else {
@@ -1498,7 +1534,7 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
           ld4g(q00 + 8 * sub + 4 * h, v00 + 4 * h); ld4g(q10 + 8 * sub + 4 * h, v10 + 4 * h);
           ld4g(q01 + 8 * sub + 4 * h, v01 + 4 * h); ld4g(q11 + 8 * sub + 4 * h, v11 + 4 * h);
         }
-        const float2* dx2 = reinterpret_cast<const float2*>(grd + (size_t)ie * GRD_LD + GRD_DX + p * LRF_CA + 6 * sub);
+        const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, (size_t)ie) + p * LRF_CA + 6 * sub);
 #pragma unroll
         for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
       } else {
@@ -1773,30 +1809,30 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (ss && on_a < 4) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
   auto wst = [&](int idx) { return idx < on_a ? st : sb; };
   if (g_wgrad_bf16)
-    hipLaunchKernelGGL(k_wgrad_w2, dim3(nch_max), dim3(256), 0, wst(0), b.grd + GRD_GO, GRD_LD, b.relu_bits, p->w3,
-                       b.act + ACT_H1, ACT_LD, w.toff, R, b.wpart, WP_W2);
+    hipLaunchKernelGGL(k_wgrad_w2, dim3(nch_max), dim3(256), 0, wst(0), b.grd + 16 * GRD_GO, GRD_LD, b.relu_bits, p->w3,
+                       b.act + 16 * ACT_H1, ACT_LD, w.toff, R, b.wpart, WP_W2);
   else
-    hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, wst(0), b.grd + GRD_DZ2, GRD_LD, b.act + ACT_H1, ACT_LD,
+    hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, wst(0), b.grd + 16 * GRD_DZ2, GRD_LD, b.act + 16 * ACT_H1, ACT_LD,
                        w.toff, R, b.wpart, WP_W2);
-  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + GRD_DZ1, GRD_LD, b.act + ACT_FEAT, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + 16 * GRD_DZ1, GRD_LD, b.act + 16 * ACT_FEAT, ACT_LD,
                      w.toff, R, b.wpart, WP_W1);
-  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(2), b.grd + GRD_DFEAT, GRD_LD, b.act + ACT_X, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(2), b.grd + 16 * GRD_DFEAT, GRD_LD, b.act + 16 * ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
-  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, wst(3), b.grd + GRD_GO, GRD_LD, b.act + ACT_H2, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, wst(3), b.grd + 16 * GRD_GO, GRD_LD, b.act + 16 * ACT_H2, ACT_LD,
                      w.toff, R, b.wpart, WP_W3);
   if (ss && on_a > 0) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream GEMMs are done behind this
   {
     WgradSegs segs;
     int nseg = 0, elems = 0;
-    auto seg = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld) {
-      segs.s[nseg++] = WgradSeg{off, ld, n_off, m, n, dst_ld, elems, dst};
+    auto seg = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld, int x_slots = 0) {
+      segs.s[nseg++] = WgradSeg{off, ld, n_off, m, n, dst_ld, elems, x_slots, dst};
       elems += m * n;
     };
     seg(WP_W2, 144, 0, 128, 128, g->w2, 128);
     seg(WP_W2, 144, 128, 128, 1, g->b2, 1);
     seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM);
     seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1);
-    seg(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72);
+    seg(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72, 1);               // the X block is in slot order
     seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
     seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
     segs.total_elems = elems;

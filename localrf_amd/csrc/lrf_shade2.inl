@@ -496,11 +496,8 @@ __device__ __forceinline__ void plane_touch(const DField& f, const float u[3], i
 //    that range; the <= gridDim.x - 1 rays that straddle a workgroup boundary are summed by whichever workgroup
 //    finishes last (release fence + counter f.ctr, zeroed by the k_march of the same call; agent-scope loads).
 // No float atomics, no spinning: results do not depend on the order in which workgroups finish.
-// the lane's 6 gathered products of one plane into the ACT row (natural channel order)
-__device__ __forceinline__ void save_x6(float* dst, const float v[8]) {
-#pragma unroll
-  for (int h = 0; h < 3; ++h) *reinterpret_cast<float2*>(dst + 2 * h) = make_float2(v[2 * h], v[2 * h + 1]);
-}
+// plain 16-byte store for save_x_plane_with (k_shade2<SAVE>)
+struct St16 { __device__ __forceinline__ void operator()(float* p, float4 q) const { *reinterpret_cast<float4*>(p) = q; } };
 template <bool COHERENT>
 __device__ __forceinline__ void finalize_ray(int ray, int nit, int pmax, uint32_t flags, const float* __restrict__ acc,
                                              const float* part, float* __restrict__ rgb, float* __restrict__ acc_out) {
@@ -627,7 +624,8 @@ __global__ __launch_bounds__(1024) void k_shade2(
       for (int i = 0; i < 6 * TOUCH; ++i) sink += touch[i];
     }
     if (!PIPE) sample_point(f, rg.o, rg.dh, s_z[k], x, u);
-    float* arow = SAVE ? act + ((size_t)t * 16 + s) * ACT_LD : nullptr;
+    float* afr = SAVE ? frag_lane_base(act, (size_t)t, ACT_LD, s, g) : nullptr;       // fragment-order ACT tile (lrf_common.h)
+    float xc[2] = {0.0f, 0.0f};
     const float w = s < cnt ? cw[(size_t)ray_c * S + j0 + s] : 0.0f;          // needed at the end of the tile
     int k_n = 0, j0_n = 0, cnt_n = 0, ray_n = ray_c;
     RayGeo rg_n = rg;
@@ -647,30 +645,29 @@ __global__ __launch_bounds__(1024) void k_shade2(
       bf16x8 bh, bl;
       const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);
       if (PIPE) plane_combine(raw0, v); else gather_app6_plane32<0>(f, at, g, v);
-      if (SAVE) save_x6(arow + ACT_X + 0 * LRF_CA + 6 * g, v);
+      if (SAVE) save_x_plane_with<0>(afr, v, xc, St16());
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       LRF_TICK(1);
       gather_app6_plane32<1>(f, at, g, v);
-      if (SAVE) save_x6(arow + ACT_X + 1 * LRF_CA + 6 * g, v);
+      if (SAVE) save_x_plane_with<1>(afr, v, xc, St16());
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
       LRF_TICK(2);
       gather_app6_plane32<2>(f, at, g, v);
-      if (SAVE) save_x6(arow + ACT_X + 2 * LRF_CA + 6 * g, v);
+      if (SAVE) save_x_plane_with<2>(afr, v, xc, St16());
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
       LRF_TICK(3);
     }
-    if (SAVE) {                        // feat (27) | 1 | 0 0 0 0 ; pad columns 72..79 of the X block
+    if (SAVE) {                        // feat (27) | 1 | 0 0 0 0
       float4 a4 = make_float4(fe[0][0], fe[0][1], fe[0][2], fe[0][3]);
       float4 b4 = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
       if (g == 2) b4.w = 1.0f;                       // column 27 = bias column of the dW1 GEMM
       if (g == 3) b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      *reinterpret_cast<float4*>(arow + ACT_FEAT + 4 * g) = a4;
-      *reinterpret_cast<float4*>(arow + ACT_FEAT + 16 + 4 * g) = b4;
-      if (g < 2) *reinterpret_cast<float4*>(arow + 72 + 4 * g) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(afr + 16 * ACT_FEAT) = a4;
+      *reinterpret_cast<float4*>(afr + 16 * (ACT_FEAT + 16)) = b4;
     }
     f32x4 h1[8];
 #pragma unroll
@@ -700,9 +697,9 @@ __global__ __launch_bounds__(1024) void k_shade2(
           h1[q][r] = relu_i(h1[q][r]);
           m1 |= min(__float_as_uint(h1[q][r]), 1u) << (4 * q + r);         // relu output: +0 or positive
         }
-        *reinterpret_cast<f32x4*>(arow + ACT_H1 + 16 * q + 4 * g) = h1[q];
+        *reinterpret_cast<f32x4*>(afr + 16 * (ACT_H1 + 16 * q)) = h1[q];
       }
-      *reinterpret_cast<float4*>(arow + ACT_H1 + 128 + 4 * g) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(afr + 16 * (ACT_H1 + 128)) = make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
       relu_bits[((size_t)t * 2 + 0) * 64 + lane] = m1;
     }
     LRF_TICK(4);
@@ -738,9 +735,9 @@ __global__ __launch_bounds__(1024) void k_shade2(
           h2[q][r] = relu_i(h2[q][r]);
           m2 |= min(__float_as_uint(h2[q][r]), 1u) << (4 * q + r);
         }
-        *reinterpret_cast<f32x4*>(arow + ACT_H2 + 16 * q + 4 * g) = h2[q];
+        *reinterpret_cast<f32x4*>(afr + 16 * (ACT_H2 + 16 * q)) = h2[q];
       }
-      *reinterpret_cast<float4*>(arow + ACT_H2 + 128 + 4 * g) =
+      *reinterpret_cast<float4*>(afr + 16 * (ACT_H2 + 128)) =
           g == 0 ? make_float4(rg.dh[0], rg.dh[1], rg.dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       relu_bits[((size_t)t * 2 + 1) * 64 + lane] = m2;
     }

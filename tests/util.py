@@ -205,7 +205,9 @@ def relu_flip_report(f, rays, z, ws):
     act_off, _, ri_off, toff_off, ACT_LD, _, ACT_H1, ACT_H2, _ = [int(v) for v in out]
     toff = ws[toff_off:toff_off + 4 * (R + 1)].view(torch.int32)
     rows = int(toff[R]) * 16
-    act = ws[act_off:act_off + rows * ACT_LD * 4].view(torch.float32).view(rows, ACT_LD)
+    # the rows are stored in MFMA-fragment order (csrc/lrf_common.h: tile, 16-column block, lane group, sample, 4 columns)
+    act = ws[act_off:act_off + rows * ACT_LD * 4].view(torch.float32).view(rows // 16, ACT_LD // 16, 4, 16, 4)
+    act = act.permute(0, 3, 1, 2, 4).reshape(rows, ACT_LD)
     rowinfo = ws[ri_off:ri_off + rows * 4].view(torch.int32)
     valid = rowinfo >= 0
     cid = rowinfo[valid].long()
