@@ -197,12 +197,12 @@ __device__ __forceinline__ void lds_add4_f32(float* p0, float v0, float* p1, flo
 // Stores into / loads from the saved rows.  Rows are written once and read once by a later kernel: with the `nt` hint
 // they do not displace the field's texels in L2 under the gathers running beside them.  LRF_ROW_NT bits: 1 = 16-byte row
 // stores (h1, h2, dz1), 2 = the X block's stores, 4 = the weight-gradient GEMMs' row loads, 8 = the dX row's
-// stores, 16 = the scatter kernels' dX loads, 32 = the small blocks (feat, go, dfeat, bias columns).  Default 15.
+// stores, 16 = the scatter kernels' dX loads, 32 = the small blocks (feat, go, dfeat, bias columns).  Default 63.
 // Measured on one box each (scripts/ab_libs.sh), forward+backward: row-major rows 2.65 (bit 1 only) / 2.41 (13) /
-// 2.57 ms (15: 8-byte X stores); fragment-order rows (lrf_common.h) 1.93-2.00 (13) / 1.89 ms (15: the X block is five
-// coalesced float4 per lane now, the row-saving forward 0.39 -> 0.35 ms).
+// 2.57 ms (15: 8-byte X stores); fragment-order rows (lrf_common.h) 1.93-2.00 (13) / 1.89-1.95 (15: the X block is
+// five coalesced float4 per lane now) / 1.87 (31) / 1.82 ms (47).
 #ifndef LRF_ROW_NT
-#define LRF_ROW_NT 15
+#define LRF_ROW_NT 63
 #endif
 __device__ __forceinline__ void row_store(float* p, f32x4 v) {
 #if LRF_ROW_NT & 1
@@ -247,6 +247,16 @@ __device__ __forceinline__ float4 row_load4(const float* p) {
 template <int P>
 __device__ __forceinline__ void save_x_plane(float* afr, const float v[8], float xc[2]) {
   save_x_plane_with<P>(afr, v, xc, [](float* p, float4 q) { row_store_b<2>(p, q); });
+}
+
+// dX of (row, plane p, lane group sub): six channels 24 p + 6 sub .. + 5 from the GRD tile's row-major dX block.
+// (Slot order like the X block -- five coalesced float4 stores per lane in k_bwd_shade_dgrad instead of nine 8-byte
+// ones -- was measured: dgrad 282 -> 262 us, but k_scatter_line<24> 178 -> 256 us, whose lanes walk the rows in
+// order and then read 24 B out of every 1 KB block; forward+backward 1.99 vs 1.94 ms.  Not adopted.)
+__device__ __forceinline__ void load_dx6(const float* __restrict__ grd, size_t row, int p, int sub, float dv[6]) {
+  const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, row) + p * LRF_CA + 6 * sub);
+#pragma unroll
+  for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
 }
 
 // ---------------------------------------------------------------- colour chain, saving rows
@@ -1425,9 +1435,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
         if (APP) {
           ld4g(r0 + 8 * sub, e0v); ld4g(r0 + 8 * sub + 4, e0v + 4);
           ld4g(r1 + 8 * sub, e1v); ld4g(r1 + 8 * sub + 4, e1v + 4);
-          const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, (size_t)ir) + p * LRF_CA + 6 * sub);
-#pragma unroll
-          for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
+          load_dx6(grd, (size_t)ir, p, sub, dv);
         } else {
           e0v[0] = r0[sub]; e1v[0] = r1[sub]; dv[0] = gf[ir];
         }
@@ -1534,9 +1542,7 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
           ld4g(q00 + 8 * sub + 4 * h, v00 + 4 * h); ld4g(q10 + 8 * sub + 4 * h, v10 + 4 * h);
           ld4g(q01 + 8 * sub + 4 * h, v01 + 4 * h); ld4g(q11 + 8 * sub + 4 * h, v11 + 4 * h);
         }
-        const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, (size_t)ie) + p * LRF_CA + 6 * sub);
-#pragma unroll
-        for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
+        load_dx6(grd, (size_t)ie, p, sub, dv);
       } else {
         v00[0] = q00[sub]; v10[0] = q10[sub]; v01[0] = q01[sub]; v11[0] = q11[sub]; dv[0] = gf[ie];
       }
