@@ -732,34 +732,34 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   constexpr int NBLK = MT + NT;                              // 16-column blocks per tile (A then B)
   constexpr int NF4 = (KT / 16) * NBLK * 64;                 // float4 per K-step of 32 rows
   constexpr int NQ = (NF4 + 255) / 256;                      // float4 per thread and tile
-  float4 pre[NQ];
-  auto fetch = [&](int rb) {                                  // global -> registers (next tile)
+  float4 pre0[NQ];
+  auto fetch = [&](float4 (&pre)[NQ], int rb) {                                  // global -> registers (next tile)
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
       const int l = q & 63, bt = q >> 6, blk = bt % NBLK, th = bt / NBLK;
       const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
+      // no branch around the load (rows behind the chunk read row r0 again and are zeroed in stage()): the compiler
+      // counts unconditional loads, so stage() waits for ITS buffer only (vmcnt(n), not vmcnt(0))
       const int row = rb + 16 * th + sr;
-      pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (q < NF4 && row < r1) {
-        const size_t tile = (size_t)(row >> 4);
-        const float* src = blk < MT ? A + tile * (size_t)(16 * lda) + blk * 256 : B + tile * (size_t)(16 * ldb) + (blk - MT) * 256;
-        pre[t] = row_load4(src + ((gq * 16 + sr) << 2));
-      }
+      const size_t tile = (size_t)((q < NF4 && row < r1 ? row : r0) >> 4);
+      const float* src = blk < MT ? A + tile * (size_t)(16 * lda) + blk * 256 : B + tile * (size_t)(16 * ldb) + (blk - MT) * 256;
+      pre[t] = row_load4(src + ((gq * 16 + sr) << 2));
     }
   };
-  fetch(r0);
-  for (int rb = r0; rb < r1; rb += KT) {
+  auto stage = [&](const float4 (&pre)[NQ], int rb) {         // registers -> LDS staging tile
     __syncthreads();                                         // previous tile fully consumed
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
       const int l = q & 63, bt = q >> 6, blk = bt % NBLK, th = bt / NBLK;
       const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      if (q < NF4) *reinterpret_cast<float4*>(&s_t[(16 * th + sr) * LD + 16 * blk + 4 * gq]) = pre[t];
+      const bool ok = rb + 16 * th + sr < r1;
+      if (q < NF4) *reinterpret_cast<float4*>(&s_t[(16 * th + sr) * LD + 16 * blk + 4 * gq]) = ok ? pre[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
-    if (rb + KT < r1) fetch(rb + KT);                        // overlaps the MFMAs below
+  };
+  auto compute = [&]() {
     if constexpr (BF16) {
 #pragma unroll
       for (int ks = 0; ks < KT / 16; ++ks) {
@@ -788,25 +788,39 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
           }
         }
       }
-      continue;
+      return;
     }
+    // (as in k_wgrad_w2: every LDS operand of the 32 rows first, behind a scheduling barrier, then the MFMAs)
+    constexpr int NKS = KSPLIT ? KT / 16 : KT / 4;
+    float a[NKS][MW], b[NKS][NT];
 #pragma unroll
-    for (int ks = 0; ks < (KSPLIT ? KT / 16 : KT / 4); ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       const int kk = KSPLIT ? 4 * ks + wave : ks;
       const float* rowp = &s_t[(4 * kk + g) * LD + i];
-      float a[MW], b[NT];
 #pragma unroll
       for (int m = 0; m < MW; ++m) {
         const int mt = KSPLIT ? m : wave + 4 * m;
-        a[m] = (mt < MT) ? rowp[16 * mt] : 0.0f;
+        a[ks][m] = (mt < MT) ? rowp[16 * mt] : 0.0f;
       }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = rowp[WA + 16 * n];
+      for (int n = 0; n < NT; ++n) b[ks][n] = rowp[WA + 16 * n];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
       for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], b[n], acc[m][n]);
-    }
+        for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[ks][m], b[ks][n], acc[m][n]);
+    };
+  // (Two prefetched steps in flight instead of one -- the loads are branch-free so that stage() waits with vmcnt(n) for
+  // its own buffer only -- were measured: the narrow products 126 -> 114, 101 -> 98 us, k_wgrad_w2 251 -> 274 us at
+  // 451 registers, forward+backward 1.99 vs 1.93-1.97 ms.  Not adopted; the branch-free loads stayed.)
+  fetch(pre0, r0);
+  for (int rb = r0; rb < r1; rb += KT) {
+    stage(pre0, rb);
+    fetch(pre0, rb + KT);
+    compute();
   }
   if (KSPLIT) {                                              // waves 1..3 hand their sums to wave 0, in order
     for (int w = 1; w < 4; ++w) {
@@ -845,15 +859,23 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 
 // dW2 (and db2) = dz2^T [relu(h1) | 1] without dz2 rows: dz2[u] = [h2_u > 0] * sum_c W3[c][u] go[c] is rank 3 plus a
 // mask, so the kernel rebuilds its A operand from 16 B of go and 16 B of ReLU mask bits per sample (and W3 in
-// registers) instead of reading 512 B of dz2 that k_bwd_shade_dgrad would have had to write first.  Otherwise
-// k_wgrad<8, 9, false, true>: M-tiles w, w + 4 per wave, 9 N-tiles of the h1 row, split-bf16 MFMAs.
+// registers) instead of reading 512 B of dz2 that k_bwd_shade_dgrad would have had to write first.  M-tiles w, w + 4 per
+// wave, 9 N-tiles of the h1 row, split-bf16 (Al Bh + Ah Bl + Ah Bh) on v_mfma_f32_16x16x32_bf16, one instruction per
+// 32-row step.  History on one box (serial trace): K = 16 instruction on a row-major fp32 staging tile, every wave
+// splitting all of B: 251-274 us (645 VALU + 108 MFMA per step in ONE wave per SIMD); this version 194 us.
 __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /* grd + GRD_GO */, int ldg,
                                                   const uint32_t* __restrict__ relu_bits, const float* __restrict__ w3 /* [3][131] */,
                                                   const float* __restrict__ B, int ldb, const int* __restrict__ toff, int R,
                                                   float* __restrict__ wpart, int wp_off) {
   constexpr int KT = 32, NT = 9, WB = NT * 16, LD = WB + 16;     // LD = 16 (mod 32)
-  __shared__ __attribute__((aligned(16))) float s_t[KT * LD];
-  __shared__ float s_go[KT][4];
+  // h1 staged TRANSPOSED and already split: s_bh / s_bl [column][32 rows (+8 pad)] bf16.  A lane's B operand of one
+  // v_mfma_f32_16x16x32_bf16 (rows 8 g .. 8 g + 7 of column 16 n + i) is then one ds_read_b128 per half (column
+  // stride 80 B: the eight lanes of a read cycle cover all 32 banks), every element is split once by the thread that
+  // staged it instead of once per wave, and the K = 32 instruction runs at twice the rate of the K = 16 one.
+  constexpr int CS = KT + 8;                                     // bf16 per column
+  __shared__ __attribute__((aligned(16))) __bf16 s_bh[WB * CS];
+  __shared__ __attribute__((aligned(16))) __bf16 s_bl[WB * CS];
+  __shared__ __attribute__((aligned(16))) float s_go[KT][4];
   __shared__ uint32_t s_m[KT][4];
   const int rows = toff[R] * 16;
   const int WGRAD_CH = wgrad_chunk_rows(rows);
@@ -874,79 +896,93 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
   }
   constexpr int NF4 = (KT / 16) * NT * 64;                 // B in fragment order, staged as in k_wgrad
   constexpr int NQ = (NF4 + 255) / 256;
-  float4 pre[NQ];
-  float4 pre_go = make_float4(0, 0, 0, 0);
-  uint32_t pre_m = 0;
-  auto fetch = [&](int rb) {
+  struct Pre { float4 b[NQ]; float4 go; uint32_t m; };
+  Pre pre0;
+  auto fetch = [&](Pre& pre, int rb) {
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
       const int l = q & 63, bt = q >> 6, blk = bt % NT, th = bt / NT;
       const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      const int row = rb + 16 * th + sr;
-      pre[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (q < NF4 && row < r1) pre[t] = row_load4(B + (size_t)(row >> 4) * (size_t)(16 * ldb) + blk * 256 + ((gq * 16 + sr) << 2));
+      const int row = rb + 16 * th + sr;                   // (branch-free loads, zeroed in stage(): see k_wgrad)
+      const int rowc = (q < NF4 && row < r1) ? row : r0;
+      pre.b[t] = row_load4(B + (size_t)(rowc >> 4) * (size_t)(16 * ldb) + blk * 256 + ((gq * 16 + sr) << 2));
     }
-    if (threadIdx.x < KT) {                                // go of row rb + tid (0 for rows behind the chunk): block 0, lane group 0
-      const int row = rb + threadIdx.x;
-      pre_go = row < r1 ? *reinterpret_cast<const float4*>(go + (size_t)(row >> 4) * (size_t)(16 * ldg) + ((row & 15) << 2)) : make_float4(0, 0, 0, 0);
-    } else if (threadIdx.x < 5 * KT) {                     // mask dword (row, lane group gg): tile row/16, layer 2, lane (row%16) + 16 gg
-      const int k = (threadIdx.x - KT) >> 2, gg = (threadIdx.x - KT) & 3;
+    {                                                      // go of row rb + tid % 32: block 0, lane group 0 (threads < KT stage it)
+      const int row = rb + (threadIdx.x & (KT - 1));
+      const int rowc = row < r1 ? row : r0;
+      pre.go = *reinterpret_cast<const float4*>(go + (size_t)(rowc >> 4) * (size_t)(16 * ldg) + ((rowc & 15) << 2));
+    }
+    {                                                      // mask dword (row, lane group gg): tile row/16, layer 2, lane (row%16) + 16 gg
+      const int e = (threadIdx.x - KT) & (4 * KT - 1), k = e >> 2, gg = e & 3;     // threads KT .. 5 KT - 1 stage it
       const int row = rb + k;
-      pre_m = row < r1 ? relu_bits[((size_t)(row >> 4) * 2 + 1) * 64 + (row & 15) + 16 * gg] : 0u;
+      const int rowc = row < r1 ? row : r0;
+      pre.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * gg];
     }
   };
-  fetch(r0);
-  for (int rb = r0; rb < r1; rb += KT) {
+  auto stage = [&](const Pre& pre, int rb) {
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       const int q = threadIdx.x + 256 * t;
       const int l = q & 63, bt = q >> 6, blk = bt % NT, th = bt / NT;
       const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      if (q < NF4) *reinterpret_cast<float4*>(&s_t[(16 * th + sr) * LD + 16 * blk + 4 * gq]) = pre[t];
-    }
-    if (threadIdx.x < KT) *reinterpret_cast<float4*>(&s_go[threadIdx.x][0]) = pre_go;
-    else if (threadIdx.x < 5 * KT) s_m[(threadIdx.x - KT) >> 2][(threadIdx.x - KT) & 3] = pre_m;
-    __syncthreads();
-    if (rb + KT < r1) fetch(rb + KT);
+      const bool ok = rb + 16 * th + sr < r1;
+      if (q < NF4) {
+        const float v[4] = {ok ? pre.b[t].x : 0.0f, ok ? pre.b[t].y : 0.0f, ok ? pre.b[t].z : 0.0f, ok ? pre.b[t].w : 0.0f};
 #pragma unroll
-    for (int ks = 0; ks < KT / 16; ++ks) {
-      s16x4 bh[NT], bl[NT];
+        for (int r = 0; r < 4; ++r) {
+          const __bf16 h = (__bf16)v[r];
+          const int at = (16 * blk + 4 * gq + r) * CS + 16 * th + sr;
+          s_bh[at] = h;
+          s_bl[at] = (__bf16)(v[r] - (float)h);
+        }
+      }
+    }
+    if (threadIdx.x < KT) *reinterpret_cast<float4*>(&s_go[threadIdx.x][0]) = rb + (int)threadIdx.x < r1 ? pre.go : make_float4(0, 0, 0, 0);
+    else if (threadIdx.x < 5 * KT) s_m[(threadIdx.x - KT) >> 2][(threadIdx.x - KT) & 3] = rb + (int)((threadIdx.x - KT) >> 2) < r1 ? pre.m : 0u;
+    __syncthreads();
+  };
+  auto compute = [&]() {
+    bf16x8 bh[NT], bl[NT];
+    float4 gq8[8];
+    uint32_t md[8];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      bh[n] = *reinterpret_cast<const bf16x8*>(&s_bh[(16 * n + i) * CS + 8 * g]);
+      bl[n] = *reinterpret_cast<const bf16x8*>(&s_bl[(16 * n + i) * CS + 8 * g]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                        // K slot (g, j) = row 8 g + j of the step
+      gq8[j] = *reinterpret_cast<const float4*>(&s_go[8 * g + j][0]);
+      md[j] = s_m[8 * g + j][i >> 2];
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // every LDS operand first: with one wave per SIMD nothing else covers the round trips
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int mt = wave + 4 * m;
+      bf16x8 ah, al;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = wr[m] * gq8[j].x + wg[m] * gq8[j].y + wb[m] * gq8[j].z;
+        const float v = relu_gate(d, md[j], 4 * mt + (i & 3));
+        const __bf16 h = (__bf16)v;
+        ah[j] = h;
+        al[j] = (__bf16)(v - (float)h);
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = s_t[(16 * ks + 4 * j + g) * LD + 16 * n + i];
-        split4_bf16(v, bh[n], bl[n]);
-      }
-      float gr[4], gg_[4], gb[4];
-      uint32_t md[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = 16 * ks + 4 * j + g;
-        gr[j] = s_go[k][0]; gg_[j] = s_go[k][1]; gb[j] = s_go[k][2];
-        md[j] = s_m[k][i >> 2];
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int mt = wave + 4 * m;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = wr[m] * gr[j] + wg[m] * gg_[j] + wb[m] * gb[j];
-          v[j] = relu_gate(d, md[j], 4 * mt + (i & 3));
-        }
-        s16x4 ah, al;
-        split4_bf16(v, ah, al);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[n], acc[m][n], 0, 0, 0);
-        }
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
       }
     }
+  };
+  fetch(pre0, r0);
+  for (int rb = r0; rb < r1; rb += KT) {
+    stage(pre0, rb);
+    fetch(pre0, rb + KT);
+    compute();
   }
   float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
 #pragma unroll
