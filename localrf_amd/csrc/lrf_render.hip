@@ -1081,12 +1081,47 @@ static void launch_march(const DField& d, const float* rays, const float* z, int
 
 using namespace lrf;
 
+// Debug: leave every CU's LDS (and, with regs, a wave's worth of vector registers) full of `pattern`, the state a
+// foreign kernel may leave behind.  A kernel that reads LDS or a register it never wrote shows it at once when the
+// pattern is a NaN (scripts/stale_probe*.py, DESIGN.md finding 17).
+namespace lrf {
+__global__ __launch_bounds__(1024) void k_poison_lds(uint32_t pattern, int n_u32, uint32_t* sink) {
+  extern __shared__ uint32_t s_poison[];
+  for (int i = threadIdx.x; i < n_u32; i += blockDim.x) s_poison[i] = pattern;
+  __syncthreads();
+  if (s_poison[(threadIdx.x * 7u) % (unsigned)n_u32] == 0x12345u) sink[0] = 1;        // (keeps the stores)
+}
+__global__ __launch_bounds__(256) void k_poison_regs(uint32_t pattern, uint32_t* sink) {
+  // 256 VGPRs + 256 AGPRs per lane, all set to the pattern
+  asm volatile(
+      ".altmacro\n"
+      ".macro poison_v n\n v_mov_b32 v\\n, %0\n.endm\n"
+      ".macro poison_a n\n v_accvgpr_write_b32 a\\n, %0\n.endm\n"
+      ".set i, 8\n.rept 248\n poison_v %%i\n.set i, i + 1\n.endr\n"
+      ".set i, 0\n.rept 256\n poison_a %%i\n.set i, i + 1\n.endr\n"
+      :: "v"(pattern) : "memory", "v255", "a255");            // (the clobbers size the kernel's register allocation)
+  if (pattern == 0x12345u && threadIdx.x == 1000) sink[0] = 2;
+}
+}  // namespace lrf
+
 extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): n GEMMs on the caller's stream
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
+int lrf_debug_poison_cu_state(uint32_t pattern, int regs, void* stream) {
+  using namespace lrf;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static uint32_t* sink = nullptr;
+  if (!sink && hipMalloc(&sink, 64) != hipSuccess) return set_err("lrf_debug_poison_cu_state: hipMalloc failed");
+  const int bytes = 160 * 1024 - 64;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+    return set_err("lrf_debug_poison_cu_state: hipFuncSetAttribute failed");
+  hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), bytes, st, pattern, bytes / 4, sink);
+  if (regs) hipLaunchKernelGGL(k_poison_regs, dim3(8192), dim3(256), 0, st, pattern, sink);
+  return hipGetLastError() == hipSuccess ? 0 : set_err("lrf_debug_poison_cu_state: launch failed");
+}
 void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 11) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
 void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
