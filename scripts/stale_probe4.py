@@ -31,7 +31,7 @@ for pipe, engine in ((0, "bf16x3"), (9, "bf16x3"), (0, "bf16x3_fused"), (0, "bf1
     for _ in range(3):
         ref, dref = rend(pipe, engine)
     ref, dref = ref.clone(), dref.clone()
-    for kind in ("sort", "fill 384 MB", "sleep"):
+    for kind in os.environ.get("KINDS", "sort,fill 384 MB,sleep").split(","):
         bad, worst, seen, dbad = 0, 0.0, {}, 0
         for it in range(n):
             if kind == "sort":
