@@ -105,6 +105,7 @@ void        lrf_debug_set_skew(int n);              /* start skew between the wa
 void        lrf_debug_set_lds_lines(int on);        /* k_march: density lines staged in LDS (default on when they fit) */
 void        lrf_debug_set_bwd_overlap(int on);      /* lrf_render_bwd: two branches on two streams (default on) */
 void        lrf_debug_set_train_fwd_engine(int engine);   /* bit 0: row-saving forward 1 = k_bwd_shade_fwd (default), 0 = k_shade2<SAVE> (slower); bit 1: dW2 GEMM on fp32 MFMAs over stored dz2 rows; bit 2: data-gradient chain on fp32 MFMAs */
+int64_t     lrf_debug_saved_row_offset(int buffer, uint64_t row, int col);   /* float offset of (row, col) inside the ACT (0) / GRD (1) region of a training workspace (MFMA-fragment order, csrc/lrf_common.h); buffer 2: X-block column of appearance channel col */
 int         lrf_debug_poison_cu_state(uint32_t pattern, int regs, void* stream);  /* fills every CU's LDS (regs != 0: also a wave's vector registers) with pattern: what a foreign kernel may leave behind */
 void        lrf_debug_set_shade_pipe(int on);       /* k_shade2: software-pipelined plane-0 gather (experiment) */
 void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */

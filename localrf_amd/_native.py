@@ -73,6 +73,7 @@ SYMBOLS = {
     "lrf_debug_set_subbatches": (None, [C.c_int]),
     "lrf_debug_set_skew": (None, [C.c_int]),
     "lrf_debug_set_lds_lines": (None, [C.c_int]),
+    "lrf_debug_saved_row_offset": (C.c_int64, [C.c_int, C.c_uint64, C.c_int]),
     "lrf_debug_poison_cu_state": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
     "lrf_debug_set_shade_pipe": (None, [C.c_int]),
     "lrf_debug_set_bwd_overlap": (None, [C.c_int]),

@@ -1122,6 +1122,20 @@ int lrf_debug_poison_cu_state(uint32_t pattern, int regs, void* stream) {
   if (regs) hipLaunchKernelGGL(k_poison_regs, dim3(8192), dim3(256), 0, st, pattern, sink);
   return hipGetLastError() == hipSuccess ? 0 : set_err("lrf_debug_poison_cu_state: launch failed");
 }
+// Where column `col` of saved row `row` lives, in floats from the start of the ACT (buffer 0) / GRD (buffer 1) region
+// of a training workspace (lrf_workspace_layout_bwd gives the regions): the fragment order of lrf_common.h, host side.
+// buffer 2: column of the ACT tile's X block that holds appearance channel `col` (x_slot_col).  -1 for bad arguments.
+int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col) {
+  using namespace lrf;
+  if (buffer == 0) return (col < 0 || col >= ACT_LD) ? -1 : (int64_t)frag_off((size_t)row, col, ACT_LD);
+  if (buffer == 1) {
+    if (col < 0 || col >= GRD_LD) return -1;
+    if (col >= GRD_DX) return (int64_t)((row >> 4) * (uint64_t)(16 * GRD_LD) + GRD_DX * 16 + (row & 15) * (GRD_LD - GRD_DX) + (col - GRD_DX));
+    return (int64_t)frag_off((size_t)row, col, GRD_LD);
+  }
+  if (buffer == 2) return (col < 0 || col >= 72) ? -1 : x_slot_col(col);
+  return -1;
+}
 void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 11) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
 void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }

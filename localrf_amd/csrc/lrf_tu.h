@@ -32,6 +32,7 @@
 #define lrf_debug_set_mlp_policy      lrf_tu2_debug_set_mlp_policy
 #define lrf_debug_set_mlp_threads     lrf_tu2_debug_set_mlp_threads
 #define lrf_debug_poison_cu_state     lrf_tu2_debug_poison_cu_state
+#define lrf_debug_saved_row_offset    lrf_tu2_debug_saved_row_offset
 #define lrf_debug_set_shade_pipe      lrf_tu2_debug_set_shade_pipe
 #define lrf_debug_set_skew            lrf_tu2_debug_set_skew
 #define lrf_debug_set_subbatches      lrf_tu2_debug_set_subbatches

@@ -56,8 +56,9 @@ def _overlap(x, y):
 # 18 (basis) + 24 (layer 1) + 96 (layer 2) [+ 12 (head)].  k_mlp has no gathers; its default policy (4) is the
 # compiler-scheduled builtin, pinned by the 200-render determinism test on the GPU; policy 0 is the hand-issued
 # fallback and is held to the rules below.
-FROM_TRAINING_UNIT = ("k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE")
-ALL_CHECKED = ("k_shade_bf16E", "k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE", "k_appE", "k_mlpILi0ELb0ELb1EE", "k_mlpILi4ELb0ELb1EE",
+WGRAD = ("k_wgrad_w2E", "k_wgradILi8ELi2ELb0ELb0EE", "k_wgradILi2ELi5ELb1ELb0EE", "k_wgradILi1ELi9ELb1ELb0EE")
+FROM_TRAINING_UNIT = ("k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE") + WGRAD
+ALL_CHECKED = WGRAD + ("k_shade_bf16E", "k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE", "k_appE", "k_mlpILi0ELb0ELb1EE", "k_mlpILi4ELb0ELb1EE",
                "k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE",
                "k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", "k_marchILb1EE", "k_marchILb0EE")
 SHIPPED = (("k_shade_bf16E", 138), ("k_bwd_shade_fwdE", 138), ("k_bwd_shade_dgradILb1EE", 135), ("k_appE", 18), ("k_mlpILi0ELb0ELb1EE", 132),
@@ -147,3 +148,27 @@ def test_scratch_use_is_bounded(asm):
         assert m, kern
         priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m[0])
         assert priv and int(priv[1]) <= limit, (kern, priv and priv[1])
+
+
+def test_weight_gradient_gemms(asm):
+    """k_wgrad_w2: split-bf16 on the K = 32 instruction only (the K = 16 form runs at half its rate on gfx950), 2 M-tiles x
+    9 N-tiles x 3 terms per 32-row step, B fragments as ds_read_b128 from the transposed pre-split tile.  All of them:
+    no scratch, and the staging loads are branch-free, so the wait in front of the LDS stage is a counted vmcnt(n)
+    placed by the compiler, not a vmcnt(0) behind a predicated block."""
+    def body(kern):
+        m = re.search(r"(^|\n)(_ZN3lrf\d+%s[^\n:]*:[^\n]*\n.*?\.end_amdhsa_kernel)" % kern, asm, re.S)
+        assert m, kern
+        return m[2]
+    w2 = body("k_wgrad_w2E")
+    assert len(re.findall(r"v_mfma_f32_16x16x32_bf16", w2)) == 54
+    assert not re.search(r"v_mfma_f32_16x16x16_bf16", w2)
+    assert len(re.findall(r"ds_read_b128", w2)) >= 18
+    for kern in WGRAD:
+        t = body(kern)
+        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", t)
+        assert priv and int(priv[1]) == 0, (kern, priv and priv[1])
+        loads = len(re.findall(r"global_load_dwordx4", t))
+        assert loads >= 3, (kern, loads)
+        for m in re.finditer(r"s_cbranch_execz (\.LBB\d+_\d+)\n", t):                  # no row load inside a predicated block
+            end = t.find("\n" + m[1] + ":", m.end())
+            assert end < 0 or "global_load_dwordx4" not in t[m.end():end], (kern, m[1])
