@@ -253,6 +253,10 @@ __device__ __forceinline__ void save_x_plane(float* afr, const float v[8], float
 // (Slot order like the X block -- five coalesced float4 stores per lane in k_bwd_shade_dgrad instead of nine 8-byte
 // ones -- was measured: dgrad 282 -> 262 us, but k_scatter_line<24> 178 -> 256 us, whose lanes walk the rows in
 // order and then read 24 B out of every 1 KB block; forward+backward 1.99 vs 1.94 ms.  Not adopted.)
+// (Also measured: k_bwd_shade_dgrad storing dX * L and dX * P -- it holds both factors when it forms the position
+// gradient -- so that the appearance scatter kernels need not re-gather the other factor's taps: 288 B more per row,
+// gradients unchanged (74 tests), forward+backward 1.94 vs 1.79 ms.  The scatters are bound by their LDS adds, not by
+// those gathers.  Not adopted.)
 __device__ __forceinline__ void load_dx6(const float* __restrict__ grd, size_t row, int p, int sub, float dv[6]) {
   const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, row) + p * LRF_CA + 6 * sub);
 #pragma unroll
