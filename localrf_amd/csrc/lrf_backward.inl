@@ -8,15 +8,18 @@
 //   k_march (+feat)      density features of every sample, compaction lists (as in the forward)
 //   k_scan_tiles         tile offsets
 //   k_bwd_shade_fwd      the split-bf16 colour chain of k_shade_bf16, additionally saving per
-//                        shaded sample: rgb and the activation row
-//                        ACT = [X | feat,1 | relu(h1),1 | relu(h2), dhat,1]
-// backward:
-//   k_bwd_shade_dgrad    per tile: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX as an
-//                        exact-fp32 MFMA chain on TRANSPOSED weight fragments (same register-
+//                        shaded sample: rgb, the ReLU masks as bits, and the activation row
+//                        ACT = [X | feat,1 | relu(h1),1 | relu(h2), dhat,1], stored in MFMA-fragment
+//                        order (lrf_common.h: 1 KB per store instruction)
+// backward (two branches on two streams, lrf_render_bwd):
+//   k_bwd_shade_dgrad    per tile: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX on TRANSPOSED
+//                        weight fragments, split-bf16 on v_mfma_f32_16x16x32_bf16 (same register-
 //                        resident trick as the forward: D layout of one layer = B operand of
-//                        the next), gradient row GRD = [go | dfeat | dz1 | dz2 | dX];
+//                        the next; <false>: exact fp32 chain), ReLU masks from the saved bits,
+//                        gradient row GRD = [go | dfeat | dz1 | (dz2) | dX];
 //                        d/d(position) of the appearance lookups -> per-tile ray partials
-//   k_wgrad<MT,NT,KS> x4 weight gradients as tall-skinny GEMMs C = A^T B over the saved rows
+//   k_wgrad_w2           dW2 = dz2^T [h1 | 1]: dz2 rebuilt from go + mask bits, split-bf16 MFMAs
+//   k_wgrad<MT,NT,KS> x3 the other weight gradients as tall-skinny GEMMs C = A^T B over the saved rows
 //                        (K = shaded samples) on v_mfma_f32_16x16x4_f32, per-chunk partials
 //   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts (1 launch)
 //   k_bwd_ray            one wavefront per ray: weights, d(loss)/d(w), suffix sums ->
@@ -31,7 +34,7 @@
 
 namespace lrf {
 
-// ---- saved rows (floats): ACT_* / GRD_* column offsets are in lrf_common.h (the row-saving forward is k_shade2<SAVE>)
+// ---- saved rows (floats): ACT_* / GRD_* column offsets and the fragment-order address functions are in lrf_common.h
 // transposed fp32 fragment image for the dgrad chain
 constexpr int IMT_W2T = 0;                          // [t'8][t8][lane64][4]  W2[16t+4g+r][16t'+i]
 constexpr int IMT_W1T = IMT_W2T + 8 * 8 * 256;      // [t'2][t8][lane64][4]  W1[16t+4g+r][16t'+i]
