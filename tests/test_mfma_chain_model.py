@@ -233,3 +233,117 @@ def test_bf16_fragment_mapping_and_split_accuracy():
     assert np.abs(exact - ref).max() < 1e-12                 # K-slot mapping is right
     split = chain_bf16(params, X, dh, split=True)
     assert np.abs(split - ref).max() < 2e-5                  # 3-term split-bf16 error budget
+
+
+# ------------------------------------------------------------------ 32 samples per wave (proposal for the next round)
+# k_shade2 re-reads 92 KB of weight fragments from LDS for every 16-sample tile and the LDS pipe is its
+# busiest unit.  v_mfma_f32_32x32x16_bf16 with 32 samples per wave halves the fragment bytes per MAC.  This model pins
+# the layout such a kernel would use, before any GPU time is spent on it:
+#   lane l = (n = l & 31: sample, h = l >> 5: K half)
+#   A operand (weights):  lane holds A[i = n][k = 8 h + j],  j = 0..7
+#   B operand (samples):  lane holds B[k = 8 h + j][n]
+#   D (16 registers):     register r of lane (n, h) = D[row = 8 (r >> 2) + 4 h + (r & 3)][col = n]
+# D -> next B with no lane movement: K-step (m, q) of the next layer (m = M-tile of this layer, q = 0, 1) takes the
+# lane's registers 8 q .. 8 q + 7 of tile m, i.e. K slot (h, j) = unit 32 m + 16 q + 8 (j >> 2) + 4 h + (j & 3); the
+# weight image is packed with that permutation (as k_pack_mlp_bf16 does for the 16-wide chain).
+def w32_unit(m, q, h, j):
+    return 32 * m + 16 * q + 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def mfma_32x32x16(A_l, B_l, c, split):
+    """A_l, B_l: [64, 8] per-lane values; c: [64, 16] accumulators."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for l in range(64):
+        n, h = l & 31, l >> 5
+        A[n, 8 * h: 8 * h + 8] = A_l[l]
+        B[8 * h: 8 * h + 8, n] = B_l[l]
+    if split:
+        Ah, Bh = to_bf16(A), to_bf16(B)
+        Al, Bl = to_bf16(A - Ah), to_bf16(B - Bh)
+        D = Al @ Bh + Ah @ Bl + Ah @ Bh
+    else:
+        D = A @ B
+    out = c.copy()
+    for l in range(64):
+        n, h = l & 31, l >> 5
+        for r in range(16):
+            out[l, r] += D[8 * (r >> 2) + 4 * h + (r & 3), n]
+    return out
+
+
+def chain_w32(params, X, dh, split):
+    """X [32, 72]: appearance products of the wave's 32 samples.  Lane (n, h) gathers the 36 channels of lane groups
+    2 h and 2 h + 1 (the padded texel stays as it is: 4 groups x 8 slots, 6 live), i.e. per plane 12 live values."""
+    basis, w1, b1, w2, b2, w3, b3 = params
+    lanes = np.arange(64)
+    n, h = lanes & 31, lanes >> 5
+    # layer 0: feat[32 (27 live)] = basis X, K = 72 channels in 5 K-steps of 16 (80 slots): K slot (h, j) of step ks is
+    # the lane's gathered value 8 ks + j of its 40 (36 live + 4 pad); channel of lane half h, value v:
+    def chan(hh, v):                                     # v = 0..35 -> appearance channel, else None (pad)
+        if v >= 36:
+            return None
+        pl, w = v // 12, v % 12                          # plane, then two lane groups x 6 channels
+        return pl * 24 + 6 * (2 * hh + w // 6) + w % 6
+    gathered = np.zeros((64, 40))
+    for l in range(64):
+        for v in range(36):
+            gathered[l, v] = X[n[l], chan(h[l], v)]
+    fe = np.zeros((64, 16))
+    for ks in range(5):
+        A_l = np.zeros((64, 8))
+        for l in range(64):
+            for j in range(8):
+                c = chan(h[l], 8 * ks + j)
+                if c is not None and n[l] < 27:
+                    A_l[l, j] = basis[n[l], c]
+        fe = mfma_32x32x16(A_l, gathered[:, 8 * ks: 8 * ks + 8], fe, split)
+    # layer 1: h1 = W1 feat + b1, M = 128 (4 tiles), K = 32 features = tile 0 of the previous layer, 2 K-steps
+    def bias_tile(b, m):
+        return np.array([[b[32 * m + 8 * (r >> 2) + 4 * h[l] + (r & 3)] for r in range(16)] for l in range(64)])
+    h1 = [bias_tile(b1, m) for m in range(4)]
+    for q in range(2):
+        Bv = fe[:, 8 * q: 8 * q + 8]
+        for m in range(4):
+            A_l = np.zeros((64, 8))
+            for l in range(64):
+                for j in range(8):
+                    u = w32_unit(0, q, h[l], j)
+                    if u < 27:
+                        A_l[l, j] = w1[32 * m + n[l], u]
+            h1[m] = mfma_32x32x16(A_l, Bv, h1[m], split)
+    # layer 2: h2 = W2 relu(h1) + b2, K = 128 units in 8 K-steps (m0, q)
+    h2 = [bias_tile(b2, m) for m in range(4)]
+    for m0 in range(4):
+        for q in range(2):
+            Bv = np.maximum(h1[m0][:, 8 * q: 8 * q + 8], 0)
+            for m in range(4):
+                A_l = np.array([[w2[32 * m + n[l], w32_unit(m0, q, h[l], j)] for j in range(8)] for l in range(64)])
+                h2[m] = mfma_32x32x16(A_l, Bv, h2[m], split)
+    # head on the VALU: each lane holds 64 of its sample's 128 units, the two halves meet with one cross-lane add
+    tot = np.zeros((32, 3))
+    for l in range(64):
+        for m in range(4):
+            for r in range(16):
+                tot[n[l]] += max(h2[m][l, r], 0) * w3[:, 32 * m + 8 * (r >> 2) + 4 * h[l] + (r & 3)]
+    return 1.0 / (1.0 + np.exp(-(tot + w3[:, 128:131] @ dh + b3)))
+
+
+def test_w32_chain_layout_and_fragment_traffic():
+    rng = np.random.default_rng(2)
+    params = _torch_like_params(rng)
+    basis, w1, b1, w2, b2, w3, b3 = params
+    X = rng.normal(size=(32, 72)) * 0.02
+    dh = rng.normal(size=3)
+    dh /= np.linalg.norm(dh)
+    feat = X @ basis.T
+    hh = np.maximum(feat @ w1.T + b1, 0)
+    hh = np.maximum(hh @ w2.T + b2, 0)
+    ref = 1.0 / (1.0 + np.exp(-(np.concatenate([hh, np.tile(dh, (32, 1))], -1) @ w3.T + b3)))
+    assert np.abs(chain_w32(params, X, dh, split=False) - ref).max() < 1e-12     # the K permutation closes
+    assert np.abs(chain_w32(params, X, dh, split=True) - ref).max() < 2e-5       # same split-bf16 budget
+    # every K-step's 16 slots are distinct units and the 8 K-steps of a 128-unit layer cover each unit once
+    seen = sorted(w32_unit(m, q, h, j) for m in range(4) for q in range(2) for h in range(2) for j in range(8))
+    assert seen == list(range(128))
+    # fragment reads per SAMPLE (1 KB each, hi + lo): 16-wide chain 2 x (6 + 8 + 32) per 16 samples, this one
+    # 2 x (5 + 8 + 32) per 32 samples
+    assert 2 * (5 + 8 + 32) / 32 < 0.5 * 2 * (6 + 8 + 32) / 16 + 1e-9
