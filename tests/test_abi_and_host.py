@@ -245,3 +245,49 @@ def test_saved_row_layout_is_a_bijection_and_matches_the_test_reader(built_lib):
     for r in (0, 5, 17, 47):
         for c in (0, 3, 4, 79, 80, 111, 112, 255, 256, 399):
             assert rowsv[r, c] == off(0, r, c)
+
+
+def test_geometric_loss_wrappers_fail_loudly_without_a_gpu_and_check_their_arguments():
+    """localrf_amd.losses (train.py:385-423): no CPU fallback; the per-view rays limit and the view-id range are checked
+    on the host before anything is launched."""
+    from localrf_amd import _native as N
+    from localrf_amd import losses
+    V, n = 2, 8
+    depth = torch.rand(V * n) + 0.5
+    dirs = torch.randn(V * n, 3)
+    ij = torch.zeros(V * n, 2, dtype=torch.int64)
+    c2w = torch.eye(3, 4)[None].repeat(4, 1, 1)
+    flow, mask = torch.zeros(V * n, 2), torch.ones(V * n)
+    with pytest.raises(N.NativeError, match="no CPU fallback"):
+        losses.flow_loss(depth, dirs, ij, c2w, [1, 2], 0, flow, mask, flow, mask, 50.0, torch.tensor([32.0, 24.0]))
+    with pytest.raises(N.NativeError, match="no CPU fallback"):
+        losses.depth_loss(depth, torch.rand(V * n), V)
+    assert N.LRF_LOSS_MAX_PER_VIEW == 4096                       # LOSS_NMAX of csrc/lrf_losses.inl: one workgroup sorts a view in LDS
+    hdr = open(os.path.join(ROOT, "localrf_amd", "csrc", "lrf_losses.inl")).read()
+    assert re.search(r"LOSS_NMAX\s*=\s*4096", hdr)
+    meta = torch.empty(V * (N.LRF_LOSS_MAX_PER_VIEW + 1), device="meta")
+    for call in (lambda: losses.depth_loss(_FakeCuda(meta), meta, V),
+                 lambda: losses.flow_loss(_FakeCuda(meta), dirs, ij, c2w, [0, 1], 0, flow, mask, flow, mask, 50.0, torch.zeros(2))):
+        with pytest.raises(ValueError, match="rays per view"):
+            call()
+    ok = _FakeCuda(torch.empty(V * n, device="meta"))
+    with pytest.raises(IndexError, match="outside cam2world"):   # ids are absolute, cam2world starts at starting_frame_id
+        losses.flow_loss(ok, dirs, ij, c2w, [3, 9], 3, flow, mask, flow, mask, 50.0, torch.zeros(2))
+    with pytest.raises(IndexError, match="outside cam2world"):
+        losses.flow_loss(ok, dirs, ij, c2w, [2, 3], 3, flow, mask, flow, mask, 50.0, torch.zeros(2))
+
+
+class _FakeCuda:
+    """A tensor stand-in whose device says cuda: lets the host-side argument checks of the wrappers run where there is
+    no GPU (they raise before any pointer is taken)."""
+
+    def __init__(self, t):
+        self._t = t
+        self.device = torch.device("cuda:0")
+
+    def reshape(self, *shape):
+        return _FakeCuda(self._t.reshape(*shape))
+
+    @property
+    def shape(self):
+        return self._t.shape
