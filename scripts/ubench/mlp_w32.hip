@@ -94,6 +94,41 @@ __global__ __launch_bounds__(512) void k_mlp_w32(const uint4* __restrict__ gimg,
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) h2[m][r] = tail[T_B2 + 32 * m + 8 * (r >> 2) + 4 * h + (r & 3)];
+    if (MODE == 2) {
+      // W2 with the next K-step's eight fragment halves requested from LDS before the current step's twelve MFMAs
+      // (two register buffers), and the three terms interleaved over the four accumulators (no MFMA waits on the one
+      // issued just before it)
+      bf16x8 Ah[2][4], Al[2][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        Ah[0][m] = __builtin_bit_cast(bf16x8, s_img[((13 + 8 * m) * 2 + 0) * 64 + lane]);
+        Al[0][m] = __builtin_bit_cast(bf16x8, s_img[((13 + 8 * m) * 2 + 1) * 64 + lane]);
+      }
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int cur = st & 1, nxt = cur ^ 1;
+        if (st + 1 < 8) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            Ah[nxt][m] = __builtin_bit_cast(bf16x8, s_img[((13 + 8 * m + st + 1) * 2 + 0) * 64 + lane]);
+            Al[nxt][m] = __builtin_bit_cast(bf16x8, s_img[((13 + 8 * m + st + 1) * 2 + 1) * 64 + lane]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[st >> 1][8 * (st & 1) + j], 0.0f);
+        bf16x8 bh, bl;
+        split8(v, bh, bl);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) h2[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[cur][m], bh, h2[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) h2[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[cur][m], bl, h2[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) h2[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[cur][m], bh, h2[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0)
 #pragma unroll
@@ -106,6 +141,7 @@ __global__ __launch_bounds__(512) void k_mlp_w32(const uint4* __restrict__ gimg,
 #pragma unroll
         for (int m = 0; m < 4; ++m) h2[m] = mma3(s_img, 13 + 8 * m + 2 * m0 + q, lane, bh, bl, h2[m]);
       }
+    }
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -185,14 +221,16 @@ int main(int argc, char** argv) {
   const int lds = IMG_U4 * 16 + T_FLOATS * 4;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_w32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_w32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_w32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   std::vector<float> out((size_t)groups * 32 * 4);
-  for (int mode = 0; mode < 2; ++mode) {
+  for (int mode = 0; mode < 3; ++mode) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
       hipEventRecord(e0);
       if (mode == 0) hipLaunchKernelGGL(k_mlp_w32<0>, dim3(256), dim3(512), lds, 0, d_img, d_tail, d_in0, groups, (float)dh[0], (float)dh[1], (float)dh[2], d_out);
-      else           hipLaunchKernelGGL(k_mlp_w32<1>, dim3(256), dim3(512), lds, 0, d_img, d_tail, d_in1, groups, (float)dh[0], (float)dh[1], (float)dh[2], d_out);
+      else if (mode == 1) hipLaunchKernelGGL(k_mlp_w32<1>, dim3(256), dim3(512), lds, 0, d_img, d_tail, d_in1, groups, (float)dh[0], (float)dh[1], (float)dh[2], d_out);
+      else           hipLaunchKernelGGL(k_mlp_w32<2>, dim3(256), dim3(512), lds, 0, d_img, d_tail, d_in1, groups, (float)dh[0], (float)dh[1], (float)dh[2], d_out);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (rep > 0 && ms < best) best = ms;
@@ -206,7 +244,7 @@ int main(int argc, char** argv) {
       const double d = fabs((double)v - ref[(size_t)(r % distinct) * 3 + c]);
       if (d > worst) worst = d;
     }
-    printf("mode %d (%s): %d rows in %.1f us, max |rgb - fp64 reference| %.2e, NaN %d -> %s\n", mode, mode == 0 ? "basis + W1 + W2 + head" : "W1 + W2 + head (k_mlp's work)",
+    printf("mode %d (%s): %d rows in %.1f us, max |rgb - fp64 reference| %.2e, NaN %d -> %s\n", mode, mode == 0 ? "basis + W1 + W2 + head" : (mode == 1 ? "W1 + W2 + head (k_mlp's work)" : "as mode 1, W2 fragments prefetched one K-step ahead"),
            groups * 32, best * 1e3, worst, nan, (worst < 2e-5 && !nan) ? "OK" : "MISMATCH");
   }
   return 0;
