@@ -695,27 +695,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
 // wave).  KSPLIT = true, for the narrow products (M-tiles < 4 would leave waves idle, and one
 // M-tile per wave means one LDS read per MFMA): every wave holds ALL MT x NT accumulator tiles and
 // takes every fourth k-step; the four partial sums meet in LDS at the end, in wave order.
-// BF16 (the 128 x 144 product, KSPLIT = false only): the MFMAs run as three v_mfma_f32_16x16x16_bf16 per 16 rows
-// (operands split into bf16 hi + lo in registers on the way out of LDS: Al x Bh + Ah x Bl + Ah x Bh, fp32 accumulate,
-// ~2^-16 relative per product) instead of four v_mfma_f32_16x16x4_f32: the fp32 matrix rate (157 TFLOP/s) made this
-// kernel matrix-pipe bound at 28 GFLOP per step (180 us of pipe); slot j of lane group g takes row 4 j + g of the
-// 16 (any bijection of k works, and this one keeps the groups' LDS reads on disjoint banks).
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split4_bf16(const float v[4], s16x4& hi, s16x4& lo) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  bf16x4 h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    h[j] = (__bf16)v[j];
-    l[j] = (__bf16)(v[j] - (float)h[j]);
-  }
-  hi = __builtin_bit_cast(s16x4, h);
-  lo = __builtin_bit_cast(s16x4, l);
-}
-template <int MT, int NT, bool KSPLIT, bool BF16 = false>
+template <int MT, int NT, bool KSPLIT>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                const int* __restrict__ toff, int R, float* __restrict__ wpart, int wp_off) {
-  static_assert(!BF16 || !KSPLIT, "the split-bf16 path exists for the M-split product only");
   constexpr int KT = 32, WA = MT * 16, WB = NT * 16;
   constexpr int LD = ((WA + WB) % 32 == 16) ? (WA + WB) : (WA + WB + 16);
   static_assert(!KSPLIT || MT * NT * 256 <= KT * LD, "cross-wave reduction reuses the staging tile");
@@ -767,36 +749,6 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
     __syncthreads();
   };
   auto compute = [&]() {
-    if constexpr (BF16) {
-#pragma unroll
-      for (int ks = 0; ks < KT / 16; ++ks) {
-        s16x4 bh[NT], bl[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = s_t[(16 * ks + 4 * j + g) * LD + WA + 16 * n + i];
-          split4_bf16(v, bh[n], bl[n]);
-        }
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-          const int mt = wave + 4 * m;
-          if (mt >= MT) continue;
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = s_t[(16 * ks + 4 * j + g) * LD + 16 * mt + i];
-          s16x4 ah, al;
-          split4_bf16(v, ah, al);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[n], acc[m][n], 0, 0, 0);
-          }
-        }
-      }
-      return;
-    }
     // (as in k_wgrad_w2: every LDS operand of the 32 rows first, behind a scheduling barrier, then the MFMAs)
     constexpr int NKS = KSPLIT ? KT / 16 : KT / 4;
     float a[NKS][MW], b[NKS][NT];

@@ -56,7 +56,7 @@ def _overlap(x, y):
 # 18 (basis) + 24 (layer 1) + 96 (layer 2) [+ 12 (head)].  k_mlp has no gathers; its default policy (4) is the
 # compiler-scheduled builtin, pinned by the 200-render determinism test on the GPU; policy 0 is the hand-issued
 # fallback and is held to the rules below.
-WGRAD = ("k_wgrad_w2E", "k_wgradILi8ELi2ELb0ELb0EE", "k_wgradILi2ELi5ELb1ELb0EE", "k_wgradILi1ELi9ELb1ELb0EE")
+WGRAD = ("k_wgrad_w2E", "k_wgradILi8ELi2ELb0EE", "k_wgradILi2ELi5ELb1EE", "k_wgradILi1ELi9ELb1EE")
 FROM_TRAINING_UNIT = ("k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE") + WGRAD
 ALL_CHECKED = WGRAD + ("k_shade_bf16E", "k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE", "k_appE", "k_mlpILi0ELb0ELb1EE", "k_mlpILi4ELb0ELb1EE",
                "k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE",
