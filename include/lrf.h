@@ -40,6 +40,8 @@ extern "C" {
                                     split-bf16 (hi+lo, 3-term) MFMA chain */
 #define LRF_FLAG_MLP_FUSED  32u  /* colour stage as round 1's fused kernel (k_shade_bf16) instead of the default k_shade2 */
 #define LRF_FLAG_MLP_SPLIT  64u  /* colour stage as two kernels, k_app (gather + basis) and k_mlp (the MFMA chain) */
+#define LRF_FLAG_MLP_W16    128u /* colour stage as round 2's k_shade2 (16 samples per wave on v_mfma_f32_16x16x32_bf16, hand-issued)
+                                    instead of the default k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16) */
 #define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,

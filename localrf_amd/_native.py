@@ -15,6 +15,7 @@ LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
 LRF_FLAG_MLP_FUSED = 32
 LRF_FLAG_MLP_SPLIT = 64
+LRF_FLAG_MLP_W16 = 128
 
 _f = C.c_void_p  # device float*
 

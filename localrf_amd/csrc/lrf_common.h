@@ -56,8 +56,27 @@ constexpr int IMGB_W3F = IMGB_TAIL + 256;              // fragment-aligned (mult
 constexpr int IMGB_ALL = IMGB_W3F + 4 * 128;           // 6656 uint4 = 106,496 B
 static_assert(IMGB_W3F % 128 == 0 && IMGB_W3F >= IMGB_U4 && IMGB_W1 % 128 == 0, "fragments are addressed in units of 128 uint4");
 
+// ---- image of the colour network for the 32-sample kernel (k_shade3, lrf_shade3.inl): v_mfma_f32_32x32x16_bf16.
+// Lane l = (n = l & 31: output row of the A operand / sample column of B and D, h = l >> 5: K half).  A fragment is
+// [part hi, lo][lane64][8 bf16] (2 KB): slot j of lane (n, h) = A[n][8 h + j].  D register r of lane (n, h) is row
+// 8 (r >> 2) + 4 h + (r & 3), column n -- so registers 8 q .. 8 q + 7 of a 32-row output tile m0 are the B operand of
+// the next layer's K-step (m0, q) once the weights are packed with the K permutation w32_unit(): no lane movement.
+//   frag ks            (0..4)  basis: A[n][slot j] = basis[n][w32_chan(h, 8 ks + j)]   (rows 27..31 zero)
+//   frag 5 + 2 m + q           W1:    A[n][slot j] = W1[32 m + n][w32_unit(0, q, h, j)] (units >= 27 zero)
+//   frag 13 + 8 m + 2 m0 + q   W2:    A[n][slot j] = W2[32 m + n][w32_unit(m0, q, h, j)]
+// then an fp32 tail: b1[128] | b2[128] | mlp_view.0.weight rows padded to 132 | b3.
+constexpr int W32_BAS = 0, W32_W1 = 5, W32_W2 = 13, W32_NFRAG = 45;
+constexpr int W32_U4 = W32_NFRAG * 2 * 64;                      // 5760 uint4 = 92,160 B
+constexpr int W32_T_B1 = 0, W32_T_B2 = 128, W32_T_W3 = 256, W32_T_W3_LD = 132, W32_T_B3 = 652, W32_T_FLOATS = 672;
+constexpr int W32_ALL_U4 = W32_U4 + W32_T_FLOATS / 4;           // 5928 uint4 = 94,848 B
+__host__ __device__ constexpr int w32_unit(int m0, int q, int h, int j) { return 32 * m0 + 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); }
+// gathered value v (0..39) of lane half h -> appearance channel 0..71 (plane v / 12, channels 12 h .. 12 h + 11 of the
+// dense 24-channel texel), -1 for the four pad slots of the fifth K-step
+__host__ __device__ constexpr int w32_chan(int h, int v) { return v >= 36 ? -1 : 24 * (v / 12) + 12 * h + v % 12; }
+
 struct Layout {
   size_t dplane[3], dline[3], aplane[3], aline[3], mlp, mlpb, total;   // float offsets
+  size_t aplane2[3], aline2[3], mlpw;     // dense 24-channel appearance planes / lines and the w32 image (k_shade3)
   int pw[3], ph[3], ll[3];
 };
 
@@ -75,6 +94,9 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
   for (int p = 0; p < 3; ++p) { L.aline[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CAS); }
   L.mlp = off; off = align64(off + IMG_FLOATS);
   L.mlpb = off; off = align64(off + (size_t)IMGB_ALL * 4);
+  for (int p = 0; p < 3; ++p) { L.aplane2[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CA); }
+  for (int p = 0; p < 3; ++p) { L.aline2[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CA); }
+  L.mlpw = off; off = align64(off + (size_t)W32_ALL_U4 * 4);
   L.total = off;
   return L;
 }
@@ -131,6 +153,8 @@ struct DField {
   const float* aplane[3]; const float* aline[3];
   const float* mlp;
   const uint4* mlpb;
+  const float* aplane2[3]; const float* aline2[3];     // dense [H][W][24] / [L][24] (k_shade3)
+  const uint4* mlpw;                                   // w32 image
   int pw[3], ph[3], ll[3];
   const float* alpha_vol; int ax, ay, az;
   float m_lo[3], m_inv[3];     // alpha-mask aabb: lo and 2/size   (tensorBase.py:57-58)

@@ -31,9 +31,7 @@ namespace lrf {
 
 constexpr int ITEM = 16;          // compact samples per shade work item = one 16-column MFMA tile
 
-#if LRF_TU != 2
 thread_local char g_err[512] = "";       // one error text per thread for the whole library (lrf_error_slot)
-#endif
 static int set_err(const char* msg, hipError_t e = hipSuccess) {
   char* slot = lrf_error_slot();
   if (e != hipSuccess) snprintf(slot, 512, "%s: %s", msg, hipGetErrorString(e));
@@ -45,8 +43,8 @@ static int set_err(const char* msg, hipError_t e = hipSuccess) {
 // ---------------------------------------------------------------------------- pack
 // [C,H,W] -> [H,W,CS] channel-last; app=1: padded appearance layout (slot app_pc(c), zero pads)
 struct PackSeg { const float* src; float* dst; int C, H, W, CS, app; };
-struct PackTab { PackSeg s[12]; };
-// all twelve plane / line tensors of a field in one launch (blockIdx.z selects; a line [C,L,1] is a plane with H = 1)
+struct PackTab { PackSeg s[18]; };
+// all plane / line tensors of a field (the appearance ones twice: padded and dense) in one launch (blockIdx.z selects; a line [C,L,1] is a plane with H = 1)
 __global__ __launch_bounds__(128) void k_pack_planes(PackTab tab) {
   const PackSeg sg = tab.s[blockIdx.z];
   const float* __restrict__ src = sg.src;
@@ -181,6 +179,47 @@ __global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
     }
     const unsigned short hi = bf16_bits(v);
     out[h] = part ? bf16_bits(v - bf16_val(hi)) : hi;
+  }
+  img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
+}
+
+// colour network -> w32 fragment image (lrf_common.h W32_*), for k_shade3.  One thread per 32-bit word.
+__global__ void k_pack_mlp_w32(LrfParams p, uint32_t* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W32_ALL_U4 * 4) return;
+  if (idx >= W32_U4 * 4) {                                     // fp32 tail
+    const int e = idx - W32_U4 * 4;
+    float v = 0.0f;
+    if (e < W32_T_B2) v = p.b1[e - W32_T_B1];
+    else if (e < W32_T_W3) v = p.b2[e - W32_T_B2];
+    else if (e < W32_T_B3) {
+      const int c = (e - W32_T_W3) / W32_T_W3_LD, u = (e - W32_T_W3) % W32_T_W3_LD;
+      if (u < LRF_FEATC + 3) v = p.w3[c * (LRF_FEATC + 3) + u];
+    } else if (e < W32_T_B3 + 3) v = p.b3[e - W32_T_B3];
+    img[idx] = __float_as_uint(v);
+    return;
+  }
+  const int u4 = idx >> 2, wj = idx & 3;
+  const int lane = u4 & 63, part = (u4 >> 6) & 1, frag = u4 >> 7;
+  const int n = lane & 31, h = lane >> 5;
+  unsigned short out[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int j = 2 * wj + hh;
+    float v = 0.0f;
+    if (frag < W32_W1) {                                       // basis_mat.weight [27,72] (tensoRF.py:25-27,196)
+      const int c = w32_chan(h, 8 * frag + j);
+      if (c >= 0 && n < LRF_APP_DIM) v = p.basis[n * 72 + c];
+    } else if (frag < W32_W2) {                                // mlp.0.weight [128,27] (tensorBase.py:105)
+      const int e = frag - W32_W1, m = e >> 1, q = e & 1;
+      const int u = w32_unit(0, q, h, j);
+      if (u < LRF_APP_DIM) v = p.w1[(32 * m + n) * LRF_APP_DIM + u];
+    } else {                                                   // mlp.2.weight [128,128] (tensorBase.py:106)
+      const int e = frag - W32_W2, m = e >> 3, m0 = (e >> 1) & 3, q = e & 1;
+      v = p.w2[(32 * m + n) * LRF_FEATC + w32_unit(m0, q, h, j)];
+    }
+    const unsigned short hi = bf16_bits(v);
+    out[hh] = part ? bf16_bits(v - bf16_val(hi)) : hi;
   }
   img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
 }
@@ -783,6 +822,7 @@ __global__ __launch_bounds__(1024) void k_shade_bf16(
 
 }  // namespace lrf
 #include "lrf_shade2.inl"
+#include "lrf_shade3.inl"
 namespace lrf {
 
 // Debug engine (LRF_FLAG_MLP_VALU): same work list, one lane per compact sample,
@@ -955,6 +995,8 @@ static DField make_dfield(const LrfField* f) {
   }
   d.mlp = base + L.mlp;
   d.mlpb = reinterpret_cast<const uint4*>(base + L.mlpb);
+  for (int p = 0; p < 3; ++p) { d.aplane2[p] = base + L.aplane2[p]; d.aline2[p] = base + L.aline2[p]; }
+  d.mlpw = reinterpret_cast<const uint4*>(base + L.mlpw);
   d.alpha_vol = f->alpha_vol;
   d.ax = f->alpha_dim[0]; d.ay = f->alpha_dim[1]; d.az = f->alpha_dim[2];
   for (int a = 0; a < 3; ++a) {
@@ -1136,16 +1178,14 @@ int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col) {
   if (buffer == 2) return (col < 0 || col >= 72) ? -1 : x_slot_col(col);
   return -1;
 }
-void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 11) ? mode : 0; }
+void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 38) ? mode : 0; }
 void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
 void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
 void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
 void lrf_debug_set_mlp_threads(int threads) { g_mlp_threads = (threads == 512 || threads == 256) ? threads : 1024; }
-void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = ((policy >= 0 && policy <= 7) || policy == 10 || policy == 14) ? policy : 4; }
+void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = ((policy >= 0 && policy <= 7) || policy == 9 || policy == 10 || policy == 14) ? policy : 4; }
 const char* lrf_last_error(void) { return lrf_error_slot(); }
-#if LRF_TU != 2
 char* lrf_error_slot(void) { return g_err; }
-#endif
 
 size_t lrf_cache_bytes(const int32_t grid[3]) { return make_layout(grid).total * sizeof(float); }
 
@@ -1161,13 +1201,17 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
     tab.s[4 * q + 1] = PackSeg{p->app_plane[q], base + L.aplane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1};
     tab.s[4 * q + 2] = PackSeg{p->density_line[q], base + L.dline[q], LRF_CD, 1, L.ll[q], LRF_CD, 0};
     tab.s[4 * q + 3] = PackSeg{p->app_line[q], base + L.aline[q], LRF_CA, 1, L.ll[q], LRF_CAS, 1};
+    tab.s[12 + 2 * q + 0] = PackSeg{p->app_plane[q], base + L.aplane2[q], LRF_CA, L.ph[q], L.pw[q], LRF_CA, 0};
+    tab.s[12 + 2 * q + 1] = PackSeg{p->app_line[q], base + L.aline2[q], LRF_CA, 1, L.ll[q], LRF_CA, 0};
     wmax = max(wmax, max(L.pw[q], L.ll[q]));
     hmax = max(hmax, L.ph[q]);
   }
-  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 12), dim3(128), 0, st, tab);
+  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 18), dim3(128), 0, st, tab);
   hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
   hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_ALL * 4 + 255) / 256), dim3(256), 0, st, *p,
                      reinterpret_cast<uint32_t*>(base + L.mlpb));
+  hipLaunchKernelGGL(k_pack_mlp_w32, dim3((W32_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p,
+                     reinterpret_cast<uint32_t*>(base + L.mlpw));
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1225,6 +1269,78 @@ static int render_fwd_one(const DField& d, const float* rays, const float* z, in
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
   // Default engine, batches whose tile offsets fit in LDS beside the image: two launches, k_march -> k_shade2<FUSE>
   // (scan and finalize folded into the colour kernel, lrf_shade2.inl).  lrf_debug_set_shade_pipe(9) = four launches.
+  // Default engine: k_march -> k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16, lrf_shade3.inl); the tile
+  // offsets are scanned inside the colour kernel when R + 1 ints fit in LDS beside the image, by k_scan_tiles_n otherwise.
+  if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED | LRF_FLAG_MLP_SPLIT | LRF_FLAG_MLP_W16))) {
+    launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
+    if (ev) LRF_HIP(hipEventRecord(ev[1], st));
+    g_last_fused = true;
+    const size_t lds_base = (size_t)W32_ALL_U4 * sizeof(uint4) + (size_t)S * sizeof(float);
+    const size_t lds_toff = (size_t)(R + 1) * sizeof(int);
+    const bool in_lds = lds_base + lds_toff + 64 <= 160 * 1024 - 256;
+    static bool attr3_done[64] = {};
+    int dev = 0;
+    LRF_HIP(hipGetDevice(&dev));
+    if (!attr3_done[dev & 63]) {
+#define LRF_ATTR3(NWV, L, TM) LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<NWV, L, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
+      LRF_ATTR3(12, true, false); LRF_ATTR3(12, false, false); LRF_ATTR3(12, true, true);
+      LRF_ATTR3(8, true, false); LRF_ATTR3(8, true, true);
+#define LRF_ATTR3V(NWV, V) LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<NWV, true, false, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<12, true, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      LRF_ATTR3V(8, 1); LRF_ATTR3V(8, 2); LRF_ATTR3V(8, 3); LRF_ATTR3V(8, 4); LRF_ATTR3V(8, 7); LRF_ATTR3V(12, 1); LRF_ATTR3V(12, 3); LRF_ATTR3V(8, 8); LRF_ATTR3V(12, 8); LRF_ATTR3V(8, 9); LRF_ATTR3V(8, 128); LRF_ATTR3V(12, 128); LRF_ATTR3V(8, 16); LRF_ATTR3V(8, 18); LRF_ATTR3V(8, 32); LRF_ATTR3V(8, 64);
+#undef LRF_ATTR3V
+#undef LRF_ATTR3
+      attr3_done[dev & 63] = true;
+    }
+    DField dd = d;
+    const bool timed = in_lds && g_dump && g_mlp_policy >= 10;   // debug: phase timing, counters -> the dump buffer
+    if (timed) dd.dump = g_dump;
+#define LRF_LAUNCH3(NWV, L, TM, LDSB) hipLaunchKernelGGL((k_shade3<NWV, L, TM>), dim3(device_cus()), dim3(NWV * 64), LDSB, st, \
+        dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out)
+#define LRF_LAUNCH3V(NWV, V) hipLaunchKernelGGL((k_shade3<NWV, true, false, V>), dim3(device_cus()), dim3(NWV * 64), lds_base + lds_toff, st, \
+        dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out)
+    if (in_lds && g_dump && g_mlp_policy == 9) {                   // debug: per-tile stage hashes -> the dump buffer (uint32 [tiles][8])
+      dd.dump = g_dump;
+      if (g_shade_pipe == 12) hipLaunchKernelGGL((k_shade3<8, true, false, 0, true>), dim3(device_cus()), dim3(8 * 64), lds_base + lds_toff, st,
+                                                 dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
+      else hipLaunchKernelGGL((k_shade3<12, true, false, 0, true>), dim3(device_cus()), dim3(12 * 64), lds_base + lds_toff, st,
+                              dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
+    } else
+    if (in_lds && g_shade_pipe >= 21 && g_shade_pipe <= 38) {
+      if (g_shade_pipe >= 37) dd.dump = g_dump;       // experiments: VAR bits, 8 waves (21..27) / 12 waves (28 = VAR 1, 29 = VAR 3)
+      switch (g_shade_pipe) {
+        case 21: LRF_LAUNCH3V(8, 1); break;
+        case 22: LRF_LAUNCH3V(8, 2); break;
+        case 23: LRF_LAUNCH3V(8, 3); break;
+        case 24: LRF_LAUNCH3V(8, 4); break;
+        case 27: LRF_LAUNCH3V(8, 7); break;
+        case 28: LRF_LAUNCH3V(12, 1); break;
+        case 30: LRF_LAUNCH3V(8, 8); break;
+        case 31: LRF_LAUNCH3V(12, 8); break;
+        case 32: LRF_LAUNCH3V(8, 9); break;
+        case 33: LRF_LAUNCH3V(8, 16); break;
+        case 34: LRF_LAUNCH3V(8, 18); break;
+        case 35: LRF_LAUNCH3V(8, 32); break;
+        case 36: LRF_LAUNCH3V(8, 64); break;
+        case 37: LRF_LAUNCH3V(8, 128); break;
+        case 38: LRF_LAUNCH3V(12, 128); break;
+        default: LRF_LAUNCH3V(12, 3); break;
+      }
+    } else
+    if (in_lds && g_shade_pipe == 12) {          // experiment: 8 waves per workgroup (two per SIMD) instead of 12
+      if (timed) LRF_LAUNCH3(8, true, true, lds_base + lds_toff); else LRF_LAUNCH3(8, true, false, lds_base + lds_toff);
+    } else if (in_lds) {
+      if (timed) LRF_LAUNCH3(12, true, true, lds_base + lds_toff); else LRF_LAUNCH3(12, true, false, lds_base + lds_toff);
+    } else {
+      hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+      LRF_LAUNCH3(12, false, false, lds_base);
+    }
+#undef LRF_LAUNCH3
+#undef LRF_LAUNCH3V
+    if (ev) LRF_HIP(hipEventRecord(ev[2], st));
+    return 0;
+  }
   const size_t lds_fused = (size_t)IMGB_U4 * sizeof(uint4) + (size_t)S * sizeof(float) + (size_t)(R + 1) * sizeof(int);
   const bool fuse = !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED | LRF_FLAG_MLP_SPLIT)) &&
                     (g_shade_pipe == 0 || g_shade_pipe >= 10) && !(g_dump && g_mlp_policy >= 10) && lds_fused + 256 <= 160 * 1024;

@@ -1,0 +1,436 @@
+// lrf_shade3.inl -- the colour stage on v_mfma_f32_32x32x16_bf16, 32 samples per wave (default engine since round 3).
+//
+// What k_shade2 (16 samples per wave on v_mfma_f32_16x16x32_bf16) taught (profiles/r07c_round_end.md): every 16-sample
+// tile re-reads the 92 KB weight image from LDS, the three-term products ran as dependent MFMA triples with hand-placed
+// wait states, and 16 waves per CU drifted into lockstep (all gathering, then all multiplying).  This kernel:
+//   * 32 samples per wave: lane (n = lane & 31, h = lane >> 5) = (sample, K half).  One A fragment now feeds 32 columns:
+//     half the LDS fragment traffic per sample, and the D registers of a layer are again the B operand of the next
+//     (K permutation folded into the packed weights, lrf_common.h W32_*): no LDS round trip, no lane movement.
+//   * compiler-scheduled builtins.  scripts/ubench/mfma_war.hip (profiles/r08a) shows the matrix pipe reads its sources at
+//     issue: hipcc's hazard table is sufficient, the hand-issued chain of k_shade2 and its 299 s_nop per tile were not
+//     needed.  The three terms of a split product go term-major over independent accumulators, so no MFMA waits for the
+//     one issued just before it.
+//   * 512-thread workgroups, one per CU: 8 waves, two per SIMD, 256 registers each.  The two waves of a SIMD alternate
+//     roles in lockstep (s_barrier between phases): while one gathers its tile (texture path), the other runs its MFMA
+//     chain (matrix pipe) -- the two pipes overlap by construction instead of by luck.
+//   * dense 24-channel appearance texels (96 B): lane half h reads channels 12 h .. 12 h + 11 of a tap as three aligned
+//     float4: 54 wave-level loads per 32 samples (k_shade2: 72), five basis K-steps of 16 instead of six.
+//   * a workgroup owns WHOLE rays (its tile range is cut at ray boundaries): every ray's tile partials are summed, in
+//     tile order, by the workgroup that wrote them -- no hand-off between workgroups, no counter, no cross-XCD visibility
+//     protocol (the boundary rays of k_shade2<FUSE> needed one).
+// Arithmetic per sample as k_shade2: split-bf16 three-term products, fp32 accumulate, VALU head, hardware exp2 / rcp.
+#pragma once
+
+namespace lrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int ITEM3 = 32;          // compact samples per work item of k_shade3 = one 32-column MFMA tile
+
+__device__ __forceinline__ bf16x8 w32_frag(const uint4* img, int frag, int part, int lane) {
+  return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
+}
+__device__ __forceinline__ void split8c(const float v[8], bf16x8& hi, bf16x8& lo) {      // hi = bf16(v), lo = bf16(v - hi)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 hh = (__bf16)v[j];
+    hi[j] = hh;
+    lo[j] = (__bf16)(v[j] - (float)hh);
+  }
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// acc[m] += A(frag0 + m * stride) x B for NM output tiles, three-term split product, term-major: the MFMAs that follow
+// each other write different accumulators
+template <int NM>
+__device__ __forceinline__ void mma3_step(const uint4* img, int frag0, int stride, int lane, bf16x8 bh, bf16x8 bl, f32x16* acc) {
+  bf16x8 ah[NM], al[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) { ah[m] = w32_frag(img, frag0 + m * stride, 0, lane); al[m] = w32_frag(img, frag0 + m * stride, 1, lane); }
+#pragma unroll
+  for (int m = 0; m < NM; ++m) acc[m] = mfma32(al[m], bh, acc[m]);
+#pragma unroll
+  for (int m = 0; m < NM; ++m) acc[m] = mfma32(ah[m], bl, acc[m]);
+#pragma unroll
+  for (int m = 0; m < NM; ++m) acc[m] = mfma32(ah[m], bh, acc[m]);
+}
+
+// the 12 appearance products of lane half h for plane p: channels 12 h .. 12 h + 11 of the dense texel, three aligned
+// float4 per tap (tensoRF.py:153-195); same per-channel arithmetic, in the same order, as gather_app6_plane32
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// DRAIN (experiment): every load of the plane issued, then s_waitcnt vmcnt(0), then the arithmetic -- no loaded register
+// is read while any vector memory operation of this wave is outstanding
+template <int p, bool DRAIN = false>
+__device__ __forceinline__ void gather_app12(const DField& f, const AxisTaps& at, int h, float X[12], uint32_t* hraw = nullptr) {
+  const int x0 = at.i0[MAT0[p]], x1 = at.i1[MAT0[p]], y0 = at.i0[MAT1[p]], y1 = at.i1[MAT1[p]];
+  const int l0 = at.i0[VEC[p]], l1 = at.i1[VEC[p]];
+  const float tx = at.t[MAT0[p]], ty = at.t[MAT1[p]], tl = at.t[VEC[p]];
+  const unsigned hb = 48u * (unsigned)h;
+  const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+  const unsigned o00 = (row0 + x0) * (LRF_CA * 4u) + hb, o10 = (row0 + x1) * (LRF_CA * 4u) + hb;
+  const unsigned o01 = (row1 + x0) * (LRF_CA * 4u) + hb, o11 = (row1 + x1) * (LRF_CA * 4u) + hb;
+  const unsigned q0 = (unsigned)l0 * (LRF_CA * 4u) + hb, q1 = (unsigned)l1 * (LRF_CA * 4u) + hb;
+  const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
+  const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
+  const float wl0 = 1.0f - tl, wl1 = tl;
+  f32x4v raw[18];
+  if (DRAIN) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      raw[6 * i + 0] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o00 + 16 * i)); raw[6 * i + 1] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o10 + 16 * i));
+      raw[6 * i + 2] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o01 + 16 * i)); raw[6 * i + 3] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o11 + 16 * i));
+      raw[6 * i + 4] = __builtin_bit_cast(f32x4v, ld4b(f.aline2[p], q0 + 16 * i));   raw[6 * i + 5] = __builtin_bit_cast(f32x4v, ld4b(f.aline2[p], q1 + 16 * i));
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), "+v"(raw[8]),
+                   "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]), "+v"(raw[15]), "+v"(raw[16]), "+v"(raw[17])
+                 :: "memory");
+    if (hraw) {
+      uint32_t a = hraw[0], b = hraw[1];
+#pragma unroll
+      for (int i = 0; i < 18; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a = a * 31u ^ __float_as_uint(raw[i][c]);
+      b = b * 31u ^ o00; b = b * 31u ^ o10; b = b * 31u ^ o01; b = b * 31u ^ o11; b = b * 31u ^ q0; b = b * 31u ^ q1;
+      b = b * 31u ^ __float_as_uint(w00); b = b * 31u ^ __float_as_uint(w11); b = b * 31u ^ __float_as_uint(wl1);
+      hraw[0] = a; hraw[1] = b;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 a = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 0]) : ld4b(f.aplane2[p], o00 + 16 * i), b = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 1]) : ld4b(f.aplane2[p], o10 + 16 * i);
+    const float4 c = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 2]) : ld4b(f.aplane2[p], o01 + 16 * i), d = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 3]) : ld4b(f.aplane2[p], o11 + 16 * i);
+    const float4 e = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 4]) : ld4b(f.aline2[p], q0 + 16 * i), q = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 5]) : ld4b(f.aline2[p], q1 + 16 * i);
+    X[4 * i]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
+    X[4 * i + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
+    X[4 * i + 2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
+    X[4 * i + 3] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e.w * wl0 + q.w * wl1);
+  }
+}
+
+// per-ray tile counts -> exclusive prefix sum, one 1024-thread block (the caller's R does not fit the LDS copy)
+template <int ITEMSZ>
+__global__ __launch_bounds__(1024) void k_scan_tiles_n(const int* __restrict__ ncomp, int R, int* __restrict__ toff) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < R; base += 1024) {
+    const int r = base + tid;
+    const int v = r < R ? (ncomp[r] + ITEMSZ - 1) / ITEMSZ : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wave; ++q) woff += s_wave[q];
+    const int carry = s_carry;
+    if (r < R) toff[r] = carry + woff + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if (tid == 0) toff[R] = s_carry;
+}
+
+// first index r in [0, n] with toff[r] >= v (toff non-decreasing, n + 1 entries)
+template <class P>
+__device__ __forceinline__ int toff_lower_bound_p(P toff, int n, int v) {
+  int lo = 0, hi = n + 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (toff[mid] >= v) hi = mid; else lo = mid + 1;
+  }
+  return lo < n ? lo : n;
+}
+
+// What one wave needs to know about a tile before it can gather: fetched one tile ahead (the loads are in flight under
+// the previous tile's chain), so the dependent chain tile -> ray -> sample index -> distance is off the critical path.
+struct Hdr3 {
+  int ray, tile_in_ray, k;       // ray, tile number inside the ray, this lane's sample index into z
+  float wgt;                     // this lane's compositing weight (0 for lanes beyond the tile's count and for K half 1)
+  RayGeo rg;
+};
+
+// NW waves per workgroup (one workgroup per CU).  LDSTOFF: the tile offsets are scanned by every workgroup itself into
+// LDS (R + 1 ints beside the image: two launches per render, k_march -> k_shade3); otherwise k_scan_tiles_n<32> ran before
+// and toff_g holds them.
+// TIMED (debug, lrf_debug_set_dump + lrf_debug_set_mlp_policy(10)): s_memtime totals per wave -> dump[block][wave][8] =
+// {prologue, gather, chain, finalize, -, -, tiles, -}
+// VAR (experiments on run-to-run differences): bit 3 = gathers drained before use (gather_app12<DRAIN>); bit 0 = no header prefetch; bit 1 = every counter drained + scheduling
+// fence between gather and chain; bit 2 = workgroup barrier between gather and chain and behind the chain (lockstep)
+// DUMPH (debug): per tile, wave-wide XOR of the bit patterns after each stage -> dump[tile][8] (uint32) =
+// {header, gathered products (split), basis output, layer 1, layer 2 first half, second half, head, -}: which stage of a
+// tile differs between two runs of the same render
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v ^= (uint32_t)__shfl_xor((int)v, d, 64);
+  return v;
+}
+template <int NW, bool LDSTOFF, bool TIMED = false, int VAR = 0, bool DUMPH = false>
+__global__ __launch_bounds__(NW * 64) void k_shade3(
+    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff_g, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
+    const float* __restrict__ cw, float* __restrict__ part, int pmax,
+    uint32_t flags, const float* __restrict__ acc, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+  constexpr int NT = NW * 64;
+  extern __shared__ uint4 s_dyn[];                             // image, tail, z[S][, toff[R + 1]]
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define LRF_TICK(i) do { if (TIMED) { const unsigned long long now_ = __builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
+  if (TIMED) tlast = __builtin_readcyclecounter();
+  uint4* img = s_dyn;
+  float* tail = reinterpret_cast<float*>(s_dyn + W32_U4);
+  float* s_z = tail + W32_T_FLOATS;
+  lds_int* s_toff = (lds_int*)(s_z + S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+  for (int i = tid; i < W32_ALL_U4; i += NT) img[i] = f.mlpw[i];
+  for (int i = tid; i < S; i += NT) s_z[i] = z[i];
+  if (LDSTOFF) {                                               // exclusive scan of ceil(ncomp / 32): eight rays per thread and round
+    __shared__ int s_wave[NW];
+    int carry = 0;
+    for (int base = 0; base < R; base += NT * 8) {
+      const int r0 = base + tid * 8;
+      int v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = r0 + i < R ? (ncomp[r0 + i] + ITEM3 - 1) / ITEM3 : 0;
+#pragma unroll
+      for (int i = 1; i < 8; ++i) v[i] += v[i - 1];
+      int incl = v[7];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+      }
+      __syncthreads();                                         // s_wave of the previous round has been read
+      if (lane == 63) s_wave[wave] = incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { const int x = s_wave[q]; woff += q < wave ? x : 0; tot += x; }
+      const int excl = carry + woff + incl - v[7];
+      if (r0 < R) s_toff[r0] = excl;
+#pragma unroll
+      for (int i = 1; i < 8; ++i) if (r0 + i < R) s_toff[r0 + i] = excl + v[i - 1];
+      carry += tot;
+    }
+    if (tid == 0) s_toff[R] = carry;
+  }
+  __syncthreads();
+  typedef typename std::conditional<LDSTOFF, const lds_int*, const int*>::type ToffP;
+  ToffP toff;
+  if constexpr (LDSTOFF) toff = s_toff; else toff = toff_g;
+
+  // this workgroup's rays [ra, rb) and tiles [T0, T1): the even split of the tile list, moved to ray boundaries
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;   // XCD-aware order
+  const int T = toff[R];
+  const int ra = __builtin_amdgcn_readfirstlane(toff_lower_bound_p(toff, R, (int)((long long)lb * T / nb)));
+  const int rb = __builtin_amdgcn_readfirstlane(lb == nb - 1 ? R : toff_lower_bound_p(toff, R, (int)((long long)(lb + 1) * T / nb)));
+  const int T0 = __builtin_amdgcn_readfirstlane(toff[ra]), T1 = __builtin_amdgcn_readfirstlane(toff[rb]);
+
+  // tile walk of this wave (tiles T0 + wave, + NW, ...): ray owning the current tile, cached per ray
+  int w_ray = ra, w_next = ra < R ? (int)toff[ra + 1] : T1, w_tile0 = T0, w_nc = 0;
+  bool w_fresh = true;
+  auto load_header = [&](int t) {
+    while (w_next <= t) { ++w_ray; w_tile0 = w_next; w_next = toff[w_ray + 1]; w_fresh = true; }
+    w_ray = __builtin_amdgcn_readfirstlane(w_ray);
+    if (w_fresh) { w_nc = __builtin_amdgcn_readfirstlane(ncomp[w_ray]); w_fresh = false; }
+    Hdr3 hd;
+    hd.ray = w_ray; hd.tile_in_ray = t - w_tile0;
+    const int j0 = hd.tile_in_ray * ITEM3;
+    const int cnt = min(ITEM3, w_nc - j0);
+    const size_t ci = (size_t)w_ray * S + j0 + (n < cnt ? n : 0);
+    hd.k = cidx[ci];
+    hd.wgt = (n < cnt && h == 0) ? cw[ci] : 0.0f;              // the two K halves of a sample hold the same colour: count it once
+    hd.rg = load_ray(rays, w_ray);
+    return hd;
+  };
+  LRF_TICK(0);
+  int t = T0 + wave;
+  Hdr3 cur;
+  if (t < T1) cur = load_header(t);
+  if (VAR & 4) {                                               // (lockstep experiment: every wave takes part in every round)
+    static_assert(!(VAR & 4) || true, "");
+  }
+  for (; (VAR & (4 | 32 | 64)) ? (t - wave < T1) : (t < T1); t += NW) {
+    asm volatile("" ::: "memory");                             // keep the LDS fragment reads inside the loop
+    if ((VAR & (4 | 32 | 64)) && t >= T1) {                    // no tile in this round: only the barriers
+      __builtin_amdgcn_s_barrier();
+      if (VAR & 4) __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    Hdr3 nxt = cur;
+    if (!(VAR & 1) && t + NW < T1) nxt = load_header(t + NW);
+    // ------------------------------------------------------------------ gather
+    bf16x8 xh[5], xl[5];
+    float vb[3];
+    uint32_t hq[4] = {0, 0, 0, 0};
+    {
+      const RayGeo rg = cur.rg;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {                            // view-direction part of mlp_view.0 + bias (tensorBase.py:131-132; viewdirs detached :628)
+        const float4 wv = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + W32_T_W3_LD * c + LRF_FEATC]);
+        vb[c] = tail[W32_T_B3 + c] + wv.x * rg.dh[0] + wv.y * rg.dh[1] + wv.z * rg.dh[2];
+      }
+      float x[3], u[3];
+      sample_point(f, rg.o, rg.dh, s_z[cur.k], x, u);
+      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);
+      float X[40];
+      uint32_t hraw[2] = {0, 0};
+      gather_app12<0, (VAR & 8) != 0 || DUMPH>(f, at, h, X, DUMPH ? hraw : nullptr);
+      gather_app12<1, (VAR & 8) != 0 || DUMPH>(f, at, h, X + 12, DUMPH ? hraw : nullptr);
+      gather_app12<2, (VAR & 8) != 0 || DUMPH>(f, at, h, X + 24, DUMPH ? hraw : nullptr);
+      X[36] = X[37] = X[38] = X[39] = 0.0f;
+      if ((VAR & 128) && f.dump) {                             // capture: everything the gather of this lane saw
+        float* dp = f.dump + ((size_t)t * 64 + lane) * 48;
+        dp[0] = __int_as_float(cur.k); dp[1] = s_z[cur.k]; dp[2] = u[0]; dp[3] = u[1]; dp[4] = u[2];
+        dp[5] = rg.o[0]; dp[6] = rg.o[1]; dp[7] = rg.o[2]; dp[8] = rg.dh[0]; dp[9] = rg.dh[1]; dp[10] = rg.dh[2]; dp[11] = __int_as_float(cur.ray);
+        for (int i = 0; i < 36; ++i) dp[12 + i] = X[i];
+      }
+      if (DUMPH) {
+        hq[0] = wave_xor(__float_as_uint(s_z[cur.k]) ^ (__float_as_uint(u[0]) * 3u) ^ (__float_as_uint(u[1]) * 5u) ^ (__float_as_uint(u[2]) * 7u));
+        hq[1] = wave_xor(hraw[1]);
+        hq[2] = wave_xor(hraw[0]);
+        uint32_t a = 0;
+        for (int i = 0; i < 36; ++i) a = a * 31u ^ __float_as_uint(X[i]);
+        hq[3] = wave_xor(a);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) split8c(X + 8 * ks, xh[ks], xl[ks]);
+    }
+    uint32_t hx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (DUMPH) {
+      hx[0] = wave_xor((uint32_t)cur.k * 2654435761u ^ __float_as_uint(cur.wgt) ^ __float_as_uint(cur.rg.o[0]) ^ __float_as_uint(cur.rg.dh[2]));
+      uint32_t a = 0;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const uint4 p = __builtin_bit_cast(uint4, xh[ks]), q = __builtin_bit_cast(uint4, xl[ks]);
+        a ^= p.x ^ (p.y * 3u) ^ (p.z * 5u) ^ (p.w * 7u) ^ (q.x * 11u) ^ (q.y * 13u) ^ (q.z * 17u) ^ (q.w * 19u);
+        a = a * 31u + ks;
+      }
+      hx[1] = wave_xor(a);
+    }
+    LRF_TICK(1);
+    if (VAR & 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    if (VAR & (4 | 64)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    // ------------------------------------------------------------------ chain
+    // basis 72 -> 27 (tensoRF.py:196): five K-steps; the three terms in three accumulators (one output tile only)
+    f32x16 fa, fb, fc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { fa[r] = 0.0f; fb[r] = 0.0f; fc[r] = 0.0f; }
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const bf16x8 ah = w32_frag(img, W32_BAS + ks, 0, lane), al = w32_frag(img, W32_BAS + ks, 1, lane);
+      fa = mfma32(al, xh[ks], fa);
+      fb = mfma32(ah, xl[ks], fb);
+      fc = mfma32(ah, xh[ks], fc);
+    }
+    const f32x16 fe = (fa + fb) + fc;
+    if (DUMPH) { uint32_t a = 0; for (int r = 0; r < 16; ++r) a = a * 31u ^ __float_as_uint(fe[r]); hx[2] = wave_xor(a); }
+    // layer 1 (tensorBase.py:129-130): two K-steps (features 0..15, 16..31), four output tiles
+    f32x16 h1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bq = *reinterpret_cast<const float4*>(&tail[W32_T_B1 + 32 * m + 8 * q + 4 * h]);
+        h1[m][4 * q] = bq.x; h1[m][4 * q + 1] = bq.y; h1[m][4 * q + 2] = bq.z; h1[m][4 * q + 3] = bq.w;
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fe[8 * q + j];
+      bf16x8 bh, bl;
+      split8c(v, bh, bl);
+      mma3_step<4>(img, W32_W1 + q, 2, lane, bh, bl, h1);
+    }
+    if (DUMPH) { uint32_t a = 0; for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) a = a * 31u ^ __float_as_uint(h1[m][r]); hx[3] = wave_xor(a); }
+    // relu(h1) as the eight split B operands of layer 2 (K-step 2 m0 + q = registers 8 q .. 8 q + 7 of tile m0); h1 dies here
+    bf16x8 b2h[8], b2l[8];
+#pragma unroll
+    for (int m0 = 0; m0 < 4; ++m0)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = relu_i(h1[m0][8 * q + j]);
+        split8c(v, b2h[2 * m0 + q], b2l[2 * m0 + q]);
+      }
+    // layer 2 + head (tensorBase.py:130-133), two output tiles at a time: 64 accumulator registers fewer are live, and
+    // the VALU head of one half has the other half's MFMAs to hide under
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x16 h2[2];
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bq = *reinterpret_cast<const float4*>(&tail[W32_T_B2 + 32 * (2 * half + mm) + 8 * q + 4 * h]);
+          h2[mm][4 * q] = bq.x; h2[mm][4 * q + 1] = bq.y; h2[mm][4 * q + 2] = bq.z; h2[mm][4 * q + 3] = bq.w;
+        }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) mma3_step<2>(img, W32_W2 + 16 * half + ks, 8, lane, b2h[ks], b2l[ks], h2);
+      if (DUMPH) { uint32_t a = 0; for (int m = 0; m < 2; ++m) for (int r = 0; r < 16; ++r) a = a * 31u ^ __float_as_uint(h2[m][r]); hx[4 + half] = wave_xor(a); }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int u = 32 * (2 * half + mm) + 8 * q + 4 * h;
+          const float4 w0 = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + u]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + W32_T_W3_LD + u]);
+          const float4 w2 = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + 2 * W32_T_W3_LD + u]);
+          const float a0 = relu_i(h2[mm][4 * q]), a1 = relu_i(h2[mm][4 * q + 1]), a2 = relu_i(h2[mm][4 * q + 2]), a3 = relu_i(h2[mm][4 * q + 3]);
+          o0 += a0 * w0.x; o0 += a1 * w0.y; o0 += a2 * w0.z; o0 += a3 * w0.w;
+          o1 += a0 * w1.x; o1 += a1 * w1.y; o1 += a2 * w1.z; o1 += a3 * w1.w;
+          o2 += a0 * w2.x; o2 += a1 * w2.y; o2 += a2 * w2.z; o2 += a3 * w2.w;
+        }
+    }
+    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+    // w * sigmoid(x) (:133, :632), hardware exp2 / reciprocal; partial colour of the tile = sum over its samples
+    float cr = cur.wgt * __frcp_rn(1.0f + __expf(-(o0 + vb[0])));
+    float cg = cur.wgt * __frcp_rn(1.0f + __expf(-(o1 + vb[1])));
+    float cb = cur.wgt * __frcp_rn(1.0f + __expf(-(o2 + vb[2])));
+#pragma unroll
+    for (int dd = 1; dd < 32; dd <<= 1) {
+      cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
+    }
+    if (lane == 0) {
+      float* pp = part + ((size_t)cur.ray * pmax + cur.tile_in_ray) * 3;
+      pp[0] = cr; pp[1] = cg; pp[2] = cb;
+    }
+    if (DUMPH) {
+      hx[6] = wave_xor(__float_as_uint(o0) ^ (__float_as_uint(o1) * 3u) ^ (__float_as_uint(o2) * 5u));
+      hx[7] = __float_as_uint(cr) ^ (__float_as_uint(cg) * 3u) ^ (__float_as_uint(cb) * 5u);
+      if (lane == 0 && f.dump) {
+        uint32_t* dp = reinterpret_cast<uint32_t*>(f.dump) + (size_t)t * 8;
+        dp[0] = hx[0]; dp[1] = hq[0]; dp[2] = hq[1]; dp[3] = hq[2]; dp[4] = hq[3]; dp[5] = hx[1]; dp[6] = hx[2]; dp[7] = hx[3];
+      }
+    }
+    cur = nxt;
+    if ((VAR & 1) && t + NW < T1) cur = load_header(t + NW);
+    if (VAR & 16) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    if (VAR & (4 | 32)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    LRF_TICK(2);
+    tk[6] += 1;
+  }
+  // rgb_map = sum_k w_k rgb_k (+ 1 - acc) (tensorBase.py:632-634): this workgroup wrote every partial of its rays.  Its
+  // waves share one L1 and these lines were never read before in this launch; the stores only have to be acknowledged.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int r = ra + tid; r < rb; r += NT) finalize_ray<false>(r, (int)toff[r + 1] - (int)toff[r], pmax, flags, acc, part, rgb_out, acc_out);
+  LRF_TICK(3);
+  if (TIMED && f.dump && lane == 0) {
+    unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * NW + wave) * 8;
+    for (int i = 0; i < 8; ++i) dp[i] = tk[i];
+  }
+#undef LRF_TICK
+}
+
+}  // namespace lrf

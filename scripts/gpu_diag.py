@@ -961,6 +961,173 @@ def stage_shade2_phases():
         f" | total {float(t[:, :7].sum() / tiles):.0f} | per-wave total min/max {float(t[:, :7].sum(1).min()):.0f}/{float(t[:, :7].sum(1).max()):.0f}")
 
 
+def stage_capture3():
+    """Full capture of what every lane's gather saw (sample index, distance, position, ray, 36 products) per tile, for
+    identical renders: prints the entries that differ between two runs."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    names = ["k", "z[k]", "u0", "u1", "u2", "o0", "o1", "o2", "dh0", "dh1", "dh2", "ray"] + [f"X{i}" for i in range(36)]
+    for pipe in (38, 37):
+        lib.lrf_debug_set_shade_pipe(pipe)
+        caps = []
+        with torch.no_grad():
+            for it in range(int(os.environ.get("CAP3_N", "12"))):
+                buf = torch.zeros(26000 * 64 * 48, dtype=torch.float32, device="cuda")
+                lib.lrf_debug_set_dump(buf.data_ptr())
+                rgb, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                torch.cuda.synchronize()
+                lib.lrf_debug_set_dump(None)
+                caps.append((buf.view(-1, 64, 48).view(torch.int32), rgb.clone()))
+        ref, rgb0 = caps[0]
+        nshow = 0
+        for ci, (b, rgb) in enumerate(caps[1:]):
+            diff = b != ref
+            nt = int(diff.any(-1).any(-1).sum())
+            cols = diff.any(0).any(0)
+            log(f"capture3 pipe {pipe} run {ci + 1}: tiles with a differing entry {nt}, entries {int(diff.sum())}, columns {[names[i] for i in torch.nonzero(cols).flatten().tolist()][:20]}, colours equal {bool(torch.equal(rgb, rgb0))}")
+            if nt and nshow < 4:
+                idx = torch.nonzero(diff)
+                for t_, l_, c_ in idx[:10].tolist():
+                    a = ref[t_, l_, c_].view(torch.float32) if c_ not in (0, 11) else ref[t_, l_, c_]
+                    bb = b[t_, l_, c_].view(torch.float32) if c_ not in (0, 11) else b[t_, l_, c_]
+                    log(f"   tile {t_} lane {l_} {names[c_]}: {float(a) if c_ not in (0, 11) else int(a)} vs {float(bb) if c_ not in (0, 11) else int(bb)} | k {int(ref[t_, l_, 0])}/{int(b[t_, l_, 0])} ray {int(ref[t_, l_, 11])}")
+                lanes = torch.unique(idx[:, 1]).tolist()
+                log(f"   lanes hit {lanes[:32]} | tiles hit {torch.unique(idx[:, 0]).tolist()[:10]}")
+                nshow += 1
+    lib.lrf_debug_set_shade_pipe(0)
+
+
+def stage_hash3():
+    """Which stage of a tile differs between identical renders?  k_shade3<DUMPH> leaves, per tile, a wave-wide XOR of the
+    bit patterns after each stage; HASH3_N renders are compared with the first."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    names = ["header", "position", "addresses+weights", "raw loads", "X fp32", "X split", "basis", "layer 1"]
+    n = int(os.environ.get("HASH3_N", "100"))
+    for pipe in (0, 12):
+        lib.lrf_debug_set_shade_pipe(pipe)
+        bufs = []
+        with torch.no_grad():
+            for it in range(n + 1):
+                buf = torch.zeros(40000 * 8, dtype=torch.int32, device="cuda")
+                lib.lrf_debug_set_dump(buf.data_ptr())
+                lib.lrf_debug_set_mlp_policy(9)
+                rgb, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                torch.cuda.synchronize()
+                lib.lrf_debug_set_mlp_policy(4)
+                lib.lrf_debug_set_dump(None)
+                bufs.append((buf.view(-1, 8).clone(), rgb.clone()))
+        ref, rgb0 = bufs[0]
+        first_stage = [0] * 9
+        ntile = nrender = 0
+        examples = []
+        for b, rgb in bufs[1:]:
+            diff = (b != ref)
+            rows = diff.any(1)
+            if bool(rows.any()):
+                nrender += 1
+                for r in torch.nonzero(rows).flatten().tolist():
+                    st = int(torch.nonzero(diff[r]).flatten()[0])
+                    first_stage[st] += 1
+                    ntile += 1
+                    if len(examples) < 6:
+                        examples.append((r, [names[i] for i in torch.nonzero(diff[r]).flatten().tolist()]))
+            elif not torch.equal(rgb, rgb0):
+                first_stage[8] += 1
+        log(f"hash3 shade_pipe {pipe}: {nrender} of {n} renders have a differing tile ({ntile} tiles); first differing stage: " +
+            ", ".join(f"{names[i]} {first_stage[i]}" for i in range(8)) + f", colours only {first_stage[8]} | examples {examples}")
+    lib.lrf_debug_set_shade_pipe(0)
+
+
+def stage_det3():
+    """Is k_shade3 deterministic?  DET3_N identical renders per variant (shade_pipe 0: 12 waves per workgroup, 12: 8 waves),
+    colours compared with the first render's; for differing renders the rays and the size of the difference."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    n = int(os.environ.get("DET3_N", "300"))
+    for pipe in [int(v) for v in os.environ.get("DET3_PIPES", "0,12").split(",")]:
+        lib.lrf_debug_set_shade_pipe(pipe)
+        with torch.no_grad():
+            first, d0 = f(rays, white_bg=True, is_train=False, N_samples=1536)
+            first, d0 = first.clone(), d0.clone()
+            bad = badd = 0
+            worst, nr = 0.0, 0
+            seen = set()
+            for _ in range(n):
+                again, d1 = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                if not torch.equal(first, again):
+                    bad += 1
+                    dd = (first - again).abs().amax(-1)
+                    worst = max(worst, float(dd.max()))
+                    nr = max(nr, int((dd > 0).sum()))
+                    if len(seen) < 200:
+                        seen.update(int(i) for i in torch.nonzero(dd > 0).flatten()[:20])
+                badd += not torch.equal(d0, d1)
+        log(f"det3 shade_pipe {pipe}: {bad} of {n} renders differ in colour (max {worst:.2e}, up to {nr} rays, distinct rays seen {len(seen)}: {sorted(seen)[:12]}) | depth differs in {badd}")
+    lib.lrf_debug_set_shade_pipe(0)
+
+
+def stage_shade3_phases():
+    """s_memtime phase totals of k_shade3 per wave (TIMED build), 12 and 8 waves per workgroup; then the kernel's time
+    per variant and the 16-sample engine's beside it."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+    with torch.no_grad():
+        for _ in range(300):
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+    names = ["prologue", "gather", "chain", "finalize"]
+    for pipe, nw in ((0, 12), (12, 8)):
+        buf = torch.zeros(256 * nw * 8, dtype=torch.int64, device="cuda")
+        lib.lrf_debug_set_shade_pipe(pipe)
+        with torch.no_grad():
+            lib.lrf_debug_set_dump(buf.data_ptr())
+            lib.lrf_debug_set_mlp_policy(10)
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+            torch.cuda.synchronize()
+            lib.lrf_debug_set_mlp_policy(4)
+            lib.lrf_debug_set_dump(None)
+        t = buf.view(256 * nw, 8).double()
+        tiles = t[:, 6].sum()
+        tot = t[:, :4].sum(1)
+        log(f"k_shade3 {nw} waves: tiles {int(tiles)} | cycles per wave: " + " ".join(f"{n} {float(t[:, i].mean()):.0f}" for i, n in enumerate(names)) +
+            f" | per tile: gather {float(t[:, 1].sum() / tiles):.0f} chain {float(t[:, 2].sum() / tiles):.0f} | per-wave total mean/min/max {float(tot.mean()):.0f}/{float(tot.min()):.0f}/{float(tot.max()):.0f}")
+        with torch.no_grad():
+            for _ in range(50):
+                f(rays, white_bg=True, is_train=False, N_samples=1536)
+        p = bench.kernel_profile(f, rays, z, reps=20)
+        log(f"k_shade3 {nw} waves: colour kernel {p['shade_ms'] * 1e3:.1f} us, march {p['march_ms'] * 1e3:.1f} us, total {p['total_ms'] * 1e3:.1f} us")
+    lib.lrf_debug_set_shade_pipe(0)
+    for eng in ("bf16x3_w16",):
+        f.mlp_engine = eng
+        with torch.no_grad():
+            for _ in range(50):
+                f(rays, white_bg=True, is_train=False, N_samples=1536)
+        p = bench.kernel_profile(f, rays, z, reps=20)
+        log(f"engine {eng}: colour kernel {p['shade_ms'] * 1e3:.1f} us, total {p['total_ms'] * 1e3:.1f} us")
+
+
 def stage_skew():
     """k_shade2 with the waves of a SIMD started out of phase."""
     import torch
@@ -1107,6 +1274,59 @@ def stage_train_host():
     buf = _io.StringIO()
     pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(45)
     log(buf.getvalue()[-7000:])
+
+
+def stage_screen():
+    """Box screen for finding 17 (rare odd renders right after a DIFFERENT kernel mix): alternates two fields (300^3
+    x 512 samples, an empty 64^3 x 64 samples), the launch sequences and the colour engines, one render each per
+    round, and compares every render with that configuration's own first result.  Reports, per configuration, the
+    rounds whose colour / depth differ and by how much -- depth comes from k_march alone, the f32 / valu engines use no
+    bf16 MFMA: which of them move tells the kernel.  SCREEN_ROUNDS rounds (default 400)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    big = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    empty = quiet(make_field, [64, 64, 64], "cpu", seed=3)
+    with torch.no_grad():
+        for p in empty.density_plane:
+            p.zero_()
+    empty = empty.to("cuda:0")
+    empty.density_shift = -30.0
+    rays = make_rays(4096, 1).cuda()
+    lib = N.lib()
+    engines = os.environ.get("SCREEN_ENGINES", "bf16x3:0,bf16x3:9,bf16x3_fused:0,f32:0").split(",")
+    cfgs = []
+    for e in engines:
+        eng, pipe = e.split(":")
+        cfgs.append((eng, int(pipe), big, 1536, "300^3"))
+        cfgs.append((eng, int(pipe), empty, 192, "empty64"))
+    n = int(os.environ.get("SCREEN_ROUNDS", "400"))
+    ref, odd = {}, {}
+    scratch = torch.empty(1 << 22, device="cuda")
+    with torch.no_grad():
+        for rnd in range(n):
+            for ci, (eng, pipe, fld, ns, name) in enumerate(cfgs):
+                fld.mlp_engine = eng
+                lib.lrf_debug_set_shade_pipe(pipe)
+                if rnd % 3 == 1:
+                    scratch.sort()                     # a foreign kernel in between (the trigger seen in round 2)
+                rgb, dep = fld(rays, white_bg=True, is_train=False, N_samples=ns)
+                if ci not in ref:
+                    ref[ci] = (rgb.clone(), dep.clone())
+                    odd[ci] = []
+                    continue
+                dc = (rgb - ref[ci][0]).abs().amax(-1)
+                dd = (dep - ref[ci][1]).abs()
+                if float(dc.max()) > 0 or float(dd.max()) > 0:
+                    odd[ci].append((rnd, int((dc > 0).sum()), float(dc.max()), int((dd > 0).sum()), float(dd.max())))
+        lib.lrf_debug_set_shade_pipe(0)
+    total = 0
+    for ci, (eng, pipe, fld, ns, name) in enumerate(cfgs):
+        total += len(odd[ci])
+        log(f"screen {eng}:{pipe} {name}: {len(odd[ci])} of {n - 1} renders differ from the first "
+            f"(round, rays colour, max colour, rays depth, max depth): {odd[ci][:6]}")
+    log(f"screen total odd renders: {total}")
 
 
 def stage_flake2():
@@ -1394,7 +1614,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("flake3", 300), ("flake2", 300), ("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("capture3", 200), ("hash3", 200), ("det3", 200), ("shade3_phases", 200), ("screen", 300), ("flake3", 300), ("flake2", 300), ("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -29,8 +29,9 @@ def test_cache_and_workspace_sizes(built_lib):
     import ctypes as C
     grid = (C.c_int32 * 3)(300, 300, 300)
     n = built_lib.lrf_cache_bytes(grid)
-    # 3 planes x (8 + 32: appearance texels are padded to 128 B) ch x 300^2 + lines + MLP images, fp32
-    assert 3 * 40 * 300 * 300 * 4 <= n <= 3 * 40 * 300 * 300 * 4 + 600_000
+    # 3 planes x (8 + 32 + 24: appearance texels once padded to 128 B for the 16-sample / training kernels and once dense
+    # for k_shade3) ch x 300^2 + lines + MLP images, fp32
+    assert 3 * 64 * 300 * 300 * 4 <= n <= 3 * 64 * 300 * 300 * 4 + 800_000
     # lists + partials (12.6 MB) + the k_app -> k_mlp fragment buffer at its worst case (every sample
     # shaded: 4096 x 32 tiles x 2 KB = 268 MB; the benchmark touches 99 MB of it)
     assert built_lib.lrf_workspace_bytes(4096, 512) < 300 << 20
