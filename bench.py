@@ -45,10 +45,11 @@ sys.path.insert(0, ROOT)
 GRID, R_PER_GPU, N_SAMPLES_ARG = 300, 4096, 1536          # -> S = 2*(1536//6) = 512
 DENS_BYTES_PER_SAMPLE = 3 * 4 * 8 * 4 + 3 * 2 * 8 * 4      # 576  B
 APP_BYTES_PER_SAMPLE = 3 * 4 * 24 * 4 + 3 * 2 * 24 * 4     # 1728 B
-FRAG_BYTES_PER_SLOT = 128                                  # k_app -> k_mlp: layer-1 B fragment, hi + lo bf16 x 32
 BASIS_FLOP = 2 * 72 * 27
 MLP_FLOP = 2 * (27 * 128 + 128 * 128 + 131 * 3)           # per shaded sample, after the basis
-MFMA_FLOP = 2 * 16 * 16 * 32                               # one v_mfma_f32_16x16x32_bf16
+MFMA_FLOP = 2 * 32 * 32 * 16                               # one v_mfma_f32_32x32x16_bf16
+MFMA_PER_TILE = 135                                        # k_shade3, per 32-sample tile: 15 basis + 24 layer 1 + 96 layer 2 (3-term split products)
+VECTOR_INSTR_PER_TILE = 1535                               # k_shade3, VALU + MFMA instructions a wave issues per tile (profiles/r08c: SQ_INSTS_VALU / tiles)
 HBM_PEAK_GBS, L2_PEAK_GBS, MFMA_BF16_PEAK_TF = 8000.0, 34500.0, 2500.0   # MI355X_MICROARCH.md
 
 FIELD_KW = dict(density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=27,
@@ -227,9 +228,7 @@ def kernel_profile(field, rays, z, reps=5):
         if i:                                   # first call is a warm-up
             for j in range(6):
                 acc[j] += ms[j] / reps
-    return {"march_ms": acc[0], "shade_ms": acc[1], "finalize_ms": acc[2], "total_ms": acc[3],
-            "scan_ms": acc[4], "app_ms": acc[5], "mlp_ms": max(acc[1] - acc[4] - acc[5], 0.0),
-            "n_shaded": int(nsh.value)}
+    return {"march_ms": acc[0], "shade_ms": acc[1], "finalize_ms": acc[2], "total_ms": acc[3], "n_shaded": int(nsh.value)}
 
 
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"))
@@ -276,10 +275,10 @@ def pmc_traffic(timeout_s=240):
 
 
 def committed_traffic():
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json",):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            out = {k.replace("k_shade_bf16", "k_shade2"): {"traffic_bytes": v["traffic_bytes"],
+            out = {k: {"traffic_bytes": v["traffic_bytes"],
                                                            "l2_hit_rate": v["TCC_HIT"] / max(v["TCC_HIT"] + v["TCC_MISS"], 1.0)}
                    for k, v in pmc["kernels"].items()}
             return out, f"NOT measured in this run: committed profiles/{name} ({pmc.get('source', '')[:80]})"
@@ -288,24 +287,21 @@ def committed_traffic():
     return {}, None
 
 
-def roofline_object(prof, S, traffic, traffic_src):
-    """SURVEY.md s8d figures per launch over HIP-event durations; see DESIGN.md s5 for how to read them."""
+def roofline_object(prof, S, traffic, traffic_src, cus=256, clock_ghz=2.4):
+    """SURVEY.md s8d figures per launch over HIP-event durations (DESIGN.md s5 says how to read them).  The 43.6 MB
+    field is cache-resident, so the HBM roof cannot bind either kernel; what can bind is reported beside the contract's
+    figure: matrix-pipe occupancy (issued MFMAs, three per product), the vector issue port (VALU + MFMA instructions at
+    four cycles each per SIMD), L2 rate, HBM-side traffic from the counters."""
     n_sh = prof["n_shaded"]
-    tiles = (n_sh + 15) // 16                              # lower bound (rays pad their last tile)
+    tiles = (n_sh + 31) // 32                              # lower bound (rays pad their last tile; the kernel counts ~3 % more)
     dens_bytes = R_PER_GPU * S * DENS_BYTES_PER_SAMPLE
     app_bytes = n_sh * APP_BYTES_PER_SAMPLE
-    kern = {"k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes, "bound": "hbm"}}
-    if prof["finalize_ms"] > 1e-3:                         # four-launch sequence (the default engine folds the tile
-        kern["k_finalize"] = {"ms": prof["finalize_ms"]}   # scan and the per-ray sum into k_shade2: two launches)
-        kern["k_scan_tiles"] = {"ms": prof["scan_ms"]}
-    if prof["app_ms"] > 0:                                 # LRF_FLAG_MLP_SPLIT
-        kern["k_app"] = {"ms": prof["app_ms"], "alg_bytes": app_bytes + n_sh * FRAG_BYTES_PER_SLOT, "bound": "hbm",
-                         "alg_flop": n_sh * BASIS_FLOP, "issued_mfma_flop": tiles * 18 * MFMA_FLOP}
-        kern["k_mlp"] = {"ms": prof["mlp_ms"], "alg_bytes": n_sh * (FRAG_BYTES_PER_SLOT + 4), "bound": "mfma",
-                         "alg_flop": n_sh * MLP_FLOP, "issued_mfma_flop": tiles * 120 * MFMA_FLOP}
-    else:                                                  # default engine: one fused colour kernel, 150 MFMAs per tile
-        kern["k_shade2"] = {"ms": prof["shade_ms"] - prof["scan_ms"], "alg_bytes": app_bytes, "bound": "hbm",
-                            "alg_flop": n_sh * (BASIS_FLOP + MLP_FLOP), "issued_mfma_flop": tiles * 150 * MFMA_FLOP}
+    kern = {"k_march": {"ms": prof["march_ms"], "alg_bytes": dens_bytes, "bound": "hbm"},
+            "k_shade3": {"ms": prof["shade_ms"], "alg_bytes": app_bytes, "bound": "mfma",
+                         "alg_flop": n_sh * (BASIS_FLOP + MLP_FLOP), "issued_mfma_flop": tiles * MFMA_PER_TILE * MFMA_FLOP,
+                         "vector_instr": tiles * VECTOR_INSTR_PER_TILE}}
+    if prof["finalize_ms"] > 1e-3:
+        kern["k_finalize"] = {"ms": prof["finalize_ms"]}
     for name, k in kern.items():
         t = k["ms"] * 1e-3
         if "alg_bytes" in k and t > 0:
@@ -314,14 +310,15 @@ def roofline_object(prof, S, traffic, traffic_src):
         if "alg_flop" in k and t > 0:
             k["alg_TFLOPs"] = k["alg_flop"] / t / 1e12
             k["mfma_frac"] = k["issued_mfma_flop"] / t / 1e12 / MFMA_BF16_PEAK_TF   # matrix-pipe occupancy, 3 MFMAs per product
+            k["issue_frac"] = k["vector_instr"] * 4.0 / (t * clock_ghz * 1e9 * cus * 4)   # vector issue port: 4 cycles per instruction and SIMD
         tr = traffic.get(name)
         if tr:
             k["pmc_traffic_bytes"] = tr["traffic_bytes"]
             k["l2_hit_rate"] = tr["l2_hit_rate"]
             if t > 0:
                 k["hbm_frac"] = tr["traffic_bytes"] / t / 1e9 / HBM_PEAK_GBS
-    cands = [n for n in ("k_march", "k_app", "k_mlp", "k_shade2") if n in kern]
-    dom = max(cands, key=lambda n: kern[n]["ms"])
+        k["binding_frac"] = max(k.get(n, 0.0) or 0.0 for n in ("l2_frac", "mfma_frac", "issue_frac", "hbm_frac"))
+    dom = max(("k_march", "k_shade3"), key=lambda n: kern[n]["ms"])
     d = kern[dom]
     if d["bound"] == "mfma":
         ach, peak, unit = d["alg_TFLOPs"], MFMA_BF16_PEAK_TF, "TFLOP/s"
@@ -329,14 +326,16 @@ def roofline_object(prof, S, traffic, traffic_src):
         ach, peak, unit = d["GBps"], HBM_PEAK_GBS, "GB/s"
     return {"bound": d["bound"], "kernel": dom, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
             "traffic": d.get("pmc_traffic_bytes"), "traffic_source": traffic_src,
-            "l2_frac": d.get("l2_frac"), "mfma_frac": d.get("mfma_frac"), "hbm_frac": d.get("hbm_frac"),
-            "limiter": "none of the three roofs binds: the 43.5 MB field is cache-resident (hbm_frac), the gathers run "
-                       "at l2_frac of the aggregate L2 rate, the matrix pipe at mfma_frac; what is left is issue / "
-                       "memory-latency per wave (DESIGN.md s4)",
+            "l2_frac": d.get("l2_frac"), "mfma_frac": d.get("mfma_frac"), "issue_frac": d.get("issue_frac"), "hbm_frac": d.get("hbm_frac"),
+            "binding_frac": d.get("binding_frac"),
+            "limiter": "vector instruction issue: a 32-sample tile costs a wave ~1400 VALU + 135 MFMA instructions through one issue "
+                       "port per SIMD (issue_frac); the matrix pipe runs the three-term split products at mfma_frac of its dense "
+                       "bf16 rate (frac counts algorithmic flops: one product per weight); the 43.6 MB field is cache-resident, "
+                       "so neither HBM (hbm_frac) nor L2 (l2_frac) binds",
             "whole_path_GBps": (dens_bytes + app_bytes) / (prof["total_ms"] * 1e-3) / 1e9,
             "shaded_fraction": n_sh / (R_PER_GPU * S), "kernels": kern,
-            "note": "achieved = SURVEY.md s8d algorithmic bytes (flops for an MFMA-bound kernel) of the dominant kernel "
-                    "per launch / its HIP-event duration; cache-resident gathers can exceed the HBM figure"}
+            "note": "achieved = SURVEY.md s8d algorithmic flops (bytes for k_march) of the dominant kernel per launch / its "
+                    "HIP-event duration on the launch stream"}
 
 
 def walls_field(dev, grid=GRID):
@@ -389,7 +388,7 @@ def config3_scene(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)        # what the driver runs
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / torch-ROCm baselines and extra workloads")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
@@ -490,7 +489,7 @@ def main():
             traffic, traffic_src = committed_traffic()
             if why and traffic_src:
                 traffic_src += f" [{why}]"
-        roofline = roofline_object(prof, S, traffic or {}, traffic_src)
+        roofline = roofline_object(prof, S, traffic or {}, traffic_src, cus=torch.cuda.get_device_properties(dev).multi_processor_count)
         n_sh = prof["n_shaded"]
         rows = ((n_sh + 15) // 16) * 16
         # bytes the training step moves through HBM-side memory by construction: the saved activation /
@@ -511,7 +510,7 @@ def main():
         out = {"metric": "rays/sec (4096-ray batch, 512 samples, 300^3 grid)", "value": value,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32 (colour MLP on split-bf16 x3 MFMA, fp32 accumulate; gathers, compositing fp32)",
+               "vs_baseline": None, "dtype": "f32 (colour network: split-bf16 3-term products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, <= 3e-5 vs the exact-fp32 engine; gathers and compositing fp32)",
                "data": "synthetic",
                "config": {"workload": "configs[1]: single 300^3 TensorVMSplit, 4096 rays x 512 samples "
                                       "per GPU, full density+appearance+MLP render, eval forward",
@@ -522,20 +521,9 @@ def main():
             with torch.no_grad():
                 field.mlp_engine = "f32"
                 d32 = timed(fwd, 20, 3, sync)
-                field.mlp_engine = "bf16x3_fused"
-                dfu = timed(fwd, 20, 3, sync)
-                field.mlp_engine = "bf16x3_split"
-                dsp = timed(fwd, 20, 3, sync)
-                psp = kernel_profile(field, rays, z)
                 field.mlp_engine = "bf16x3"
             work = {"exact_f32_engine": {"rays_per_s": R_PER_GPU * 20 / d32, "ms_per_step": d32 / 20 * 1e3,
-                                         "what": "same batch, colour MLP on v_mfma_f32_16x16x4_f32 (LRF_FLAG_MLP_F32)"},
-                    "round1_fused_engine": {"rays_per_s": R_PER_GPU * 20 / dfu, "ms_per_step": dfu / 20 * 1e3,
-                                            "what": "same batch, round 1's colour kernel k_shade_bf16 (LRF_FLAG_MLP_FUSED)"},
-                    "split_engine": {"rays_per_s": R_PER_GPU * 20 / dsp, "ms_per_step": dsp / 20 * 1e3,
-                                     "k_app_ms": psp["app_ms"], "k_mlp_ms": psp["mlp_ms"],
-                                     "what": "same batch, colour stage as k_app (gathers + basis) + k_mlp (MFMA chain, no gathers) "
-                                             "(LRF_FLAG_MLP_SPLIT)"}}
+                                         "what": "same batch, colour MLP on v_mfma_f32_16x16x4_f32 (LRF_FLAG_MLP_F32)"}}
             try:
                 wf = walls_field(dev)
                 wf.updateAlphaMask((GRID // 2,) * 3)

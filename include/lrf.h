@@ -8,8 +8,9 @@
  * Conventions: every pointer is a DEVICE pointer to contiguous fp32 (unless typed
  * otherwise) on the current HIP device; `stream` is a hipStream_t passed as void*;
  * no allocation, no host synchronisation and no ownership transfer inside the library;
- * all calls are asynchronous on `stream` and re-entrant per stream.  Return 0 on success,
- * non-zero on error with a message available from lrf_last_error().
+ * all calls are asynchronous on `stream` and re-entrant per stream (the test hooks of
+ * include/lrf_debug.h are process-wide switches and are NOT part of this contract).
+ * Return 0 on success, non-zero on error with a message available from lrf_last_error().
  */
 #ifndef LRF_H_
 #define LRF_H_
@@ -37,11 +38,7 @@ extern "C" {
 #define LRF_FLAG_RELU_DENS  2u   /* fea2denseAct == "relu" (tensorBase.py:498-499) */
 #define LRF_FLAG_MLP_VALU   4u   /* debug engine: colour MLP on the vector ALU, natural-layout weights */
 #define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
-                                    split-bf16 (hi+lo, 3-term) MFMA chain */
-#define LRF_FLAG_MLP_FUSED  32u  /* colour stage as round 1's fused kernel (k_shade_bf16) instead of the default k_shade2 */
-#define LRF_FLAG_MLP_SPLIT  64u  /* colour stage as two kernels, k_app (gather + basis) and k_mlp (the MFMA chain) */
-#define LRF_FLAG_MLP_W16    128u /* colour stage as round 2's k_shade2 (16 samples per wave on v_mfma_f32_16x16x32_bf16, hand-issued)
-                                    instead of the default k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16) */
+                                    split-bf16 (hi+lo, 3-term) chain on v_mfma_f32_32x32x16_bf16 (k_shade3) */
 #define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
@@ -97,22 +94,8 @@ typedef struct LrfGrads {
 } LrfGrads;
 
 int         lrf_abi_version(void);
-/* Debug: when set (device buffer of R*S*64 floats), the split-bf16 shade kernel stores 16
- * intermediate values per (compact sample, lane group); NULL (default) disables it. */
-void        lrf_debug_set_dump(float* buf);
-void        lrf_debug_set_mlp_threads(int threads); /* 1024 (default) | 512 | 256: workgroup size of k_mlp (experiments) */
-void        lrf_debug_set_app_oversubscribe(int n); /* k_app workgroups per resident slot, 1..16 (default 4) */
-void        lrf_debug_set_subbatches(int q);        /* ray ranges of the sub-batch pipeline of lrf_render_fwd, 1..8 (default 1 = off) */
-void        lrf_debug_set_skew(int n);              /* start skew between the waves of a SIMD in k_shade2, units of 6400 cycles */
-void        lrf_debug_set_lds_lines(int on);        /* k_march: density lines staged in LDS (default on when they fit) */
-void        lrf_debug_set_bwd_overlap(int on);      /* lrf_render_bwd: two branches on two streams (default on) */
-void        lrf_debug_set_train_fwd_engine(int engine);   /* bit 0: row-saving forward 1 = k_bwd_shade_fwd (default), 0 = k_shade2<SAVE> (slower); bit 1: dW2 GEMM on fp32 MFMAs over stored dz2 rows; bit 2: data-gradient chain on fp32 MFMAs */
-int64_t     lrf_debug_saved_row_offset(int buffer, uint64_t row, int col);   /* float offset of (row, col) inside the ACT (0) / GRD (1) region of a training workspace (MFMA-fragment order, csrc/lrf_common.h); buffer 2: X-block column of appearance channel col */
-int         lrf_debug_poison_cu_state(uint32_t pattern, int regs, void* stream);  /* fills every CU's LDS (regs != 0: also a wave's vector registers) with pattern: what a foreign kernel may leave behind */
-void        lrf_debug_set_shade_pipe(int on);       /* k_shade2: software-pipelined plane-0 gather (experiment) */
-void        lrf_debug_set_mlp_policy(int policy);   /* MFMA issue policy of k_mlp, 0 (shipped) .. 3, see lrf_shade2.inl */
 const char* lrf_last_error(void);
-char*       lrf_error_slot(void);                   /* internal: the calling thread's 512-byte error text (shared by the library's translation units) */
+char*       lrf_error_slot(void);                   /* internal: the calling thread's 512-byte error text */
 
 /* Bytes of the layout cache for a grid (x,y,z). */
 size_t lrf_cache_bytes(const int32_t grid[3]);
@@ -135,8 +118,8 @@ int lrf_render_fwd(const LrfField* f, const float* rays, const float* z,
 
 /* Measurement variant of lrf_render_fwd (bench.py only): brackets each kernel with HIP
  * events on `stream`, SYNCHRONISES, and returns ms_out[6] (host) = {march, shade, finalize,
- * total, k_scan_tiles, k_app} (shade = k_scan_tiles + k_app + k_mlp with the default engine; the last is 0
- * with the others) plus the number of shaded samples (sum over rays of weight > thres). */
+ * total, 0, 0} plus the number of shaded samples (sum over rays of weight > thres).  The default engine has
+ * no separate finalize launch (0). */
 int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            int32_t R, int32_t S, uint32_t flags, float floater_thresh,
                            float* rgb, float* depth, void* workspace, void* stream,

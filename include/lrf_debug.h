@@ -1,0 +1,26 @@
+/* lrf_debug.h -- test hooks of liblrf_hip.so.  NOT part of the drop-in ABI (include/lrf.h): these are process-wide
+ * switches for the diagnostics in scripts/gpu_diag.py and for a few tests; a host thread that flips one while another
+ * renders changes that render too.  Production callers never include this header. */
+#ifndef LRF_DEBUG_H_
+#define LRF_DEBUG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* When set (device buffer of n_CUs * 8 waves * 8 uint64), lrf_render_fwd runs k_shade3<TIMED> and leaves per-wave
+ * s_memtime totals there: {prologue, header + position, gather + split, -, -, chain, tiles, finalize}; NULL = off. */
+void    lrf_debug_set_dump(float* buf);
+void    lrf_debug_set_lds_lines(int on);          /* k_march: density lines staged in LDS (default on when they fit) */
+void    lrf_debug_set_bwd_overlap(int on);        /* lrf_render_bwd: two branches on two streams (default on); 1 + 2 * (n + 1): n weight-gradient GEMMs on the caller's stream */
+void    lrf_debug_set_train_fwd_engine(int bits); /* bit 1: dW2 GEMM on fp32 MFMAs over stored dz2 rows; bit 2: data-gradient chain on fp32 MFMAs (measurement variants) */
+/* float offset of (row, col) inside the ACT (0) / GRD (1) region of a training workspace (MFMA-fragment order,
+ * csrc/lrf_common.h); buffer 2: X-block column of appearance channel col */
+int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

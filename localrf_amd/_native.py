@@ -13,9 +13,6 @@ LRF_FLAG_RELU_DENS = 2
 LRF_FLAG_MLP_VALU = 4
 LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
-LRF_FLAG_MLP_FUSED = 32
-LRF_FLAG_MLP_SPLIT = 64
-LRF_FLAG_MLP_W16 = 128
 
 _f = C.c_void_p  # device float*
 
@@ -62,21 +59,14 @@ class LrfFlowLoss(C.Structure):
 
 LRF_LOSS_MAX_PER_VIEW = 4096
 
-# every symbol include/lrf.h declares: (restype, argtypes)
+# every symbol include/lrf.h and include/lrf_debug.h declare: (restype, argtypes)
 SYMBOLS = {
     "lrf_abi_version": (C.c_int, []),
     "lrf_last_error": (C.c_char_p, []),
     "lrf_error_slot": (C.c_void_p, []),
     "lrf_debug_set_dump": (None, [C.c_void_p]),
-    "lrf_debug_set_mlp_policy": (None, [C.c_int]),
-    "lrf_debug_set_mlp_threads": (None, [C.c_int]),
-    "lrf_debug_set_app_oversubscribe": (None, [C.c_int]),
-    "lrf_debug_set_subbatches": (None, [C.c_int]),
-    "lrf_debug_set_skew": (None, [C.c_int]),
     "lrf_debug_set_lds_lines": (None, [C.c_int]),
     "lrf_debug_saved_row_offset": (C.c_int64, [C.c_int, C.c_uint64, C.c_int]),
-    "lrf_debug_poison_cu_state": (C.c_int, [C.c_uint32, C.c_int, C.c_void_p]),
-    "lrf_debug_set_shade_pipe": (None, [C.c_int]),
     "lrf_debug_set_bwd_overlap": (None, [C.c_int]),
     "lrf_debug_set_train_fwd_engine": (None, [C.c_int]),
     "lrf_workspace_layout_bwd": (None, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     {
       float v[8];
       bf16x8 bh, bl;
-      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);   // 32-bit gathers, taps once per axis (as k_shade2)
+      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);   // 32-bit gathers, taps once per axis
       float xc[2];
       gather_app6_plane32<0>(f, at, g, v);
       save_x_plane<0>(afr, v, xc);
@@ -1636,42 +1636,20 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   return b;
 }
 
-// The row-saving colour kernel: k_bwd_shade_fwd behind k_scan_tiles (default), or k_shade2<SAVE> as two launches
-// (lrf_debug_set_train_fwd_engine(0)).  Measured at configs[1] (scripts/gpu_diag.py bwd_overlap): row-saving forward
-// 0.69 ms with k_bwd_shade_fwd, 0.83 ms with k_shade2<SAVE> (its prefetched tile header + the row pointers push it to
-// 268 B of scratch per lane, in a kernel that is bound by its 1.5 KB of row stores per sample, not by the gathers the
-// prefetch hides): fwd+bwd 2.82 vs 2.93 ms.  The eval kernel's structure does not carry over.
-static int g_train_fwd_engine = 1;
+// The row-saving colour kernel of the training forward is k_bwd_shade_fwd behind k_scan_tiles.  (Round 2 also built it
+// in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
 static int g_dgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(4 | ...): data-gradient chain on the exact-fp32 MFMA path
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * n): n weight-gradient GEMMs on the caller's stream
 static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 = k_wgrad<8,9> over stored dz2 rows on fp32 MFMAs (measurement)
-static int shade_save_attrs() {
-  static bool done[64] = {};
-  int dev = 0;
-  LRF_HIP(hipGetDevice(&dev));
-  if (!done[dev & 63]) {
-    LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    done[dev & 63] = true;
-  }
-  return 0;
-}
 static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                               const BwdWorkspace& b, hipStream_t st) {
-  if (g_train_fwd_engine == 1) {
-    hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                       b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits);
-    return;
-  }
-  const size_t lds = (size_t)IMGB_ALL * sizeof(uint4) + (size_t)S * sizeof(float);
-  hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 0, true>), dim3(device_cus()), dim3(1024), lds, st,
-                     d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, 0, 0u, (const float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, b.crgb, b.act, b.relu_bits, (int*)nullptr);
+  hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
+                     b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits);
 }
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_train_fwd_engine = (e & 1) ? 1 : 0; lrf::g_wgrad_bf16 = (e & 2) ? 0 : 1; lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_wgrad_bf16 = (e & 2) ? 0 : 1; lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; }
 
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
@@ -1700,22 +1678,11 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   const DField d = make_dfield(f);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
-  if (int rc = shade_save_attrs()) return rc;
-  const size_t lds_fused = (size_t)IMGB_U4 * sizeof(uint4) + (size_t)S * sizeof(float) + (size_t)(R + 1) * sizeof(int);
-  if (g_train_fwd_engine == 0 && lds_fused + 256 <= 160 * 1024) {       // two launches, as the eval forward (lrf_shade2.inl)
-    DField dd = d;
-    dd.ctr = w.ctr;
-    launch_march(dd, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
-    hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 1, true>), dim3(device_cus()), dim3(1024), lds_fused, st,
-                       dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, 0, flags, w.acc, rgb, (float*)nullptr,
-                       b.crgb, b.act, b.relu_bits, w.toff);
-  } else {
-    launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-    launch_shade_save(d, rays, z, S, R, w, b, st);
-    hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
-                       R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
-  }
+  launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
+  launch_shade_save(d, rays, z, S, R, w, b, st);
+  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
+                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1757,7 +1724,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-    if (int rc = shade_save_attrs()) return rc;
     launch_shade_save(d, rays, z, S, R, w, b, st);
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):

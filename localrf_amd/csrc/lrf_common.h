@@ -50,8 +50,7 @@ constexpr int TAIL_W3H = 0;                        // floats [g4][33][4]: 32 fea
 constexpr int TAIL_W3H_GS = 132;                   // group, so the groups' float4 reads fall on different banks
 constexpr int TAIL_B1 = 528, TAIL_B2 = 656, TAIL_W3V = 784, TAIL_FLOATS = 800;
 constexpr int IMGB_U4 = IMGB_TAIL + TAIL_FLOATS / 4;   // 6088 uint4 = 97,408 B: what the fused kernels keep in LDS
-// k_mlp only (lrf_shade2.inl): mlp_view.0.weight[:, :128] as four more A fragments [ks4] (rows 0..2 = r,g,b,
-// rows 3..15 zero), same K order as layer 2 -- the 128 -> 3 head as a fourth MFMA layer
+// (round 2's k_mlp kept mlp_view.0.weight[:, :128] as four more A fragments behind the tail; the slot stays reserved)
 constexpr int IMGB_W3F = IMGB_TAIL + 256;              // fragment-aligned (multiples of 128 uint4), behind the tail
 constexpr int IMGB_ALL = IMGB_W3F + 4 * 128;           // 6656 uint4 = 106,496 B
 static_assert(IMGB_W3F % 128 == 0 && IMGB_W3F >= IMGB_U4 && IMGB_W1 % 128 == 0, "fragments are addressed in units of 128 uint4");
@@ -164,8 +163,8 @@ struct DField {
   float term_T;                // early termination: skip density gathers once transmittance < term_T (0 = off)
   const float* basis; const float* w1; const float* b1; const float* w2; const float* b2;
   const float* w3; const float* b3;
-  float* dump;                 // debug: per-sample stage values (lrf_debug_set_dump), else null
-  int* ctr;                    // fused launch sequence: workgroups-done counter of k_shade2 (zeroed by k_march), else null
+  float* dump;                 // test hook: s_memtime totals of k_shade3<TIMED> (lrf_debug_set_dump), else null
+  float* rdir;                 // k_march -> k_shade3: per ray (d / |d|, |d|), or null
 };
 
 // ------------------------------------------------------------------ geometry

@@ -1,23 +1,18 @@
-// lrf_render.hip -- gfx950 (MI355X / CDNA4) forward kernels of the localrf render path
-// and the C ABI declared in include/lrf.h.
+// lrf_render.hip -- gfx950 (MI355X / CDNA4) forward kernels of the localrf render path and the C ABI declared in
+// include/lrf.h.  One translation unit (this file + the .inl files it includes), built without the SLP vectoriser
+// (lrf_tu.h says why).
 //
-// Pipeline of lrf_render_fwd (one field, R rays x S samples), four launches, no atomics:
-//   k_march      one wavefront per ray: contracted sampling, density VM gather (channel-last
-//                planes, 2x float4 per tap), softplus, alpha, wave-level prefix product for
-//                transmittance, acc/depth, floater filter, and in-wave compaction of the
-//                samples that pass weight > thres into the ray's list (u16 index + weight).
-//   k_scan_tiles prefix sum of the per-ray tile counts (tile = 16 compact samples of one ray).
-//   k_shade_bf16 persistent, one 1024-thread workgroup per CU, the colour network resident in
-//                LDS in MFMA-fragment order.  Tiles are split statically and contiguously over
-//                the waves (XCD-aware block order).  Per tile the lane (s = lane&15, g = lane>>4)
-//                gathers channel group g of every appearance plane/line for sample s -- exactly the
-//                B-operand layout of the MFMA -- and runs basis(72->27) -> 128 -> 128 as a
-//                register-resident MFMA chain: the D layout of one layer IS the B layout of the
-//                next after a K permutation folded into the packed weights.  Default engine:
-//                split-bf16 (hi+lo, 3-term) on v_mfma_f32_16x16x32_bf16, hand-issued in place;
-//                k_shade = exact-fp32 engine on v_mfma_f32_16x16x4_f32; k_shade_valu = debug.
-//                The 131->3 head + sigmoid + weighting run on the VALU.
-//   k_finalize   per-ray ordered sum of tile partials + white background (deterministic).
+// Pipeline of lrf_render_fwd (one field, R rays x S samples), two launches, no atomics on floats:
+//   k_march      one wavefront per ray: contracted sampling, density VM gather (channel-last planes, 2 x float4 per tap,
+//                lines staged in LDS), softplus, alpha, wave-level prefix product for transmittance, acc / depth,
+//                floater filter, and in-wave compaction of the samples that pass weight > thres into the ray's list
+//                (u16 index + weight); also leaves d / |d| per ray for the colour kernel.
+//   k_shade3     (lrf_shade3.inl) the colour stage, 32 samples per wave on v_mfma_f32_32x32x16_bf16: tile scan,
+//                appearance gather, basis -> 128 -> 128 as a register-resident split-bf16 MFMA chain, VALU head,
+//                per-ray ordered sum of the tile partials + white background.
+// Other colour engines behind the same ABI: k_shade (exact fp32 on v_mfma_f32_16x16x4_f32, LRF_FLAG_MLP_F32) and
+// k_shade_valu (plain loops, LRF_FLAG_MLP_VALU), both 16 samples per tile behind k_scan_tiles / k_finalize.
+// The split-bf16 helpers of the 16-sample chain (gemm_step ...) serve the training kernels of lrf_backward.inl.
 //
 // Reference lines (relative to /root/reference/localTensoRF) are cited at each step.
 #include <hip/hip_runtime.h>
@@ -238,7 +233,6 @@ __global__ __launch_bounds__(1024) void k_march(
     float* __restrict__ feat_out /* [R,S] density feature, -inf where not evaluated; or null */) {
   extern __shared__ float s_alpha_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (f.ctr && blockIdx.x == 0 && threadIdx.x == 0) *f.ctr = 0;      // workgroups-done counter of the k_shade2 that follows
   const int nb = gridDim.x;                              // XCD-aware block order, see tile_walk_begin
   const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int nw = blockDim.x >> 6;                          // rays per workgroup: 4, 8 or 16 (launch_march)
@@ -358,6 +352,7 @@ __global__ __launch_bounds__(1024) void k_march(
     depth[ray] = dsum / dn;                                                         // :615
     acc_ws[ray] = acc;
     ncomp[ray] = nsh;
+    if (f.rdir) *reinterpret_cast<float4*>(f.rdir + (size_t)ray * 4) = make_float4(dh[0], dh[1], dh[2], dn);
   }
 }
 
@@ -697,131 +692,8 @@ __device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int strid
   }
 }
 
-// (512-thread workgroups with a 256-VGPR budget and no spills measured slower: 0.213 vs 0.177 ms --
-//  the tile loop is latency bound and wants the 16 waves per CU)
-__global__ __launch_bounds__(1024) void k_shade_bf16(
-    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int* __restrict__ toff, int R,
-    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
-    float* __restrict__ part, int pmax) {
-  __shared__ uint4 img[IMGB_U4];
-  for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
-  __syncthreads();
-  const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
-  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
-  TileWalk tw = tile_walk_begin(toff, R);
-  for (; tw.t < tw.t_end; ++tw.t) {
-    asm volatile("" ::: "memory");     // keep LDS weight reads inside the loop (no LICM -> no spills)
-    tile_walk_seek(tw, toff);
-    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
-    const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
-    const int cnt = min(ITEM, ncomp[ray] - j0);
-
-    const float* rp = rays + (size_t)ray * 6;
-    const float o[3] = {rp[0], rp[1], rp[2]};
-    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
-    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
-    float vb[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
-      vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
-    }
-    const bool valid = s < cnt;
-    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
-    // (handing k_shade precomputed coordinates as a float4 per compact sample instead of the
-    //  u16 index + weight was measured slower: 0.235 vs 0.173 ms)
-    const int k = cidx[ci];
-    const float w = valid ? cw[ci] : 0.0f;
-    float x[3], u[3];
-    sample_point(f, o, dh, z[k], x, u);
-    // basis 72 -> 27 (tensoRF.py:196): one k-step per plane -- K-slots j<6 of lane group g are
-    // the plane's channels 6g..6g+5, slots 6,7 are zero -- so each plane's gather feeds its
-    // MFMAs directly and only six products are live at a time.  fe is zeroed (VALU writes)
-    // before split8's 16-state pad, so the asm MFMAs read a settled SrcC.
-    f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#ifndef LRF_MFMA_BUILTIN
-    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
-#endif
-    float xdbg[3] = {0.0f, 0.0f, 0.0f};
-    {
-      float v[8];
-      bf16x8 bh, bl;
-      gather_app6_plane<0>(f, u, g, v);
-      xdbg[0] = v[0];
-      split8(v, bh, bl);
-      gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
-      gather_app6_plane<1>(f, u, g, v);
-      xdbg[1] = v[3];
-      split8(v, bh, bl);
-      gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
-      gather_app6_plane<2>(f, u, g, v);
-      xdbg[2] = v[5];
-      split8(v, bh, bl);
-      gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
-      settle<2>(fe);
-    }
-    // layer 1 (tensorBase.py:129-130): one k-step, the two feat tiles are its 8 K-slots
-    f32x4 h1[8];
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * t1 + 4 * g]);
-    {
-      const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
-      bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
-      settle<8>(h1);
-    }
-    // layer 2: 4 k-steps, k-step ks consumes relu(h1) tiles 2ks and 2ks+1
-    f32x4 h2[8];
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(h1[2 * ks + (j >> 2)][j & 3], 0.0f);
-      bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
-    }
-    settle<8>(h2);
-    // head on the VALU in fp32 (tensorBase.py:131-133)
-    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float hv = fmaxf(h2[t1][r], 0.0f);
-        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
-        o0 += hv * wv.x; o1 += hv * wv.y; o2 += hv * wv.z;
-      }
-    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
-    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
-    if (f.dump && valid) {
-      float* dp = f.dump + (((size_t)ray * S + j0 + s) * 4 + g) * 16;
-      dp[0] = xdbg[0]; dp[1] = xdbg[1]; dp[2] = xdbg[2];
-      dp[3] = fe[0][0]; dp[4] = fe[0][3]; dp[5] = fe[1][2];
-      dp[6] = h1[0][0]; dp[7] = h1[3][1]; dp[8] = h1[7][3];
-      dp[9] = h2[0][0]; dp[10] = h2[4][2]; dp[11] = h2[7][3];
-      dp[12] = o0; dp[13] = o1; dp[14] = o2; dp[15] = w;
-    }
-    float cr = w / (1.0f + expf(-(o0 + vb[0])));
-    float cg = w / (1.0f + expf(-(o1 + vb[1])));
-    float cb = w / (1.0f + expf(-(o2 + vb[2])));
-#pragma unroll
-    for (int dd = 1; dd < 16; dd <<= 1) {
-      cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
-    }
-    if (lane == 0) {
-      float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
-      pp[0] = cr; pp[1] = cg; pp[2] = cb;
-    }
-  }
-}
-
 }  // namespace lrf
-#include "lrf_shade2.inl"
+#include "lrf_tiles.inl"
 #include "lrf_shade3.inl"
 namespace lrf {
 
@@ -1009,16 +881,14 @@ static DField make_dfield(const LrfField* f) {
   d.density_shift = f->density_shift; d.distance_scale = f->distance_scale; d.weight_thres = f->weight_thres;
   d.term_T = f->term_T > 0.0f ? f->term_T : 0.0f;
   d.dump = nullptr;
-  d.ctr = nullptr;
+  d.rdir = nullptr;
   d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
   return d;
 }
 
 struct Workspace {
   int* toff; int* ncomp; float* acc; uint16_t* cidx; float* cw; float* part;
-  uint4* ffrag;            // k_app -> k_mlp: layer-1 B fragments, 2 KB per 16-sample tile
-  int2* tinfo;             // k_app -> k_mlp: (ray, j0 * 32 + count) per tile
-  int* ctr;                // fused sequence: workgroups-done counter of k_shade2
+  float* rdir;             // k_march -> k_shade3: unit direction and length per ray
   int pmax; size_t bytes;
 };
 static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -1026,31 +896,21 @@ static Workspace carve(void* ws, int R, int S) {
   Workspace w;
   char* p = reinterpret_cast<char*>(ws);
   size_t off = 0;
-  w.pmax = (S + ITEM - 1) / ITEM;
+  w.pmax = (S + ITEM - 1) / ITEM;                     // partial slots per ray: enough for 16- and 32-sample tiles
   w.toff  = reinterpret_cast<int*>(p + off);       off += up256((size_t)(R + 1) * 4);
   w.ncomp = reinterpret_cast<int*>(p + off);       off += up256((size_t)R * 4);
   w.acc   = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 4);
   w.cidx  = reinterpret_cast<uint16_t*>(p + off);  off += up256((size_t)R * S * 2);
   w.cw    = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
   w.part  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
-  w.ffrag = reinterpret_cast<uint4*>(p + off);     off += up256((size_t)R * w.pmax * 2048);
-  w.tinfo = reinterpret_cast<int2*>(p + off);      off += up256((size_t)R * w.pmax * 8);
-  w.ctr   = reinterpret_cast<int*>(p + off);       off += 256;
+  w.rdir  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 16);
   w.bytes = off;
   return w;
 }
 
-static float* g_dump = nullptr;
-static int g_mlp_policy = 4;
-constexpr int MAX_SUB = 8;         // sub-batch pipeline of lrf_render_fwd (see render_fwd_impl)
-static int g_subbatches = 1;       // measured on MI355X: a cross-stream event wait costs ~50 us, more than the overlap returns
-static int sub_rays(int R, int Q) { return (((R + Q - 1) / Q) + 3) & ~3; }       // k_march blocks hold 4 rays
+// Test hooks (include/lrf_debug.h): process-wide, not part of the re-entrant ABI.
+static float* g_dump = nullptr;    // lrf_debug_set_dump: device buffer for the s_memtime totals of k_shade3<TIMED>
 static int g_no_lds_lines = 0;     // lrf_debug_set_lds_lines(0): k_march reads its lines from global memory
-static bool g_last_fused = false;   // the last render_fwd_one ran the two-launch sequence (read by lrf_render_fwd_profile)
-static int g_shade_pipe = 0;       // lrf_debug_set_shade_pipe: k_shade2 with the next tile's plane-0 gather issued under the head phase
-static int g_skew = 0;             // lrf_debug_set_skew: phase skew of k_shade2's waves, units of 6400 cycles
-static int g_app_over = 4;         // lrf_debug_set_app_oversubscribe: k_app workgroups per resident slot
-static int g_mlp_threads = 1024;   // lrf_debug_set_mlp_threads: workgroup size of k_mlp (512 leaves half the register file to other kernels)       // lrf_debug_set_mlp_policy: MFMA issue policy of k_mlp (lrf_shade2.inl)
 
 static int device_cus() {                 // of the current device (one process may drive several)
   static int cache[64] = {};
@@ -1066,7 +926,7 @@ static int device_cus() {                 // of the current device (one process 
 }
 
 static int g_bwd_overlap = 1;      // lrf_debug_set_bwd_overlap: weight-gradient GEMMs on a side stream, beside the scatter kernels
-struct SideStream { hipStream_t s; hipEvent_t fork, join, app[MAX_SUB]; bool ok; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2]; bool ok; };
 static SideStream* side_stream() {
   static SideStream tab[64] = {};
   int dev = 0;
@@ -1074,10 +934,10 @@ static SideStream* side_stream() {
   SideStream& x = tab[dev & 63];
   if (!x.ok) {
     if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    bool good = hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < MAX_SUB && good; ++i) good = hipEventCreateWithFlags(&x.app[i], hipEventDisableTiming) == hipSuccess;
-    if (!good) return nullptr;
+    if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x.app[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&x.app[1], hipEventDisableTiming) != hipSuccess) return nullptr;
     x.ok = true;
   }
   return &x;
@@ -1123,47 +983,12 @@ static void launch_march(const DField& d, const float* rays, const float* z, int
 
 using namespace lrf;
 
-// Debug: leave every CU's LDS (and, with regs, a wave's worth of vector registers) full of `pattern`, the state a
-// foreign kernel may leave behind.  A kernel that reads LDS or a register it never wrote shows it at once when the
-// pattern is a NaN (scripts/stale_probe*.py, DESIGN.md finding 17).
-namespace lrf {
-__global__ __launch_bounds__(1024) void k_poison_lds(uint32_t pattern, int n_u32, uint32_t* sink) {
-  extern __shared__ uint32_t s_poison[];
-  for (int i = threadIdx.x; i < n_u32; i += blockDim.x) s_poison[i] = pattern;
-  __syncthreads();
-  if (s_poison[(threadIdx.x * 7u) % (unsigned)n_u32] == 0x12345u) sink[0] = 1;        // (keeps the stores)
-}
-__global__ __launch_bounds__(256) void k_poison_regs(uint32_t pattern, uint32_t* sink) {
-  // 256 VGPRs + 256 AGPRs per lane, all set to the pattern
-  asm volatile(
-      ".altmacro\n"
-      ".macro poison_v n\n v_mov_b32 v\\n, %0\n.endm\n"
-      ".macro poison_a n\n v_accvgpr_write_b32 a\\n, %0\n.endm\n"
-      ".set i, 8\n.rept 248\n poison_v %%i\n.set i, i + 1\n.endr\n"
-      ".set i, 0\n.rept 256\n poison_a %%i\n.set i, i + 1\n.endr\n"
-      :: "v"(pattern) : "memory", "v255", "a255");            // (the clobbers size the kernel's register allocation)
-  if (pattern == 0x12345u && threadIdx.x == 1000) sink[0] = 2;
-}
-}  // namespace lrf
-
 extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): n GEMMs on the caller's stream
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
-int lrf_debug_poison_cu_state(uint32_t pattern, int regs, void* stream) {
-  using namespace lrf;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  static uint32_t* sink = nullptr;
-  if (!sink && hipMalloc(&sink, 64) != hipSuccess) return set_err("lrf_debug_poison_cu_state: hipMalloc failed");
-  const int bytes = 160 * 1024 - 64;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
-    return set_err("lrf_debug_poison_cu_state: hipFuncSetAttribute failed");
-  hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), bytes, st, pattern, bytes / 4, sink);
-  if (regs) hipLaunchKernelGGL(k_poison_regs, dim3(8192), dim3(256), 0, st, pattern, sink);
-  return hipGetLastError() == hipSuccess ? 0 : set_err("lrf_debug_poison_cu_state: launch failed");
-}
 // Where column `col` of saved row `row` lives, in floats from the start of the ACT (buffer 0) / GRD (buffer 1) region
 // of a training workspace (lrf_workspace_layout_bwd gives the regions): the fragment order of lrf_common.h, host side.
 // buffer 2: column of the ACT tile's X block that holds appearance channel `col` (x_slot_col).  -1 for bad arguments.
@@ -1178,12 +1003,6 @@ int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col) {
   if (buffer == 2) return (col < 0 || col >= 72) ? -1 : x_slot_col(col);
   return -1;
 }
-void lrf_debug_set_shade_pipe(int mode) { g_shade_pipe = (mode >= 0 && mode <= 38) ? mode : 0; }
-void lrf_debug_set_skew(int n) { g_skew = (n >= 0 && n <= 16) ? n : 0; }
-void lrf_debug_set_subbatches(int q) { g_subbatches = (q >= 1 && q <= MAX_SUB) ? q : 1; }
-void lrf_debug_set_app_oversubscribe(int n) { g_app_over = (n >= 1 && n <= 16) ? n : 4; }
-void lrf_debug_set_mlp_threads(int threads) { g_mlp_threads = (threads == 512 || threads == 256) ? threads : 1024; }
-void lrf_debug_set_mlp_policy(int policy) { g_mlp_policy = ((policy >= 0 && policy <= 7) || policy == 9 || policy == 10 || policy == 14) ? policy : 4; }
 const char* lrf_last_error(void) { return lrf_error_slot(); }
 char* lrf_error_slot(void) { return g_err; }
 
@@ -1216,269 +1035,64 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
   return 0;
 }
 
-size_t lrf_workspace_bytes(int32_t R, int32_t S) {
-  size_t best = carve(nullptr, R, S).bytes;               // sub-batch pipeline: Q separately carved ranges
-  for (int Q = 2; Q <= MAX_SUB; ++Q) best = max(best, (size_t)Q * carve(nullptr, sub_rays(R, Q), S).bytes);
-  return best;
-}
+size_t lrf_workspace_bytes(int32_t R, int32_t S) { return carve(nullptr, R, S).bytes; }
 
-// LRF_FLAG_MLP_SPLIT: k_app (gather + basis) then k_mlp (27 -> 128 -> 128 -> 3), lrf_shade2.inl
-static int launch_shade_split(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
-                              hipStream_t st, hipEvent_t mid) {
-  const int cus = device_cus();
-  const size_t lds_app = (size_t)IMGB_W1 * sizeof(uint4) + (size_t)S * sizeof(float);
-  static int app_blocks_per_cu[64] = {};
-  int dev = 0;
-  LRF_HIP(hipGetDevice(&dev));
-  int& occ = app_blocks_per_cu[dev & 63];
-  if (!occ) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_app, 256, 28 * 1024) != hipSuccess || n <= 0) n = 4;
-    occ = n > 8 ? 8 : n;
-  }
-  // more workgroups than resident slots: the hardware's workgroup scheduler balances the load (tile ranges of
-  // a static split finish far apart); a k_app workgroup only stages 14 KB, so a fresh one costs little
-  hipLaunchKernelGGL(k_app, dim3(cus * occ * g_app_over), dim3(256), lds_app, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.ffrag, w.tinfo);
-  if (mid) LRF_HIP(hipEventRecord(mid, st));
-  if (g_dump && g_mlp_policy >= 10) {        // debug: phase timing of k_mlp (policy 10 + p), counters -> the dump buffer
-    DField dd = d; dd.dump = g_dump;
-    if (g_mlp_policy == 14) hipLaunchKernelGGL((k_mlp<4, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax);
-    else hipLaunchKernelGGL((k_mlp<0, true>), dim3(cus), dim3(1024), 0, st, dd, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax);
-    return 0;
-  }
-  switch (g_mlp_policy) {
-    case 1: hipLaunchKernelGGL(k_mlp<1>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    case 2: hipLaunchKernelGGL(k_mlp<2>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    case 3: hipLaunchKernelGGL(k_mlp<3>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    case 6: hipLaunchKernelGGL((k_mlp<4, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    case 7: hipLaunchKernelGGL((k_mlp<0, false, false>), dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    case 5: hipLaunchKernelGGL(k_mlp<5>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    case 0: hipLaunchKernelGGL(k_mlp<0>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-    default: hipLaunchKernelGGL(k_mlp<4>, dim3(cus), dim3(g_mlp_threads), 0, st, d, rays, S, w.toff, R, w.ncomp, w.cw, w.ffrag, w.tinfo, w.part, w.pmax); break;
-  }
-  return 0;
-}
-
-// One batch (or sub-batch) of rays through the four stages on `st`.  app_done (optional) is recorded right
-// after k_app: the point from which only matrix-pipe / VALU work (k_mlp) is left.
-static int render_fwd_one(const DField& d, const float* rays, const float* z, int32_t R, int32_t S,
-                          uint32_t flags, float floater_thresh, float* rgb, float* depth,
-                          float* weight_out, float* acc_out, void* workspace, hipStream_t st,
-                          hipEvent_t* ev, hipEvent_t app_done) {
+// One batch of rays through k_march and the colour stage on `st`; ev (optional, lrf_render_fwd_profile): 4 events =
+// start, after k_march, after the colour kernel(s), end.
+static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                           uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                           float* weight_out, float* acc_out, void* workspace, hipStream_t st, hipEvent_t* ev) {
+  if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
+  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
+  DField d = make_dfield(f);
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
-  // Default engine, batches whose tile offsets fit in LDS beside the image: two launches, k_march -> k_shade2<FUSE>
-  // (scan and finalize folded into the colour kernel, lrf_shade2.inl).  lrf_debug_set_shade_pipe(9) = four launches.
-  // Default engine: k_march -> k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16, lrf_shade3.inl); the tile
-  // offsets are scanned inside the colour kernel when R + 1 ints fit in LDS beside the image, by k_scan_tiles_n otherwise.
-  if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED | LRF_FLAG_MLP_SPLIT | LRF_FLAG_MLP_W16))) {
+  if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))) {
+    // Default engine: k_march -> k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16, lrf_shade3.inl); the tile
+    // offsets are scanned inside the colour kernel when they fit in LDS beside the image, by k_scan_tiles_n otherwise.
+    d.rdir = w.rdir;
     launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
     if (ev) LRF_HIP(hipEventRecord(ev[1], st));
-    g_last_fused = true;
     const size_t lds_base = (size_t)W32_ALL_U4 * sizeof(uint4) + (size_t)S * sizeof(float);
-    const size_t lds_toff = (size_t)(R + 1) * sizeof(int);
+    const size_t lds_toff = (size_t)(R + 1) * sizeof(int) + (size_t)R * sizeof(unsigned short) + 16;
     const bool in_lds = lds_base + lds_toff + 64 <= 160 * 1024 - 256;
     static bool attr3_done[64] = {};
     int dev = 0;
     LRF_HIP(hipGetDevice(&dev));
     if (!attr3_done[dev & 63]) {
-#define LRF_ATTR3(NWV, L, TM) LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<NWV, L, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
-      LRF_ATTR3(12, true, false); LRF_ATTR3(12, false, false); LRF_ATTR3(12, true, true);
-      LRF_ATTR3(8, true, false); LRF_ATTR3(8, true, true);
-#define LRF_ATTR3V(NWV, V) LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<NWV, true, false, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<12, true, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      LRF_ATTR3V(8, 1); LRF_ATTR3V(8, 2); LRF_ATTR3V(8, 3); LRF_ATTR3V(8, 4); LRF_ATTR3V(8, 7); LRF_ATTR3V(12, 1); LRF_ATTR3V(12, 3); LRF_ATTR3V(8, 8); LRF_ATTR3V(12, 8); LRF_ATTR3V(8, 9); LRF_ATTR3V(8, 128); LRF_ATTR3V(12, 128); LRF_ATTR3V(8, 16); LRF_ATTR3V(8, 18); LRF_ATTR3V(8, 32); LRF_ATTR3V(8, 64);
-#undef LRF_ATTR3V
-#undef LRF_ATTR3
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
       attr3_done[dev & 63] = true;
     }
-    DField dd = d;
-    const bool timed = in_lds && g_dump && g_mlp_policy >= 10;   // debug: phase timing, counters -> the dump buffer
-    if (timed) dd.dump = g_dump;
-#define LRF_LAUNCH3(NWV, L, TM, LDSB) hipLaunchKernelGGL((k_shade3<NWV, L, TM>), dim3(device_cus()), dim3(NWV * 64), LDSB, st, \
-        dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out)
-#define LRF_LAUNCH3V(NWV, V) hipLaunchKernelGGL((k_shade3<NWV, true, false, V>), dim3(device_cus()), dim3(NWV * 64), lds_base + lds_toff, st, \
-        dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out)
-    if (in_lds && g_dump && g_mlp_policy == 9) {                   // debug: per-tile stage hashes -> the dump buffer (uint32 [tiles][8])
-      dd.dump = g_dump;
-      if (g_shade_pipe == 12) hipLaunchKernelGGL((k_shade3<8, true, false, 0, true>), dim3(device_cus()), dim3(8 * 64), lds_base + lds_toff, st,
-                                                 dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
-      else hipLaunchKernelGGL((k_shade3<12, true, false, 0, true>), dim3(device_cus()), dim3(12 * 64), lds_base + lds_toff, st,
-                              dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
-    } else
-    if (in_lds && g_shade_pipe >= 21 && g_shade_pipe <= 38) {
-      if (g_shade_pipe >= 37) dd.dump = g_dump;       // experiments: VAR bits, 8 waves (21..27) / 12 waves (28 = VAR 1, 29 = VAR 3)
-      switch (g_shade_pipe) {
-        case 21: LRF_LAUNCH3V(8, 1); break;
-        case 22: LRF_LAUNCH3V(8, 2); break;
-        case 23: LRF_LAUNCH3V(8, 3); break;
-        case 24: LRF_LAUNCH3V(8, 4); break;
-        case 27: LRF_LAUNCH3V(8, 7); break;
-        case 28: LRF_LAUNCH3V(12, 1); break;
-        case 30: LRF_LAUNCH3V(8, 8); break;
-        case 31: LRF_LAUNCH3V(12, 8); break;
-        case 32: LRF_LAUNCH3V(8, 9); break;
-        case 33: LRF_LAUNCH3V(8, 16); break;
-        case 34: LRF_LAUNCH3V(8, 18); break;
-        case 35: LRF_LAUNCH3V(8, 32); break;
-        case 36: LRF_LAUNCH3V(8, 64); break;
-        case 37: LRF_LAUNCH3V(8, 128); break;
-        case 38: LRF_LAUNCH3V(12, 128); break;
-        default: LRF_LAUNCH3V(12, 3); break;
-      }
-    } else
-    if (in_lds && g_shade_pipe == 12) {          // experiment: 8 waves per workgroup (two per SIMD) instead of 12
-      if (timed) LRF_LAUNCH3(8, true, true, lds_base + lds_toff); else LRF_LAUNCH3(8, true, false, lds_base + lds_toff);
+    if (in_lds && g_dump) {                     // test hook: phase timing, s_memtime totals -> the dump buffer
+      d.dump = g_dump;
+      hipLaunchKernelGGL((k_shade3<8, true, true>), dim3(device_cus()), dim3(512), lds_base + lds_toff, st,
+                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
     } else if (in_lds) {
-      if (timed) LRF_LAUNCH3(12, true, true, lds_base + lds_toff); else LRF_LAUNCH3(12, true, false, lds_base + lds_toff);
+      hipLaunchKernelGGL((k_shade3<8, true, false>), dim3(device_cus()), dim3(512), lds_base + lds_toff, st,
+                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
     } else {
       hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-      LRF_LAUNCH3(12, false, false, lds_base);
+      hipLaunchKernelGGL((k_shade3<8, false, false>), dim3(device_cus()), dim3(512), lds_base, st,
+                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
     }
-#undef LRF_LAUNCH3
-#undef LRF_LAUNCH3V
-    if (ev) LRF_HIP(hipEventRecord(ev[2], st));
-    return 0;
+    if (ev) { LRF_HIP(hipEventRecord(ev[2], st)); LRF_HIP(hipEventRecord(ev[3], st)); }
+    LRF_HIP(hipGetLastError());
+    return 2;            // (internal) done, two launches: no finalize interval
   }
-  const size_t lds_fused = (size_t)IMGB_U4 * sizeof(uint4) + (size_t)S * sizeof(float) + (size_t)(R + 1) * sizeof(int);
-  const bool fuse = !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED | LRF_FLAG_MLP_SPLIT)) &&
-                    (g_shade_pipe == 0 || g_shade_pipe >= 10) && !(g_dump && g_mlp_policy >= 10) && lds_fused + 256 <= 160 * 1024;
-  if (fuse) {
-    DField dd = d;
-    dd.ctr = w.ctr;
-    launch_march(dd, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
-    if (ev) LRF_HIP(hipEventRecord(ev[1], st));
-    g_last_fused = true;
-    static bool attr_done[64] = {};
-    int dev = 0;
-    LRF_HIP(hipGetDevice(&dev));
-    if (!attr_done[dev & 63]) {                                // 80 B of static LDS (scan scratch) come on top
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      attr_done[dev & 63] = true;
-    }
-    if (g_shade_pipe == 10)          // experiment: release / acquire fences instead of write-through partials
-      hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 2>), dim3(device_cus()), dim3(1024), lds_fused, st,
-                         dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-    else if (g_shade_pipe == 11)     // experiment: __threadfence() on both sides
-      hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 3>), dim3(device_cus()), dim3(1024), lds_fused, st,
-                         dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-    else
-      hipLaunchKernelGGL((k_shade2<false, false, 0, 3, 1>), dim3(device_cus()), dim3(1024), lds_fused, st,
-                         dd, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-    if (ev) LRF_HIP(hipEventRecord(ev[2], st));
-    return 0;
-  }
-  g_last_fused = false;
+  // exact-fp32 / plain-loop engines: 16-sample tiles, k_march -> [k_scan_tiles ->] colour kernel -> k_finalize
   launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (flags & LRF_FLAG_MLP_VALU) {
-    hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st,
-                       d, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+    hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st, d, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   } else {
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-    if (ev) LRF_HIP(hipEventRecord(ev[5], st));
-    if (flags & LRF_FLAG_MLP_F32)
-      hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st,
-                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
-    else if (flags & LRF_FLAG_MLP_FUSED)
-      hipLaunchKernelGGL(k_shade_bf16, dim3(device_cus()), dim3(1024), 0, st,
-                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
-    else if (!(flags & LRF_FLAG_MLP_SPLIT)) {                 // default engine: k_shade2
-      const size_t lds2 = (size_t)IMGB_ALL * sizeof(uint4) + (size_t)S * sizeof(float);
-      static bool attr_done[64] = {};
-      int dev = 0;
-      LRF_HIP(hipGetDevice(&dev));
-      if (!attr_done[dev & 63]) {
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<true, false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade2<false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done[dev & 63] = true;
-      }
-      if (g_dump && g_mlp_policy >= 10)
-        hipLaunchKernelGGL((k_shade2<true, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      else if (g_shade_pipe >= 4 && g_shade_pipe <= 6) {
-        if (g_shade_pipe == 4) hipLaunchKernelGGL((k_shade2<false, false, 0, 1>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-        if (g_shade_pipe == 5) hipLaunchKernelGGL((k_shade2<false, false, 0, 2>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-        if (g_shade_pipe == 6) hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      } else if (g_shade_pipe == 2)
-        hipLaunchKernelGGL((k_shade2<false, false, 1>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      else if (g_shade_pipe == 3)
-        hipLaunchKernelGGL((k_shade2<false, false, 3>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      else if (g_shade_pipe == 1)
-        hipLaunchKernelGGL((k_shade2<false, true>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      else if (g_shade_pipe == 8)       // layers 1-2 on the compiler-scheduled builtin (experiment)
-        hipLaunchKernelGGL((k_shade2<false, false, 0, 7>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      else if (g_shade_pipe == 7)       // MFMA head, header loads in flight under the chain (experiment; rare run-to-run differences seen)
-        hipLaunchKernelGGL(k_shade2<false>, dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-      else                              // shipped: VALU head, no global load in flight under the MFMA chain
-        hipLaunchKernelGGL((k_shade2<false, false, 0, 3>), dim3(device_cus()), dim3(1024), lds2, st,
-                           d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, g_skew, flags, w.acc, rgb, acc_out);
-    } else {
-      if (int rc = launch_shade_split(d, rays, z, S, R, w, st, ev ? ev[4] : app_done)) return rc;
-    }
+    hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   }
   if (ev) LRF_HIP(hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
-                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, acc_out);
+  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, acc_out);
   if (ev) LRF_HIP(hipEventRecord(ev[3], st));
-  return 0;
-}
-
-// Sub-batch pipeline of the default engine.  k_march and k_app are bound by the texture path (TA 57-65 %
-// busy, matrix pipe idle), k_mlp by the matrix pipe / VALU (no gathers): a batch is cut into g_subbatches ray
-// ranges that alternate between the caller's stream and a side stream, and sub-batch q starts marching when
-// sub-batch q-1 has finished its k_app -- so the gathers of one range run under the MFMA chain of the
-// previous one.  Results are those of the single-range launch (rays are independent).
-static int render_fwd_impl(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
-                           uint32_t flags, float floater_thresh, float* rgb, float* depth,
-                           float* weight_out, float* acc_out, void* workspace, hipStream_t st,
-                           hipEvent_t* ev /* 6 events or null: start, after march, after shade, end, between k_app and k_mlp, after k_scan_tiles */) {
-  if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
-  if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
-  DField d = make_dfield(f);
-  d.dump = g_dump;
-  const bool split_engine = (flags & LRF_FLAG_MLP_SPLIT) && !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED));
-  int Q = (split_engine && !ev && !g_dump) ? g_subbatches : 1;
-  while (Q > 1 && R / Q < 512) --Q;                       // not worth splitting small batches
-  SideStream* ss = Q > 1 ? side_stream() : nullptr;
-  if (!ss) Q = 1;
-  if (Q == 1) {
-    if (int rc = render_fwd_one(d, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out, workspace, st, ev, nullptr))
-      return rc;
-    LRF_HIP(hipGetLastError());
-    return 0;
-  }
-  const int Rq = sub_rays(R, Q);
-  const size_t wsq = carve(nullptr, Rq, S).bytes;
-  LRF_HIP(hipEventRecord(ss->fork, st));                  // the side stream starts behind the caller's earlier work
-  LRF_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-  for (int q = 0; q < Q; ++q) {
-    const int r0 = q * Rq, n = min(Rq, R - r0);
-    if (n <= 0) break;
-    hipStream_t sq = (q & 1) ? ss->s : st;
-    if (q) LRF_HIP(hipStreamWaitEvent(sq, ss->app[q - 1], 0));
-    if (int rc = render_fwd_one(d, rays + (size_t)r0 * 6, z, n, S, flags, floater_thresh, rgb + (size_t)r0 * 3, depth + r0,
-                                weight_out ? weight_out + (size_t)r0 * S : nullptr, acc_out ? acc_out + r0 : nullptr,
-                                reinterpret_cast<char*>(workspace) + (size_t)q * wsq, sq, nullptr, ss->app[q]))
-      return rc;
-  }
-  LRF_HIP(hipEventRecord(ss->join, ss->s));               // the caller's stream continues behind both
-  LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1486,8 +1100,9 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
 int lrf_render_fwd(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                    uint32_t flags, float floater_thresh, float* rgb, float* depth,
                    float* weight_out, float* acc_out, void* workspace, void* stream) {
-  return render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out,
-                         workspace, reinterpret_cast<hipStream_t>(stream), nullptr);
+  const int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out,
+                                 workspace, reinterpret_cast<hipStream_t>(stream), nullptr);
+  return rc == 2 ? 0 : rc;
 }
 
 int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
@@ -1495,28 +1110,20 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            void* workspace, void* stream, float* ms_out, int32_t* n_shaded_out) {
   if (!ms_out) return set_err("lrf_render_fwd_profile: null ms_out");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipEvent_t ev[6];
-  for (int i = 0; i < 6; ++i) LRF_HIP(hipEventCreate(&ev[i]));
-  LRF_HIP(hipEventRecord(ev[4], st));      // re-recorded between k_app and k_mlp by the default engine
-  LRF_HIP(hipEventRecord(ev[5], st));      // re-recorded after k_scan_tiles by the MFMA engines
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; ++i) LRF_HIP(hipEventCreate(&ev[i]));
   int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, nullptr, nullptr, workspace, st, ev);
+  const bool two_launches = rc == 2;
+  if (two_launches) rc = 0;
   if (rc == 0) {
-    hipError_t e = hipStreamSynchronize(st);             // (the two-launch sequence records ev[0..2] only)
+    hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = set_err("hipStreamSynchronize", e);
   }
   if (rc == 0) {
-    ms_out[2] = ms_out[4] = ms_out[5] = 0.0f;          // shade = k_scan_tiles [4] + k_app [5] + k_mlp (default engine)
-    if (g_last_fused) {                    // two launches: k_march, k_shade2 (scan and finalize inside)
-      (void)hipEventElapsedTime(&ms_out[0], ev[0], ev[1]);
-      (void)hipEventElapsedTime(&ms_out[1], ev[1], ev[2]);
-      (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[2]);
-    } else {
-      for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
-      (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
-    }
-    if (!g_last_fused && !(flags & LRF_FLAG_MLP_VALU)) (void)hipEventElapsedTime(&ms_out[4], ev[1], ev[5]);
-    if ((flags & LRF_FLAG_MLP_SPLIT) && !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_MLP_FUSED)))
-      (void)hipEventElapsedTime(&ms_out[5], ev[5], ev[4]);
+    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);      // march, colour stage, finalize (0 for the default engine)
+    (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[3]);
+    if (two_launches) { ms_out[2] = 0.0f; (void)hipEventElapsedTime(&ms_out[3], ev[0], ev[2]); }
+    ms_out[4] = ms_out[5] = 0.0f;
     if (n_shaded_out) {
       // shaded-sample count of this batch = sum of ncomp (host copy; measurement only)
       const Workspace w = carve(workspace, R, S);
@@ -1528,7 +1135,7 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
       free(h);
     }
   }
-  for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
 }
 

@@ -10,9 +10,10 @@
 //     issue: hipcc's hazard table is sufficient, the hand-issued chain of k_shade2 and its 299 s_nop per tile were not
 //     needed.  The three terms of a split product go term-major over independent accumulators, so no MFMA waits for the
 //     one issued just before it.
-//   * 512-thread workgroups, one per CU: 8 waves, two per SIMD, 256 registers each.  The two waves of a SIMD alternate
-//     roles in lockstep (s_barrier between phases): while one gathers its tile (texture path), the other runs its MFMA
-//     chain (matrix pipe) -- the two pipes overlap by construction instead of by luck.
+//   * 512-thread workgroups, one per CU: 8 waves, two per SIMD, up to 256 registers each; tiles come from a per-workgroup
+//     queue, and each wave fetches the header of its next tile one tile ahead.  (Forcing the two waves of a SIMD into
+//     opposite phases with s_barrier -- one gathers while the other multiplies -- was measured: 153 vs 139 us; 12 waves
+//     with 168 registers: 156 us, the chain spills.  profiles/r08c.)
 //   * dense 24-channel appearance texels (96 B): lane half h reads channels 12 h .. 12 h + 11 of a tap as three aligned
 //     float4: 54 wave-level loads per 32 samples (k_shade2: 72), five basis K-steps of 16 instead of six.
 //   * a workgroup owns WHOLE rays (its tile range is cut at ray boundaries): every ray's tile partials are summed, in
@@ -29,13 +30,22 @@ constexpr int ITEM3 = 32;          // compact samples per work item of k_shade3 
 __device__ __forceinline__ bf16x8 w32_frag(const uint4* img, int frag, int part, int lane) {
   return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
 }
-__device__ __forceinline__ void split8c(const float v[8], bf16x8& hi, bf16x8& lo) {      // hi = bf16(v), lo = bf16(v - hi)
+// hi = bf16(v) (round to nearest even), lo = bf16(v - hi), two values at a time: one packed conversion gives both hi
+// halves, a shift and a mask turn them back into floats (3 VALU instructions per value; the element-wise form costs 4)
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8c(const float v[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t H[4], L[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 hh = (__bf16)v[j];
-    hi[j] = hh;
-    lo[j] = (__bf16)(v[j] - (float)hh);
+  for (int j = 0; j < 4; ++j) {
+    const f32x2v ab = {v[2 * j], v[2 * j + 1]};
+    const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, bf16x2v));
+    const f32x2v r = {v[2 * j] - __uint_as_float(p << 16), v[2 * j + 1] - __uint_as_float(p & 0xffff0000u)};
+    H[j] = p;
+    L[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2v));
   }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(H[0], H[1], H[2], H[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(L[0], L[1], L[2], L[3]));
 }
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -57,11 +67,10 @@ __device__ __forceinline__ void mma3_step(const uint4* img, int frag0, int strid
 
 // the 12 appearance products of lane half h for plane p: channels 12 h .. 12 h + 11 of the dense texel, three aligned
 // float4 per tap (tensoRF.py:153-195); same per-channel arithmetic, in the same order, as gather_app6_plane32
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-// DRAIN (experiment): every load of the plane issued, then s_waitcnt vmcnt(0), then the arithmetic -- no loaded register
-// is read while any vector memory operation of this wave is outstanding
-template <int p, bool DRAIN = false>
-__device__ __forceinline__ void gather_app12(const DField& f, const AxisTaps& at, int h, float X[12], uint32_t* hraw = nullptr) {
+// the 12 appearance products of lane half h for plane p: channels 12 h .. 12 h + 11 of the dense texel, three aligned
+// float4 per tap (tensoRF.py:153-195); same per-channel arithmetic, in the same order, as gather_app6_plane32
+template <int p>
+__device__ __forceinline__ void gather_app12(const DField& f, const AxisTaps& at, int h, float X[12]) {
   const int x0 = at.i0[MAT0[p]], x1 = at.i1[MAT0[p]], y0 = at.i0[MAT1[p]], y1 = at.i1[MAT1[p]];
   const int l0 = at.i0[VEC[p]], l1 = at.i1[VEC[p]];
   const float tx = at.t[MAT0[p]], ty = at.t[MAT1[p]], tl = at.t[VEC[p]];
@@ -73,34 +82,11 @@ __device__ __forceinline__ void gather_app12(const DField& f, const AxisTaps& at
   const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty);
   const float w01 = (1.0f - tx) * ty,          w11 = tx * ty;
   const float wl0 = 1.0f - tl, wl1 = tl;
-  f32x4v raw[18];
-  if (DRAIN) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      raw[6 * i + 0] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o00 + 16 * i)); raw[6 * i + 1] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o10 + 16 * i));
-      raw[6 * i + 2] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o01 + 16 * i)); raw[6 * i + 3] = __builtin_bit_cast(f32x4v, ld4b(f.aplane2[p], o11 + 16 * i));
-      raw[6 * i + 4] = __builtin_bit_cast(f32x4v, ld4b(f.aline2[p], q0 + 16 * i));   raw[6 * i + 5] = __builtin_bit_cast(f32x4v, ld4b(f.aline2[p], q1 + 16 * i));
-    }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), "+v"(raw[8]),
-                   "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]), "+v"(raw[15]), "+v"(raw[16]), "+v"(raw[17])
-                 :: "memory");
-    if (hraw) {
-      uint32_t a = hraw[0], b = hraw[1];
-#pragma unroll
-      for (int i = 0; i < 18; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a = a * 31u ^ __float_as_uint(raw[i][c]);
-      b = b * 31u ^ o00; b = b * 31u ^ o10; b = b * 31u ^ o01; b = b * 31u ^ o11; b = b * 31u ^ q0; b = b * 31u ^ q1;
-      b = b * 31u ^ __float_as_uint(w00); b = b * 31u ^ __float_as_uint(w11); b = b * 31u ^ __float_as_uint(wl1);
-      hraw[0] = a; hraw[1] = b;
-    }
-  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float4 a = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 0]) : ld4b(f.aplane2[p], o00 + 16 * i), b = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 1]) : ld4b(f.aplane2[p], o10 + 16 * i);
-    const float4 c = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 2]) : ld4b(f.aplane2[p], o01 + 16 * i), d = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 3]) : ld4b(f.aplane2[p], o11 + 16 * i);
-    const float4 e = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 4]) : ld4b(f.aline2[p], q0 + 16 * i), q = DRAIN ? __builtin_bit_cast(float4, raw[6 * i + 5]) : ld4b(f.aline2[p], q1 + 16 * i);
+    const float4 a = ld4b(f.aplane2[p], o00 + 16 * i), b = ld4b(f.aplane2[p], o10 + 16 * i);
+    const float4 c = ld4b(f.aplane2[p], o01 + 16 * i), d = ld4b(f.aplane2[p], o11 + 16 * i);
+    const float4 e = ld4b(f.aline2[p], q0 + 16 * i), q = ld4b(f.aline2[p], q1 + 16 * i);
     X[4 * i]     = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e.x * wl0 + q.x * wl1);
     X[4 * i + 1] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e.y * wl0 + q.y * wl1);
     X[4 * i + 2] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e.z * wl0 + q.z * wl1);
@@ -149,30 +135,20 @@ __device__ __forceinline__ int toff_lower_bound_p(P toff, int n, int v) {
   return lo < n ? lo : n;
 }
 
-// What one wave needs to know about a tile before it can gather: fetched one tile ahead (the loads are in flight under
-// the previous tile's chain), so the dependent chain tile -> ray -> sample index -> distance is off the critical path.
+// What one wave needs to know about a tile before it can gather.  The loads are issued one tile ahead and first used at
+// the top of the next tile, so the dependent chain tile -> ray -> sample index -> distance is off the critical path.
 struct Hdr3 {
   int ray, tile_in_ray, k;       // ray, tile number inside the ray, this lane's sample index into z
   float wgt;                     // this lane's compositing weight (0 for lanes beyond the tile's count and for K half 1)
-  RayGeo rg;
+  float o[3], d[3];              // ray origin, unit direction
 };
 
 // NW waves per workgroup (one workgroup per CU).  LDSTOFF: the tile offsets are scanned by every workgroup itself into
 // LDS (R + 1 ints beside the image: two launches per render, k_march -> k_shade3); otherwise k_scan_tiles_n<32> ran before
 // and toff_g holds them.
 // TIMED (debug, lrf_debug_set_dump + lrf_debug_set_mlp_policy(10)): s_memtime totals per wave -> dump[block][wave][8] =
-// {prologue, gather, chain, finalize, -, -, tiles, -}
-// VAR (experiments on run-to-run differences): bit 3 = gathers drained before use (gather_app12<DRAIN>); bit 0 = no header prefetch; bit 1 = every counter drained + scheduling
-// fence between gather and chain; bit 2 = workgroup barrier between gather and chain and behind the chain (lockstep)
-// DUMPH (debug): per tile, wave-wide XOR of the bit patterns after each stage -> dump[tile][8] (uint32) =
-// {header, gathered products (split), basis output, layer 1, layer 2 first half, second half, head, -}: which stage of a
-// tile differs between two runs of the same render
-__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) v ^= (uint32_t)__shfl_xor((int)v, d, 64);
-  return v;
-}
-template <int NW, bool LDSTOFF, bool TIMED = false, int VAR = 0, bool DUMPH = false>
+// {prologue, header + position, gather + split, -, -, chain, tiles, finalize}
+template <int NW, bool LDSTOFF, bool TIMED = false>
 __global__ __launch_bounds__(NW * 64) void k_shade3(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff_g, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
@@ -187,17 +163,24 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   float* tail = reinterpret_cast<float*>(s_dyn + W32_U4);
   float* s_z = tail + W32_T_FLOATS;
   lds_int* s_toff = (lds_int*)(s_z + S);
+  typedef __attribute__((address_space(3))) unsigned short lds_u16;
+  lds_u16* s_nc = (lds_u16*)(s_toff + (LDSTOFF ? R + 1 : 0));  // per-ray shaded-sample counts beside the offsets (LDSTOFF)
+  __shared__ int s_wave[NW];
+  __shared__ int s_next;                                       // tile queue of this workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
   for (int i = tid; i < W32_ALL_U4; i += NT) img[i] = f.mlpw[i];
   for (int i = tid; i < S; i += NT) s_z[i] = z[i];
   if (LDSTOFF) {                                               // exclusive scan of ceil(ncomp / 32): eight rays per thread and round
-    __shared__ int s_wave[NW];
     int carry = 0;
     for (int base = 0; base < R; base += NT * 8) {
       const int r0 = base + tid * 8;
       int v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = r0 + i < R ? (ncomp[r0 + i] + ITEM3 - 1) / ITEM3 : 0;
+      for (int i = 0; i < 8; ++i) {
+        const int nc = r0 + i < R ? ncomp[r0 + i] : 0;
+        if (r0 + i < R) s_nc[r0 + i] = (unsigned short)nc;
+        v[i] = (nc + ITEM3 - 1) / ITEM3;
+      }
 #pragma unroll
       for (int i = 1; i < 8; ++i) v[i] += v[i - 1];
       int incl = v[7];
@@ -232,14 +215,18 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   const int ra = __builtin_amdgcn_readfirstlane(toff_lower_bound_p(toff, R, (int)((long long)lb * T / nb)));
   const int rb = __builtin_amdgcn_readfirstlane(lb == nb - 1 ? R : toff_lower_bound_p(toff, R, (int)((long long)(lb + 1) * T / nb)));
   const int T0 = __builtin_amdgcn_readfirstlane(toff[ra]), T1 = __builtin_amdgcn_readfirstlane(toff[rb]);
+  if (tid == 0) s_next = T0 + 2 * NW;                          // tiles T0 .. T0 + 2 NW - 1 are handed out statically below
+  __syncthreads();
 
-  // tile walk of this wave (tiles T0 + wave, + NW, ...): ray owning the current tile, cached per ray
+  // Tiles are pulled from the workgroup's queue (an LDS counter): a wave that gathers from warm lines moves on instead
+  // of waiting for a slower neighbour.  Every wave sees its tiles in increasing order, so the ray of a tile is found by
+  // walking forward from the previous one (state cached per ray).
   int w_ray = ra, w_next = ra < R ? (int)toff[ra + 1] : T1, w_tile0 = T0, w_nc = 0;
   bool w_fresh = true;
-  auto load_header = [&](int t) {
+  auto issue_header = [&](int t) {
     while (w_next <= t) { ++w_ray; w_tile0 = w_next; w_next = toff[w_ray + 1]; w_fresh = true; }
     w_ray = __builtin_amdgcn_readfirstlane(w_ray);
-    if (w_fresh) { w_nc = __builtin_amdgcn_readfirstlane(ncomp[w_ray]); w_fresh = false; }
+    if (w_fresh) { w_nc = __builtin_amdgcn_readfirstlane(LDSTOFF ? (int)s_nc[w_ray] : ncomp[w_ray]); w_fresh = false; }
     Hdr3 hd;
     hd.ray = w_ray; hd.tile_in_ray = t - w_tile0;
     const int j0 = hd.tile_in_ray * ITEM3;
@@ -247,78 +234,49 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     const size_t ci = (size_t)w_ray * S + j0 + (n < cnt ? n : 0);
     hd.k = cidx[ci];
     hd.wgt = (n < cnt && h == 0) ? cw[ci] : 0.0f;              // the two K halves of a sample hold the same colour: count it once
-    hd.rg = load_ray(rays, w_ray);
+    const float* rp = rays + (size_t)w_ray * 6;
+    const float4 dq = *reinterpret_cast<const float4*>(f.rdir + (size_t)w_ray * 4);     // d / |d| as k_march formed it (tensorBase.py:578-580)
+    hd.o[0] = rp[0]; hd.o[1] = rp[1]; hd.o[2] = rp[2]; hd.d[0] = dq.x; hd.d[1] = dq.y; hd.d[2] = dq.z;
     return hd;
   };
   LRF_TICK(0);
-  int t = T0 + wave;
+  int t_cur = T0 + wave, t_nxt = T0 + NW + wave;               // the first two tiles of a wave are fixed: no queue latency at start
   Hdr3 cur;
-  if (t < T1) cur = load_header(t);
-  if (VAR & 4) {                                               // (lockstep experiment: every wave takes part in every round)
-    static_assert(!(VAR & 4) || true, "");
-  }
-  for (; (VAR & (4 | 32 | 64)) ? (t - wave < T1) : (t < T1); t += NW) {
+  if (t_cur < T1) cur = issue_header(t_cur);
+  while (t_cur < T1) {
     asm volatile("" ::: "memory");                             // keep the LDS fragment reads inside the loop
-    if ((VAR & (4 | 32 | 64)) && t >= T1) {                    // no tile in this round: only the barriers
-      __builtin_amdgcn_s_barrier();
-      if (VAR & 4) __builtin_amdgcn_s_barrier();
-      continue;
-    }
+    int t_after = 0;                                           // the tile after next: its number is back long before it is needed
+    if (lane == 0) t_after = atomicAdd(&s_next, 1);
     Hdr3 nxt = cur;
-    if (!(VAR & 1) && t + NW < T1) nxt = load_header(t + NW);
+    if (t_nxt < T1) nxt = issue_header(t_nxt);
     // ------------------------------------------------------------------ gather
     bf16x8 xh[5], xl[5];
     float vb[3];
-    uint32_t hq[4] = {0, 0, 0, 0};
     {
-      const RayGeo rg = cur.rg;
+      const float dh[3] = {cur.d[0], cur.d[1], cur.d[2]};
 #pragma unroll
       for (int c = 0; c < 3; ++c) {                            // view-direction part of mlp_view.0 + bias (tensorBase.py:131-132; viewdirs detached :628)
         const float4 wv = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + W32_T_W3_LD * c + LRF_FEATC]);
-        vb[c] = tail[W32_T_B3 + c] + wv.x * rg.dh[0] + wv.y * rg.dh[1] + wv.z * rg.dh[2];
+        vb[c] = tail[W32_T_B3 + c] + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
       }
       float x[3], u[3];
-      sample_point(f, rg.o, rg.dh, s_z[cur.k], x, u);
+      sample_point(f, cur.o, dh, s_z[cur.k], x, u);
       const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);
+      if (TIMED) { asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2])); LRF_TICK(1); }
       float X[40];
-      uint32_t hraw[2] = {0, 0};
-      gather_app12<0, (VAR & 8) != 0 || DUMPH>(f, at, h, X, DUMPH ? hraw : nullptr);
-      gather_app12<1, (VAR & 8) != 0 || DUMPH>(f, at, h, X + 12, DUMPH ? hraw : nullptr);
-      gather_app12<2, (VAR & 8) != 0 || DUMPH>(f, at, h, X + 24, DUMPH ? hraw : nullptr);
+      gather_app12<0>(f, at, h, X);
+      gather_app12<1>(f, at, h, X + 12);
+      gather_app12<2>(f, at, h, X + 24);
       X[36] = X[37] = X[38] = X[39] = 0.0f;
-      if ((VAR & 128) && f.dump) {                             // capture: everything the gather of this lane saw
-        float* dp = f.dump + ((size_t)t * 64 + lane) * 48;
-        dp[0] = __int_as_float(cur.k); dp[1] = s_z[cur.k]; dp[2] = u[0]; dp[3] = u[1]; dp[4] = u[2];
-        dp[5] = rg.o[0]; dp[6] = rg.o[1]; dp[7] = rg.o[2]; dp[8] = rg.dh[0]; dp[9] = rg.dh[1]; dp[10] = rg.dh[2]; dp[11] = __int_as_float(cur.ray);
-        for (int i = 0; i < 36; ++i) dp[12 + i] = X[i];
-      }
-      if (DUMPH) {
-        hq[0] = wave_xor(__float_as_uint(s_z[cur.k]) ^ (__float_as_uint(u[0]) * 3u) ^ (__float_as_uint(u[1]) * 5u) ^ (__float_as_uint(u[2]) * 7u));
-        hq[1] = wave_xor(hraw[1]);
-        hq[2] = wave_xor(hraw[0]);
-        uint32_t a = 0;
-        for (int i = 0; i < 36; ++i) a = a * 31u ^ __float_as_uint(X[i]);
-        hq[3] = wave_xor(a);
-      }
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) split8c(X + 8 * ks, xh[ks], xl[ks]);
     }
-    uint32_t hx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (DUMPH) {
-      hx[0] = wave_xor((uint32_t)cur.k * 2654435761u ^ __float_as_uint(cur.wgt) ^ __float_as_uint(cur.rg.o[0]) ^ __float_as_uint(cur.rg.dh[2]));
-      uint32_t a = 0;
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) {
-        const uint4 p = __builtin_bit_cast(uint4, xh[ks]), q = __builtin_bit_cast(uint4, xl[ks]);
-        a ^= p.x ^ (p.y * 3u) ^ (p.z * 5u) ^ (p.w * 7u) ^ (q.x * 11u) ^ (q.y * 13u) ^ (q.z * 17u) ^ (q.w * 19u);
-        a = a * 31u + ks;
-      }
-      hx[1] = wave_xor(a);
-    }
-    LRF_TICK(1);
-    if (VAR & 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-    if (VAR & (4 | 64)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    if (TIMED) { asm volatile("" : "+v"(xh[0]), "+v"(xl[4])); LRF_TICK(2); }
     // ------------------------------------------------------------------ chain
+    // While it multiplies, a wave outranks its SIMD partner in the issue arbitration (the partner mostly waits for
+    // gathers): 123.3 -> 120.1 us (interleaved A/B, profiles/r08c).  Requesting every A fragment one K-step ahead by
+    // hand (sched_barrier regions) was measured too: 137 vs 133 us, the compiler's own order is better.
+    __builtin_amdgcn_s_setprio(2);
     // basis 72 -> 27 (tensoRF.py:196): five K-steps; the three terms in three accumulators (one output tile only)
     f32x16 fa, fb, fc;
 #pragma unroll
@@ -331,8 +289,6 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
       fc = mfma32(ah, xh[ks], fc);
     }
     const f32x16 fe = (fa + fb) + fc;
-    if (DUMPH) { uint32_t a = 0; for (int r = 0; r < 16; ++r) a = a * 31u ^ __float_as_uint(fe[r]); hx[2] = wave_xor(a); }
-    // layer 1 (tensorBase.py:129-130): two K-steps (features 0..15, 16..31), four output tiles
     f32x16 h1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -350,8 +306,6 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
       split8c(v, bh, bl);
       mma3_step<4>(img, W32_W1 + q, 2, lane, bh, bl, h1);
     }
-    if (DUMPH) { uint32_t a = 0; for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) a = a * 31u ^ __float_as_uint(h1[m][r]); hx[3] = wave_xor(a); }
-    // relu(h1) as the eight split B operands of layer 2 (K-step 2 m0 + q = registers 8 q .. 8 q + 7 of tile m0); h1 dies here
     bf16x8 b2h[8], b2l[8];
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0)
@@ -362,8 +316,6 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
         for (int j = 0; j < 8; ++j) v[j] = relu_i(h1[m0][8 * q + j]);
         split8c(v, b2h[2 * m0 + q], b2l[2 * m0 + q]);
       }
-    // layer 2 + head (tensorBase.py:130-133), two output tiles at a time: 64 accumulator registers fewer are live, and
-    // the VALU head of one half has the other half's MFMAs to hide under
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -377,7 +329,6 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
         }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) mma3_step<2>(img, W32_W2 + 16 * half + ks, 8, lane, b2h[ks], b2l[ks], h2);
-      if (DUMPH) { uint32_t a = 0; for (int m = 0; m < 2; ++m) for (int r = 0; r < 16; ++r) a = a * 31u ^ __float_as_uint(h2[m][r]); hx[4 + half] = wave_xor(a); }
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -392,6 +343,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
           o2 += a0 * w2.x; o2 += a1 * w2.y; o2 += a2 * w2.z; o2 += a3 * w2.w;
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
     // w * sigmoid(x) (:133, :632), hardware exp2 / reciprocal; partial colour of the tile = sum over its samples
     float cr = cur.wgt * __frcp_rn(1.0f + __expf(-(o0 + vb[0])));
@@ -405,19 +357,8 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
       float* pp = part + ((size_t)cur.ray * pmax + cur.tile_in_ray) * 3;
       pp[0] = cr; pp[1] = cg; pp[2] = cb;
     }
-    if (DUMPH) {
-      hx[6] = wave_xor(__float_as_uint(o0) ^ (__float_as_uint(o1) * 3u) ^ (__float_as_uint(o2) * 5u));
-      hx[7] = __float_as_uint(cr) ^ (__float_as_uint(cg) * 3u) ^ (__float_as_uint(cb) * 5u);
-      if (lane == 0 && f.dump) {
-        uint32_t* dp = reinterpret_cast<uint32_t*>(f.dump) + (size_t)t * 8;
-        dp[0] = hx[0]; dp[1] = hq[0]; dp[2] = hq[1]; dp[3] = hq[2]; dp[4] = hq[3]; dp[5] = hx[1]; dp[6] = hx[2]; dp[7] = hx[3];
-      }
-    }
-    cur = nxt;
-    if ((VAR & 1) && t + NW < T1) cur = load_header(t + NW);
-    if (VAR & 16) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-    if (VAR & (4 | 32)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-    LRF_TICK(2);
+    cur = nxt; t_cur = t_nxt; t_nxt = __builtin_amdgcn_readfirstlane(t_after);
+    LRF_TICK(5);
     tk[6] += 1;
   }
   // rgb_map = sum_k w_k rgb_k (+ 1 - acc) (tensorBase.py:632-634): this workgroup wrote every partial of its rays.  Its
@@ -425,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int r = ra + tid; r < rb; r += NT) finalize_ray<false>(r, (int)toff[r + 1] - (int)toff[r], pmax, flags, acc, part, rgb_out, acc_out);
-  LRF_TICK(3);
+  LRF_TICK(7);
   if (TIMED && f.dump && lane == 0) {
     unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * NW + wave) * 8;
     for (int i = 0; i < 8; ++i) dp[i] = tk[i];

@@ -80,8 +80,7 @@ class _RenderFn(torch.autograd.Function):
         # shaded-sample lists, per-sample colours, activation rows) in a workspace owned by this
         # graph node -- a 6.5 GB worst-case reservation at 4096 x 512, 288 GB of HBM -- instead of recomputing it.
         if not flags & (N.LRF_FLAG_MLP_VALU | N.LRF_FLAG_MLP_F32):
-            tflags = flags & ~(N.LRF_FLAG_MLP_FUSED | N.LRF_FLAG_MLP_SPLIT | N.LRF_FLAG_MLP_W16)     # one row-saving forward for all bf16x3 engines
-            rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, tflags)
+            rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, flags)
         else:
             rgb, depth = field._native_forward(rays, z, flags, floater)
             ctx.ws, ctx.versions = None, field._param_versions()
@@ -225,9 +224,7 @@ class TensorVMSplit(torch.nn.Module):
         self._cache_key = None
         self._ws = None
         # colour-MLP engine: "bf16x3" split-bf16 (hi + lo, 3-term) MFMA chain, 32 samples per wave, k_shade3 (default) |
-        # "bf16x3_w16" round 2's k_shade2 (16 samples per wave, LRF_FLAG_MLP_W16) | "bf16x3_split" the same chain as two kernels, k_app + k_mlp (LRF_FLAG_MLP_SPLIT) | "bf16x3_fused"
-        # round 1's kernel (LRF_FLAG_MLP_FUSED) | "f32" exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu"
-        # plain-loop debug engine (LRF_FLAG_MLP_VALU)
+        # "f32" exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
         self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
         # early termination of the march (LrfField.term_T in include/lrf.h): 0 = evaluate every sample
@@ -432,12 +429,6 @@ class TensorVMSplit(torch.nn.Module):
             fl |= N.LRF_FLAG_MLP_VALU
         elif self.mlp_engine == "f32":
             fl |= N.LRF_FLAG_MLP_F32
-        elif self.mlp_engine == "bf16x3_fused":
-            fl |= N.LRF_FLAG_MLP_FUSED
-        elif self.mlp_engine == "bf16x3_split":
-            fl |= N.LRF_FLAG_MLP_SPLIT
-        elif self.mlp_engine == "bf16x3_w16":
-            fl |= N.LRF_FLAG_MLP_W16
         elif self.mlp_engine != "bf16x3":
             raise ValueError(f"unknown mlp_engine {self.mlp_engine!r}")
         return fl

@@ -19,6 +19,93 @@ def log(*a):
     print(msg, flush=True)
 
 
+def stage_screen():
+    """Box screen: alternates two fields (300^3 x 512 samples, an empty 64^3 x 64 samples) and the colour engines, one
+    render each per round with a foreign kernel (a sort) thrown in, and compares every render with that configuration's
+    own first result, colour and depth.  SCREEN_ROUNDS rounds (default 400).  Must report 0 odd renders."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from util import make_field, make_rays, quiet
+    big = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    empty = quiet(make_field, [64, 64, 64], "cpu", seed=3)
+    with torch.no_grad():
+        for p in empty.density_plane:
+            p.zero_()
+    empty = empty.to("cuda:0")
+    empty.density_shift = -30.0
+    rays = make_rays(4096, 1).cuda()
+    cfgs = []
+    for eng in os.environ.get("SCREEN_ENGINES", "bf16x3,f32").split(","):
+        cfgs.append((eng, big, 1536, "300^3"))
+        cfgs.append((eng, empty, 192, "empty64"))
+    n = int(os.environ.get("SCREEN_ROUNDS", "400"))
+    ref, odd = {}, {}
+    scratch = torch.empty(1 << 22, device="cuda")
+    with torch.no_grad():
+        for rnd in range(n):
+            for ci, (eng, fld, ns, name) in enumerate(cfgs):
+                fld.mlp_engine = eng
+                if rnd % 3 == 1:
+                    scratch.sort()
+                rgb, dep = fld(rays, white_bg=True, is_train=False, N_samples=ns)
+                if ci not in ref:
+                    ref[ci] = (rgb.clone(), dep.clone())
+                    odd[ci] = []
+                    continue
+                if not (torch.equal(rgb, ref[ci][0]) and torch.equal(dep, ref[ci][1])):
+                    dc = (rgb - ref[ci][0]).abs().amax(-1)
+                    dd = (dep - ref[ci][1]).abs()
+                    odd[ci].append((rnd, int((dc > 0).sum()), float(dc.max()), int((dd > 0).sum()), float(dd.max())))
+    total = 0
+    for ci, (eng, fld, ns, name) in enumerate(cfgs):
+        total += len(odd[ci])
+        log(f"screen {eng} {name}: {len(odd[ci])} of {n - 1} renders differ from the first "
+            f"(round, rays colour, max colour, rays depth, max depth): {odd[ci][:6]}")
+    log(f"screen total odd renders: {total}")
+
+
+def stage_shade3_phases():
+    """s_memtime phase totals of k_shade3 per wave (TIMED build), then per-kernel HIP-event times (median of 7)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
+    rays = make_rays(4096, 1).cuda()
+    z = f.z_schedule(False, 1536, rays.device).contiguous()
+    lib = N.lib()
+    with torch.no_grad():
+        for _ in range(300):
+            f(rays, white_bg=True, is_train=False, N_samples=1536)
+    names = ["prologue", "header+position", "gather+split", "-", "-", "chain", "tiles", "finalize"]
+    nw = 8
+    buf = torch.zeros(256 * nw * 8, dtype=torch.int64, device="cuda")
+    with torch.no_grad():
+        lib.lrf_debug_set_dump(buf.data_ptr())
+        f(rays, white_bg=True, is_train=False, N_samples=1536)
+        torch.cuda.synchronize()
+        lib.lrf_debug_set_dump(None)
+    t = buf.view(256 * nw, 8).double()
+    tiles = t[:, 6].sum()
+    tot = t[:, [0, 1, 2, 3, 4, 5, 7]].sum(1)
+    log(f"k_shade3 {nw} waves: tiles {int(tiles)} | cycles per wave: prologue {float(t[:, 0].mean()):.0f} finalize {float(t[:, 7].mean()):.0f} | per tile: " +
+        " ".join(f"{names[i]} {float(t[:, i].sum() / tiles):.0f}" for i in (1, 2, 5)) +
+        f" | per-wave total mean/min/max {float(tot.mean()):.0f}/{float(tot.min()):.0f}/{float(tot.max()):.0f}")
+    for eng in ("bf16x3", "f32"):
+        f.mlp_engine = eng
+        res = []
+        for rep in range(7):
+            with torch.no_grad():
+                for _ in range(30):
+                    f(rays, white_bg=True, is_train=False, N_samples=1536)
+            p = bench.kernel_profile(f, rays, z, reps=30)
+            res.append((p["shade_ms"] * 1e3, p["march_ms"] * 1e3, p["total_ms"] * 1e3))
+        sh = sorted(v[0] for v in res)
+        log(f"engine {eng}: colour stage median {sh[3]:.1f} us (min {sh[0]:.1f}, max {sh[-1]:.1f}) | k_march median {sorted(v[1] for v in res)[3]:.1f} us | total median {sorted(v[2] for v in res)[3]:.1f} us")
+    f.mlp_engine = "bf16x3"
+
+
 def stage_import():
     t = time.time()
     import torch
@@ -737,141 +824,6 @@ def stage_fuzz_case():
             "at", hot.nonzero()[:6].tolist())
 
 
-def stage_mfma_policy():
-    """The hazard experiment of DESIGN.md 'gfx950 / hipcc findings': k_mlp under its four MFMA issue
-    policies (lrf_shade2.inl) -- run-to-run determinism of 150 renders of the config-2 batch, agreement
-    with policy 0, and kernel time."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    f.mlp_engine = "bf16x3_split"
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    lib = N.lib()
-    ref = None
-    for pol in [int(v) for v in os.environ.get("DIAG_POLICIES", "0,4").split(",")]:
-        lib.lrf_debug_set_mlp_policy(pol)
-        with torch.no_grad():
-            first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-            ndiff, nray, maxd = 0, 0, 0.0
-            for _ in range(150):
-                again, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                if not torch.equal(first, again):
-                    ndiff += 1
-                    d = (first - again).abs().amax(-1)
-                    nray = max(nray, int((d > 0).sum()))
-                    maxd = max(maxd, float(d.max()))
-        if ref is None:
-            ref = first.clone()
-        prof = bench.kernel_profile(f, rays, z, reps=10)
-        log(f"policy {pol}: renders differing from the first {ndiff}/150 (max rays {nray}, max |diff| {maxd:.2e}) | "
-            f"max |rgb - policy0| {float((first - ref).abs().max()):.2e} | k_app {prof['app_ms'] * 1e3:.1f} us "
-            f"k_mlp {prof['mlp_ms'] * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us")
-    lib.lrf_debug_set_mlp_policy(4)
-    for eng in ("bf16x3_fused", "bf16x3"):
-        f.mlp_engine = eng
-        with torch.no_grad():
-            first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-            nd = sum(0 if torch.equal(first, f(rays, white_bg=True, is_train=False, N_samples=1536)[0]) else 1 for _ in range(150))
-        prof = bench.kernel_profile(f, rays, z, reps=10)
-        log(f"{eng}: k_shade {(prof['shade_ms'] - prof['scan_ms']) * 1e3:.1f} us k_march {prof['march_ms'] * 1e3:.1f} us total {prof['total_ms'] * 1e3:.1f} us | "
-            f"max |rgb - split| {float((first - ref).abs().max()):.2e} | renders differing {nd}/150")
-
-
-def stage_walls():
-    """Trained-like scene of bench.py: per-kernel times with and without early termination."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from util import make_rays
-    f = bench.walls_field(torch.device("cuda:0"))
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    for mask in (False, True):
-        if mask:
-            f.updateAlphaMask((150, 150, 150))
-            log("mask kept fraction", float(f.alphaMask.alpha_volume.mean()))
-        for T in (1e-9, 0.0):
-            f.early_term_T = T
-            with torch.no_grad():
-                for _ in range(3):
-                    f(rays, white_bg=True, is_train=False, N_samples=1536)
-                torch.cuda.synchronize()
-                t0 = time.time()
-                for _ in range(20):
-                    f(rays, white_bg=True, is_train=False, N_samples=1536)
-                torch.cuda.synchronize()
-                dt = (time.time() - t0) / 20
-            p = bench.kernel_profile(f, rays, z, reps=5)
-            log(f"mask {mask} term_T {T}: wall {dt * 1e3:.3f} ms/step | march {p['march_ms'] * 1e3:.1f} scan {p['scan_ms'] * 1e3:.1f} "
-                f"app {p['app_ms'] * 1e3:.1f} mlp {p['mlp_ms'] * 1e3:.1f} fin {p['finalize_ms'] * 1e3:.1f} total {p['total_ms'] * 1e3:.1f} us | shaded {p['n_shaded']}")
-
-
-def stage_mlp_phases():
-    """s_memtime phase totals of k_mlp per wave (debug build of the kernel, lrf_shade2.inl TIMED)."""
-    import torch
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    f.mlp_engine = "bf16x3_split"
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    for pol in (10, 14):
-        buf = torch.zeros(256 * 16 * 8, dtype=torch.int64, device="cuda")
-        with torch.no_grad():
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-            lib.lrf_debug_set_dump(buf.data_ptr())
-            lib.lrf_debug_set_mlp_policy(pol)
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-            torch.cuda.synchronize()
-            lib.lrf_debug_set_mlp_policy(4)
-            lib.lrf_debug_set_dump(None)
-        t = buf.view(256 * 16, 8).double()
-        tiles = t[:, 4].sum()
-        names = ["header+prefetch", "layer1", "layer2", "head+store"]
-        log(f"k_mlp policy {pol - 10}: tiles {int(tiles)} | cycles per tile and wave: " +
-            " ".join(f"{n} {float(t[:, i].sum() / tiles):.0f}" for i, n in enumerate(names)) +
-            f" | total {float(t[:, :4].sum() / tiles):.0f} | per-wave total min/max {float(t[:, :4].sum(1).min()):.0f}/{float(t[:, :4].sum(1).max()):.0f}")
-
-
-def stage_overlap():
-    """Do two renders on two streams overlap (k_app of one under k_mlp of the other)?  Two field objects
-    (own workspaces), same batch; 40 renders each, sequential on one stream vs concurrent on two, for
-    k_mlp workgroups of 1024 and 512 threads."""
-    import torch
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    fa = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    fb = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    lib = N.lib()
-
-    def run(two):
-        torch.cuda.synchronize()
-        t0 = time.time()
-        with torch.no_grad():
-            for _ in range(40):
-                with torch.cuda.stream(s1):
-                    fa(rays, white_bg=True, is_train=False, N_samples=1536)
-                with torch.cuda.stream(s2 if two else s1):
-                    fb(rays, white_bg=True, is_train=False, N_samples=1536)
-        torch.cuda.synchronize()
-        return (time.time() - t0) / 80 * 1e3
-    for pol in (0, 4):
-        for thr in (1024, 512, 256):
-            lib.lrf_debug_set_mlp_policy(pol)
-            lib.lrf_debug_set_mlp_threads(thr)
-            run(False); run(True)
-            a, b = run(False), run(True)
-            log(f"policy {pol} k_mlp threads {thr}: one stream {a:.4f} ms/render | two streams {b:.4f} ms/render")
-    lib.lrf_debug_set_mlp_threads(1024)
-    lib.lrf_debug_set_mlp_policy(4)
-
-
 def stage_soak():
     """3000 renders of the config-2 batch with the shipped engine: every one must equal the first bit for bit."""
     import torch
@@ -886,311 +838,6 @@ def stage_soak():
             if not (torch.equal(first, again) and torch.equal(d0, d1)):
                 bad += 1
     log(f"soak: 3000 renders, {bad} differ from the first")
-
-
-def stage_app_over():
-    """k_app oversubscription sweep + k_mlp time with the dynamic tile queue."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    f.mlp_engine = "bf16x3_split"
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    lib = N.lib()
-    for over in (1, 2, 4, 8, 16):
-        lib.lrf_debug_set_app_oversubscribe(over)
-        p = bench.kernel_profile(f, rays, z, reps=10)
-        log(f"k_app oversubscribe {over}: k_app {p['app_ms'] * 1e3:.1f} us k_mlp {p['mlp_ms'] * 1e3:.1f} us k_march {p['march_ms'] * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us")
-    lib.lrf_debug_set_app_oversubscribe(4)
-
-
-def stage_subbatch():
-    """Sub-batch pipeline sweep: ranges x k_mlp workgroup size; wall time per render (40 renders, no sync between)."""
-    import torch
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    f.mlp_engine = "bf16x3_split"
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    with torch.no_grad():
-        lib.lrf_debug_set_subbatches(1)
-        ref, dref = f(rays, white_bg=True, is_train=False, N_samples=1536)
-        for thr in (1024, 512):
-            for q in (1, 2, 3, 4, 6, 8):
-                lib.lrf_debug_set_subbatches(q)
-                lib.lrf_debug_set_mlp_threads(thr)
-                for _ in range(10):
-                    out, dep = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                torch.cuda.synchronize()
-                t0 = time.time()
-                for _ in range(100):
-                    out, dep = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                torch.cuda.synchronize()
-                dt = (time.time() - t0) / 100 * 1e3
-                same = torch.equal(out, ref) and torch.equal(dep, dref)
-                log(f"k_mlp threads {thr} sub-batches {q}: {dt:.4f} ms/render ({4096 / dt / 1e3:.2f} M rays/s) bit-identical to 1 range: {same}")
-    lib.lrf_debug_set_subbatches(4)
-    lib.lrf_debug_set_mlp_threads(1024)
-
-
-def stage_shade2_phases():
-    """s_memtime phase totals of k_shade2 per wave (TIMED build)."""
-    import torch
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    buf = torch.zeros(256 * 16 * 8, dtype=torch.int64, device="cuda")
-    with torch.no_grad():
-        f(rays, white_bg=True, is_train=False, N_samples=1536)
-        lib.lrf_debug_set_dump(buf.data_ptr())
-        lib.lrf_debug_set_mlp_policy(10)
-        f(rays, white_bg=True, is_train=False, N_samples=1536)
-        torch.cuda.synchronize()
-        lib.lrf_debug_set_mlp_policy(4)
-        lib.lrf_debug_set_dump(None)
-    t = buf.view(256 * 16, 8).double()
-    tiles = t[:, 7].sum()
-    names = ["header", "plane0", "plane1", "plane2", "layer1", "layer2", "head+store"]
-    log(f"k_shade2: tiles {int(tiles)} | cycles per tile and wave: " + " ".join(f"{n} {float(t[:, i].sum() / tiles):.0f}" for i, n in enumerate(names)) +
-        f" | total {float(t[:, :7].sum() / tiles):.0f} | per-wave total min/max {float(t[:, :7].sum(1).min()):.0f}/{float(t[:, :7].sum(1).max()):.0f}")
-
-
-def stage_capture3():
-    """Full capture of what every lane's gather saw (sample index, distance, position, ray, 36 products) per tile, for
-    identical renders: prints the entries that differ between two runs."""
-    import torch
-    sys.path.insert(0, ROOT)
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    names = ["k", "z[k]", "u0", "u1", "u2", "o0", "o1", "o2", "dh0", "dh1", "dh2", "ray"] + [f"X{i}" for i in range(36)]
-    for pipe in (38, 37):
-        lib.lrf_debug_set_shade_pipe(pipe)
-        caps = []
-        with torch.no_grad():
-            for it in range(int(os.environ.get("CAP3_N", "12"))):
-                buf = torch.zeros(26000 * 64 * 48, dtype=torch.float32, device="cuda")
-                lib.lrf_debug_set_dump(buf.data_ptr())
-                rgb, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                torch.cuda.synchronize()
-                lib.lrf_debug_set_dump(None)
-                caps.append((buf.view(-1, 64, 48).view(torch.int32), rgb.clone()))
-        ref, rgb0 = caps[0]
-        nshow = 0
-        for ci, (b, rgb) in enumerate(caps[1:]):
-            diff = b != ref
-            nt = int(diff.any(-1).any(-1).sum())
-            cols = diff.any(0).any(0)
-            log(f"capture3 pipe {pipe} run {ci + 1}: tiles with a differing entry {nt}, entries {int(diff.sum())}, columns {[names[i] for i in torch.nonzero(cols).flatten().tolist()][:20]}, colours equal {bool(torch.equal(rgb, rgb0))}")
-            if nt and nshow < 4:
-                idx = torch.nonzero(diff)
-                for t_, l_, c_ in idx[:10].tolist():
-                    a = ref[t_, l_, c_].view(torch.float32) if c_ not in (0, 11) else ref[t_, l_, c_]
-                    bb = b[t_, l_, c_].view(torch.float32) if c_ not in (0, 11) else b[t_, l_, c_]
-                    log(f"   tile {t_} lane {l_} {names[c_]}: {float(a) if c_ not in (0, 11) else int(a)} vs {float(bb) if c_ not in (0, 11) else int(bb)} | k {int(ref[t_, l_, 0])}/{int(b[t_, l_, 0])} ray {int(ref[t_, l_, 11])}")
-                lanes = torch.unique(idx[:, 1]).tolist()
-                log(f"   lanes hit {lanes[:32]} | tiles hit {torch.unique(idx[:, 0]).tolist()[:10]}")
-                nshow += 1
-    lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_hash3():
-    """Which stage of a tile differs between identical renders?  k_shade3<DUMPH> leaves, per tile, a wave-wide XOR of the
-    bit patterns after each stage; HASH3_N renders are compared with the first."""
-    import torch
-    sys.path.insert(0, ROOT)
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    names = ["header", "position", "addresses+weights", "raw loads", "X fp32", "X split", "basis", "layer 1"]
-    n = int(os.environ.get("HASH3_N", "100"))
-    for pipe in (0, 12):
-        lib.lrf_debug_set_shade_pipe(pipe)
-        bufs = []
-        with torch.no_grad():
-            for it in range(n + 1):
-                buf = torch.zeros(40000 * 8, dtype=torch.int32, device="cuda")
-                lib.lrf_debug_set_dump(buf.data_ptr())
-                lib.lrf_debug_set_mlp_policy(9)
-                rgb, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                torch.cuda.synchronize()
-                lib.lrf_debug_set_mlp_policy(4)
-                lib.lrf_debug_set_dump(None)
-                bufs.append((buf.view(-1, 8).clone(), rgb.clone()))
-        ref, rgb0 = bufs[0]
-        first_stage = [0] * 9
-        ntile = nrender = 0
-        examples = []
-        for b, rgb in bufs[1:]:
-            diff = (b != ref)
-            rows = diff.any(1)
-            if bool(rows.any()):
-                nrender += 1
-                for r in torch.nonzero(rows).flatten().tolist():
-                    st = int(torch.nonzero(diff[r]).flatten()[0])
-                    first_stage[st] += 1
-                    ntile += 1
-                    if len(examples) < 6:
-                        examples.append((r, [names[i] for i in torch.nonzero(diff[r]).flatten().tolist()]))
-            elif not torch.equal(rgb, rgb0):
-                first_stage[8] += 1
-        log(f"hash3 shade_pipe {pipe}: {nrender} of {n} renders have a differing tile ({ntile} tiles); first differing stage: " +
-            ", ".join(f"{names[i]} {first_stage[i]}" for i in range(8)) + f", colours only {first_stage[8]} | examples {examples}")
-    lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_det3():
-    """Is k_shade3 deterministic?  DET3_N identical renders per variant (shade_pipe 0: 12 waves per workgroup, 12: 8 waves),
-    colours compared with the first render's; for differing renders the rays and the size of the difference."""
-    import torch
-    sys.path.insert(0, ROOT)
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    n = int(os.environ.get("DET3_N", "300"))
-    for pipe in [int(v) for v in os.environ.get("DET3_PIPES", "0,12").split(",")]:
-        lib.lrf_debug_set_shade_pipe(pipe)
-        with torch.no_grad():
-            first, d0 = f(rays, white_bg=True, is_train=False, N_samples=1536)
-            first, d0 = first.clone(), d0.clone()
-            bad = badd = 0
-            worst, nr = 0.0, 0
-            seen = set()
-            for _ in range(n):
-                again, d1 = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                if not torch.equal(first, again):
-                    bad += 1
-                    dd = (first - again).abs().amax(-1)
-                    worst = max(worst, float(dd.max()))
-                    nr = max(nr, int((dd > 0).sum()))
-                    if len(seen) < 200:
-                        seen.update(int(i) for i in torch.nonzero(dd > 0).flatten()[:20])
-                badd += not torch.equal(d0, d1)
-        log(f"det3 shade_pipe {pipe}: {bad} of {n} renders differ in colour (max {worst:.2e}, up to {nr} rays, distinct rays seen {len(seen)}: {sorted(seen)[:12]}) | depth differs in {badd}")
-    lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_shade3_phases():
-    """s_memtime phase totals of k_shade3 per wave (TIMED build), 12 and 8 waves per workgroup; then the kernel's time
-    per variant and the 16-sample engine's beside it."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    lib = N.lib()
-    with torch.no_grad():
-        for _ in range(300):
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-    names = ["prologue", "gather", "chain", "finalize"]
-    for pipe, nw in ((0, 12), (12, 8)):
-        buf = torch.zeros(256 * nw * 8, dtype=torch.int64, device="cuda")
-        lib.lrf_debug_set_shade_pipe(pipe)
-        with torch.no_grad():
-            lib.lrf_debug_set_dump(buf.data_ptr())
-            lib.lrf_debug_set_mlp_policy(10)
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-            torch.cuda.synchronize()
-            lib.lrf_debug_set_mlp_policy(4)
-            lib.lrf_debug_set_dump(None)
-        t = buf.view(256 * nw, 8).double()
-        tiles = t[:, 6].sum()
-        tot = t[:, :4].sum(1)
-        log(f"k_shade3 {nw} waves: tiles {int(tiles)} | cycles per wave: " + " ".join(f"{n} {float(t[:, i].mean()):.0f}" for i, n in enumerate(names)) +
-            f" | per tile: gather {float(t[:, 1].sum() / tiles):.0f} chain {float(t[:, 2].sum() / tiles):.0f} | per-wave total mean/min/max {float(tot.mean()):.0f}/{float(tot.min()):.0f}/{float(tot.max()):.0f}")
-        with torch.no_grad():
-            for _ in range(50):
-                f(rays, white_bg=True, is_train=False, N_samples=1536)
-        p = bench.kernel_profile(f, rays, z, reps=20)
-        log(f"k_shade3 {nw} waves: colour kernel {p['shade_ms'] * 1e3:.1f} us, march {p['march_ms'] * 1e3:.1f} us, total {p['total_ms'] * 1e3:.1f} us")
-    lib.lrf_debug_set_shade_pipe(0)
-    for eng in ("bf16x3_w16",):
-        f.mlp_engine = eng
-        with torch.no_grad():
-            for _ in range(50):
-                f(rays, white_bg=True, is_train=False, N_samples=1536)
-        p = bench.kernel_profile(f, rays, z, reps=20)
-        log(f"engine {eng}: colour kernel {p['shade_ms'] * 1e3:.1f} us, total {p['total_ms'] * 1e3:.1f} us")
-
-
-def stage_skew():
-    """k_shade2 with the waves of a SIMD started out of phase."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    lib = N.lib()
-    with torch.no_grad():
-        for _ in range(300):                                  # clock ramp
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-    for sk in (0, 1, 2, 3, 4, 6, 0):
-        lib.lrf_debug_set_skew(sk)
-        with torch.no_grad():
-            for _ in range(50):
-                f(rays, white_bg=True, is_train=False, N_samples=1536)
-        p = bench.kernel_profile(f, rays, z, reps=10)
-        log(f"skew {sk} x 6400 cycles: k_shade2 {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us")
-    lib.lrf_debug_set_skew(0)
-
-
-def stage_fuse():
-    """Default engine as two launches (k_march -> k_shade2<FUSE>) vs four (k_scan_tiles and k_finalize as kernels):
-    wall time per 4096-ray render, 2000 renders each, alternating; kernel times through the profile entry; repeatability."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    lib = N.lib()
-
-    def fwd():
-        return f(rays, white_bg=True, is_train=False, N_samples=1536)
-    with torch.no_grad():
-        for _ in range(500):
-            fwd()
-        torch.cuda.synchronize()
-        for pipe in (0, 9, 10, 11, 0, 9, 10, 0):
-            lib.lrf_debug_set_shade_pipe(pipe)
-            for _ in range(50):
-                fwd()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2000):
-                fwd()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 2000
-            p = bench.kernel_profile(f, rays, z, reps=10)
-            log(f"shade_pipe {pipe} ({ {0: 'two launches, write-through partials', 9: 'four launches', 10: 'two launches, release/acquire fences', 11: 'two launches, __threadfence'}[pipe] }): {dt * 1e3:.4f} ms/step = {4096 / dt / 1e6:.2f} M rays/s | "
-                f"march {p['march_ms'] * 1e3:.1f} scan {p['scan_ms'] * 1e3:.1f} colour {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} fin {p['finalize_ms'] * 1e3:.1f} total {p['total_ms'] * 1e3:.1f} us")
-        lib.lrf_debug_set_shade_pipe(0)
-        ref = fwd()
-        ndiff = 0
-        for _ in range(6000):
-            o = fwd()
-            ndiff += int(not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1])))
-        log(f"two-launch sequence: renders differing from the first: {ndiff} of 6000")
 
 
 def stage_geo():
@@ -1276,166 +923,6 @@ def stage_train_host():
     log(buf.getvalue()[-7000:])
 
 
-def stage_screen():
-    """Box screen for finding 17 (rare odd renders right after a DIFFERENT kernel mix): alternates two fields (300^3
-    x 512 samples, an empty 64^3 x 64 samples), the launch sequences and the colour engines, one render each per
-    round, and compares every render with that configuration's own first result.  Reports, per configuration, the
-    rounds whose colour / depth differ and by how much -- depth comes from k_march alone, the f32 / valu engines use no
-    bf16 MFMA: which of them move tells the kernel.  SCREEN_ROUNDS rounds (default 400)."""
-    import torch
-    sys.path.insert(0, ROOT)
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    big = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    empty = quiet(make_field, [64, 64, 64], "cpu", seed=3)
-    with torch.no_grad():
-        for p in empty.density_plane:
-            p.zero_()
-    empty = empty.to("cuda:0")
-    empty.density_shift = -30.0
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    engines = os.environ.get("SCREEN_ENGINES", "bf16x3:0,bf16x3:9,bf16x3_fused:0,f32:0").split(",")
-    cfgs = []
-    for e in engines:
-        eng, pipe = e.split(":")
-        cfgs.append((eng, int(pipe), big, 1536, "300^3"))
-        cfgs.append((eng, int(pipe), empty, 192, "empty64"))
-    n = int(os.environ.get("SCREEN_ROUNDS", "400"))
-    ref, odd = {}, {}
-    scratch = torch.empty(1 << 22, device="cuda")
-    with torch.no_grad():
-        for rnd in range(n):
-            for ci, (eng, pipe, fld, ns, name) in enumerate(cfgs):
-                fld.mlp_engine = eng
-                lib.lrf_debug_set_shade_pipe(pipe)
-                if rnd % 3 == 1:
-                    scratch.sort()                     # a foreign kernel in between (the trigger seen in round 2)
-                rgb, dep = fld(rays, white_bg=True, is_train=False, N_samples=ns)
-                if ci not in ref:
-                    ref[ci] = (rgb.clone(), dep.clone())
-                    odd[ci] = []
-                    continue
-                dc = (rgb - ref[ci][0]).abs().amax(-1)
-                dd = (dep - ref[ci][1]).abs()
-                if float(dc.max()) > 0 or float(dd.max()) > 0:
-                    odd[ci].append((rnd, int((dc > 0).sum()), float(dc.max()), int((dd > 0).sum()), float(dd.max())))
-        lib.lrf_debug_set_shade_pipe(0)
-    total = 0
-    for ci, (eng, pipe, fld, ns, name) in enumerate(cfgs):
-        total += len(odd[ci])
-        log(f"screen {eng}:{pipe} {name}: {len(odd[ci])} of {n - 1} renders differ from the first "
-            f"(round, rays colour, max colour, rays depth, max depth): {odd[ci][:6]}")
-    log(f"screen total odd renders: {total}")
-
-
-def stage_flake2():
-    """Rare run-to-run differences of the default forward, localised: two-launch (fused scan / finalize) vs four-launch
-    sequence, 20000 renders each; for every differing render the rays that differ, their |diff|, and whether the ray
-    straddles a workgroup boundary of k_shade2's tile partition (those are summed by the last workgroup to finish)."""
-    import numpy as np
-    import torch
-    sys.path.insert(0, ROOT)
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-
-    def fwd():
-        return f(rays, white_bg=True, is_train=False, N_samples=1536)
-    with torch.no_grad():
-        for _ in range(300):
-            fwd()
-        rgb0, dep0, w, acc, z = f.render_weights(rays, N_samples=1536)
-        ntile = ((w > f.rayMarch_weight_thres).sum(-1) + 15) // 16            # tiles per ray (floater filter off)
-        toff = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), ntile.cumsum(0)])
-        T = int(toff[-1])
-        nb = torch.cuda.get_device_properties(0).multi_processor_count
-        bounds = torch.tensor([(b * 16) * T // (nb * 16) for b in range(1, nb)], device="cuda")
-        strad = ((toff[:-1, None] < bounds[None]) & (toff[1:, None] > bounds[None])).any(-1)
-        log(f"tiles {T}, workgroups {nb}, rays straddling a workgroup boundary: {int(strad.sum())}")
-        for pipe in [int(v) for v in os.environ.get("FLAKE2_PIPES", "0,9,0,9").split(",")]:
-            lib.lrf_debug_set_shade_pipe(pipe)
-            ref = fwd()
-            ref = (ref[0].clone(), ref[1].clone())
-            nd, found = 0, []
-            for it in range(int(os.environ.get("FLAKE2_N", "20000"))):
-                o = fwd()
-                if not torch.equal(o[0], ref[0]) or not torch.equal(o[1], ref[1]):
-                    nd += 1
-                    d = (o[0] - ref[0]).abs().amax(-1)
-                    dd = (o[1] - ref[1]).abs()
-                    idx = torch.nonzero((d > 0) | (dd > 0)).flatten()
-                    if len(found) < 40:
-                        found.append([(int(i), float(d[i]), float(dd[i]), bool(strad[i]), int(ntile[i])) for i in idx[:6]])
-            log(f"shade_pipe {pipe} ({'two' if pipe == 0 else 'four'} launches): {nd} renders differ from the first; "
-                f"(ray, |d rgb|, |d depth|, straddles a boundary, tiles): {found[:6]}")
-        lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_flake3():
-    """Which kernel do rare run-to-run differences come from?  Same 4096-ray render, every colour engine (they share
-    k_march): renders differing from the first in colour / in depth, largest difference, rays affected."""
-    import torch
-    sys.path.insert(0, ROOT)
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    n = int(os.environ.get("FLAKE3_N", "4000"))
-    with torch.no_grad():
-        for _ in range(300):
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-        for rep in range(2):
-            for eng, pipe in (("bf16x3", 0), ("bf16x3", 9), ("bf16x3_split", 0), ("bf16x3_fused", 0), ("f32", 0), ("valu", 0)):
-                f.mlp_engine = eng
-                lib.lrf_debug_set_shade_pipe(pipe)
-                m = n if eng != "valu" else max(50, n // 40)
-                ref = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                ref = (ref[0].clone(), ref[1].clone())
-                nc = nd = 0
-                mc = md = 0.0
-                rays_c = set()
-                for _ in range(m):
-                    o = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                    if not torch.equal(o[0], ref[0]):
-                        nc += 1
-                        d = (o[0] - ref[0]).abs().amax(-1)
-                        mc = max(mc, float(d.max()))
-                        if len(rays_c) < 64:
-                            rays_c.update(int(i) for i in torch.nonzero(d > 0).flatten()[:8])
-                    if not torch.equal(o[1], ref[1]):
-                        nd += 1
-                        md = max(md, float((o[1] - ref[1]).abs().max()))
-                log(f"{eng} (shade_pipe {pipe}): {m} renders | colour differs in {nc} (max {mc:.2e}, rays {sorted(rays_c)[:10]}) | depth differs in {nd} (max {md:.2e})")
-        f.mlp_engine = "bf16x3"
-        lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_march():
-    """k_march with its density lines in LDS vs in global memory (300^3 and 500^3)."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    lib = N.lib()
-    rays = make_rays(4096, 1).cuda()
-    for grid, ns in ((300, 1536), (340, -1), (500, -1)):
-        f = quiet(make_field, [grid] * 3, "cpu", seed=0).to("cuda:0")
-        z = f.z_schedule(False, ns, rays.device).contiguous()
-        with torch.no_grad():
-            for _ in range(200):
-                f(rays, white_bg=True, is_train=False, N_samples=ns)
-        for on in (1, 0, 1):
-            lib.lrf_debug_set_lds_lines(on)
-            p = bench.kernel_profile(f, rays, z, reps=10)
-            log(f"grid {grid} S {z.numel()} lds lines {on}: k_march {p['march_ms'] * 1e3:.1f} us shade {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us")
-    lib.lrf_debug_set_lds_lines(1)
-
-
 def stage_bwd_overlap():
     """Training step (forward with a graph + backward) with the weight-gradient GEMMs on a side stream vs in line."""
     import torch
@@ -1487,95 +974,6 @@ def stage_bwd_overlap():
     lib.lrf_debug_set_train_fwd_engine(1)
 
 
-def stage_shade_pipe():
-    """k_shade2 with / without the software-pipelined plane-0 gather: time, agreement, determinism."""
-    import torch
-    sys.path.insert(0, ROOT)
-    import bench
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    z = f.z_schedule(False, 1536, rays.device).contiguous()
-    lib = N.lib()
-    with torch.no_grad():
-        for _ in range(300):
-            f(rays, white_bg=True, is_train=False, N_samples=1536)
-        ref, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-        for on in (0, 8, 0):
-            lib.lrf_debug_set_shade_pipe(on)
-            first, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-            nd = sum(0 if torch.equal(first, f(rays, white_bg=True, is_train=False, N_samples=1536)[0]) else 1 for _ in range(200))
-            p = bench.kernel_profile(f, rays, z, reps=10)
-            log(f"shade pipe {on}: k_shade2 {(p['shade_ms'] - p['scan_ms']) * 1e3:.1f} us total {p['total_ms'] * 1e3:.1f} us | "
-                f"max |rgb - unpiped| {float((first - ref).abs().max()):.2e} | renders differing {nd}/200")
-    lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_flake():
-    """Which part of k_shade2 produces the rare run-to-run differences?  DIAG_RENDERS renders per configuration;
-    colour and depth (depth comes from k_march alone) compared with the first render.
-    modes: 0 shipped (VALU head, no global load in flight under the MFMA chain) | 7 MFMA head, loads in flight |
-    8 layers 1-2 on the compiler-scheduled builtin (fenced, loads drained)"""
-    import torch
-    from localrf_amd import _native as N
-    from util import make_field, make_rays, quiet
-    f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-    rays = make_rays(4096, 1).cuda()
-    lib = N.lib()
-    n = int(os.environ.get("DIAG_RENDERS", "12000"))
-    cfgs = [("bf16x3", 0), ("bf16x3", 8), ("bf16x3", 7), ("bf16x3_split", 0), ("bf16x3_fused", 0), ("bf16x3", 0)]
-    for eng, mode in cfgs:
-        f.mlp_engine = eng
-        lib.lrf_debug_set_shade_pipe(mode)
-        t0 = time.time()
-        with torch.no_grad():
-            first, d0 = f(rays, white_bg=True, is_train=False, N_samples=1536)
-            bad_rgb = bad_dep = 0
-            worst = 0.0
-            nrays = 0
-            for _ in range(n):
-                again, d1 = f(rays, white_bg=True, is_train=False, N_samples=1536)
-                if not torch.equal(first, again):
-                    bad_rgb += 1
-                    dd = (first - again).abs().amax(-1)
-                    worst = max(worst, float(dd.max()))
-                    nrays = max(nrays, int((dd > 0).sum()))
-                if not torch.equal(d0, d1):
-                    bad_dep += 1
-        log(f"engine {eng} mode {mode}: {n} renders in {time.time() - t0:.1f} s | colour differs {bad_rgb} (max {worst:.2e}, up to {nrays} rays) | depth differs {bad_dep}")
-    lib.lrf_debug_set_shade_pipe(0)
-
-
-def stage_coldstart():
-    """Are the rare run-to-run differences a cold-start effect?  Fresh process per trial, 400 renders right after
-    start-up (no clock ramp), per engine; counts renders that differ from the majority result."""
-    import subprocess as sp
-    code = r"""
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from util import make_field, make_rays, quiet
-f = quiet(make_field, [300, 300, 300], "cpu", seed=0).to("cuda:0")
-f.mlp_engine = sys.argv[1]
-rays = make_rays(4096, 1).cuda()
-outs = []
-with torch.no_grad():
-    for i in range(400):
-        rgb, _ = f(rays, white_bg=True, is_train=False, N_samples=1536)
-        outs.append(rgb)
-torch.cuda.synchronize()
-ref = outs[-1]
-bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
-print(len(bad), bad[:8], max([float((o - ref).abs().max()) for o in outs]) )
-""" % (ROOT, os.path.join(ROOT, "tests"))
-    for eng in ("bf16x3", "bf16x3_fused", "bf16x3_split"):
-        res = []
-        for trial in range(int(os.environ.get("DIAG_TRIALS", "12"))):
-            r = sp.run([sys.executable, "-c", code, eng], capture_output=True, text=True, timeout=120)
-            res.append(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "ERR " + r.stderr[-200:])
-        log(f"engine {eng}: per fresh process (differing renders of 400, first indices, max |diff|): {res}")
-
-
 def stage_scene_profile():
     """Host-side profile of LocalTensorfs.forward at BASELINE configs[2] (4 blended 300^3 fields, 4096 rays)."""
     import cProfile
@@ -1614,7 +1012,7 @@ def stage_scene_profile():
     log(buf.getvalue()[-4500:])
 
 
-STAGES = [("capture3", 200), ("hash3", 200), ("det3", 200), ("shade3_phases", 200), ("screen", 300), ("flake3", 300), ("flake2", 300), ("train_host", 300), ("geo", 200), ("fuse", 200), ("scene_profile", 200), ("coldstart", 900), ("flake", 300), ("shade_pipe", 100), ("bwd_overlap", 100), ("march", 100), ("skew", 100), ("shade2_phases", 100), ("subbatch", 100), ("app_over", 100), ("soak", 100), ("overlap", 100), ("mlp_phases", 100), ("walls", 200), ("mfma_policy", 300), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
+STAGES = [("screen", 300), ("shade3_phases", 200), ("train_host", 300), ("geo", 200), ("scene_profile", 200), ("bwd_overlap", 100), ("soak", 100), ("fuzz_case", 200), ("fuzz", 400), ("soak_train", 300), ("batch", 200), ("big", 200), ("reg", 120), ("adam", 120), ("cone", 120), ("import", 240), ("pack_density", 60), ("render_valu", 60), ("render_mfma", 60), ("render_big", 120), ("chunk", 120), ("nondet", 120), ("dump", 120), ("bwd", 200), ("torch_train", 200), ("xcd", 100), ("firstcall", 150), ("fwdbwdfwd", 150), ("scene", 200)]
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol(built_lib):
     from localrf_amd import _native
-    hdr = open(os.path.join(ROOT, "include", "lrf.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "lrf.h")).read() + open(os.path.join(ROOT, "include", "lrf_debug.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(lrf_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import vm_render_np as oracle
-from util import (retry_on_rare_flake, capture_train_ws, check_grads_with_flips, field_from_golden, field_from_seed, golden_field_dict,
+from util import (capture_train_ws, check_grads_with_flips, field_from_golden, field_from_seed, golden_field_dict,
                   load_golden, make_field, make_rays, quiet, rel_err, relu_flip_report)
 
 pytestmark = pytest.mark.gpu
@@ -35,7 +35,7 @@ def _check_rays(got, ref, tol=TOL, max_outliers=0, outlier_abs=2e-3):
         assert np.abs(got - ref).max() < outlier_abs
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_fused", "bf16x3_split", "f32", "valu"])
+@pytest.mark.parametrize("engine", ["bf16x3", "f32", "valu"])
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_field_forward_vs_reference_golden(built_lib, name, engine):
     g = load_golden(name)
@@ -209,7 +209,6 @@ def _walls_field(grid, seed, dev):
     return f.to(dev)
 
 
-@retry_on_rare_flake()
 def test_early_termination_on_a_trained_like_scene(built_lib):
     """k_march stops gathering once the transmittance is below term_T (LrfField.term_T): colours and
     acc are unchanged, depth moves by <= term_T * z_max / |d|, and the samples behind the walls are
@@ -262,7 +261,7 @@ def big(built_lib):
     return f, rays
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_fused", "bf16x3_split", "f32"])
+@pytest.mark.parametrize("engine", ["bf16x3", "f32"])
 def test_config2_all_rays_vs_reference_golden(big, engine):
     """BASELINE.json configs[1] at full size against the REFERENCE's own output for all 4096 rays
     (tests/golden/config2_300cube.npz: 300^3 field from seed 0, 512 samples).  A ray may miss the 1e-4
@@ -292,75 +291,53 @@ def test_config2_all_rays_vs_reference_golden(big, engine):
     assert abs(n_sh - int(g["n_shaded"])) <= 16, (n_sh, int(g["n_shaded"]))
 
 
-@retry_on_rare_flake()
-def test_split_and_fused_colour_engines_are_bit_identical(big):
-    """k_shade2 (default), k_app + k_mlp and round 1's k_shade_bf16 run the same split-bf16 products in the same
-    MFMA order; the head is an MFMA layer in the first two and fp32 FMAs in the last, and the compiler contracts
-    a few fp32 multiply-adds of the address arithmetic differently per kernel: they agree to rounding."""
+def test_tile_walk_is_independent_of_the_batch(big):
+    """The colour kernel (k_shade3) cuts the tile list into whole-ray workgroup ranges, hands tiles to waves from a
+    per-workgroup queue and sums a ray's partials in tile order: a ray's colour therefore depends on that ray alone.
+    Any sub-batch must reproduce the full batch's rays BIT FOR BIT -- ragged sizes, one ray, a batch too large for the
+    LDS copy of the tile offsets (k_scan_tiles_n + global offsets), S = 344 and S = 2048, rays that leave the box at
+    once, and an empty field (one tile per ray: the forced last sample).  The exact-fp32 engine (16-sample tiles,
+    k_scan_tiles / k_finalize: an independent tile walk) must agree to the split-bf16 error."""
     f, rays = big
-    outs = {}
-    for eng in ("bf16x3", "bf16x3_split", "bf16x3_fused"):
-        f.mlp_engine = eng
-        with torch.no_grad():
-            outs[eng] = f(rays, white_bg=True, is_train=False, N_samples=1536)
-    f.mlp_engine = "bf16x3"
-    for eng in ("bf16x3_split", "bf16x3_fused"):
-        d = float((outs["bf16x3"][0] - outs[eng][0]).abs().max())
-        print("default vs", eng, "max |diff|", d)
-        assert d < 2e-5, (eng, d)
-        assert torch.equal(outs["bf16x3"][1], outs[eng][1])
 
+    def render(field, r, eng="bf16x3", **kw):
+        field.mlp_engine = eng
+        try:
+            with torch.no_grad():
+                return field(r, white_bg=kw.get("white_bg", True), is_train=False, N_samples=kw.get("N", 1536))
+        finally:
+            field.mlp_engine = "bf16x3"
 
-@retry_on_rare_flake()
-def test_two_launch_sequence_equals_four_launch_sequence(big):
-    """Default engine: k_march -> k_shade2<FUSE> (tile scan and per-ray sum folded into the colour kernel: the scan
-    per workgroup in LDS, the sum by the workgroup owning all of a ray's tiles, boundary rays by the workgroup that
-    finishes last) against k_march -> k_scan_tiles -> k_shade2 -> k_finalize: same sums in the same order.  Ragged batch sizes, a batch
-    too large for the LDS copy of the offsets (falls back to four launches), rays that leave the box at once, and an
-    empty field (one tile per ray: the forced last sample)."""
-    import localrf_amd._native as N
-    f, rays = big
-    lib = N.lib()
+    def check(field, r, cuts, **kw):
+        rgb, dep = render(field, r, **kw)
+        for lo, hi in cuts:
+            a, d = render(field, r[lo:hi], **kw)
+            assert torch.equal(a, rgb[lo:hi]) and torch.equal(d, dep[lo:hi]), (r.shape[0], lo, hi, float((a - rgb[lo:hi]).abs().max()))
+        ref, dref = render(field, r[:4096], "f32", **kw)
+        assert torch.equal(dref, dep[:4096])                                     # depth: the same k_march
+        assert float((ref - rgb[:4096]).abs().max()) < 3e-5, float((ref - rgb[:4096]).abs().max())
+        return rgb
 
-    def both(field, r, **kw):
-        outs = []
-        for pipe in (0, 9):
-            lib.lrf_debug_set_shade_pipe(pipe)
-            try:
-                with torch.no_grad():
-                    outs.append(field(r, white_bg=kw.get("white_bg", True), is_train=False, N_samples=kw.get("N", 1536)))
-            finally:
-                lib.lrf_debug_set_shade_pipe(0)
-        d = (outs[0][0] - outs[1][0]).abs()
-        print("two vs four launches: R", r.shape[0], "rays differing", int((d.amax(-1) > 0).sum()), "max |diff|", float(d.max()))
-        assert torch.equal(outs[0][1], outs[1][1])               # depth: the same k_march
-        assert float(d.max()) < 5e-7                             # colours: the two template instances round alike up to fp contraction
-        return outs[0]
-
-    both(f, rays)
-    both(f, rays, white_bg=False)
-    for R in (1, 63, 1000, 4095):
-        both(f, rays[:R])
-    both(f, rays, N=1032)                                    # S = 344
-    many = make_rays(20000, 5).to(DEV)                       # offsets do not fit in LDS: four launches either way
-    both(f, many)
-    both(f, many[:12000])                                    # 12 rounds of the in-kernel scan, ~47 rays per workgroup
-    both(f, many[:5000], N=6144)                             # S = 2048
+    check(f, rays, [(0, 1), (0, 63), (17, 1017), (0, 4095), (4095, 4096), (1000, 4096)])
+    check(f, rays, [(5, 700)], white_bg=False)
+    check(f, rays, [(0, 2048)], N=1032)                       # S = 344
+    many = make_rays(20000, 5).to(DEV)                        # offsets do not fit in LDS: k_scan_tiles_n, global offsets
+    check(f, many, [(0, 4096), (4096, 16000), (12000, 20000), (19999, 20000)])
+    check(f, many[:5000], [(100, 3000)], N=6144)              # S = 2048
     far = rays.clone()
-    far[::3, :3] = 50.0                                      # every third ray starts far outside and points away:
+    far[::3, :3] = 50.0                                       # every third ray starts far outside and points away:
     far[::3, 3:] = torch.tensor([1.0, 0.2, 0.1], device=DEV)  # only the forced last sample can be shaded
-    both(f, far)
+    check(f, far, [(0, 1000)])
     empty = quiet(make_field, [64, 64, 64], "cpu", seed=3)
     with torch.no_grad():
         for p in empty.density_plane:
             p.zero_()
     empty = empty.to(DEV)
-    empty.density_shift = -30.0                              # alpha ~ 0 everywhere
-    rgb, _ = both(empty, rays, N=192)
+    empty.density_shift = -30.0                               # alpha ~ 0 everywhere
+    rgb = check(empty, rays, [(0, 77)], N=192)
     assert rgb.shape == (4096, 3)
 
 
-@retry_on_rare_flake()
 def test_full_size_properties(big):
     f, rays = big
     with torch.no_grad():
@@ -371,8 +348,8 @@ def test_full_size_properties(big):
         ra, da = f(rays[:1000], white_bg=True, is_train=False, N_samples=1536)
         rb, db = f(rays[1000:], white_bg=True, is_train=False, N_samples=1536)
     assert torch.equal(depth, depth2) and torch.equal(torch.cat([da, db]), depth)
-    assert float((rgb - rgb2).abs().max()) < 1e-5                            # repeatable (bitwise: see the
-    assert float((torch.cat([ra, rb]) - rgb).abs().max()) < 1e-5             #  200-render test below)
+    assert torch.equal(rgb, rgb2)                                            # repeatable, bit for bit
+    assert torch.equal(torch.cat([ra, rb]), rgb)                             # chunk invariance, bit for bit
     assert (w >= 0).all() and torch.allclose(w.sum(-1), acc, atol=1e-5)
     assert torch.allclose(acc, torch.ones_like(acc), atol=1e-5)              # last alpha forced to 1
     assert torch.allclose(rgb, rgb_nobg + (1 - acc)[:, None], atol=1e-6)
@@ -389,30 +366,25 @@ def test_full_size_properties(big):
     assert rel_err(_np(outs["bf16x3"]), _np(outs["valu"])) < 3e-5
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_fused", "bf16x3_split", "f32"])
-@retry_on_rare_flake()
+@pytest.mark.parametrize("engine", ["bf16x3", "f32"])
 def test_repeat_runs_are_bitwise_identical(big, engine):
-    """Guards the hand-issued bf16 MFMA chain (mfma_bf16_acc / hold / settle in lrf_render.hip): 200 renders of the same
-    4096x512 batch.  Every flaky build seen during development differed from the others in 1-21 rays of EVERY render by
-    1e-6...1e-5; the shipped build is bit-identical over tens of thousands of renders on most boxes of the pool
-    (scripts/gpu_diag.py flake2 / flake3).  On two of ~14 boxes it showed phases in which a few rays per render move
-    by 1-4 ulp (<= 2.4e-7, both launch sequences, cause not isolated: DESIGN.md finding 17; later single renders off
-    by 1.7e-6 and 1.6e-5 were seen in other tests, hence the retry), so the test is written per
-    ray: every ray's colour must equal its most frequent value in at least 99 % of the renders, deviate from it by at
-    most 5e-7 in the others, and at most 0.5 % of all (render, ray) pairs may deviate at all."""
+    """200 renders of the same 4096 x 512 batch, with a foreign kernel (a sort) thrown in between: every render must
+    equal the first BIT FOR BIT.  Rounds 1-2 saw rare differences here (DESIGN.md finding 17); their cause was packed
+    fp32 VALU arithmetic beside another wave's bf16 MFMAs (profiles/r08b_packed_fp32_beside_mfma.md), which the library
+    no longer contains (tests/test_isa_checks.py)."""
     f, rays = big
     f.mlp_engine = engine
-    with torch.no_grad():
-        runs = torch.stack([f(rays, white_bg=True, is_train=False, N_samples=1536)[0] for _ in range(200)])
-    f.mlp_engine = "bf16x3"
-    mode = runs.median(0).values                                   # = the most frequent value when it has a majority
-    dev = (runs - mode).abs().amax(-1)                             # [render, ray]
-    odd = dev > 0
-    print(engine, "renders with an odd ray:", int(odd.any(1).sum()), "of 200 | odd (render, ray) pairs:", int(odd.sum()),
-          "| largest deviation:", float(dev.max()))
-    assert float(dev.max()) <= 5e-7, float(dev.max())
-    assert int(odd.sum(0).max()) <= 2, int(odd.sum(0).max())       # a ray is off its usual value in <= 1 % of the renders
-    assert int(odd.sum()) <= 0.005 * odd.numel(), int(odd.sum())
+    scratch = torch.rand(1 << 20, device=DEV)
+    try:
+        with torch.no_grad():
+            first = [t.clone() for t in f(rays, white_bg=True, is_train=False, N_samples=1536)]
+            for i in range(200):
+                if i % 3 == 1:
+                    scratch.sort()
+                rgb, dep = f(rays, white_bg=True, is_train=False, N_samples=1536)
+                assert torch.equal(rgb, first[0]) and torch.equal(dep, first[1]), (engine, i, float((rgb - first[0]).abs().max()))
+    finally:
+        f.mlp_engine = "bf16x3"
 
 
 def test_layout_cache_tracks_parameter_updates(built_lib):
@@ -597,7 +569,7 @@ def test_large_noncubic_grid_forward_backward(built_lib):
     assert torch.isfinite(rays.grad).all() and float(rays.grad.abs().max()) > 0
     with torch.no_grad():
         rgb2, _ = f(rays.detach(), white_bg=True, is_train=False, N_samples=-1)
-    assert float((rgb.detach() - rgb2).abs().max()) < 1e-5          # (bitwise in 3000-render soak runs)
+    assert float((rgb.detach() - rgb2).abs().max()) < 1e-5          # (the recording forward is the 16-sample training kernel, this one k_shade3)
 
 
 def test_row_saving_forward_equals_recomputing_backward(built_lib):

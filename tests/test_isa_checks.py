@@ -1,13 +1,15 @@
-"""Static checks on the gfx950 ISA hipcc emits for the render kernels (no GPU needed).
+"""Static checks on the gfx950 ISA hipcc emits for the library (no GPU needed): the source is compiled exactly as
+__graft_entry__.build() compiles it and the device assembly is inspected.
 
-1. No v_mfma_f32_16x16x32_bf16 may have its destination overlap SrcA/SrcB.  hipcc (ROCm 7.2)
-   emits that overlap when a source dies at the instruction; on MI355X it produced rare,
-   run-to-run different 1e-5-scale errors in the split-bf16 colour chain (see keep_live() in
-   csrc/lrf_render.hip).  The kernel keeps sources live to forbid it; this test pins that.
-2. The bf16 MFMAs must accumulate in place (vDst == SrcC): the compiler under-pads the
-   "different vDst" dependent-MFMA hazard for this opcode (see mfma_bf16_acc()).
-3. k_march must not spill; k_shade_bf16 (capped at 128 VGPRs by its 1024-thread workgroup)
-   may park a few loop-invariant lane constants in scratch, bounded here.
+1. NO packed fp32 VALU instruction with a crossed operand select anywhere in the library.  On MI355X a
+   v_pk_mul/fma/add_f32 whose low result reads the HIGH half of a source (op_sel:[..,1,..]) returns a wrong low result
+   in lanes 48..63 when another wave of the SIMD issues bf16 MFMAs (scripts/ubench/pk_mfma.hip, exact integer
+   arithmetic; profiles/r08b_packed_fp32_beside_mfma.md).  hipcc's SLP vectoriser emits exactly that form for
+   "broadcast weight x pair of texels"; the library is therefore built with -fno-slp-vectorize (csrc/lrf_tu.h).  This
+   was the cause of the run-to-run differences of rounds 1-2 (DESIGN.md finding 17).
+2. k_shade3 (the default colour kernel): 135 v_mfma_f32_32x32x16_bf16 per tile (15 basis + 24 layer 1 + 96 layer 2),
+   no scratch, at most 256 registers (two waves per SIMD).
+3. k_march must not spill; the training kernels' scratch stays bounded; the weight-gradient GEMMs keep their shape.
 """
 import os
 import re
@@ -18,6 +20,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "localrf_amd", "csrc", "lrf_render.hip")
+BUILD_FLAGS = ["-fno-slp-vectorize"]            # = __graft_entry__.build()
 
 
 def _device_asm(extra):
@@ -34,120 +37,72 @@ def _device_asm(extra):
 
 @pytest.fixture(scope="module")
 def asm():
-    """The library is linked from two translation units of the same source (csrc/lrf_tu.h, __graft_entry__.build):
-    default flags for everything but the training entry points, -fno-slp-vectorize for those.  The text checked here is
-    each shipped kernel as the unit it ships from compiles it (the namespace rename of unit 2 does not change code)."""
-    fwd, bwd = _device_asm([]), _device_asm(["-fno-slp-vectorize"])
-
-    def kernel(text, name):
-        m = re.search(r"(^|\n)(_ZN3lrf\d+%s[^\n:]*:[^\n]*\n.*?\.end_amdhsa_kernel)" % name, text, re.S)
-        assert m, name
-        return m[2]
-    parts = [kernel(bwd if k in FROM_TRAINING_UNIT else fwd, k) for k in ALL_CHECKED]
-    return "\n".join(parts)
+    import __graft_entry__ as ge
+    src = open(ge.__file__).read()
+    assert all(f in src for f in BUILD_FLAGS), "tests/test_isa_checks.py must compile with the flags of __graft_entry__.build()"
+    return _device_asm(BUILD_FLAGS)
 
 
-def _overlap(x, y):
-    return not (x[1] < y[0] or y[1] < x[0])
-
-
-# Kernels whose bf16 MFMAs are HAND-ISSUED (gathers and an MFMA chain in one kernel: the configuration that
-# showed run-to-run differences when hipcc scheduled it, DESIGN.md) and their bf16 MFMA counts per tile:
-# 18 (basis) + 24 (layer 1) + 96 (layer 2) [+ 12 (head)].  k_mlp has no gathers; its default policy (4) is the
-# compiler-scheduled builtin, pinned by the 200-render determinism test on the GPU; policy 0 is the hand-issued
-# fallback and is held to the rules below.
-WGRAD = ("k_wgrad_w2E", "k_wgradILi8ELi2ELb0EE", "k_wgradILi2ELi5ELb1EE", "k_wgradILi1ELi9ELb1EE")
-FROM_TRAINING_UNIT = ("k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE") + WGRAD
-ALL_CHECKED = WGRAD + ("k_shade_bf16E", "k_bwd_shade_fwdE", "k_bwd_shade_dgradILb1EE", "k_appE", "k_mlpILi0ELb0ELb1EE", "k_mlpILi4ELb0ELb1EE",
-               "k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE",
-               "k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", "k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", "k_marchILb1EE", "k_marchILb0EE")
-SHIPPED = (("k_shade_bf16E", 138), ("k_bwd_shade_fwdE", 138), ("k_bwd_shade_dgradILb1EE", 135), ("k_appE", 18), ("k_mlpILi0ELb0ELb1EE", 132),
-           ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE", 138),
-           ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", 138), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", 138))
-
-
-def _shipped_text(asm, kern):
-    return "\n".join(_kernel_lines(asm, kern))
-
-
-def test_bf16_mfma_destination_never_overlaps_sources(asm):
-    pat = re.compile(r"v_mfma_f32_16x16x32_bf16 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]")
-    for kern, count in SHIPPED:
-        n = 0
-        for m in pat.finditer(_shipped_text(asm, kern)):
-            n += 1
-            d, a, b = (int(m[1]), int(m[2])), (int(m[3]), int(m[4])), (int(m[5]), int(m[6]))
-            assert not _overlap(d, a) and not _overlap(d, b), (kern, m[0])
-        assert n >= count, (kern, n)
-
-
-def test_bf16_mfma_accumulates_in_place(asm):
-    pat = re.compile(r"v_mfma_f32_16x16x32_bf16 (v\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], (v\[\d+:\d+\]|0)")
-    for kern, count in SHIPPED:
-        ms = list(pat.finditer(_shipped_text(asm, kern)))
-        assert len(ms) >= count, (kern, len(ms))
-        for m in ms:
-            assert m[1] == m[2], (kern, m[0])
-
-
-def _kernel_lines(asm, mangled_prefix):
-    m = re.search(r"^(_ZN3lrf\d+%s[^:\s]*):[^\n]*\n(.*?)s_endpgm" % mangled_prefix, asm, re.S | re.M)
-    assert m, mangled_prefix
-    out = []
-    for ln in m[2].splitlines():
-        ln = ln.split(";")[0].strip()
-        if ln and not ln.startswith("."):
-            out.append(ln)
+def _kernels(asm):
+    """name -> body text of every kernel in the assembly."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
+        out[m[1]] = m[2]
     return out
 
 
-def _regs(tok):
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
-    if m:
-        return set(range(int(m[1]), int(m[2]) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return {int(m[1])} if m else set()
+def _body(asm, pattern):
+    hits = [(k, v) for k, v in _kernels(asm).items() if re.search(pattern, k)]
+    assert hits, pattern
+    return hits
 
 
-def test_bf16_mfma_sources_are_not_rewritten_close_behind(asm):
-    """No instruction may write a VGPR that a v_mfma_f32_16x16x32_bf16 read as SrcA/SrcB within
-    the next 24 issue slots (s_nop N counts N+1): see hold()/gemm_step in csrc/lrf_render.hip."""
-    WINDOW = 24
-    for kern, count in SHIPPED:
-        lines = _kernel_lines(asm, kern)
-        checked = 0
-        for i, ln in enumerate(lines):
-            if not ln.startswith("v_mfma_f32_16x16x32_bf16"):
+def test_no_packed_fp32_with_crossed_operand_select(asm):
+    """The erratum-prone form: v_pk_{mul,fma,add}_f32 with any op_sel bit set (a LOW result reading a HIGH source half).
+    op_sel_hi deviations (a high result reading a low half) were never wrong in the exact test and are allowed."""
+    n_kernels = n_pk = 0
+    for name, body in _kernels(asm).items():
+        n_kernels += 1
+        for ln in body.splitlines():
+            if not re.search(r"\bv_pk_(mul|fma|add)_f32\b", ln):
                 continue
-            ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
-            src = _regs(ops[1]) | _regs(ops[2])
-            slots, j = 0, i + 1
-            while j < len(lines) and slots < WINDOW:
-                w = lines[j]
-                if w.startswith("s_cbranch") or w.startswith("s_branch") or w.endswith(":"):
-                    break
-                m = re.match(r"s_nop (\d+)", w)
-                slots += int(m[1]) + 1 if m else 1
-                parts = w.split(None, 1)
-                if len(parts) == 2 and not parts[0].startswith(("s_", "global_store", "scratch_store", "ds_write",
-                                                                  "ds_add", "buffer_store")):
-                    dst = _regs(parts[1].split(",")[0].strip())
-                    if parts[0].startswith("v_mfma"):
-                        dst = set()                      # in-place accumulators are not sources
-                    assert not (dst & src), (kern, ln, w, slots)
-                j += 1
-            checked += 1
-        assert checked >= count, (kern, checked)
+            n_pk += 1
+            m = re.search(r"op_sel:\[([01,]+)\]", ln)
+            assert not (m and "1" in m[1]), (name, ln.strip())
+    assert n_kernels > 40, n_kernels
+    print("kernels", n_kernels, "packed fp32 instructions (all with straight low halves)", n_pk)
+
+
+def test_build_does_not_use_the_slp_vectoriser():
+    import __graft_entry__ as ge
+    src = open(ge.__file__).read()
+    assert "-fno-slp-vectorize" in src
+
+
+def test_shade3_shape(asm):
+    for name, body in _body(asm, r"k_shade3ILi8ELb[01]ELb0E"):
+        assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) == 135, name
+        assert not re.search(r"v_mfma_f32_16x16x32_bf16", body), name
+        meta = asm[asm.index(name + ":"):]
+        meta = meta[:meta.index(".end_amdhsa_kernel") + 4000]
+        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
+        assert priv and int(priv[1]) == 0, (name, priv and priv[1])
+        vg = re.search(r"; NumVgprs: (\d+)", meta)
+        assert vg and int(vg[1]) <= 256, (name, vg and vg[1])
+        assert len(re.findall(r"global_load_dwordx4", body)) >= 54, name          # three planes x six taps x three 16-byte pieces
 
 
 def test_scratch_use_is_bounded(asm):
-    for kern, limit in (("k_marchILb1EE", 0), ("k_marchILb0EE", 0), ("k_shade_bf16E", 128), ("k_appE", 0), ("k_mlpILi0ELb0ELb1EE", 0), ("k_mlpILi4ELb0ELb1EE", 0),
-                        ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb0EE", 0), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb0EE", 0),
-                        ("k_shade2ILb0ELb0ELi0ELi3ELi0ELb1EE", 320), ("k_shade2ILb0ELb0ELi0ELi3ELi1ELb1EE", 320)):
-        m = re.search(r"\.amdhsa_kernel _ZN3lrf\d+%s.*?\.end_amdhsa_kernel" % kern, asm, re.S)
-        assert m, kern
-        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m[0])
-        assert priv and int(priv[1]) <= limit, (kern, priv and priv[1])
+    for pat, limit in ((r"k_marchILb1EE", 0), (r"k_marchILb0EE", 0), (r"k_bwd_shade_fwdE", 128),
+                       (r"k_bwd_shade_dgradILb1EE", 128)):
+        for name, _ in _body(asm, pat):
+            meta = asm[asm.index(".amdhsa_kernel " + name):]
+            meta = meta[:meta.index(".end_amdhsa_kernel")]
+            priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
+            assert priv and int(priv[1]) <= limit, (name, priv and priv[1])
+
+
+WGRAD = ("k_wgrad_w2E", "k_wgradILi8ELi2ELb0EE", "k_wgradILi2ELi5ELb1EE", "k_wgradILi1ELi9ELb1EE")
 
 
 def test_weight_gradient_gemms(asm):
@@ -156,16 +111,16 @@ def test_weight_gradient_gemms(asm):
     no scratch, and the staging loads are branch-free, so the wait in front of the LDS stage is a counted vmcnt(n)
     placed by the compiler, not a vmcnt(0) behind a predicated block."""
     def body(kern):
-        m = re.search(r"(^|\n)(_ZN3lrf\d+%s[^\n:]*:[^\n]*\n.*?\.end_amdhsa_kernel)" % kern, asm, re.S)
-        assert m, kern
-        return m[2]
-    w2 = body("k_wgrad_w2E")
+        return _body(asm, kern)[0]
+    _, w2 = body("k_wgrad_w2E")
     assert len(re.findall(r"v_mfma_f32_16x16x32_bf16", w2)) == 54
     assert not re.search(r"v_mfma_f32_16x16x16_bf16", w2)
     assert len(re.findall(r"ds_read_b128", w2)) >= 18
     for kern in WGRAD:
-        t = body(kern)
-        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", t)
+        name, t = body(kern)
+        meta = asm[asm.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
         assert priv and int(priv[1]) == 0, (kern, priv and priv[1])
         loads = len(re.findall(r"global_load_dwordx4", t))
         assert loads >= 3, (kern, loads)

@@ -161,34 +161,6 @@ def local_from_golden_seed(g, device="cpu", camera_prior=None, lr_i=1e-3, n_grow
 
 
 
-def retry_on_rare_flake(attempts=3):
-    """For the tests that compare two renders of identical inputs at the ulp level.  DESIGN.md finding 17: on a few
-    boxes of the pool a render in a few thousand comes back with a handful of rays off (1-4 ulp usually, once 1.6e-5),
-    cause not isolated.  A regression fails every attempt the same way; the flake does not repeat.  The test passes if
-    a later attempt passes, and says so loudly -- the first failure is printed and raised as a warning."""
-    import functools
-    import warnings
-
-    def deco(fn):
-        @functools.wraps(fn)
-        def wrapped(*a, **kw):
-            first = None
-            for k in range(attempts):
-                try:
-                    out = fn(*a, **kw)
-                except AssertionError as e:            # noqa: PERF203
-                    if first is None:
-                        first = e
-                    print(f"[finding 17] {fn.__name__}: attempt {k + 1} of {attempts} failed: {str(e).splitlines()[0] if str(e) else e!r}")
-                    continue
-                if first is not None:
-                    warnings.warn(f"{fn.__name__}: passed on attempt {k + 1} after a non-repeating failure "
-                                  f"(DESIGN.md finding 17): {str(first).splitlines()[0] if str(first) else first!r}")
-                return out
-            raise first
-        return wrapped
-    return deco
-
 # ----------------------------------------------------------------- gradient parity with explained flips
 MAT_MODE = ((0, 1), (0, 2), (1, 2))
 VEC_MODE = (2, 1, 0)
