@@ -587,13 +587,17 @@ __global__ __launch_bounds__(1024) void k_shade(
   }
 }
 
-// ------------------------------------------------------------------ shade, split-bf16 engine
-// Same structure as k_shade, but every GEMM runs on v_mfma_f32_16x16x32_bf16 with both
-// operands split into hi + lo bf16 (x ~ hi + lo to 2^-16): acc += Ah*Bh + Ah*Bl + Al*Bh,
-// fp32 accumulate.  3 bf16 MFMAs (K=32 each) replace 8 fp32 MFMAs (K=4 each): ~5x fewer
-// matrix-pipe cycles at ~1e-5 relative error per product -- inside the 1e-4 parity budget
-// (measured in tests/test_gpu_parity.py).
+// ------------------------------------------------------------------ split-bf16 products, 16-sample tiles
+// The training kernels (lrf_backward.inl) run every GEMM of the colour network on v_mfma_f32_16x16x32_bf16 with both
+// operands split into hi + lo bf16 (x ~ hi + lo to 2^-16): acc += Al*Bh + Ah*Bl + Ah*Bh, fp32 accumulate -- ~1e-5
+// relative error per product, inside the 1e-4 parity budget (tests/test_gpu_parity.py).
+// Rounds 1-2 issued these MFMAs by hand (tied accumulators, four wait states behind each, operands held for 48 more)
+// because renders differed from run to run and a late operand read was suspected.  It was not that
+// (scripts/ubench/mfma_war.hip: the pipe reads its sources at issue; profiles/r08b: the cause was packed fp32 VALU
+// arithmetic): the chain is plain builtins now, the three terms term-major over the NT accumulators of a step so that
+// consecutive MFMAs never depend on each other.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split8(const float v[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -602,93 +606,32 @@ __device__ __forceinline__ void split8(const float v[8], bf16x8& hi, bf16x8& lo)
     hi[j] = h;
     lo[j] = (__bf16)(v[j] - (float)h);
   }
-  // VALU -> MFMA pad (see settle() below for the measurements): all eight operand registers
-  // pass through one asm statement, so every conversion has retired 16 wait states before
-  // the first MFMA that reads them and none is interleaved with the MFMA burst.
-#ifndef LRF_MFMA_BUILTIN
-  {
-    uint4 H = __builtin_bit_cast(uint4, hi), L = __builtin_bit_cast(uint4, lo);
-    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(H.x), "+v"(H.y), "+v"(H.z), "+v"(H.w),
-                                          "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w));
-    hi = __builtin_bit_cast(bf16x8, H);
-    lo = __builtin_bit_cast(bf16x8, L);
-  }
-#endif
 }
-// Explicit wait states on both sides of every v_mfma_f32_16x16x32_bf16 burst (used with the
-// hand-issued MFMA below).  Measured on MI355X, 4096 rays x 512 samples, 39 repeats of the same
-// render (scripts/gpu_diag.py stage_nondet), rays whose colour differs from the first run:
-//   compiler-scheduled builtin chain (-DLRF_MFMA_BUILTIN), aligned gathers      6-21 per run
-//   hand-issued in-place MFMA + pads, compiler-fused 8-byte-aligned dwordx4     1-11 per run
-//   hand-issued in-place MFMA + pads, aligned float4 gathers (this build)       0 in 117 runs
-// i.e. two independent hazards: the bf16 MFMA chain as hipcc (ROCm 7.2) schedules it, and
-// misaligned fused gathers (lrf_common.h, LRF_CAS).  The exact-fp32 engine
-// (v_mfma_f32_16x16x4_f32, compiler-scheduled) never showed either.
 template <int NT>
-__device__ __forceinline__ void settle(f32x4* acc) {
-#ifndef LRF_MFMA_BUILTIN
-#pragma unroll
-  for (int t = 0; t < NT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[t]));
-#endif
-}
-// acc += A x B on v_mfma_f32_16x16x32_bf16, hand-issued.
-// Two things the compiler-scheduled builtin got wrong on MI355X (hipcc ROCm 7.2), both
-// timing dependent -- they show up when the four waves of a SIMD contend for the matrix pipe:
-//  (1) it may give the MFMA a destination different from its SrcC and under-pads that
-//      dependent-MFMA hazard, so the next MFMA of a chain read a half-written accumulator;
-//  (2) it reloads the A-fragment registers (ds_read_b128 into the same VGPRs) right behind an
-//      MFMA that still reads them: `v_mfma ..., v[40:43], ...` / `ds_read_b128 v[40:43]`.
-// Symptom of either: basis-layer outputs tens of percent off in a few hundred of 48K tiles,
-// different tiles every run (scripts/gpu_diag.py stage_nondet / stage_dump).
-// Here the accumulator is tied ("+v": vDst == SrcC, the case the hardware forwards back to
-// back) and every MFMA is followed, inside the same asm statement, by four wait states: the
-// next instruction of this wave -- a dependent MFMA, or a load that overwrites an operand --
-// issues a full MFMA occupancy (16 cycles) later.  Hazards the compiler no longer sees because
-// of the asm are padded by hand: operands are final 16 wait states before (split8), results
-// are read 24 wait states after (settle).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void settle(f32x4*) {}          // (was: wait states behind a hand-issued chain)
 __device__ __forceinline__ void mfma_bf16_acc(bf16x8 a, bf16x8 b, f32x4& acc) {
-#ifdef LRF_MFMA_BUILTIN
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-#else
-  const i32x4 ai = __builtin_bit_cast(i32x4, a), bi = __builtin_bit_cast(i32x4, b);
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 3" : "+v"(acc) : "v"(ai), "v"(bi));
-#endif
 }
 __device__ __forceinline__ bf16x8 lds_frag(const uint4* img, int frag, int part, int lane) {
   return __builtin_bit_cast(bf16x8, img[(frag * 2 + part) * 64 + lane]);
 }
-// Operand registers of an issued MFMA must not be rewritten for a while: the matrix pipe is
-// shared by the four waves of a SIMD and (measured) an MFMA can read its SrcA/SrcB tens of
-// cycles after the wave has moved on -- hipcc reused the B-operand VGPRs for address
-// arithmetic ~14 issue slots behind the last MFMA of a k-step and, once in ~25K tiles, that
-// MFMA multiplied garbage (first-layer outputs 25 % off; scripts/gpu_diag.py stage_dump).
-// hold() keeps a fragment allocated up to this point in program order; gemm_step ends with
-// 48 wait states during which all of its operands are still held.  tests/test_isa_checks.py
-// checks the emitted ISA for this distance.
-__device__ __forceinline__ void hold(bf16x8 v) {
-  const i32x4 u = __builtin_bit_cast(i32x4, v);
-  asm volatile("" :: "v"(u));
-}
-// acc[t1] += A(frag0 + t1*stride) x B for t1 in [0, NT), three-term split product
-template <int NT>
+// acc[t1] += A(frag0 + t1*stride) x B for t1 in [0, NT), three-term split product; the accumulators are taken G at a
+// time (the training kernels run 1024-thread workgroups: 128 registers per lane, a fragment pair costs eight)
+template <int NT, int G = (NT < 2 ? NT : 2)>
 __device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int stride, int lane,
                                           bf16x8 bh, bf16x8 bl, f32x4* acc) {
-  bf16x8 pah = bh, pal = bl;                                 // previous A fragments (dummy at t1 = 0)
 #pragma unroll
-  for (int t1 = 0; t1 < NT; ++t1) {
-    const bf16x8 ah = lds_frag(img, frag0 + t1 * stride, 0, lane);
-    const bf16x8 al = lds_frag(img, frag0 + t1 * stride, 1, lane);
-    mfma_bf16_acc(al, bh, acc[t1]);
-    mfma_bf16_acc(ah, bl, acc[t1]);
-    mfma_bf16_acc(ah, bh, acc[t1]);
-    hold(pah); hold(pal);                                    // >= 3 MFMAs (60 cycles) behind their last use
-    pah = ah; pal = al;
-  }
-  {
-    const i32x4 a0 = __builtin_bit_cast(i32x4, pah), a1 = __builtin_bit_cast(i32x4, pal);
-    const i32x4 b0 = __builtin_bit_cast(i32x4, bh), b1 = __builtin_bit_cast(i32x4, bl);
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" :: "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+  for (int t0 = 0; t0 < NT; t0 += G) {
+    bf16x8 ah[G], al[G];
+#pragma unroll
+    for (int t1 = 0; t1 < G; ++t1)
+      if (t0 + t1 < NT) { ah[t1] = lds_frag(img, frag0 + (t0 + t1) * stride, 0, lane); al[t1] = lds_frag(img, frag0 + (t0 + t1) * stride, 1, lane); }
+#pragma unroll
+    for (int t1 = 0; t1 < G; ++t1) if (t0 + t1 < NT) mfma_bf16_acc(al[t1], bh, acc[t0 + t1]);
+#pragma unroll
+    for (int t1 = 0; t1 < G; ++t1) if (t0 + t1 < NT) mfma_bf16_acc(ah[t1], bl, acc[t0 + t1]);
+#pragma unroll
+    for (int t1 = 0; t1 < G; ++t1) if (t0 + t1 < NT) mfma_bf16_acc(ah[t1], bh, acc[t0 + t1]);
   }
 }
 
