@@ -62,10 +62,42 @@ def app_feature(fld, u):
     return F.linear(x, fld["basis_mat.weight"])
 
 
-def late_view_mlp(fld, feat, viewdirs):
-    """models/tensorBase.py:115-135 with fea_pe = view_pe = 0."""
-    h = F.relu(F.linear(feat, fld["renderModule.mlp.0.weight"], fld["renderModule.mlp.0.bias"]))
-    h = F.relu(F.linear(h, fld["renderModule.mlp.2.weight"], fld["renderModule.mlp.2.bias"]))
+def late_view_mlp(fld, feat, viewdirs, masks=None, info=None):
+    """models/tensorBase.py:115-135 with fea_pe = view_pe = 0.
+
+    masks = (has [A] bool, m1 [A,128] bool, m2 [A,128] bool): for the samples with `has`, the two ReLUs are replaced by
+    multiplication with the GIVEN 0/1 masks (the masks another implementation of the same network used on these samples).
+    ReLU'(0) is a jump: a unit whose pre-activation differs from 0 by less than the rounding difference of two
+    implementations gets mask 1 in one and 0 in the other, and the gradients differ by that unit's whole contribution.
+    With the masks forced both sides differentiate the SAME piecewise-linear function, so gradients can be compared at
+    rounding level; the forward value moves by |pre-activation| of the flipped units (~1e-8).  info (dict, optional)
+    receives the number of units whose given mask differs from this chain's own sign and the largest |pre-activation|
+    among them."""
+    p1 = F.linear(feat, fld["renderModule.mlp.0.weight"], fld["renderModule.mlp.0.bias"])
+    if info is not None and info.get("want_masks"):
+        info["own_m1"] = p1.detach() > 0
+    if masks is None:
+        h = F.relu(p1)
+    else:
+        has, m1, m2 = masks
+        own = p1.detach() > 0
+        use = torch.where(has[:, None], m1, own)
+        h = p1 * use.to(p1.dtype)
+    p2 = F.linear(h, fld["renderModule.mlp.2.weight"], fld["renderModule.mlp.2.bias"])
+    if info is not None and info.get("want_masks"):
+        info["own_m2"] = p2.detach() > 0
+    if masks is None:
+        h = F.relu(p2)
+    else:
+        own2 = p2.detach() > 0
+        use2 = torch.where(has[:, None], m2, own2)
+        h = p2 * use2.to(p2.dtype)
+        if info is not None:
+            f1, f2 = (use != own), (use2 != own2)
+            info["n_flips"] = info.get("n_flips", 0) + int(f1.sum() + f2.sum())
+            mp = torch.cat([p1.detach()[f1].abs(), p2.detach()[f2].abs(), torch.zeros(1, device=p1.device)]).max()
+            info["max_pre"] = max(info.get("max_pre", 0.0), float(mp))
+            info["n_forced"] = info.get("n_forced", 0) + int(has.sum())
     o = F.linear(torch.cat([h, viewdirs], -1), fld["renderModule.mlp_view.0.weight"],
                  fld["renderModule.mlp_view.0.bias"])
     return torch.sigmoid(o)
@@ -79,8 +111,10 @@ def alpha2weights(alpha):
 
 
 def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, density_shift=-5.0,
-                 distance_scale=25.0, weight_thres=1e-3):
-    """models/tensorBase.py:567-636 (softplus density, late-view shading).  z: [1,S]."""
+                 distance_scale=25.0, weight_thres=1e-3, fea2dense_act="softplus", relu_masks=None, info=None):
+    """models/tensorBase.py:567-636 (softplus or relu density :495-499, late-view shading).  z: [1,S].
+    relu_masks = (lin [A'] int64 sorted = ray * S + sample of the samples another implementation shaded, m1, m2 [A',128]
+    bool): forced ReLU masks of the colour network for those samples (late_view_mlp)."""
     o, d = rays[:, :3], rays[:, 3:6]
     n = torch.norm(d, dim=-1, keepdim=True)
     dh = d / n
@@ -99,7 +133,8 @@ def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, density_shift=
     u = (x - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1
     sigma = torch.zeros(x.shape[:2], device=x.device)
     if valid.any():
-        sigma[valid] = F.softplus(density_feature(fld, u[valid]) + density_shift)
+        df = density_feature(fld, u[valid])
+        sigma[valid] = F.softplus(df + density_shift) if fea2dense_act == "softplus" else F.relu(df)     # tensorBase.py:495-499
     alpha = 1.0 - torch.exp(-sigma * dists * distance_scale)
     w = alpha2weights(alpha)
     acc = w.sum(-1)
@@ -113,7 +148,16 @@ def render_field(fld, rays, z, white_bg=True, floater_thresh=0.0, density_shift=
     rgb = torch.zeros(x.shape[:2] + (3,), device=x.device)
     if shade.any():
         vd = dh[:, None, :].expand(x.shape)[shade].clone().detach()     # tensorBase.py:628
-        rgb[shade] = late_view_mlp(fld, app_feature(fld, u[shade]), vd)
+        masks = None
+        if info is not None and info.get("want_masks"):
+            info["own_lin"] = torch.nonzero(shade.reshape(-1)).flatten()
+        if relu_masks is not None and relu_masks[0].numel() > 0:
+            lin, m1, m2 = relu_masks
+            mine = torch.nonzero(shade.reshape(-1)).flatten()            # row-major = the order of u[shade]
+            pos = torch.searchsorted(lin.contiguous(), mine).clamp(max=max(lin.numel() - 1, 0))
+            has = lin[pos] == mine
+            masks = (has, m1[pos], m2[pos])
+        rgb[shade] = late_view_mlp(fld, app_feature(fld, u[shade]), vd, masks, info)
     rgb_map = (w[..., None] * rgb).sum(-2)
     if white_bg:
         rgb_map = rgb_map + (1.0 - acc[:, None])

@@ -2,6 +2,7 @@
 real reference (tests/golden/make_golden.py).  This is what pins parity."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import vm_render_np as oracle
 from util import golden_field_dict, load_golden, rel_err
@@ -459,3 +460,58 @@ def test_upsample_matches_reference():
         assert np.abs(v.numpy() - g["up." + k]).max() <= 1e-6, k
         n += 1
     assert n == 12
+
+
+def test_torch_port_forced_relu_masks():
+    """oracle/vm_render_torch.py with the colour network's ReLU masks forced (the gradient tests of the GPU suite feed the
+    kernel's masks in): forcing the port's OWN masks changes nothing; flipping one (sample, unit) is counted, moves the
+    output by that unit's pre-activation only, and moves the gradients."""
+    from oracle import vm_render_torch as ot
+    g = load_golden("field_small_train_grad")
+    fld = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in golden_field_dict(g).items()}
+    rays = torch.from_numpy(g["rays"])
+    z = torch.from_numpy(oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"])))[None]
+    names = ["basis_mat.weight", "renderModule.mlp.0.weight", "renderModule.mlp.2.weight", "app_plane.1", "density_line.0"]
+
+    def grads(masks, info=None):
+        leaves = {k: fld[k].clone().requires_grad_(True) for k in names}
+        rgb, depth = ot.render_field({**fld, **leaves}, rays, z, True, 0.0, relu_masks=masks, info=info)
+        (rgb.sum() + depth.sum()).backward()
+        return rgb.detach(), {k: leaves[k].grad for k in names}
+    info = {"want_masks": True}
+    rgb0, g0 = grads(None, info)
+    lin, m1, m2 = info["own_lin"], info["own_m1"], info["own_m2"]
+    assert lin.numel() > 1000 and bool((lin[1:] > lin[:-1]).all())
+    info1 = {}
+    rgb1, g1 = grads((lin, m1, m2), info1)
+    assert info1["n_flips"] == 0 and info1["n_forced"] == lin.numel()
+    assert torch.equal(rgb0, rgb1)
+    for k in names:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-6 * float(g0[k].abs().max()), k
+    m2f = m2.clone()
+    m2f[7, 5] = ~m2f[7, 5]
+    info2 = {}
+    rgb2, g2 = grads((lin, m1, m2f), info2)
+    assert info2["n_flips"] == 1
+    assert float((g2["renderModule.mlp.2.weight"] - g0["renderModule.mlp.2.weight"]).abs().max()) > 0
+    # a sub-list of forced samples leaves the others on their own masks
+    info3 = {}
+    grads((lin[::2], m1[::2], m2[::2]), info3)
+    assert info3["n_forced"] == lin[::2].numel() and info3["n_flips"] == 0
+
+
+def test_torch_port_relu_density_matches_numpy_oracle():
+    """fea2denseAct = "relu" (tensorBase.py:498-499) in the torch port against the numpy oracle."""
+    from oracle import vm_render_torch as ot
+    g = load_golden("field_small_eval")
+    fldn = golden_field_dict(g)
+    fldn["fea2denseAct"] = "relu"
+    for k in list(fldn):
+        if k.startswith("density_plane"):
+            fldn[k] = fldn[k] * 3.0
+    rays = g["rays"].astype(np.float32)
+    zn = oracle.z_schedule(int(g["N_samples"]))
+    rn, dn = oracle.render_field(fldn, rays, zn, True, 0.0)
+    fldt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in fldn.items() if isinstance(v, np.ndarray)}
+    rt, dt = ot.render_field(fldt, torch.from_numpy(rays), torch.from_numpy(zn)[None], True, 0.0, fea2dense_act="relu")
+    assert rel_err(rt.numpy(), rn) < 2e-5 and rel_err(dt.numpy(), dn) < 2e-5

@@ -161,7 +161,7 @@ def local_from_golden_seed(g, device="cpu", camera_prior=None, lr_i=1e-3, n_grow
 
 
 
-# ----------------------------------------------------------------- gradient parity with explained flips
+# ----------------------------------------------------------------- gradient parity with forced ReLU masks
 MAT_MODE = ((0, 1), (0, 2), (1, 2))
 VEC_MODE = (2, 1, 0)
 
@@ -187,19 +187,13 @@ class capture_train_ws:
         del self.f._native_forward_train
 
 
-def relu_flip_report(f, rays, z, ws):
-    """Where does the kernel's colour network sit on the other side of a ReLU kink than the
-    reference's fp32 op chain?  ReLU'(0) is a jump: a hidden unit whose pre-activation is within the
-    rounding difference of the two implementations (split-bf16 MFMA chain vs ATen fp32 GEMM, ~1e-6)
-    gets mask 1 in one and 0 in the other, and that sample's gradient moves by that unit's whole
-    contribution.  Reads the ReLU masks out of the activation rows the training forward saved,
-    recomputes the pre-activations of the same samples with the reference's torch ops, and returns the
-    flipped (sample, unit) pairs together with what they can touch: texel footprints in the appearance
-    planes / lines, rays, hidden units.  Call after backward (rowinfo is written by the dgrad kernel)."""
+def kernel_relu_masks(f, rays, z, ws):
+    """The ReLU masks the kernel's colour network used in the training forward that filled workspace `ws`
+    (lrf_render_fwd_train): read out of the saved activation rows (relu(h1), relu(h2) > 0), per shaded sample.
+    Returns (lin, m1, m2, n_shaded): lin = ray * S + sample, sorted; m1, m2 [n,128] bool.  Call after backward (rowinfo
+    is written by the data-gradient kernel)."""
     import ctypes as C
-    import torch.nn.functional as F
     from localrf_amd import _native as N
-    from oracle import vm_render_torch as ot
     R, S = rays.shape[0], z.numel()
     out = (C.c_uint64 * 9)()
     N.lib().lrf_workspace_layout_bwd(R, S, (C.c_int32 * 3)(*f._grid_host), out)
@@ -211,87 +205,44 @@ def relu_flip_report(f, rays, z, ws):
     act = act.permute(0, 3, 1, 2, 4).reshape(rows, ACT_LD)
     rowinfo = ws[ri_off:ri_off + rows * 4].view(torch.int32)
     valid = rowinfo >= 0
-    cid = rowinfo[valid].long()
-    ray, k = cid // S, cid % S
+    lin = rowinfo[valid].long()
     m1 = act[valid][:, ACT_H1:ACT_H1 + 128] > 0
     m2 = act[valid][:, ACT_H2:ACT_H2 + 128] > 0
-    fld = {kk: v.detach() for kk, v in f.state_dict().items()}
-    r = rays.detach()
-    o, d = r[ray, :3], r[ray, 3:]
-    dh = d / d.norm(dim=-1, keepdim=True)
-    x = o + dh * z.view(-1)[k][:, None]
-    m = x.abs().amax(dim=-1, keepdim=True).clamp(min=1e-6)
-    x = torch.where(m <= 1, x, ((2 * m - 1) / (m ** 2)) * x)
-    u = (x - fld["aabb"][0]) * (2.0 / (fld["aabb"][1] - fld["aabb"][0])) - 1
-    feat = ot.app_feature(fld, u)
-    h1p = F.linear(feat, fld["renderModule.mlp.0.weight"], fld["renderModule.mlp.0.bias"])
-    h2p = F.linear(F.relu(h1p), fld["renderModule.mlp.2.weight"], fld["renderModule.mlp.2.bias"])
-    f1, f2 = m1 != (h1p > 0), m2 != (h2p > 0)
-    hit = (f1.any(-1) | f2.any(-1))
-    rep = {"n_shaded": int(valid.sum()), "n_flips": int(f1.sum() + f2.sum()), "n_samples": int(hit.sum()),
-           "rays": torch.unique(ray[hit]), "units1": f1.any(0), "units2": f2.any(0),
-           "max_pre": float(torch.cat([h1p[f1].abs(), h2p[f2].abs(), torch.zeros(1, device=u.device)]).max())}
-    uh = u[hit]
-    planes, lines = [], []
-    for p in range(3):
-        W, H, L = f._grid_host[MAT_MODE[p][0]], f._grid_host[MAT_MODE[p][1]], f._grid_host[VEC_MODE[p]]
-        pm = torch.zeros(H, W, dtype=torch.bool, device=u.device)
-        lm = torch.zeros(L, dtype=torch.bool, device=u.device)
-        if uh.shape[0]:
-            def taps(c, n):
-                ix = ((c + 1) * 0.5 * (n - 1)).clamp(0, n - 1)
-                i0 = ix.floor().long()
-                return i0, (i0 + 1).clamp(max=n - 1)
-            x0, x1 = taps(uh[:, MAT_MODE[p][0]], W)
-            y0, y1 = taps(uh[:, MAT_MODE[p][1]], H)
-            l0, l1 = taps(uh[:, VEC_MODE[p]], L)
-            for yy in (y0, y1):
-                for xx in (x0, x1):
-                    pm[yy, xx] = True
-            lm[l0] = True
-            lm[l1] = True
-        planes.append(pm)
-        lines.append(lm)
-    rep["planes"], rep["lines"] = planes, lines
-    return rep
+    order = torch.argsort(lin)
+    return lin[order], m1[order], m2[order], int(valid.sum())
 
 
-def flip_allowed_mask(name, like, rep):
-    """Entries of gradient tensor `name` (shaped like `like`) that a flip found by relu_flip_report can touch."""
-    if name.startswith("app_plane.") or name.startswith("app_line."):
-        p = int(name[-1])
-        m = rep["planes"][p][None, None] if "plane" in name else rep["lines"][p][None, None, :, None]
-        return m.expand(like.shape).contiguous()
-    if name == "rays":
-        m = torch.zeros(like.shape, dtype=torch.bool, device=like.device)
-        m[rep["rays"]] = True
-        return m
-    if name.startswith("density_"):
-        return torch.zeros(like.shape, dtype=torch.bool, device=like.device)
-    return torch.full(like.shape, rep["n_flips"] > 0, dtype=torch.bool, device=like.device)
+def port_gradients(f, rays, z, g_rgb, g_depth, white, masks, names):
+    """Gradients of (rgb * g_rgb).sum() + (depth * g_depth).sum() through the reference's ATen op chain
+    (oracle/vm_render_torch.py, pinned to the reference goldens) on the field's parameters and on the rays, with the
+    colour network's ReLU masks FORCED to `masks` (kernel_relu_masks) for the samples the kernel shaded -- both sides then
+    differentiate the same piecewise-linear function.  Returns (grads by name, info): info counts the (sample, unit)
+    pairs where the forced mask differs from the port's own sign (n_flips) and their largest |pre-activation|."""
+    from oracle import vm_render_torch as ot
+    fld = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in f.named_parameters()}
+    r2 = rays.detach().clone().requires_grad_(True)
+    info = {}
+    a2, b2 = ot.render_field({**fld, **leaves}, r2, z.reshape(1, -1), white, 0.0, density_shift=float(f.density_shift),
+                             weight_thres=f.rayMarch_weight_thres, fea2dense_act=f.fea2denseAct,
+                             relu_masks=masks[:3] if masks is not None else None, info=info)
+    ((a2 * g_rgb).sum() + (b2 * g_depth).sum()).backward()
+    grads = {n: (r2.grad if n == "rays" else leaves[n].grad) for n in names}
+    return grads, info
 
 
-def check_grads_with_flips(mine, ref, rep, tol=1e-4, flip_tol=5e-2, dense_flip_tol=2e-2, subset=None, gmax=None):
-    """mine / ref: name -> gradient tensor (state-dict names, plus "rays").  Every entry must agree to
-    `tol` of the tensor's largest reference magnitude, except what a ReLU flip found by
-    relu_flip_report can touch: the flipped samples' texel footprints in the appearance planes / lines
-    and their rays (bounded by flip_tol), and -- only when flips exist -- the dense network tensors
-    (bounded by dense_flip_tol).  Density gradients never depend on the colour network's masks.
-    subset / gmax: name -> flat indices / max magnitude when `ref` holds only part of a tensor
-    (make_golden.pack_grad).  Returns name -> (error outside the flip-touched entries, error inside)."""
+def check_grads(mine, ref, tol=1e-4, subset=None, gmax=None):
+    """Every gradient tensor within `tol` of its largest reference magnitude -- no exceptions.  subset / gmax:
+    name -> flat indices / max magnitude when `ref` holds only part of a tensor (make_golden.pack_grad)."""
     worst = {}
     for name, gm in mine.items():
         gr = ref[name]
-        allowed = flip_allowed_mask(name, gm, rep)
+        if gr is None:
+            gr = torch.zeros_like(gm)
         if subset is not None and name in subset:
-            gm, allowed = gm.reshape(-1)[subset[name]], allowed.reshape(-1)[subset[name]]
-        gm, gr, allowed = gm.reshape(-1), gr.reshape(-1), allowed.reshape(-1)
+            gm = gm.reshape(-1)[subset[name]]
+        gm, gr = gm.reshape(-1), gr.reshape(-1)
         den = max(float(gmax[name]) if gmax is not None else float(gr.abs().max()), 1e-12)
-        err = (gm - gr).abs() / den
-        e_out = float(err[~allowed].max()) if (~allowed).any() else 0.0
-        e_in = float(err[allowed].max()) if allowed.any() else 0.0
-        worst[name] = (e_out, e_in)
-        dense = not (name.startswith("app_") or name.startswith("density_") or name == "rays")
-        assert e_out <= tol, (name, "outside flip-touched entries", e_out, rep["n_flips"])
-        assert e_in <= (dense_flip_tol if dense else flip_tol), (name, "inside flip-touched entries", e_in, rep["n_flips"])
+        worst[name] = float((gm - gr).abs().max()) / den
+        assert worst[name] <= tol, (name, worst[name])
     return worst
