@@ -501,7 +501,8 @@ class TensorVMSplit(torch.nn.Module):
         flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
         grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
         g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
-        self._grad_flat = (flat, keep)         # see grad_bucket(): data-parallel all-reduce without copies
+        self._grad_flat = (flat, keep, offs[-2])   # see grad_bucket(): data-parallel all-reduce without copies
+        self._grad_fresh = True                    # written by THIS backward (localrf_amd.dist reduces fresh buckets only)
         if R == 0:
             return g_rays, grads
         cg = N.LrfGrads()
@@ -530,7 +531,7 @@ class TensorVMSplit(torch.nn.Module):
         return g_rays, grads
 
     def grad_bucket(self):
-        """(flat, params): the ONE flat fp32 buffer holding the gradients of all 19 parameter tensors
+        """(flat, params): the parameter part of the ONE flat fp32 buffer holding the gradients of all 19 parameter tensors
         after a backward, if .grad of every parameter is still a view of it (autograd adopts the views
         when .grad was None, i.e. after zero_grad(set_to_none=True) -- what the optimisers here do).
         localrf_amd.dist.allreduce_grads reduces it in place: one collective, no copies.  None when the
@@ -538,13 +539,13 @@ class TensorVMSplit(torch.nn.Module):
         gf = getattr(self, "_grad_flat", None)
         if gf is None:
             return None
-        flat, _ = gf
+        flat, _, n_param = gf
         base = flat.untyped_storage().data_ptr()
         ps = [p for p in self._param_list() if p.requires_grad]
         for p in ps:
             if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
                 return None
-        return flat, ps
+        return flat[:n_param], ps                    # the parameter part: the d/d rays tail behind it is rank-local
 
     # ------------------------------------------------------------------ sampling
     def z_schedule(self, is_train, N_samples, device):

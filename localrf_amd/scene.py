@@ -122,7 +122,11 @@ class LocalTensorfs(torch.nn.Module):
                 torch.cat([self.blending_weights, fresh], dim=1), requires_grad=False)
             world2rf = -self.t_c2w[-1].clone().detach()
             # reference parks the finished field on the CPU here (:132); with 288 GB of HBM it
-            # stays resident.
+            # stays resident.  Its optimiser is gone: drop its gradients (35-96 MB) with it.
+            for p in self.tensorfs[-1].parameters():
+                p.grad = None
+            self.tensorfs[-1]._grad_flat = None
+            self.tensorfs[-1]._grad_fresh = False
         else:
             world2rf = torch.zeros(3, device=self.device)
         self.tensorfs.append(TensorVMSplit(device=self.device, **self.tensorf_args))

@@ -109,6 +109,69 @@ def test_two_rank_render_gradients_match_single_rank(tmp_path):
     assert got["bytes"] == 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
 
 
+# three iterations; every iteration samples FOUR of the eight views, so that each rank gets two and four views get no
+# gradient anywhere (the reference steps one tiny Adam per view: local_tensorfs.py:229-249)
+_STEP_VIEWS = ([0, 1, 2, 3], [4, 5, 2, 7], [0, 6, 1, 5])
+
+
+def _train_steps(model, shard=None):
+    """Per-view Adam optimisers for rotations / translations + one for the field, stepped the way
+    LocalTensorfs.optimizer_step does: zero_grad(set_to_none) -> backward -> [gradient all-reduce] -> step."""
+    from localrf_amd.dist import allreduce_grads
+    opts_r = [torch.optim.Adam([p], lr=5e-3, betas=(0.9, 0.99)) for p in model.r]
+    opts_t = [torch.optim.Adam([p], lr=5e-4, betas=(0.9, 0.99)) for p in model.t]
+    opt_f = torch.optim.Adam(model.field.parameters(), lr=1e-3, betas=(0.9, 0.99))
+    g = torch.Generator().manual_seed(11)
+    for views in _STEP_VIEWS:
+        view_ids = torch.tensor(views)
+        ray_ids = torch.randint(0, 16 * 12, (4 * 24,), generator=g)
+        target = torch.rand(4 * 24, 3, generator=g)
+        for o in opts_r + opts_t + [opt_f]:
+            o.zero_grad(set_to_none=True)
+        if shard is None:
+            loss = _loss(model, ray_ids, view_ids, target)
+        else:
+            rank, world = shard
+            per, n = 24, 4 // world
+            loss = _loss(model, ray_ids[rank * n * per:(rank + 1) * n * per], view_ids[rank * n:(rank + 1) * n],
+                         target[rank * n * per:(rank + 1) * n * per])
+        loss.backward()
+        if shard is not None:
+            allreduce_grads(model)
+        for o in opts_r + opts_t + [opt_f]:
+            o.step()
+    steps_r = [int(o.state[o.param_groups[0]["params"][0]].get("step", torch.tensor(0))) for o in opts_r]
+    return steps_r
+
+
+def _worker_steps(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = OracleScene()
+    steps = _train_steps(model, shard=(rank, world))
+    if rank == 0:
+        torch.save({"params": {n: p.detach().clone() for n, p in model.named_parameters()}, "steps": steps}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_steps_match_single_rank_with_unsampled_views(tmp_path):
+    """Views nobody sampled in an iteration must stay untouched under data parallelism, exactly as on one rank: their
+    .grad stays None after allreduce_grads (no zero gradient is invented), so Adam neither moves them by momentum nor
+    advances their step counter.  Three iterations, per-view optimisers, 2 ranks vs 1 rank: same parameters, same
+    per-view step counts."""
+    out = str(tmp_path / "steps.pt")
+    mp.spawn(_worker_steps, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = OracleScene()
+    steps = _train_steps(model)
+    assert steps == got["steps"], (steps, got["steps"])
+    assert steps == [2, 2, 2, 1, 1, 2, 1, 1]                      # how often each view was sampled
+    for n, p in model.named_parameters():
+        a = got["params"][n]
+        assert float((a - p.detach()).abs().max()) <= 1e-5 * max(float(p.detach().abs().max()), 1e-3), n
+
+
 def test_shard_views_keeps_rays_per_view_integral():
     from localrf_amd.dist import shard_views
     ray_ids, view_ids = torch.arange(16 * 10), torch.arange(16)

@@ -651,6 +651,34 @@ def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
     assert got[0]["bytes"] >= 4 * sum(p.numel() for p in lt.tensorfs[-1].parameters() if p.requires_grad)
 
 
+def test_bench_under_torch_distributed_run_one_rank(tmp_path):
+    """The driver launches the multi-GPU bench as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.
+    The same plumbing with N = 1: RCCL process group on this GPU, barrier + max-over-ranks timing, the train step with its
+    gradient all-reduce call, one JSON line from rank 0 -- so that the first real 8-GPU run cannot fail on it."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--no-baselines", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=root,
+                       env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 1e6 and abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert "RCCL" in d["train_step"]["what"] or "allreduce" in d["train_step"]["what"], d["train_step"]["what"]
+    assert d["roofline"]["kernel"] in ("k_shade3", "k_march") and d["roofline"]["bound"] in ("hbm", "mfma")
+
+
 def test_progressive_training_driver_on_synthetic_frames():
     """scripts/train_synth.py: the loop of the reference's train.py:349-474 (sample -> forward -> loss + density_L1 ->
     optimizer_step -> progressive append_frame / append_rf, upsample schedule, alpha-mask rebuilds) around
