@@ -579,6 +579,168 @@ def case_config3(LocalTensorfs, name, grid=(300, 300, 300), seed=33):
     save(name, **arrs)
 
 
+def case_trajectory(TensorVMSplit, LocalTensorfs, name, seed=91):
+    """30 optimisation iterations of the REAL LocalTensorfs on CPU through tests/trajectory.py::run: photometric L1 +
+    density L1 -> optimizer_step, crossing two append_frame, the switch to refining, one upsample (fresh Adam), one
+    alpha-mask rebuild, the end of regularisation, append_rf and the first iterations of the second field.  Recorded:
+    the initial state, the initial state of the second field, the sample distances z of every forward (the train-mode
+    jitter), losses / colours / depths of every iteration and the final state.  A second run from an initial state
+    perturbed by 1e-6 (relative) measures how far the reference's OWN trajectory moves under a last-bit change: the
+    replay's tolerance on the final parameters is stated against that, not guessed."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import trajectory as tj
+    import warnings
+    kw = dict(FIELD_KW)
+    kw.update(tj.FIELD_OVER)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    view_u, ray_ids = tj.batches(seed + 3)
+    target = tj.targets()
+
+    def fresh():
+        torch.manual_seed(seed)
+        scene_kw = {k: (dict(v) if isinstance(v, dict) else v) for k, v in tj.SCENE_KW.items()}
+        lt = quiet(LocalTensorfs, device="cpu", aabb=aabb, gridSize=list(tj.GRID), **scene_kw, **kw)
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for i in range(len(lt.r_c2w)):
+                lt.t_c2w[i].add_(0.04 * i + 0.02 * torch.randn(3, generator=g))
+                lt.r_c2w[i].add_(0.03 * torch.randn(3, 2, generator=g))
+            for p in lt.tensorfs[-1].density_plane:             # a density field with structure: the alpha mask rebuilt
+                p.mul_(10.0)                                    # at it 14 keeps about half of its cells
+            for p in lt.tensorfs[-1].density_line:
+                p.mul_(3.0)
+        return lt
+
+    z_log = []
+    orig = TensorVMSplit.sample_ray_contracted
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        z_log.append(out[1][0].detach().numpy().copy())
+        return out
+
+    def one_run(lt, rf1_state=None):
+        rf1 = {}
+
+        def after_append_rf(scene):
+            if rf1_state is not None:                                  # second run: same second field as the first
+                scene.tensorfs[-1].load_state_dict(rf1_state)
+            rf1.update({k: v.detach().clone() for k, v in scene.tensorfs[-1].state_dict().items()})
+        z_log.clear()
+        TensorVMSplit.sample_ray_contracted = spy
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.manual_seed(seed + 2)
+                log = quiet(tj.run, lt, view_u, ray_ids, target, "cpu", after_append_rf=after_append_rf)
+        finally:
+            TensorVMSplit.sample_ray_contracted = orig
+        return log, [z.copy() for z in z_log], rf1
+
+    lt = fresh()
+    init = {k: v.detach().numpy().copy() for k, v in lt.state_dict().items()}
+    log, zs, rf1 = one_run(lt)
+    assert len(zs) == tj.N_ITERS, len(zs)
+    final = {k: v.detach().numpy().copy() for k, v in lt.state_dict().items()}
+    final_rgb, final_depth = quiet(tj.final_render, lt, "cpu")
+
+    # the reference against itself: initial parameters moved by 1e-6 relative, same jitter, same second field
+    lt2 = fresh()
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for p in lt2.parameters():
+            if p.is_floating_point() and p.requires_grad:
+                p.mul_(1 + 1e-6 * (2 * torch.rand(p.shape, generator=g) - 1))
+    z_first = [z.copy() for z in zs]
+    torch.manual_seed(seed + 2)
+    log2, zs2, _ = one_run(lt2, rf1_state=rf1)
+    assert all(np.array_equal(a, b) for a, b in zip(z_first, zs2)), "the two reference runs must share their jitter"
+    final2 = {k: v.detach().numpy().copy() for k, v in lt2.state_dict().items()}
+    final_rgb2, final_depth2 = quiet(tj.final_render, lt2, "cpu")
+
+    # ... and when every gradient it computes is off by 1e-5 of that tensor's largest gradient element, which is the
+    # bar the gradient parity tests hold the HIP path to (tests/test_gpu_parity.py): Adam divides by the running
+    # gradient magnitude, so elements whose own gradient is that small move by a visible fraction of the learning rate
+    lt3 = fresh()
+    g3 = torch.Generator().manual_seed(seed + 6)
+
+    def noisy(grad):
+        return grad + (grad != 0) * 1e-5 * grad.abs().max() * (2 * torch.rand(grad.shape, generator=g3) - 1)   # exact zeros stay zero
+
+    def hook_all(scene):
+        for p_ in scene.parameters():
+            if p_.requires_grad and not getattr(p_, "_noisy", False):
+                p_.register_hook(noisy)
+                p_._noisy = True
+    hook_all(lt3)
+    orig_append_rf, orig_append_frame = LocalTensorfs.append_rf, LocalTensorfs.append_frame
+
+    def append_rf_hooked(self, *a, **k):
+        out = orig_append_rf(self, *a, **k)
+        if self is lt3:
+            self.tensorfs[-1].load_state_dict(rf1)
+            hook_all(self)
+        return out
+
+    def append_frame_hooked(self, *a, **k):
+        out = orig_append_frame(self, *a, **k)
+        if self is lt3:
+            hook_all(self)
+        return out
+    LocalTensorfs.append_rf, LocalTensorfs.append_frame = append_rf_hooked, append_frame_hooked
+    try:
+        log3, zs3, _ = one_run(lt3, rf1_state=rf1)
+    finally:
+        LocalTensorfs.append_rf, LocalTensorfs.append_frame = orig_append_rf, orig_append_frame
+    assert all(np.array_equal(a, b) for a, b in zip(z_first, zs3))
+    final3 = {k: v.detach().numpy().copy() for k, v in lt3.state_dict().items()}
+
+    arrs = dict(seed=np.array(seed), view_u=view_u, ray_ids=ray_ids,
+                photo=np.array([r["photo"] for r in log], np.float64), l1=np.array([r["l1"] for r in log], np.float64),
+                total=np.array([r["total"] for r in log], np.float64),
+                regularize=np.array([r["regularize"] for r in log]), rf_iter=np.array([r["rf_iter"] for r in log]),
+                n_fields=np.array([r["n_fields"] for r in log]), grid_it=np.array([r["grid"] for r in log]),
+                nSamples_it=np.array([r["nSamples"] for r in log]), has_mask=np.array([r["has_mask"] for r in log]),
+                can_add_rf=np.array([r["can_add_rf"] for r in log]),
+                views=np.array([r["views"] for r in log]),
+                rgb=np.stack([r["rgb"] for r in log]), depth=np.stack([r["depth"] for r in log]),
+                photo_perturbed=np.array([r["photo"] for r in log2], np.float64))
+    for it, z in enumerate(zs):
+        arrs[f"z.{it}"] = z
+    arrs.update({f"init.{k}": v for k, v in init.items()})
+    arrs.update({f"rf1.{k}": v.numpy() for k, v in rf1.items()})
+    arrs.update({f"final.{k}": v for k, v in final.items()})
+    for k in final:                                                    # reference-vs-reference drift per tensor
+        if final[k].dtype.kind == "f" and final[k].shape == final2[k].shape:
+            arrs[f"drift.{k}"] = np.array(float(np.abs(final[k] - final2[k]).max()))
+            arrs[f"drift_l2.{k}"] = np.array(float(np.linalg.norm(final[k] - final2[k]) / max(np.linalg.norm(final[k]), 1e-30)))
+            d3 = np.abs(final[k] - final3[k])
+            arrs[f"gdrift.{k}"] = np.array(float(d3.max()))
+            arrs[f"gdrift_l2.{k}"] = np.array(float(np.linalg.norm(d3) / max(np.linalg.norm(final[k]), 1e-30)))
+            arrs[f"gdrift_n.{k}"] = np.array(int((d3 > 1e-3 * np.abs(final[k]).max()).sum()))
+    arrs["photo_gnoise"] = np.array([r["photo"] for r in log3], np.float64)
+    arrs.update(final_rgb=final_rgb, final_depth=final_depth,
+                final_rgb_drift=np.array(float(np.abs(final_rgb - final_rgb2).max())),
+                final_depth_drift=np.array(float((np.abs(final_depth - final_depth2) / np.abs(final_depth)).max())))
+    mask = lt.tensorfs[0].alphaMask
+    arrs["mask_kept"] = np.array(float(mask.alpha_volume.mean()))
+    print("trajectory: photo", np.round(arrs["photo"], 5).tolist())
+    print("trajectory: l1", np.round(arrs["l1"], 6).tolist())
+    print("trajectory: rf_iter", arrs["rf_iter"].tolist(), "fields", arrs["n_fields"].tolist())
+    print("trajectory: grids", [tuple(g) for g in arrs["grid_it"][[0, 12, 29]]], "mask kept", float(arrs["mask_kept"]),
+          "has_mask", arrs["has_mask"].tolist())
+    worst = max((float(v), k) for k, v in arrs.items() if k.startswith("drift."))
+    print("trajectory: final render drift rgb", float(arrs["final_rgb_drift"]), "depth rel", float(arrs["final_depth_drift"]),
+          "worst l2 drift", max((float(v), k) for k, v in arrs.items() if k.startswith("drift_l2.")))
+    print("trajectory: reference with 1e-5 gradient noise: worst final max drift / max|p|",
+          sorted(((float(v) / float(np.abs(arrs["final." + k[7:]]).max()), float(arrs["gdrift_l2." + k[7:]]), int(arrs["gdrift_n." + k[7:]]), k)
+                  for k, v in arrs.items() if k.startswith("gdrift.") and np.abs(arrs["final." + k[7:]]).max() > 0), reverse=True)[:4],
+          "photo", float((np.abs(arrs["photo"] - arrs["photo_gnoise"]) / arrs["photo"]).max()))
+    print("trajectory: reference-vs-perturbed-reference worst final drift", worst,
+          "photo drift", float(np.abs(arrs["photo"] - arrs["photo_perturbed"]).max()))
+    save(name, **arrs)
+
+
 def main():
     TensorVMSplit, AlphaGridMask, LocalTensorfs = import_reference()
     only = set(sys.argv[1:])
@@ -593,7 +755,8 @@ def main():
               "prior": lambda: case_local_train_views(LocalTensorfs, "local_train_prior.npz", (20, 24, 28), 45, [0, 1, 3, 4], camera_prior=True),
               "config3": lambda: case_config3(LocalTensorfs, "config3_4x300.npz"),
               "upsample": lambda: case_upsample(TensorVMSplit, "upsample_grid.npz"),
-              "geo": lambda: case_geo_losses("geo_losses.npz")}
+              "geo": lambda: case_geo_losses("geo_losses.npz"),
+              "trajectory": lambda: case_trajectory(TensorVMSplit, LocalTensorfs, "trajectory_30it.npz")}
         for k in only:
             r2[k]()
         return
@@ -623,6 +786,8 @@ def main():
     case_config3(LocalTensorfs, "config3_4x300.npz")
     case_upsample(TensorVMSplit, "upsample_grid.npz")
     case_geo_losses("geo_losses.npz")
+    # round 3
+    case_trajectory(TensorVMSplit, LocalTensorfs, "trajectory_30it.npz")
 
 
 if __name__ == "__main__":

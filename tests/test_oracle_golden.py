@@ -515,3 +515,42 @@ def test_torch_port_relu_density_matches_numpy_oracle():
     fldt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in fldn.items() if isinstance(v, np.ndarray)}
     rt, dt = ot.render_field(fldt, torch.from_numpy(rays), torch.from_numpy(zn)[None], True, 0.0, fea2dense_act="relu")
     assert rel_err(rt.numpy(), rn) < 2e-5 and rel_err(dt.numpy(), dn) < 2e-5
+
+
+# ----------------------------------------------------------------------------- round-3 golden: the 30-iteration trajectory
+def test_trajectory_golden_first_iteration_and_events():
+    """tests/golden/trajectory_30it.npz (the REAL LocalTensorfs stepped 30 times by tests/trajectory.py): the plain-torch
+    scene chain + field port reproduce iteration 0 from the recorded initial state and sample distances, and the file
+    holds every event the GPU replay is meant to cross."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from localrf_amd.rays import sixD_to_mtx
+    from util import torch_scene_chain
+    import trajectory as tj
+    g = load_golden("trajectory_30it")
+    sd = {k[5:]: _t(v) for k, v in g.items() if k.startswith("init.")}
+    views = [int(v) for v in g["views"][0]]
+    ray_ids = _t(g["ray_ids"][0].astype(np.int64))
+    focal = sd["init_focal"] * sd["focal_offset"]
+    center = torch.tensor([float(tj.W), float(tj.H)]) * sd["center_rel"]
+    c2w = torch.cat([sixD_to_mtx(torch.stack([sd[f"r_c2w.{v}"] for v in views])),
+                     torch.stack([sd[f"t_c2w.{v}"] for v in views])[..., None]], -1)
+    rays, dirs, ij = torch_scene_chain(ray_ids, c2w, sd["world2rf.0"][None], focal, center, tj.PER_VIEW, tj.W, tj.H, False)
+    fld = {k[len("tensorfs.0."):]: v for k, v in sd.items() if k.startswith("tensorfs.0.")}
+    rgb, depth = ot.render_field(fld, rays[0], _t(g["z.0"])[None], True, 0.0)
+    ex = torch.stack([sd[f"exposure.{v}"] for v in views]).repeat_interleave(tj.PER_VIEW, 0)
+    rgbs = torch.bmm(ex, rgb[..., None])[..., 0].clamp(0, 1)
+    assert rel_err(rgbs.numpy(), g["rgb"][0]) < 2e-6 and rel_err(depth.numpy(), g["depth"][0]) < 2e-6
+    want = torch.cat([_t(tj.targets())[v][ray_ids[k * tj.PER_VIEW:(k + 1) * tj.PER_VIEW]] for k, v in enumerate(views)], 0)
+    assert abs(float((0.25 * (rgbs - want).abs()).mean()) - float(g["photo"][0])) < 1e-7
+    vu, ri = tj.batches(int(g["seed"]) + 3)
+    assert np.array_equal(vu, g["view_u"]) and np.array_equal(ri, g["ray_ids"])
+    # the events
+    assert g["rf_iter"].tolist() == [0] * 6 + list(range(1, 17)) + [0] * 6 + [1, 2]
+    assert g["n_fields"].tolist() == [1] * 22 + [2] * 8 and g["can_add_rf"].tolist() == [False] * 21 + [True] + [False] * 8
+    assert g["grid_it"][11].tolist() == [20, 20, 20] and g["grid_it"][12].tolist() == [26, 26, 26]
+    assert g["nSamples_it"][12] > g["nSamples_it"][11] and len(g["z.12"]) == 2 * (int(g["nSamples_it"][12]) // 6)
+    assert g["has_mask"].tolist() == [False] * 15 + [True] * 7 + [False] * 8 and 0.2 < float(g["mask_kept"]) < 0.8
+    assert g["regularize"].tolist() == [True] * 18 + [False] * 5 + [True] * 7
+    assert "init.r_c2w.3" in g and "init.r_c2w.4" not in g and "final.r_c2w.6" in g and "final.r_c2w.7" not in g
+    assert g["photo"][21] < 0.85 * g["photo"][0] and g["photo"][22] > g["photo"][21]      # learns; the new field starts over
