@@ -75,7 +75,12 @@ class SyntheticFrames:
         dirs = torch.stack([(ii.float() + 0.5 - W / 2) / focal, -(jj.float() + 0.5 - H / 2) / focal,
                             -torch.ones(H, W)], -1).reshape(-1, 3)
         self.images, depths = [], []
-        cam_t = torch.tensor([[0.04 * f, 0.01 * math.sin(0.5 * f), 0.0] for f in range(n_frames)])   # true camera path
+        # true camera path: 0.04 per frame along an arc that stays inside |x|, |z| <= 0.6, well clear of the teacher's walls
+        # at +-1.2 (round 2 walked +x in a straight line and reached the wall at frame 30: the target flow grew from 1.4
+        # to 15 pixels and the teacher's median depth fell from 0.97 to 0.09 over the run, which is what the "rising"
+        # geometric losses of profiles/r02_train_synth_500.json were: see profiles/r09a_geo_curve.md)
+        cam_t = torch.tensor([[0.6 * math.sin(f / 15.0), 0.01 * math.sin(0.5 * f), 0.6 * (1 - math.cos(f / 15.0)) - 0.3]
+                              for f in range(n_frames)])
         with torch.no_grad():
             for f in range(n_frames):
                 rays = torch.cat([cam_t[f].expand_as(dirs), dirs], -1).to(dev)
@@ -83,6 +88,7 @@ class SyntheticFrames:
                 self.images.append(rgb.clamp(0, 1))
                 depths.append(dep)
         self.images = torch.stack(self.images)                        # [F, H*W, 3] on the device
+        self.cam_t = cam_t
         # what RAFT / DPT give the reference (dataLoader/localrf_dataset.py): flow to the next / previous frame and an
         # inverse depth per pixel -- here exact, from the teacher's depth and the true (rotation-free) camera path
         depths = torch.stack(depths)                                  # [F, H*W]
@@ -120,8 +126,23 @@ class SyntheticFrames:
         return view_t, pix_t.reshape(-1), (view_t[:, None], pix_t)
 
 
+def geo_by_field(curve):
+    """Per field: the forward-flow error relative to the magnitude of the target flow, and the depth loss, at the first
+    and the last recorded regularising iteration of that field (the schedule weight reg_w decays in between)."""
+    out = []
+    for fld in sorted({c["field"] for c in curve}):
+        cs = [c for c in curve if c["field"] == fld and c["target_flow_mag"] > 0]
+        if len(cs) >= 2:
+            out.append({"field": fld, "records": len(cs), "frames_first": cs[0]["frames"], "frames_last": cs[-1]["frames"],
+                        "flow_rel_first": cs[0]["fwd_err"] / cs[0]["target_flow_mag"], "flow_rel_last": cs[-1]["fwd_err"] / cs[-1]["target_flow_mag"],
+                        "flow_rel_min": min(c["fwd_err"] / c["target_flow_mag"] for c in cs),
+                        "target_flow_first_last": [cs[0]["target_flow_mag"], cs[-1]["target_flow_mag"]],
+                        "depth_first": cs[0]["depth"], "depth_last": cs[-1]["depth"], "depth_max": max(c["depth"] for c in cs)})
+    return out
+
+
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25):
     from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -151,7 +172,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     # refinement / a new field here
     L1_weight, add_frames_every, n_overlap = 1e-2, max(1, round(100 * sc)), 3
     n_added, last_add, it = 0, 0, 0
-    losses, per_res, events, geo_vals = [], {}, [], []
+    losses, per_res, events, geo_vals, geo_curve = [], {}, [], [], []
     torch.cuda.reset_peak_memory_stats(dev)
     mem_marks = []
     training = True
@@ -189,6 +210,38 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             dl = geo_losses.depth_loss(depth_map, data.invdepths[vsel[:, None], psel], view_ids.shape[0])
             total = total + fl * 1.0 * reg_w / ((W + H) / 2) + dl * 0.1 * reg_w
             geo_vals.append((float(fl.detach()), float(dl.detach())) if it % 25 == 0 else None)
+            if it % geo_every == 0:                                    # the curve, phase by phase (profiles/r09*_geo_curve)
+                lo, hi = data.active_frames_bounds
+                with torch.no_grad():
+                    t_est = torch.stack([lt.t_c2w[f].detach() for f in range(lo, hi)]).cpu()
+                    step_est = (t_est[1:] - t_est[:-1]).norm(dim=-1).mean() if hi - lo > 1 else torch.zeros(())
+                    rel = (t_est - t_est[:1]) - (data.cam_t[lo:hi] - data.cam_t[lo:lo + 1])
+                    # diagnostics in plain torch (train.py:388-404 restated; not the loss that is optimised)
+                    c2w = lt.get_cam2world(starting_id=start).detach()
+                    fr = (vsel - start).long()
+                    nxt = (fr + 1).clamp(max=c2w.shape[0] - 1)
+                    Rn, tn = c2w[nxt, :3, :3], c2w[nxt, :3, 3]
+                    Rc, tc = c2w[fr, :3, :3], c2w[fr, :3, 3]
+                    dm = depth_map.detach().reshape(fr.shape[0], -1)
+                    pts = directions.detach().reshape(fr.shape[0], -1, 3) * dm[..., None]
+                    p_w = torch.einsum("vij,vnj->vni", Rc, pts) + tc[:, None]
+                    q = torch.einsum("vji,vnj->vni", Rn, p_w - tn[:, None])
+                    f_, c_ = lt.focal(W).detach(), lt.center(W, H).detach()
+                    # pts2px (utils/utils.py:15-21): x / z * f + cx - 0.5 with the camera looking down -z, y up
+                    px = torch.stack([q[..., 0] / -q[..., 2] * f_ + c_[0] - 0.5, -q[..., 1] / -q[..., 2] * f_ + c_[1] - 0.5], -1)
+                    pred = px - ij.detach().reshape(fr.shape[0], -1, 2).float()
+                    tgt = data.fwd_flow[vsel[:, None], psel]
+                    ok = (fr < c2w.shape[0] - 1)
+                    cosang = ((torch.einsum("vii->v", torch.einsum("vji,vjk->vik", Rc, Rn)) - 1) / 2).clamp(-1, 1)
+                    diag = {"pred_flow_mag": float(pred[ok].norm(dim=-1).mean()) if ok.any() else 0.0,
+                            "target_flow_mag": float(tgt[ok].norm(dim=-1).mean()) if ok.any() else 0.0,
+                            "fwd_err": float((pred - tgt)[ok].abs().sum(-1).mean()) if ok.any() else 0.0,
+                            "depth_median": float(dm.median()), "teacher_depth_median": float((1.0 / data.invdepths[vsel[:, None], psel]).median()),
+                            "rot_step_deg": float(torch.rad2deg(torch.acos(cosang))[ok].mean()) if ok.any() else 0.0}
+                geo_curve.append({**diag, "it": it, "field": len(lt.tensorfs) - 1, "rf_iter": int(lt.rf_iter[-1]), "refining": bool(lt.is_refining),
+                                  "reg_w": float(reg_w), "flow": geo_vals[-1][0], "depth": geo_vals[-1][1], "photo": float(loss.detach()),
+                                  "frames": [lo, hi], "res": int(lt.tensorfs[-1].gridSize[0]),
+                                  "pose_err": float(rel.norm(dim=-1).mean()), "est_step": float(step_est), "true_step": 0.04})
         if lt.regularize:
             tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)         # train.py:425-429, opt.py:111-113
             total = total + tv + l1
@@ -253,6 +306,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             "peak_memory_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30, "memory_marks_GB": [(i, m / 2 ** 30) for i, m in mem_marks],
             "geometric_losses": {"iterations_with_them": len(geo_vals), "flow_first_last": [v[0] for v in geo_vals if v][:1] + [v[0] for v in geo_vals if v][-1:],
                                  "depth_first_last": [v[1] for v in geo_vals if v][:1] + [v[1] for v in geo_vals if v][-1:]},
+            "geo_curve": geo_curve, "geo_by_field": geo_by_field(geo_curve),
             "checkpoint_roundtrip": bool(same), "checkpoint_keys_follow_reference": bool(keys_ok), "world": world,
             "final_resolution": res}
 
@@ -290,9 +344,9 @@ def main():
     out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
               dev=f"cuda:{local}", ddp=ddp, geo=not args.no_geo, log=lambda m: print(m, file=sys.stderr, flush=True))
     if not ddp or int(os.environ["RANK"]) == 0:
-        print(json.dumps(out))
+        print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)))
         if args.json:
-            json.dump(out, open(args.json, "w"), indent=1)
+            json.dump(out, open(args.json, "w"), indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
     if ddp:
         dist.destroy_process_group()
 

@@ -688,13 +688,25 @@ def test_progressive_training_driver_on_synthetic_frames():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import train_synth
-    out = train_synth.run(frames=16, final=96, iters_per_frame=12, n_max_frames=6, dev=DEV)
+    out = train_synth.run(frames=16, final=96, iters_per_frame=12, n_max_frames=6, dev=DEV, geo_every=5)
     assert out["finite"] and out["iterations"] > 100, out
     assert out["loss_last"] < 0.7 * out["loss_first"], (out["loss_first"], out["loss_last"])
     assert out["fields"] >= 2 and out["frames"] == 16, (out["fields"], out["frames"], out["events"])
     assert len(out["ms_per_iteration_by_resolution"]) >= 3 and out["final_resolution"] >= 90, out["ms_per_iteration_by_resolution"]
     assert out["checkpoint_roundtrip"] and out["checkpoint_keys_follow_reference"]
     assert out["target_image_stats"]["std"] > 0.05, out["target_image_stats"]       # the teacher scene is not blank
+    # the optical-flow / monocular-depth terms (train.py:385-423), field by field while they are in the loss: the camera
+    # stays in free space, so the target flow keeps its magnitude over the run (round 2's straight path walked into the
+    # teacher's wall: target flow x10, which is what "flow loss 2.0 -> 13" in profiles/r02_train_synth_500.json was --
+    # profiles/r09a_geo_curve.md), and the optimisation brings the flow error of the first field down relative to it
+    by_field = out["geo_by_field"]
+    assert by_field and by_field[0]["field"] == 0 and by_field[0]["records"] >= 4, by_field
+    for f in by_field:
+        lo, hi = f["target_flow_first_last"]
+        assert 0.4 < hi / lo < 2.5 and 0.3 < lo < 4.0, f
+        assert f["flow_rel_min"] < 1.3 and f["depth_last"] < 0.2, f
+    assert by_field[0]["flow_rel_first"] > 0.9                                      # all poses equal at the start: predicted flow 0
+    assert by_field[0]["flow_rel_last"] < 0.8 * by_field[0]["flow_rel_first"], by_field[0]
 
 
 def test_upsample_vs_reference_golden(built_lib):
