@@ -167,6 +167,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   lds_u16* s_nc = (lds_u16*)(s_toff + (LDSTOFF ? R + 1 : 0));  // per-ray shaded-sample counts beside the offsets (LDSTOFF)
   __shared__ int s_wave[NW];
   __shared__ int s_next;                                       // tile queue of this workgroup
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
   for (int i = tid; i < W32_ALL_U4; i += NT) img[i] = f.mlpw[i];
   for (int i = tid; i < S; i += NT) s_z[i] = z[i];
@@ -275,7 +276,10 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     // ------------------------------------------------------------------ chain
     // While it multiplies, a wave outranks its SIMD partner in the issue arbitration (the partner mostly waits for
     // gathers): 123.3 -> 120.1 us (interleaved A/B, profiles/r08c).  Requesting every A fragment one K-step ahead by
-    // hand (sched_barrier regions) was measured too: 137 vs 133 us, the compiler's own order is better.
+    // hand (sched_barrier regions) was measured too: 137 vs 133 us, the compiler's own order is better.  Starting the
+    // second wave of every SIMD 8 K / 16 K / 32 K cycles late changes nothing (123.4 / 123.1 / 124.7 / 127.7 us): the waves
+    // are not phase-locked; a wave issues one instruction per 4-cycle slot and the loop body is 1882 of them (1265 VALU,
+    // 135 MFMA, 196 LDS, 58 VMEM, 228 SALU): instruction count is what is left to cut.
     __builtin_amdgcn_s_setprio(2);
     // basis 72 -> 27 (tensoRF.py:196): five K-steps; the three terms in three accumulators (one output tile only)
     f32x16 fa, fb, fc;
