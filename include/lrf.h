@@ -197,6 +197,27 @@ int lrf_scene_blend_bwd(const float* g_rgbs, const float* g_depth, const float* 
                         const float* exposure, int32_t R, int32_t per_view, int32_t n_rf,
                         float* g_rgb_f, float* g_depth_f, float* g_exposure, void* stream);
 
+/* LocalTensorfs.forward without a tape (local_tensorfs.py:397-499) in one call: lrf_scene_rays, then for every chunk of
+ * `chunk` rays (<= 0: all at once) lrf_render_fwd of every active field in the reference's order (:440-474), then
+ * lrf_scene_blend.  `fields` is a HOST array of n_rf entries; each field brings its own z schedule (S depends on the
+ * field's grid, tensorBase.py:252-262), engine flags and workspace (lrf_workspace_bytes(min(chunk, R), S) bytes; fields
+ * may share one, the launches are serialised on `stream`).  Scratch supplied by the caller: rays [n_rf,R,6],
+ * rgb_f [n_rf,R,3], depth_f [n_rf,R].  Outputs as lrf_scene_rays / lrf_scene_blend. */
+#define LRF_SCENE_MAX_FIELDS 64
+typedef struct LrfSceneField {
+  const LrfField* field;
+  const float*    z;          /* [S] device */
+  int32_t         S;
+  uint32_t        flags;      /* LRF_FLAG_* of lrf_render_fwd */
+  void*           workspace;
+} LrfSceneField;
+int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const float* cam2world, const float* world2rf,
+                  int32_t n_rf, const float* focal, const float* center, int32_t W, int32_t H, int32_t fov360,
+                  const LrfSceneField* fields, float floater_thresh, int32_t chunk,
+                  const float* blend_w, const float* exposure,
+                  float* rays, float* rgb_f, float* depth_f, float* directions, int64_t* ij,
+                  float* rgbs, float* depth, void* stream);
+
 /* Optimiser step after the path: torch.optim.Adam with the reference's settings
  * (local_tensorfs.py:88-97,146,245; no weight decay, no amsgrad) over up to LRF_ADAM_MAX tensors in
  * one launch.  p, m (exp_avg), v (exp_avg_sq) are updated in place; step_size = lr / (1 - beta1^t)

@@ -32,6 +32,11 @@ class LrfField(C.Structure):
                 ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
 
 
+class LrfSceneField(C.Structure):
+    _fields_ = [("field", C.POINTER(LrfField)), ("z", _f), ("S", C.c_int32), ("flags", C.c_uint32),
+                ("workspace", C.c_void_p)]
+
+
 class LrfGrads(C.Structure):
     _fields_ = [("density_plane", _f * 3), ("density_line", _f * 3),
                 ("app_plane", _f * 3), ("app_line", _f * 3),
@@ -111,6 +116,9 @@ SYMBOLS = {
     "lrf_scene_rays_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int32, _f, _f, C.c_int32,
                                      C.c_int32, C.c_int32, _f, _f, _f, _f, _f, C.c_void_p]),
     "lrf_scene_blend": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
+    "lrf_scene_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32, C.c_int32,
+                                C.c_int32, C.POINTER(LrfSceneField), C.c_float, C.c_int32, _f, _f,
+                                _f, _f, _f, _f, C.c_void_p, _f, _f, C.c_void_p]),
     "lrf_scene_blend_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f,
                                       C.c_void_p]),
 }

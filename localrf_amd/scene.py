@@ -24,7 +24,7 @@ from ._native import NativeError
 from .field import AlphaGridMask, TensorVMSplit
 from .rays import N_to_reso, mtx_to_sixD, sixD_to_mtx
 from .optim import FusedAdam
-from .scene_ops import pose_assemble, scene_blend, scene_rays
+from .scene_ops import pose_assemble, scene_blend, scene_forward, scene_rays
 
 _ADAM_BETAS = (0.9, 0.99)
 
@@ -399,50 +399,48 @@ class LocalTensorfs(torch.nn.Module):
         per_view = n_rays // n_views
 
         shifts = torch.stack([world2rf[rf] for rf in active], dim=0)
-        rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole)
         for rf in active:
             if self.tensorfs[rf].device != dev:
                 self.tensorfs[rf].to(dev)                       # stays there (no shuttle back)
 
         # `chunk` bounds the reference's peak memory (:440: chunk // n_active rays per field call).  Rays are
         # independent, so the result does not depend on it; with 288 GB of HBM a field renders up to
-        # self.min_chunk rays per call whatever the caller's chunk (4 fields x 4096 rays, chunk 4096: 4 calls
-        # instead of 16 -- the forward was host-bound on those launches)
+        # self.min_chunk rays per call whatever the caller's chunk
         chunk = max(1, chunk // len(active), self.min_chunk)
-        taped = torch.is_grad_enabled() and (rays.requires_grad or any(
-            p.requires_grad for rf in active for p in self.tensorfs[rf].parameters()))
-        if taped:
-            cols_rgb, cols_dep = [], []
-            for k, rf in enumerate(active):
-                parts = [self.tensorfs[rf](rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
-                                           N_samples=-1, refine=self.is_refining, floater_thresh=floater_thresh)
-                         for lo in range(0, n_rays, chunk)]
-                cols_rgb.append(parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], 0))
-                cols_dep.append(parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0))
-            rgb_f = cols_rgb[0][None] if len(active) == 1 else torch.stack(cols_rgb, 0)
-            dep_f = cols_dep[0][None] if len(active) == 1 else torch.stack(cols_dep, 0)
-        else:                                                   # fields write straight into the blend input
-            rgb_f = torch.empty(len(active), n_rays, 3, device=dev)
-            dep_f = torch.empty(len(active), n_rays, device=dev)
-            for lo in range(0, n_rays, chunk):                  # same chunk/field order as :440-474
-                for k, rf in enumerate(active):
-                    self.tensorfs[rf](rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
-                                      N_samples=-1, refine=self.is_refining, floater_thresh=floater_thresh,
-                                      out=(rgb_f[k, lo:lo + chunk], dep_f[k, lo:lo + chunk]))
+        taped = torch.is_grad_enabled() and (cam2world.requires_grad or shifts.requires_grad or any(
+            p.requires_grad for rf in active for p in self.tensorfs[rf].parameters()) or any(
+            t is not None and t.requires_grad for t in (focal, center)))
+        if not taped and not is_train:                          # one native call for the whole scene forward (lrf_scene_fwd)
+            return scene_forward(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole,
+                                 [self.tensorfs[rf] for rf in active], white_bg, floater_thresh, chunk, bw,
+                                 self._exposure_for(view_ids, test_id))
+        rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole)
+        cols_rgb, cols_dep = [], []
+        for k, rf in enumerate(active):
+            parts = [self.tensorfs[rf](rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
+                                       N_samples=-1, refine=self.is_refining, floater_thresh=floater_thresh)
+                     for lo in range(0, n_rays, chunk)]
+            cols_rgb.append(parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], 0))
+            cols_dep.append(parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], 0))
+        rgb_f = cols_rgb[0][None] if len(active) == 1 else torch.stack(cols_rgb, 0)
+        dep_f = cols_dep[0][None] if len(active) == 1 else torch.stack(cols_dep, 0)
 
-        exposure = None
-        if self.lr_exposure_init > 0:                           # per-view 3x3 colour transform (:481-496)
-            if test_id:
-                prev = torch.clamp(view_ids - 1, min=0)         # scalar bounds: no blocking upload
-                prev[prev == view_ids] = 1
-                nxt = torch.clamp(view_ids + 1, max=len(self.exposure) - 1)
-                nxt[prev == view_ids] = len(self.exposure) - 2
-                stacked = torch.stack(list(self.exposure), dim=0).clone().detach()
-                exposure = (stacked[prev] + stacked[nxt]) / 2
-            else:
-                exposure = torch.stack(list(self.exposure), dim=0)[view_ids]
+        exposure = self._exposure_for(view_ids, test_id)
         rgbs, depth_maps = scene_blend(rgb_f, dep_f, bw, exposure, per_view)
         return rgbs, depth_maps, directions, ij
+
+    def _exposure_for(self, view_ids, test_id):
+        """Per-view 3x3 colour transform (local_tensorfs.py:481-496); None when exposure is not optimised."""
+        if self.lr_exposure_init <= 0:
+            return None
+        if test_id:                                             # a held-out view borrows its neighbours' (:483-492)
+            prev = torch.clamp(view_ids - 1, min=0)             # scalar bounds: no blocking upload
+            prev[prev == view_ids] = 1
+            nxt = torch.clamp(view_ids + 1, max=len(self.exposure) - 1)
+            nxt[prev == view_ids] = len(self.exposure) - 2
+            stacked = torch.stack(list(self.exposure), dim=0).clone().detach()
+            return (stacked[prev] + stacked[nxt]) / 2
+        return torch.stack(list(self.exposure), dim=0)[view_ids]
 
     def _ones(self, n, dev):
         key = (n, str(dev))

@@ -169,3 +169,49 @@ def scene_blend(rgb_f, dep_f, blend_w, exposure, per_view):
     """-> (clamp(E_v * sum_k w[v,k] rgb_k, 0, 1) [R,3], sum_k w[v,k] depth_k [R])."""
     _require_gpu(rgb_f)
     return _SceneBlendFn.apply(rgb_f, dep_f, blend_w, exposure, int(per_view))
+
+
+def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360, fields, white_bg, floater_thresh,
+                  chunk, blend_w, exposure):
+    """LocalTensorfs.forward without a tape as ONE native call (lrf_scene_fwd): rays of every active field, the per-field
+    renders in the reference's chunk / field order (local_tensorfs.py:440-474), blend, exposure, clamp.
+    `fields`: the active TensorVMSplit objects; world2rf [n_rf,3].  -> (rgbs [R,3], depth [R], directions [R,3], ij [R,2])."""
+    _require_gpu(ray_ids)
+    dev = ray_ids.device
+    R, n_rf = int(ray_ids.shape[0]), len(fields)
+    if R % per_view:
+        raise ValueError("number of rays must be a multiple of the number of views")
+    c2w = _f32c(cam2world[:, :3, :])
+    w2rf = _f32c(world2rf)
+    fo = None if fov360 else _f32c(focal)
+    ce = None if fov360 else _f32c(center)
+    bw = _f32c(blend_w)
+    ex = None if exposure is None else _f32c(exposure)
+    n_chunk = R if chunk <= 0 else min(int(chunk), R)
+    arr = (N.LrfSceneField * n_rf)()
+    keep = []
+    for k, f in enumerate(fields):
+        f._require_gpu(ray_ids)
+        f._ensure_cache()
+        z = f.z_schedule(False, -1, dev).detach().contiguous().float().view(-1)
+        cf = f._c_field()
+        ws = f._workspace(max(n_chunk, 1), int(z.shape[0]), dev)
+        keep += [z, cf, ws]
+        arr[k].field = C.pointer(cf)
+        arr[k].z = z.data_ptr()
+        arr[k].S = int(z.shape[0])
+        arr[k].flags = f._flags(bool(white_bg))
+        arr[k].workspace = ws.data_ptr()
+    rays = torch.empty(n_rf, R, 6, dtype=torch.float32, device=dev)
+    rgb_f = torch.empty(n_rf, R, 3, dtype=torch.float32, device=dev)
+    dep_f = torch.empty(n_rf, R, dtype=torch.float32, device=dev)
+    dirs = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    ij = torch.empty(R, 2, dtype=torch.int64, device=dev)
+    rgbs = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    if R:
+        N.check(N.lib().lrf_scene_fwd(ray_ids.data_ptr(), R, int(per_view), N.ptr(c2w), N.ptr(w2rf), n_rf, N.ptr(fo), N.ptr(ce),
+                                      int(W), int(H), int(bool(fov360)), arr, float(floater_thresh), int(n_chunk),
+                                      N.ptr(bw), N.ptr(ex), N.ptr(rays), N.ptr(rgb_f), N.ptr(dep_f), N.ptr(dirs), ij.data_ptr(),
+                                      N.ptr(rgbs), N.ptr(depth), _stream(dev)), "lrf_scene_fwd")
+    return rgbs, depth, dirs, ij

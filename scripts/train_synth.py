@@ -209,7 +209,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                                       lt.focal(W), lt.center(W, H))
             dl = geo_losses.depth_loss(depth_map, data.invdepths[vsel[:, None], psel], view_ids.shape[0])
             total = total + fl * 1.0 * reg_w / ((W + H) / 2) + dl * 0.1 * reg_w
-            geo_vals.append((float(fl.detach()), float(dl.detach())) if it % 25 == 0 else None)
+            geo_vals.append((float(fl.detach()), float(dl.detach())) if it % geo_every == 0 else None)
             if it % geo_every == 0:                                    # the curve, phase by phase (profiles/r09*_geo_curve)
                 lo, hi = data.active_frames_bounds
                 with torch.no_grad():

@@ -515,14 +515,15 @@ def test_config3_full_size_vs_reference_golden():
     g = load_golden("config3_4x300")
     lt = local_from_golden_seed(g, DEV, lr_i=0, n_grow=3)
     ray_ids, view_ids = _t(g["ray_ids"]).to(DEV), _t(g["view_ids"]).to(DEV)
-    seen = {}                                            # the rays every field was asked to render, in call order
-    hooks = [f.register_forward_pre_hook(lambda m, a, i=i: seen.setdefault(i, []).append(a[0].detach().clone()))
-             for i, f in enumerate(lt.tensorfs)]
-    with torch.no_grad():
+    with torch.no_grad():                                # (one native call: lrf_scene_fwd)
         rgbs, depths, _, _ = lt(ray_ids, view_ids, int(g["W"]), int(g["H"]), is_train=False,
                                 blending_weights=_t(g["bw"]).to(DEV), chunk=4096)
-    for h in hooks:
-        h.remove()
+        # the rays every field rendered, for the per-ray threshold check below (the same kernel the call used)
+        from localrf_amd.scene_ops import scene_rays
+        W, H = int(g["W"]), int(g["H"])
+        per_field_rays, _, _ = scene_rays(ray_ids, lt.get_cam2world(view_ids.tolist()), torch.stack(list(lt.world2rf), 0),
+                                          lt.focal(W), lt.center(W, H), ray_ids.shape[0] // view_ids.shape[0], W, H, False)
+    seen = {i: [per_field_rays[i]] for i in range(len(lt.tensorfs))}
     e_rgb = np.abs(rgbs.cpu().numpy() - g["rgbs"]).max(-1)
     e_dep = np.abs(depths.cpu().numpy() - g["depths"]) / np.maximum(np.abs(g["depths"]), 1e-3)
     assert e_dep.max() < 1e-4, e_dep.max()
@@ -917,3 +918,46 @@ def test_trajectory_replay_vs_reference_golden():
     e_dep = float((np.abs(depth - g["final_depth"]) / np.abs(g["final_depth"])).max())
     print("trajectory: final eval render through both fields: colour %.2e, relative depth %.2e" % (e_rgb, e_dep))
     assert e_rgb < 5e-4 and e_dep < 1e-3
+
+
+@pytest.mark.parametrize("chunk,min_chunk,test_id", [(16384, 65536, False), (192, 1, False), (4096, 65536, True)])
+def test_scene_forward_single_native_call_equals_the_per_field_path(chunk, min_chunk, test_id):
+    """lrf_scene_fwd (what LocalTensorfs.forward calls when no gradient is recorded: rays of every active field, the
+    per-field renders in the reference's chunk / field order, blend, exposure) against the same scene put together by
+    hand (lrf_scene_rays -> TensorVMSplit.forward per field on the whole batch -> lrf_scene_blend): bit-identical, including a
+    chunk that splits the batch unevenly and the held-out-view exposure of local_tensorfs.py:483-492."""
+    from localrf_amd import LocalTensorfs
+    from util import load_golden
+    g = load_golden("local_4fields")
+    W, H = int(g["W"]), int(g["H"])
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).to(DEV)
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=(W, H),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device=DEV, lr_upsample_reset=True,
+               aabb=aabb, gridSize=[int(v) for v in g["grid"]], **FIELD_KW)
+    quiet(lt.load, {k[3:]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items() if k.startswith("lt.")})
+    lt = lt.to(DEV)
+    lt.min_chunk = min_chunk
+    ray_ids = torch.from_numpy(g["ray_ids"]).to(DEV)
+    view_ids = torch.from_numpy(g["view_ids"]).to(DEV)
+    assert len(lt.tensorfs) >= 3
+    with torch.no_grad():
+        native = lt(ray_ids, view_ids, W, H, is_train=False, white_bg=True, chunk=chunk, test_id=test_id, floater_thresh=0.0)
+        # the same scene by hand: one launch group per step, every field on the whole batch
+        from localrf_amd.scene_ops import scene_blend, scene_rays
+        views = view_ids.tolist()
+        host = lt._blending_host()[views]
+        active = torch.nonzero(host.sum(0))[:, 0].tolist()
+        assert len(active) >= 2
+        rays, dirs, ij = scene_rays(ray_ids, lt.get_cam2world(views), torch.stack([lt.world2rf[rf] for rf in active], 0),
+                                    lt.focal(W), lt.center(W, H), ray_ids.shape[0] // len(views), W, H, False)
+        cols = [lt.tensorfs[rf](rays[k], is_train=False, white_bg=True, N_samples=-1) for k, rf in enumerate(active)]
+        bw = lt.blending_weights[view_ids][:, active]
+        rgbs, depth = scene_blend(torch.stack([c[0] for c in cols]), torch.stack([c[1] for c in cols]), bw,
+                                  lt._exposure_for(view_ids, test_id), ray_ids.shape[0] // len(views))
+    for a, b, name in zip((rgbs, depth, dirs, ij), native, ("rgbs", "depth", "directions", "ij")):
+        assert torch.equal(a, b), name
+    if test_id:                                                 # and the reference's own values for this call
+        assert np.abs(native[0].cpu().numpy() - g["rgbs_testid"]).max() < 1e-4
