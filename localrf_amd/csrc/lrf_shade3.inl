@@ -65,6 +65,7 @@ __device__ __forceinline__ void mma3_step(const uint4* img, int frag0, int strid
   for (int m = 0; m < NM; ++m) acc[m] = mfma32(ah[m], bh, acc[m]);
 }
 
+
 // the 12 appearance products of lane half h for plane p: channels 12 h .. 12 h + 11 of the dense texel, three aligned
 // float4 per tap (tensoRF.py:153-195); same per-channel arithmetic, in the same order, as gather_app6_plane32
 // the 12 appearance products of lane half h for plane p: channels 12 h .. 12 h + 11 of the dense texel, three aligned
@@ -279,7 +280,10 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     // hand (sched_barrier regions) was measured too: 137 vs 133 us, the compiler's own order is better.  Starting the
     // second wave of every SIMD 8 K / 16 K / 32 K cycles late changes nothing (123.4 / 123.1 / 124.7 / 127.7 us): the waves
     // are not phase-locked; a wave issues one instruction per 4-cycle slot and the loop body is 1882 of them (1265 VALU,
-    // 135 MFMA, 196 LDS, 58 VMEM, 228 SALU): instruction count is what is left to cut.
+    // 135 MFMA, 196 LDS, 58 VMEM, 228 SALU): instruction count is what is left to cut.  Also measured and dropped: layer 2
+    // with double-buffered A fragments and sched_group_barrier(DS_READ, MFMA) pinning (125.0 vs 122.2 us), the scheduler
+    // strategies max-ilp (131.5) and max-memory-clause (133.8).
+    __builtin_amdgcn_iglp_opt(0);                             // DS-read / MFMA interleave of the small-GEMM heuristic: 122.7 -> 121.2 us (scripts/ab_shade.sh)
     __builtin_amdgcn_s_setprio(2);
     // basis 72 -> 27 (tensoRF.py:196): five K-steps; the three terms in three accumulators (one output tile only)
     f32x16 fa, fb, fc;
