@@ -166,6 +166,11 @@ int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size,
                         const float* jitter, int32_t R, int32_t N,
                         float* pts, float* t, uint8_t* inside, void* stream);
 
+/* TensorBase.sample_ray_contracted (tensorBase.py:419-443): pts [R,S,3] = contract(o + d z) for a caller-supplied
+ * schedule z [S] (the second return value of the reference's method; its third is all-true).  rays_o, rays_d [R,3]. */
+int lrf_sample_ray_contracted(const float* rays_o, const float* rays_d, const float* z, int32_t R, int32_t S,
+                              float* pts, void* stream);
+
 /* Scene-level ends of the path: LocalTensorfs.forward (local_tensorfs.py:382-499).
  * View of ray r is r / per_view (repeat_interleave at local_tensorfs.py:437); R % per_view == 0.
  *

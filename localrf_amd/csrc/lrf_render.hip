@@ -767,6 +767,19 @@ __global__ void k_app_feature(DField f, const float* __restrict__ u, int P, floa
 }
 
 // tensorBase.py:396-417
+// TensorBase.sample_ray_contracted (tensorBase.py:419-443) as a public call: pts[r][k] = contract(o_r + d_r z_k).  (The render
+// kernels do this per sample in registers; this entry exists for callers of the reference's method.)
+__global__ __launch_bounds__(256) void k_sample_contracted(const float* __restrict__ ro, const float* __restrict__ rd,
+                                                           const float* __restrict__ z, int R, int S, float* __restrict__ pts) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)R * S) return;
+  const int r = (int)(i / S), k = (int)(i % S);
+  const float zk = z[k];
+  float x = ro[3 * r] + rd[3 * r] * zk, y = ro[3 * r + 1] + rd[3 * r + 1] * zk, w = ro[3 * r + 2] + rd[3 * r + 2] * zk;
+  contract3(x, y, w);
+  pts[3 * i] = x; pts[3 * i + 1] = y; pts[3 * i + 2] = w;
+}
+
 __global__ void k_sample_ray_aabb(const float* __restrict__ rays, float lo0, float lo1, float lo2,
                                   float hi0, float hi1, float hi2, float step, float near_, float far_,
                                   const float* __restrict__ jitter, int R, int N,
@@ -1140,6 +1153,17 @@ int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size,
   hipLaunchKernelGGL(k_sample_ray_aabb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      rays, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], step_size, near_, far_,
                      jitter, R, N, pts, t, inside);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+int lrf_sample_ray_contracted(const float* rays_o, const float* rays_d, const float* z, int32_t R, int32_t S,
+                              float* pts, void* stream) {
+  if (!rays_o || !rays_d || !z || !pts) return set_err("lrf_sample_ray_contracted: null argument");
+  const size_t n = (size_t)R * S;
+  if (!n) return 0;
+  hipLaunchKernelGGL(k_sample_contracted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     rays_o, rays_d, z, R, S, pts);
   LRF_HIP(hipGetLastError());
   return 0;
 }

@@ -572,6 +572,20 @@ class TensorVMSplit(torch.nn.Module):
             self._z_cache[(h, str(device))] = z
         return z
 
+    def sample_ray_contracted(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        """tensorBase.py:419-443 with its signature and return values: (rays_pts [R,S,3] contracted sample positions,
+        interpx [1,S] sample distances, ~mask_outbbox [R,S] all True).  forward() does this per sample inside k_march /
+        k_shade3; the method is here for callers of the reference's API."""
+        self._require_gpu(rays_o)
+        dev = rays_o.device
+        z = self.z_schedule(is_train, N_samples, dev).detach().contiguous().float().view(-1)
+        ro, rd = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        R, S = ro.shape[0], z.shape[0]
+        pts = torch.empty(R, S, 3, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_sample_ray_contracted(N.ptr(ro), N.ptr(rd), N.ptr(z), R, S, N.ptr(pts),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "lrf_sample_ray_contracted")
+        return pts, z[None], torch.ones(R, S, dtype=torch.bool, device=dev)
+
     def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1, jitter=None):
         """AABB march (tensorBase.py:396-417), via lrf_sample_ray_aabb.  `jitter` [R] (extension)
         replaces the per-ray torch.rand draw of train mode (:408-409) so a recorded draw can be replayed."""

@@ -170,6 +170,29 @@ def test_sample_ray_aabb_vs_reference_golden(built_lib):
         assert (inside.cpu().numpy() != g["inside" + sfx]).mean() < 0.002   # points within rounding of a box face
 
 
+@pytest.mark.parametrize("name", ["field_small_eval", "field_small_floater", "field_small_train_grad"])
+def test_sample_ray_contracted_vs_reference_golden(built_lib, name):
+    """TensorBase.sample_ray_contracted as a public method (tensorBase.py:419-443): positions and distances recorded from
+    the reference's own call (eval schedule; the train golden replays its recorded jitter), mask all True."""
+    g = load_golden(name)
+    f = quiet(field_from_golden, g, DEV)
+    rays = torch.from_numpy(g["rays"]).to(DEV)
+    vd = rays[:, 3:6] / rays[:, 3:6].norm(dim=-1, keepdim=True)
+    train = "U" in g
+    if train:
+        f.z_override = torch.from_numpy(oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"])))
+    pts, z, ok = f.sample_ray_contracted(rays[:, :3], vd, is_train=train, N_samples=int(g["N_samples"]))
+    S = 2 * (int(g["N_samples"]) // 6)
+    assert pts.shape == (rays.shape[0], S, 3) and z.shape == (1, S) and ok.shape == (rays.shape[0], S) and bool(ok.all())
+    if "z" in g:
+        assert np.abs(_np(z)[0] - g["z"]).max() <= 2e-7 * np.abs(g["z"]).max()
+    if "xyz0" in g:
+        assert np.abs(_np(pts)[:4] - g["xyz0"]).max() < 2e-6
+    # and against the numpy oracle for every ray
+    want = oracle.contract(rays[:, None, :3].cpu().numpy() + vd[:, None, :].cpu().numpy() * _np(z)[0][None, :, None])
+    assert np.abs(_np(pts) - want).max() < 2e-6
+
+
 def test_alpha_mask_rebuild_vs_reference_golden(built_lib):
     """updateAlphaMask on the device (lrf_dense_alpha + lrf_alpha_pool_threshold) against the binary
     volumes the reference's updateAlphaMask produced (tensorBase.py:518-536), including a rebuild
