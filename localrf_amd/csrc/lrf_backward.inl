@@ -1639,7 +1639,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 // The row-saving colour kernel of the training forward is k_bwd_shade_fwd behind k_scan_tiles.  (Round 2 also built it
 // in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
 static int g_dgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(4 | ...): data-gradient chain on the exact-fp32 MFMA path
-static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * n): n weight-gradient GEMMs on the caller's stream
+static int g_wgrad_split = 2;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
 static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 = k_wgrad<8,9> over stored dz2 rows on fp32 MFMAs (measurement)
 static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                               const BwdWorkspace& b, hipStream_t st) {
@@ -1729,11 +1729,16 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
   //   caller's stream: k_bwd_shade_dgrad -> k_wgrad_w2 (dW2) -> appearance bins + scatter                  [-> join] -> ray partials, unpack
   //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) k_wgrad (dW1, dbasis, dW3) -> (dW2 done) reduce
-  // (how many of the four GEMMs stay on the caller's stream is g_wgrad_split: 0..4 measured 2.53 / 2.45 / 2.53 / 2.57 / 2.59 ms)
+  // (how many of the four GEMMs stay on the caller's stream is g_wgrad_split: 0..4 measured 2.53 / 2.45 / 2.53 / 2.57 / 2.59 ms in
+  // round 2; 2.00 / 1.90 / 1.86 / 1.92 / 2.01 ms with the round-3 kernels, 2.20 ms on one stream: two stay)
   // k_bwd_ray and the density scatter need nothing from the data-gradient kernel (the appearance lookups' position
   // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
   // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
   SideStream* ss = g_bwd_overlap ? side_stream() : nullptr;
+  // the side stream and its fork / join events are per device: host threads that enqueue backward passes on the same
+  // device take turns (enqueueing is ~0.3 ms of host time; the kernels themselves still overlap on the GPU)
+  std::unique_lock<std::mutex> side_lock;
+  if (ss) side_lock = std::unique_lock<std::mutex>(ss->mu);
   hipStream_t sb = st;
   if (ss) {
     LRF_HIP(hipEventRecord(ss->fork, st));

@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 #include "lrf_common.h"
 
 namespace lrf {
@@ -882,12 +883,14 @@ static int device_cus() {                 // of the current device (one process 
 }
 
 static int g_bwd_overlap = 1;      // lrf_debug_set_bwd_overlap: weight-gradient GEMMs on a side stream, beside the scatter kernels
-struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2]; bool ok; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2]; bool ok; std::mutex mu; };
 static SideStream* side_stream() {
-  static SideStream tab[64] = {};
+  static SideStream tab[64];
+  static std::mutex init_mu;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   SideStream& x = tab[dev & 63];
+  std::lock_guard<std::mutex> lk(init_mu);
   if (!x.ok) {
     if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||

@@ -139,15 +139,18 @@ class LocalTensorfs(SceneLifecycle):
 
         # `chunk` bounds the reference's peak memory (:440: chunk // n_active rays per field call).  Rays are
         # independent, so the result does not depend on it; with 288 GB of HBM a field renders up to
-        # self.min_chunk rays per call whatever the caller's chunk
-        chunk = max(1, chunk // len(active), self.min_chunk)
+        # self.min_chunk rays per call whatever the caller's chunk when no gradient is recorded
+        per_field = max(1, chunk // len(active))
         taped = torch.is_grad_enabled() and (cam2world.requires_grad or shifts.requires_grad or any(
             p.requires_grad for rf in active for p in self.tensorfs[rf].parameters()) or any(
             t is not None and t.requires_grad for t in (focal, center)))
         if not taped and not is_train:                          # one native call for the whole scene forward (lrf_scene_fwd)
             return scene_forward(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole,
-                                 [self.tensorfs[rf] for rf in active], white_bg, floater_thresh, chunk, bw,
+                                 [self.tensorfs[rf] for rf in active], white_bg, floater_thresh,
+                                 max(per_field, self.min_chunk), bw,
                                  self._exposure_for(view_ids, test_id))
+        # with a tape the caller's chunk is honoured as is: the row-saving workspace is ~1.6 MB per ray at S = 512
+        chunk = per_field
         rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole)
         cols_rgb, cols_dep = [], []
         for k, rf in enumerate(active):
