@@ -234,7 +234,7 @@ def kernel_profile(field, rays, z, reps=5):
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"))
 
 
-def pmc_traffic(timeout_s=240):
+def pmc_traffic(timeout_s=240, mode="fwd"):
     """HBM-side bytes per launch of every lrf kernel, measured now: one rocprofv3 --kernel-trace --pmc
     child per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass), each re-running this script
     for a few steps.  traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half the bytes
@@ -245,7 +245,9 @@ def pmc_traffic(timeout_s=240):
     for ctrs in PMC_PASSES:
         d = tempfile.mkdtemp(prefix="lrf_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "-d", d, "-o", "pmc", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--child"]
+               os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--child", mode]
+        if mode == "train":
+            cmd += ["--preroll-ms", "0"]                         # no eval renders in the counted run
         try:
             r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=timeout_s,
                                capture_output=True, text=True)
@@ -262,6 +264,7 @@ def pmc_traffic(timeout_s=240):
                     acc.setdefault((short.split("<")[0], ctr), []).append(val)
             for (k, ctr), vals in acc.items():
                 per.setdefault(k, {})[ctr] = sum(vals) / len(vals)
+                per[k]["launches"] = len(vals)
         except Exception as e:                               # noqa: BLE001
             return None, f"rocprofv3 pass {ctrs}: {e!r}"
         finally:
@@ -269,7 +272,7 @@ def pmc_traffic(timeout_s=240):
     out = {}
     for k, c in per.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            out[k] = {"traffic_bytes": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
+            out[k] = {"traffic_bytes": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024, "launches": c.get("launches", 0),
                       "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0)}
     return out, "rocprofv3 --kernel-trace --pmc, 2 passes of this run; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"
 
@@ -392,7 +395,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / torch-ROCm baselines and extra workloads")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
-    ap.add_argument("--child", action="store_true", help="(internal) the timed loop only: what the PMC passes profile")
+    ap.add_argument("--child", nargs="?", const="fwd", default=None, choices=("fwd", "train"),
+                    help="(internal) the timed loop only: what the PMC passes profile (fwd: eval forward; train: training step)")
     ap.add_argument("--preroll-ms", type=float, default=150.0, help="untimed GPU clock ramp before the warm-up steps")
     args = ap.parse_args()
 
@@ -447,8 +451,8 @@ def main():
             for _ in range(20):
                 fwd()
             torch.cuda.synchronize(dev)
-        dt = timed(fwd, args.steps, args.warmup, sync)
-    if args.child:
+        dt = timed(fwd, args.steps, args.warmup, sync) if args.child != "train" else 1.0
+    if args.child == "fwd":
         return
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if ddp:
@@ -472,6 +476,8 @@ def main():
         opt.step()
     t_steps = max(5, min(args.steps, 20))
     dtt = timed(train_step, t_steps, 3, sync)
+    if args.child == "train":                                 # the PMC passes count exactly (3 + t_steps) training steps
+        return
     tmax = torch.tensor([dtt], device=dev, dtype=torch.float64)
     if ddp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -507,6 +513,21 @@ def main():
                               "bytes_per_step": train_bytes,
                               "note": "materialised rows + feature / gradient buffers + Adam, by construction; per-kernel "
                                       "times in profiles/"}}
+        if world == 1 and not args.no_pmc:                   # HBM-side bytes of one training step, measured (not by construction)
+            tr_k, tr_src = pmc_traffic(mode="train")
+            if tr_k:
+                per_step = {k: v["traffic_bytes"] * v["launches"] / (3 + 10) for k, v in tr_k.items()}   # child: --steps 10, 3 warm-up
+                total = sum(per_step.values())
+                train["roofline"].update({"traffic": total, "traffic_source": tr_src + "; sum over the lrf kernels of one step "
+                                                                                 "(the optimiser and the few ATen elementwise kernels not included)",
+                                          "achieved": total / (dtt / t_steps) / 1e9, "frac": total / (dtt / t_steps) / 1e9 / HBM_PEAK_GBS,
+                                          "by_construction_bytes": train_bytes,
+                                          "traffic_top": dict(sorted(per_step.items(), key=lambda kv: -kv[1])[:6]),
+                                          "note": "achieved = PMC traffic of the step's kernels / step time; by_construction_bytes = "
+                                                  "materialised rows + feature / gradient buffers + Adam"})
+            else:
+                train["roofline"]["traffic"] = None
+                train["roofline"]["traffic_source"] = tr_src
         out = {"metric": "rays/sec (4096-ray batch, 512 samples, 300^3 grid)", "value": value,
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
