@@ -569,8 +569,26 @@ def main():
                 with torch.no_grad():
                     c3 = lambda: lt(ray_ids, view_ids, 64, 48, is_train=False, blending_weights=bw, chunk=4096)   # noqa: E731
                     d3 = timed(c3, 20, 3, sync)
+                    # per-kernel table: every field on the rays the scene forward hands it (same kernels, HIP events)
+                    from localrf_amd.scene_ops import scene_rays
+                    ids_d = ray_ids.to(dev)
+                    rays4, _, _ = scene_rays(ids_d, lt.get_cam2world(view_ids), torch.stack(list(lt.world2rf), 0), lt.focal(64),
+                                             lt.center(64, 48), ids_d.shape[0] // len(view_ids), 64, 48, False)
+                    per_field = []
+                    for k, fk in enumerate(lt.tensorfs):
+                        zk = fk.z_schedule(False, -1, dev).contiguous()
+                        pk = kernel_profile(fk, rays4[k].contiguous(), zk, reps=10)
+                        per_field.append({"k_march_ms": pk["march_ms"], "k_shade3_ms": pk["shade_ms"], "n_shaded": pk["n_shaded"]})
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        c3()
+                    host_ms = (time.perf_counter() - t0) / 50 * 1e3
+                    torch.cuda.synchronize(dev)
                 work["config3_4x300"] = {"what": "configs[2]: LocalTensorfs, 4 blended 300^3 fields, 4096 rays, default S=344, "
-                                                 "ids and blending weights handed over on the host", "rays_per_s": 4096 * 20 / d3, "ms_per_step": d3 / 20 * 1e3}
+                                                 "ids and blending weights handed over on the host; one native call (lrf_scene_fwd)",
+                                         "rays_per_s": 4096 * 20 / d3, "ms_per_step": d3 / 20 * 1e3,
+                                         "host_enqueue_ms": host_ms, "kernels_per_field": per_field,
+                                         "kernel_sum_ms": sum(q["k_march_ms"] + q["k_shade3_ms"] for q in per_field)}
                 del lt
             except Exception as e:                           # noqa: BLE001
                 work["config3_4x300"] = {"error": repr(e)}
