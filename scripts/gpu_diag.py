@@ -968,7 +968,7 @@ def stage_bwd_overlap():
         if ref is None:
             ref = gsum
         worst = max(abs(gsum[k] - ref[k]) / max(ref[k], 1e-30) for k in ref)
-        log(f"bwd overlap {on & 1}{'' if on < 2 else f' ({(on >> 1) - 1} GEMMs on the caller stream)'}, row-saving forward {'k_shade2<SAVE>' if (eng & 1) == 0 else 'k_bwd_shade_fwd'}, dW2 on {'fp32' if eng & 2 else 'split-bf16'} MFMA: fwd+bwd {dt:.3f} ms (forward alone {dtf:.3f} ms) | "
+        log(f"bwd overlap {on & 1}{'' if on < 2 else f' ({(on >> 1) - 1} GEMMs on the caller stream)'}, dW2 on {'fp32' if eng & 2 else 'split-bf16'} MFMA: fwd+bwd {dt:.3f} ms (forward alone {dtf:.3f} ms) | "
             f"max relative change of a gradient's |sum| vs first run {worst:.2e}")
     lib.lrf_debug_set_bwd_overlap(7)
     lib.lrf_debug_set_train_fwd_engine(1)
