@@ -231,9 +231,10 @@ def port_gradients(f, rays, z, g_rgb, g_depth, white, masks, names):
     return grads, info
 
 
-def check_grads(mine, ref, tol=1e-4, subset=None, gmax=None):
+def check_grads(mine, ref, tol=1e-4, subset=None, gmax=None, tol_for=None):
     """Every gradient tensor within `tol` of its largest reference magnitude -- no exceptions.  subset / gmax:
-    name -> flat indices / max magnitude when `ref` holds only part of a tensor (make_golden.pack_grad)."""
+    name -> flat indices / max magnitude when `ref` holds only part of a tensor (make_golden.pack_grad).
+    tol_for: name -> tolerance for tensors with a stated, separately justified bar."""
     worst = {}
     for name, gm in mine.items():
         gr = ref[name]
@@ -244,5 +245,5 @@ def check_grads(mine, ref, tol=1e-4, subset=None, gmax=None):
         gm, gr = gm.reshape(-1), gr.reshape(-1)
         den = max(float(gmax[name]) if gmax is not None else float(gr.abs().max()), 1e-12)
         worst[name] = float((gm - gr).abs().max()) / den
-        assert worst[name] <= tol, (name, worst[name])
+        assert worst[name] <= (tol_for or {}).get(name, tol), (name, worst[name])
     return worst
