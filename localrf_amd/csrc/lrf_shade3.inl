@@ -282,7 +282,9 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     // are not phase-locked; a wave issues one instruction per 4-cycle slot and the loop body is 1882 of them (1265 VALU,
     // 135 MFMA, 196 LDS, 58 VMEM, 228 SALU): instruction count is what is left to cut.  Also measured and dropped: layer 2
     // with double-buffered A fragments and sched_group_barrier(DS_READ, MFMA) pinning (125.0 vs 122.2 us), the scheduler
-    // strategies max-ilp (131.5) and max-memory-clause (133.8).
+    // strategies max-ilp (131.5) and max-memory-clause (133.8); the weight image copied by direct global -> LDS loads
+    // under the first tile's gathers (prologue 20.8 K -> 15.8 K cycles, but every arrangement of the loop that allows it
+    // costs the chain 0.9-3.3 K cycles per tile in the compiler's schedule: 122.6-127.5 us against 121.3-123.9).
     __builtin_amdgcn_iglp_opt(0);                             // DS-read / MFMA interleave of the small-GEMM heuristic: 122.7 -> 121.2 us (scripts/ab_shade.sh)
     __builtin_amdgcn_s_setprio(2);
     // basis 72 -> 27 (tensoRF.py:196): five K-steps; the three terms in three accumulators (one output tile only)

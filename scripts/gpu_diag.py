@@ -78,7 +78,7 @@ def stage_shade3_phases():
     with torch.no_grad():
         for _ in range(300):
             f(rays, white_bg=True, is_train=False, N_samples=1536)
-    names = ["prologue", "header+position", "gather+split", "-", "-", "chain", "tiles", "finalize"]
+    names = ["prologue rest", "header+position", "gather+split", "image copy", "scan", "chain", "tiles", "finalize"]
     nw = 8
     buf = torch.zeros(256 * nw * 8, dtype=torch.int64, device="cuda")
     with torch.no_grad():
@@ -89,7 +89,7 @@ def stage_shade3_phases():
     t = buf.view(256 * nw, 8).double()
     tiles = t[:, 6].sum()
     tot = t[:, [0, 1, 2, 3, 4, 5, 7]].sum(1)
-    log(f"k_shade3 {nw} waves: tiles {int(tiles)} | cycles per wave: prologue {float(t[:, 0].mean()):.0f} finalize {float(t[:, 7].mean()):.0f} | per tile: " +
+    log(f"k_shade3 {nw} waves: tiles {int(tiles)} | cycles per wave: prologue {float(t[:, 0].mean()):.0f} (+ image copy {float(t[:, 3].mean()):.0f}, scan {float(t[:, 4].mean()):.0f}) finalize {float(t[:, 7].mean()):.0f} | per tile: " +
         " ".join(f"{names[i]} {float(t[:, i].sum() / tiles):.0f}" for i in (1, 2, 5)) +
         f" | per-wave total mean/min/max {float(tot.mean()):.0f}/{float(tot.min()):.0f}/{float(tot.max()):.0f}")
     for eng in ("bf16x3", "f32"):

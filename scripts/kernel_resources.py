@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I",
+asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I",
                       os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", "-",
                       os.path.join(ROOT, "localrf_amd", "csrc", "lrf_render.hip")],
                      capture_output=True, text=True).stdout
