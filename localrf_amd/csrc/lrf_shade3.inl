@@ -148,7 +148,7 @@ struct Hdr3 {
 // LDS (R + 1 ints beside the image: two launches per render, k_march -> k_shade3); otherwise k_scan_tiles_n<32> ran before
 // and toff_g holds them.
 // TIMED (debug, lrf_debug_set_dump + lrf_debug_set_mlp_policy(10)): s_memtime totals per wave -> dump[block][wave][8] =
-// {prologue, header + position, gather + split, -, -, chain, tiles, finalize}
+// {rest of the prologue, header + position, gather + split, image copy, scan, chain, tiles, finalize}
 template <int NW, bool LDSTOFF, bool TIMED = false>
 __global__ __launch_bounds__(NW * 64) void k_shade3(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
   for (int i = tid; i < W32_ALL_U4; i += NT) img[i] = f.mlpw[i];
   for (int i = tid; i < S; i += NT) s_z[i] = z[i];
+  if (TIMED) { __syncthreads(); LRF_TICK(3); }                 // (TIMED only: image + z in LDS)
   if (LDSTOFF) {                                               // exclusive scan of ceil(ncomp / 32): eight rays per thread and round
     int carry = 0;
     for (int base = 0; base < R; base += NT * 8) {
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     if (tid == 0) s_toff[R] = carry;
   }
   __syncthreads();
+  LRF_TICK(4);                                                 // (TIMED only: scan done)
   typedef typename std::conditional<LDSTOFF, const lds_int*, const int*>::type ToffP;
   ToffP toff;
   if constexpr (LDSTOFF) toff = s_toff; else toff = toff_g;
