@@ -564,6 +564,17 @@ def main():
                 del wf
             except Exception as e:                           # noqa: BLE001
                 work["trained_like"] = {"error": repr(e)}
+            try:                                             # the same field on a 16 x larger batch (an eval image is rendered this way)
+                big = make_rays(16 * R_PER_GPU, 7).to(dev)
+                with torch.no_grad():
+                    fb = lambda: field(big, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)   # noqa: E731
+                    d_big = timed(fb, 5, 2, sync)
+                work["batch_65536"] = {"what": "same field and sample count, 65536 rays per call (three launches: the tile offsets of "
+                                               "this many rays do not fit in LDS beside the weight image)",
+                                       "rays_per_s": 16 * R_PER_GPU * 5 / d_big, "ms_per_step": d_big / 5 * 1e3}
+                del big
+            except Exception as e:                           # noqa: BLE001
+                work["batch_65536"] = {"error": repr(e)}
             try:
                 lt, ray_ids, view_ids, bw = config3_scene(dev)
                 with torch.no_grad():
