@@ -170,7 +170,14 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   __shared__ int s_next;                                       // tile queue of this workgroup
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
-  for (int i = tid; i < W32_ALL_U4; i += NT) img[i] = f.mlpw[i];
+  {
+    // Every workgroup starts its copy of the 95 KB image at a different place.  Started at the same place, the CUs of an
+    // XCD ask the same L2 channel for the same line at the same time and the copy runs at ~11 B / cycle / CU (8.2 K
+    // cycles); rotated it takes 5.0 K (colour stage 120.6 -> 119.4 us, scripts/ab_shade.sh).  Rotating the reads of the
+    // per-ray counts and of k_march's line staging the same way gains nothing measurable.
+    const int rot = (int)((blockIdx.x * 37u) % 93u) * 64;
+    for (int i = tid; i < W32_ALL_U4; i += NT) { int j = i + rot; if (j >= W32_ALL_U4) j -= W32_ALL_U4; img[j] = f.mlpw[j]; }
+  }
   for (int i = tid; i < S; i += NT) s_z[i] = z[i];
   if (TIMED) { __syncthreads(); LRF_TICK(3); }                 // (TIMED only: image + z in LDS)
   if (LDSTOFF) {                                               // exclusive scan of ceil(ncomp / 32): eight rays per thread and round
