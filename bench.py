@@ -291,8 +291,8 @@ def committed_traffic():
 
 
 def roofline_object(prof, S, traffic, traffic_src, cus=256, clock_ghz=2.4):
-    """SURVEY.md s8d figures per launch over HIP-event durations (DESIGN.md s5 says how to read them).  The 43.6 MB
-    field is cache-resident, so the HBM roof cannot bind either kernel; what can bind is reported beside the contract's
+    """SURVEY.md s8d figures per launch over HIP-event durations (DESIGN.md s5 says how to read them).  The 34.6 MB
+    the forward touches of the field are cache-resident, so the HBM roof cannot bind either kernel; what can bind is reported beside the contract's
     figure: matrix-pipe occupancy (issued MFMAs, three per product), the vector issue port (VALU + MFMA instructions at
     four cycles each per SIMD), L2 rate, HBM-side traffic from the counters."""
     n_sh = prof["n_shaded"]
@@ -333,7 +333,7 @@ def roofline_object(prof, S, traffic, traffic_src, cus=256, clock_ghz=2.4):
             "binding_frac": d.get("binding_frac"),
             "limiter": "vector instruction issue: a 32-sample tile costs a wave ~1400 VALU + 135 MFMA instructions through one issue "
                        "port per SIMD (issue_frac); the matrix pipe runs the three-term split products at mfma_frac of its dense "
-                       "bf16 rate (frac counts algorithmic flops: one product per weight); the 43.6 MB field is cache-resident, "
+                       "bf16 rate (frac counts algorithmic flops: one product per weight); the 34.6 MB the forward touches of the field is cache-resident, "
                        "so neither HBM (hbm_frac) nor L2 (l2_frac) binds",
             "whole_path_GBps": (dens_bytes + app_bytes) / (prof["total_ms"] * 1e-3) / 1e9,
             "shaded_fraction": n_sh / (R_PER_GPU * S), "kernels": kern,
