@@ -462,6 +462,7 @@ def main():
     value = world * R_PER_GPU * args.steps / dt
 
     # ---- training step, every N: forward with a graph, backward, gradient all-reduce (RCCL), FusedAdam
+    sd_init = {k: v.detach().clone() for k, v in field.state_dict().items()}     # the workloads below render the untrained field again
     opt = FusedAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     gr = torch.randn(R_PER_GPU, 3, device=dev)
     gd = torch.randn(R_PER_GPU, device=dev)
@@ -478,6 +479,8 @@ def main():
     dtt = timed(train_step, t_steps, 3, sync)
     if args.child == "train":                                 # the PMC passes count exactly (3 + t_steps) training steps
         return
+    field.load_state_dict(sd_init)
+    del sd_init
     tmax = torch.tensor([dtt], device=dev, dtype=torch.float64)
     if ddp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
