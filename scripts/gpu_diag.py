@@ -79,7 +79,7 @@ def stage_shade3_phases():
         for _ in range(300):
             f(rays, white_bg=True, is_train=False, N_samples=1536)
     names = ["prologue rest", "header+position", "gather+split", "image copy", "scan", "chain", "tiles", "finalize"]
-    nw = int(os.environ.get("DIAG_NW", "8"))                 # (experiment builds with other workgroup sizes: scripts/build_variant.sh -DLRF_S3_NW=..)
+    nw = int(os.environ.get("DIAG_NW", "8"))                 # waves per workgroup of the build under test
     buf = torch.zeros(256 * nw * 8, dtype=torch.int64, device="cuda")
     with torch.no_grad():
         lib.lrf_debug_set_dump(buf.data_ptr())
