@@ -279,10 +279,14 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
   for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
   __syncthreads();
   const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
-  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
   TileWalk tw = tile_walk_begin(toff, R);
   for (; tw.t < tw.t_end; ++tw.t) {
     asm volatile("" ::: "memory");
+    // the lane's coordinates are re-derived per tile (two instructions) instead of being kept -- and spilled -- across the
+    // 1800-instruction loop body
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int s = lane & 15, g = lane >> 4;
     tile_walk_seek(tw, toff);
     const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
     const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
@@ -319,7 +323,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       save_x_plane<1>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
-      gather_app6_plane32<2>(f, at, g, v);
+      __builtin_amdgcn_sched_barrier(0);                 // the third plane's gathers stay behind the second's products: with all three
+      gather_app6_plane32<2>(f, at, g, v);               // in flight at once the kernel spilled 8 registers per tile (same speed)
       save_x_plane<2>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
@@ -472,10 +477,14 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     for (int i = threadIdx.x; i < IMT_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, s = lane & 15, g = lane >> 4;
   TileWalk tw = tile_walk_begin(toff, R);
   for (; tw.t < tw.t_end; ++tw.t) {
     asm volatile("" ::: "memory");
+    // the lane's coordinates are re-derived per tile (two instructions) instead of being kept -- and spilled -- across the
+    // 1800-instruction loop body
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int s = lane & 15, g = lane >> 4;
     tile_walk_seek(tw, toff);
     const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
     const int tile = tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM);

@@ -462,13 +462,13 @@ __device__ __forceinline__ TileWalk tile_walk_begin(const int* __restrict__ toff
     const int mid = (lo + hi) >> 1;
     if (toff[mid] <= tw.t) lo = mid; else hi = mid;
   }
-  tw.ray = lo;
-  tw.next_off = toff[lo + 1];
+  tw.ray = __builtin_amdgcn_readfirstlane(lo);            // (wave-uniform: kept in scalar registers across the tile loop)
+  tw.next_off = __builtin_amdgcn_readfirstlane(toff[lo + 1]);
   return tw;
 }
 // advance to the ray owning tile tw.t (skips rays without shaded samples)
 __device__ __forceinline__ void tile_walk_seek(TileWalk& tw, const int* __restrict__ toff) {
-  while (tw.next_off <= tw.t) { ++tw.ray; tw.next_off = toff[tw.ray + 1]; }
+  while (tw.next_off <= tw.t) { ++tw.ray; tw.next_off = __builtin_amdgcn_readfirstlane(toff[tw.ray + 1]); }
 }
 
 __global__ __launch_bounds__(1024) void k_shade(
