@@ -25,6 +25,17 @@ from .rays import N_to_reso, mtx_to_sixD, sixD_to_mtx
 
 _ADAM_BETAS = (0.9, 0.99)
 
+# constructor arguments of local_tensorfs.LocalTensorfs that are kept verbatim, and the attribute each one is stored under
+# (checkpoints written by get_kwargs / save round-trip through the same table)
+_CTOR_ATTRS = (
+    ("fov", "fov"), ("n_init_frames", "n_init_frames"), ("n_overlap", "n_overlap"),
+    ("n_iters_per_frame", "n_iters_per_frame"), ("n_iters_reg", "n_iters_reg_per_frame"),
+    ("lr_R_init", "lr_R_init"), ("lr_t_init", "lr_t_init"), ("lr_i_init", "lr_i_init"), ("lr_exposure_init", "lr_exposure_init"),
+    ("rf_lr_init", "rf_lr_init"), ("rf_lr_basis", "rf_lr_basis"), ("lr_decay_target_ratio", "lr_decay_target_ratio"),
+    ("N_voxel_list", "N_voxel_per_frame_list"), ("update_AlphaMask_list", "update_AlphaMask_per_frame_list"),
+    ("lr_upsample_reset", "lr_upsample_reset"),
+)
+
 
 class SceneLifecycle(torch.nn.Module):
     def __init__(self, fov, n_init_frames, n_overlap, WH, n_iters_per_frame, n_iters_reg,
@@ -32,23 +43,14 @@ class SceneLifecycle(torch.nn.Module):
                  lr_decay_target_ratio, N_voxel_list, update_AlphaMask_list, camera_prior,
                  device, lr_upsample_reset, **tensorf_args):
         super().__init__()
-        self.fov = fov
-        self.n_init_frames = n_init_frames
-        self.n_overlap = n_overlap
+        given = dict(locals())
+        for arg, attr in _CTOR_ATTRS:                           # constructor argument -> attribute of the reference's name
+            setattr(self, attr, given[arg])
         self.W, self.H = WH
-        self.n_iters_per_frame = n_iters_per_frame
-        self.n_iters_reg_per_frame = n_iters_reg
-        self.lr_R_init, self.lr_t_init = lr_R_init, lr_t_init
-        self.lr_i_init, self.lr_exposure_init = lr_i_init, lr_exposure_init
-        self.rf_lr_init, self.rf_lr_basis = rf_lr_init, rf_lr_basis
-        self.lr_decay_target_ratio = lr_decay_target_ratio
-        self.N_voxel_per_frame_list = N_voxel_list
-        self.update_AlphaMask_per_frame_list = update_AlphaMask_list
         self.device = torch.device(device)
         self.camera_prior = camera_prior
         self.tensorf_args = tensorf_args
         self.is_refining = False
-        self.lr_upsample_reset = lr_upsample_reset
         # utils/utils.py:386 calls torch.cross without `dim`, which picks the FIRST axis of size 3:
         # for a batch of exactly 3 views that is the view axis, not xyz.  True reproduces the
         # reference result (checked against a reference-recorded golden); False = the cross product
@@ -60,12 +62,10 @@ class SceneLifecycle(torch.nn.Module):
         # lower bound of the rays per field call in forward (see there); 1 = chunk exactly as the reference
         self.min_chunk = 65536
 
-        self.lr_factor = 1
-        self.regularize = True
-        self.n_iters_reg = self.n_iters_reg_per_frame
-        self.n_iters = self.n_iters_per_frame
-        self.update_AlphaMask_list = update_AlphaMask_list
-        self.N_voxel_list = N_voxel_list
+        # schedule state until optimizer_step rescales it by the number of training frames (local_tensorfs.py:77-82)
+        self.lr_factor, self.regularize = 1, True
+        self.n_iters, self.n_iters_reg = n_iters_per_frame, n_iters_reg
+        self.N_voxel_list, self.update_AlphaMask_list = N_voxel_list, update_AlphaMask_list
 
         # per-frame pose / exposure parameters, each with its own Adam (local_tensorfs.py:88-97)
         self.r_c2w = torch.nn.ParameterList()
@@ -236,17 +236,8 @@ class SceneLifecycle(torch.nn.Module):
 
     def get_kwargs(self):
         """local_tensorfs.py:301-324."""
-        kw = {
-            "camera_prior": None, "fov": self.fov, "n_init_frames": self.n_init_frames,
-            "n_overlap": self.n_overlap, "WH": (self.W, self.H),
-            "n_iters_per_frame": self.n_iters_per_frame, "n_iters_reg": self.n_iters_reg_per_frame,
-            "lr_R_init": self.lr_R_init, "lr_t_init": self.lr_t_init, "lr_i_init": self.lr_i_init,
-            "lr_exposure_init": self.lr_exposure_init, "rf_lr_init": self.rf_lr_init,
-            "rf_lr_basis": self.rf_lr_basis, "lr_decay_target_ratio": self.lr_decay_target_ratio,
-            "N_voxel_list": self.N_voxel_per_frame_list,
-            "update_AlphaMask_list": self.update_AlphaMask_per_frame_list,
-            "lr_upsample_reset": self.lr_upsample_reset,
-        }
+        kw = {arg: getattr(self, attr) for arg, attr in _CTOR_ATTRS}
+        kw.update(camera_prior=None, WH=(self.W, self.H))
         kw.update(self.tensorfs[0].get_kwargs())
         return kw
 
