@@ -551,6 +551,7 @@ def main():
             try:
                 wf = walls_field(dev)
                 wf.updateAlphaMask((GRID // 2,) * 3)
+                wf.early_term_T = 1e-9                        # the opt-in (default 0 = reference semantics): north_star's early termination
                 with torch.no_grad():
                     wfwd = lambda: wf(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)   # noqa: E731
                     d_on = timed(wfwd, 20, 3, sync)
@@ -559,7 +560,7 @@ def main():
                     d_off = timed(wfwd, 20, 3, sync)
                     p_off = kernel_profile(wf, rays, z)
                 work["trained_like"] = {
-                    "what": "300^3 field, empty space inside a box of dense walls + device-rebuilt alpha mask, same 4096 x 512 batch",
+                    "what": "300^3 field, empty space inside a box of dense walls + device-rebuilt alpha mask, same 4096 x 512 batch; early termination opted in (early_term_T = 1e-9; the class default is 0 = every sample evaluated)",
                     "rays_per_s": R_PER_GPU * 20 / d_on, "ms_per_step": d_on / 20 * 1e3,
                     "k_march_ms": p_on["march_ms"], "shaded_fraction": p_on["n_shaded"] / (R_PER_GPU * S),
                     "without_early_termination": {"rays_per_s": R_PER_GPU * 20 / d_off, "ms_per_step": d_off / 20 * 1e3,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 2
+#define LRF_ABI_VERSION 3      /* 3: lrf_render_bwd_wait, unknown flag bits rejected, training rows without h1 (round 4) */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -40,6 +40,7 @@ extern "C" {
 #define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
                                     split-bf16 (hi+lo, 3-term) chain on v_mfma_f32_32x32x16_bf16 (k_shade3) */
 #define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
+#define LRF_FLAG_ALL        31u  /* any other bit is an error (a caller built against another ABI version) */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
  * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with
@@ -145,6 +146,13 @@ int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, con
                    const float* g_rgb, const float* g_depth,
                    const LrfGrads* g, float* g_rays,
                    void* workspace, void* stream);
+
+/* Data-parallel hand-off (no reference counterpart): makes `stream` wait until one bucket of the gradients
+ * of the most recent lrf_render_bwd enqueued on the current device is final, so that a collective over that bucket can
+ * start while the rest of the backward still runs.  bucket 0: density planes + lines (the per-ray branch finishes
+ * early), 1: colour network (basis, mlp, mlp_view), 2: appearance planes + lines (= everything).  Error if no
+ * lrf_render_bwd ran on this device. */
+int lrf_render_bwd_wait(int32_t bucket, void* stream);
 
 /* Debug / parity diagnostics: byte offsets inside the training workspace of {activation rows, gradient rows,
  * rowinfo (row -> ray*S+k or ~0), toff} and the row strides / column offsets {ACT_LD, GRD_LD, ACT_H1, ACT_H2}

@@ -88,6 +88,7 @@ SYMBOLS = {
     "lrf_workspace_bytes_bwd": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "lrf_render_bwd": (C.c_int, [C.POINTER(LrfField), C.POINTER(LrfParams), _f, _f, C.c_int32, C.c_int32,
                                  C.c_uint32, _f, _f, C.POINTER(LrfGrads), _f, C.c_void_p, C.c_void_p]),
+    "lrf_render_bwd_wait": (C.c_int, [C.c_int32, C.c_void_p]),
     "lrf_density_feature": (C.c_int, [C.POINTER(LrfField), _f, C.c_int32, _f, C.c_void_p]),
     "lrf_app_feature": (C.c_int, [C.POINTER(LrfField), _f, C.c_int32, _f, C.c_void_p]),
     "lrf_sample_ray_aabb": (C.c_int, [_f, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _f,
@@ -144,7 +145,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if h.lrf_abi_version() != 2:
+        if h.lrf_abi_version() != 3:
             raise NativeError("localrf_amd: ABI version mismatch")
         _lib = h
     return _lib

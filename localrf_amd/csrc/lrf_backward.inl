@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
 // channel-last gradient images -> += the reference layouts ([C,H,W] planes, [C,L] lines taken as
 // H = 1), all twelve tensors in one launch: blockIdx.z selects the tensor.
 struct UnpackSeg { const float* src; float* dst; int C, H, W, CS, app; };
-struct UnpackTab { UnpackSeg s[12]; };
+struct UnpackTab { UnpackSeg s[6]; };
 __global__ __launch_bounds__(128) void k_unpack_grads(UnpackTab tab) {
   // a block takes 128 consecutive texels of one row: their CS-float records are one contiguous span of the image, read
   // as float4 into LDS (the per-texel reads of the straightforward loop were 4 bytes at a 32- or 128-byte stride), then
@@ -1683,6 +1683,7 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
     return set_err("lrf_render_fwd_train: need R > 0 and 2 <= S <= LRF_MAX_S_TRAIN (2048: the per-ray backward keeps 16 B per sample in LDS)");
   if (flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))
     return set_err("lrf_render_fwd_train: the row-saving forward runs the split-bf16 engine only");
+  if (flags & ~LRF_FLAG_ALL) return set_err("lrf_render_fwd_train: unknown flag bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const DField d = make_dfield(f);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
@@ -1704,6 +1705,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     return set_err("lrf_render_bwd: null argument");
   if (R <= 0 || S < 2 || S > LRF_MAX_S_TRAIN)
     return set_err("lrf_render_bwd: need R > 0 and 2 <= S <= LRF_MAX_S_TRAIN (2048: the per-ray backward keeps 16 B per sample in LDS)");
+  if (flags & ~LRF_FLAG_ALL) return set_err("lrf_render_bwd: unknown flag bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const DField d = make_dfield(f);
   const Layout L = make_layout(f->grid);
@@ -1711,21 +1713,22 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const Workspace& w = b.fw;
   const int cus = device_cus();
   {
-    static bool lds_attr_done[64] = {};    // dynamic LDS above 64 KB has to be opted into once per device
+    static std::once_flag lds_attr_once[64];   // dynamic LDS above 64 KB has to be opted into once per device
+    static hipError_t lds_attr_err[64];
     int dev_id = 0;
     LRF_HIP(hipGetDevice(&dev_id));
-    bool& lds_attr_set = lds_attr_done[dev_id & 63];
-    if (!lds_attr_set) {
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true, 1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4));
-      lds_attr_set = true;
-    }
+    std::call_once(lds_attr_once[dev_id & 63], [dev_id] {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true, 1024>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4);
+      lds_attr_err[dev_id & 63] = e;
+    });
+    LRF_HIP(lds_attr_err[dev_id & 63]);
   }
   LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
   if (g_dgrad_bf16) hipLaunchKernelGGL(k_pack_mlp_bf16_t, dim3((IMTB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
@@ -1743,11 +1746,24 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // k_bwd_ray and the density scatter need nothing from the data-gradient kernel (the appearance lookups' position
   // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
   // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
-  SideStream* ss = g_bwd_overlap ? side_stream() : nullptr;
+  SideStream* sx = side_stream();                          // also holds the bucket events of lrf_render_bwd_wait
+  SideStream* ss = g_bwd_overlap ? sx : nullptr;
   // the side stream and its fork / join events are per device: host threads that enqueue backward passes on the same
   // device take turns (enqueueing is ~0.3 ms of host time; the kernels themselves still overlap on the GPU)
   std::unique_lock<std::mutex> side_lock;
-  if (ss) side_lock = std::unique_lock<std::mutex>(ss->mu);
+  if (sx) side_lock = std::unique_lock<std::mutex>(sx->mu);
+  // gradient images -> += the reference's layouts, per branch: the density tensors are final as soon as the per-ray
+  // branch is through (bucket 0), the appearance tensors at the very end (bucket 2)
+  UnpackTab tab_d, tab_a;
+  int wmax = 1, hmax = 1;
+  for (int q = 0; q < 3; ++q) {
+    tab_d.s[2 * q + 0] = UnpackSeg{b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0};
+    tab_d.s[2 * q + 1] = UnpackSeg{b.gcache + L.dline[q], g->density_line[q], LRF_CD, 1, L.ll[q], LRF_CD, 0};
+    tab_a.s[2 * q + 0] = UnpackSeg{b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1};
+    tab_a.s[2 * q + 1] = UnpackSeg{b.gcache + L.aline[q], g->app_line[q], LRF_CA, 1, L.ll[q], LRF_CAS, 1};
+    wmax = max(wmax, max(L.pw[q], L.ll[q]));
+    hmax = max(hmax, L.ph[q]);
+  }
   hipStream_t sb = st;
   if (ss) {
     LRF_HIP(hipEventRecord(ss->fork, st));
@@ -1781,6 +1797,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024),
                      sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), sb,
                      d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
+  hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 6), dim3(128), 0, sb, tab_d);
+  if (sx) LRF_HIP(hipEventRecord(sx->bucket[0], sb));
 
   // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
   // weight gradients: the first g_wgrad_split of the four GEMMs (dW2, dW1, dbasis, dW3) stay on the caller's stream
@@ -1820,6 +1838,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     if (ss && on_a > 0) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));      // partials of the caller's-stream GEMMs
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, sb, b.wpart, w.toff, R, segs);
   }
+  if (sx) LRF_HIP(hipEventRecord(sx->bucket[1], sb));
   if (ss) LRF_HIP(hipEventRecord(ss->join, sb));
 
   // ---- caller's stream: appearance scatter (its own bin buffers: the density scatter may still be running)
@@ -1836,19 +1855,19 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // ---- join: both branches done
   if (ss) LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   hipLaunchKernelGGL(k_rays_add_rpart, dim3((R + 255) / 256), dim3(256), 0, st, rays, R, w.ncomp, b.rpart, w.pmax, g_rays);
-  {
-    UnpackTab tab;
-    int wmax = 1, hmax = 1;
-    for (int q = 0; q < 3; ++q) {
-      tab.s[4 * q + 0] = UnpackSeg{b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0};
-      tab.s[4 * q + 1] = UnpackSeg{b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1};
-      tab.s[4 * q + 2] = UnpackSeg{b.gcache + L.dline[q], g->density_line[q], LRF_CD, 1, L.ll[q], LRF_CD, 0};
-      tab.s[4 * q + 3] = UnpackSeg{b.gcache + L.aline[q], g->app_line[q], LRF_CA, 1, L.ll[q], LRF_CAS, 1};
-      wmax = max(wmax, max(L.pw[q], L.ll[q]));
-      hmax = max(hmax, L.ph[q]);
-    }
-    hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 12), dim3(128), 0, st, tab);
-  }
+  hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 6), dim3(128), 0, st, tab_a);
+  if (sx) { LRF_HIP(hipEventRecord(sx->bucket[2], st)); sx->bucket_set = true; }
   LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lrf_render_bwd_wait(int32_t bucket, void* stream) {
+  using namespace lrf;
+  if (bucket < 0 || bucket > 2) return set_err("lrf_render_bwd_wait: bucket must be 0 (density), 1 (colour network) or 2 (appearance = all)");
+  SideStream* sx = side_stream();
+  if (!sx) return set_err("lrf_render_bwd_wait: no event resources on this device");
+  std::lock_guard<std::mutex> lk(sx->mu);
+  if (!sx->bucket_set) return set_err("lrf_render_bwd_wait: no lrf_render_bwd has run on this device");
+  LRF_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), sx->bucket[bucket], 0));
   return 0;
 }

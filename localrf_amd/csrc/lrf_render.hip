@@ -883,7 +883,7 @@ static int device_cus() {                 // of the current device (one process 
 }
 
 static int g_bwd_overlap = 1;      // lrf_debug_set_bwd_overlap: weight-gradient GEMMs on a side stream, beside the scatter kernels
-struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2]; bool ok; std::mutex mu; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2], bucket[3]; bool ok, bucket_set; std::mutex mu; };   // bucket[]: lrf_render_bwd_wait
 static SideStream* side_stream() {
   static SideStream tab[64];
   static std::mutex init_mu;
@@ -897,6 +897,9 @@ static SideStream* side_stream() {
         hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x.app[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x.app[1], hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int q = 0; q < 3; ++q)
+      if (hipEventCreateWithFlags(&x.bucket[q], hipEventDisableTiming) != hipSuccess) return nullptr;
+    x.bucket_set = false;
     x.ok = true;
   }
   return &x;
@@ -916,12 +919,12 @@ static void launch_march(const DField& d, const float* rays, const float* z, int
   if (nw) {
     const size_t lds = (size_t)nw * S * sizeof(float) + lds_l;
     if (lds > 64 * 1024) {
-      static bool attr_done[64] = {};
+      static std::once_flag attr_once[64];                  // per device; host threads may render concurrently
       int dev = 0;
-      if (hipGetDevice(&dev) == hipSuccess && !attr_done[dev & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done[dev & 63] = true;
-      }
+      if (hipGetDevice(&dev) == hipSuccess)
+        std::call_once(attr_once[dev & 63], [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
     }
     hipLaunchKernelGGL(k_march<true>, dim3((R + nw - 1) / nw), dim3(64 * nw), lds, st,
                        d, rays, z, R, S, flags, floater, depth, acc, w_all, ncomp, cidx, cw, feat);
@@ -1003,6 +1006,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
                            float* weight_out, float* acc_out, void* workspace, hipStream_t st, hipEvent_t* ev) {
   if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
   if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
+  if (flags & ~(LRF_FLAG_ALL & ~LRF_FLAG_ROWS_SAVED)) return set_err("lrf_render_fwd: unknown flag bits (caller built against another ABI version?)");
   DField d = make_dfield(f);
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
@@ -1015,15 +1019,17 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
     const size_t lds_base = (size_t)W32_ALL_U4 * sizeof(uint4) + (size_t)S * sizeof(float);
     const size_t lds_toff = (size_t)(R + 1) * sizeof(int) + (size_t)R * sizeof(unsigned short) + 16;
     const bool in_lds = lds_base + lds_toff + 64 <= 160 * 1024 - 256;
-    static bool attr3_done[64] = {};
+    static std::once_flag attr3_once[64];                  // per device; the launch below must not overtake the opt-in on another host thread
+    static hipError_t attr3_err[64];
     int dev = 0;
     LRF_HIP(hipGetDevice(&dev));
-    if (!attr3_done[dev & 63]) {
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      LRF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-      attr3_done[dev & 63] = true;
-    }
+    std::call_once(attr3_once[dev & 63], [dev] {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      attr3_err[dev & 63] = e;
+    });
+    LRF_HIP(attr3_err[dev & 63]);
     if (in_lds && g_dump) {                     // test hook: phase timing, s_memtime totals -> the dump buffer
       d.dump = g_dump;
       hipLaunchKernelGGL((k_shade3<8, true, true>), dim3(device_cus()), dim3(512), lds_base + lds_toff, st,

@@ -33,7 +33,7 @@ def _all_reduce(t, group, async_op=False):
 
 
 def _field_buckets(params_or_module):
-    """(flat parameter-gradient buffer, parameters it holds) for every TensorVMSplit whose LAST backward wrote its
+    """(field, flat parameter-gradient buffer, parameters it holds) for every TensorVMSplit whose LAST backward wrote its
     gradients into one flat buffer that .grad still views (TensorVMSplit.grad_bucket).  A field that took no part in
     the last backward -- a finished field of a LocalTensorfs keeps its old .grad forever, nothing zeroes it -- is not
     fresh and is left alone: its stale buffer is neither reduced nor divided."""
@@ -44,23 +44,61 @@ def _field_buckets(params_or_module):
         gb = getattr(m, "grad_bucket", None)
         if gb is not None and getattr(m, "_grad_fresh", False):
             b = gb()
-            if b is not None:
-                out.append(b)
+            out.append((m,) + (tuple(b) if b is not None else (None, None)))   # (m, None, None): fresh, but .grad no longer views the bucket
             m._grad_fresh = False
     return out
 
 
-def allreduce_grads(params, group=None, average=False):
+_prep_streams = {}
+
+
+def _reduce_field_chunks(field, flat, group, works):
+    """All-reduce one field's flat gradient buffer as its three branches -- density planes / lines (8.7 MB at 300^3),
+    appearance planes / lines (26 MB), colour network (0.1 MB) -- instead of one 34.8 MB collective behind the whole
+    backward.  The backward finishes the density branch early (its own stream, lrf_render_bwd): on the GPU each chunk
+    is handed to the collective from a side stream that waits only for the event lrf_render_bwd recorded when that
+    chunk became final (lrf_render_bwd_wait), so RCCL moves the density gradients over xGMI while the colour-network
+    backward and the appearance scatter still run.  Same sums as one flat all-reduce (chunks are disjoint views)."""
+    segs = getattr(field, "grad_segments", lambda: None)()
+    if not segs:
+        works.append((_all_reduce(flat, group, async_op=True), None))
+        return
+    early = flat.is_cuda and dist.get_backend(group) != "gloo" and hasattr(field, "_wait_bwd_bucket")
+    for which, (a, b) in enumerate(segs):
+        if b <= a:
+            continue
+        chunk = flat[a:b]
+        if early:
+            dev = flat.device
+            prep = _prep_streams.get(dev)
+            if prep is None:
+                prep = _prep_streams[dev] = torch.cuda.Stream(dev)
+            field._wait_bwd_bucket(which, prep)               # prep waits for that bucket's event only
+            with torch.cuda.stream(prep):
+                works.append((_all_reduce(chunk, group, async_op=True), None))
+        else:
+            works.append((_all_reduce(chunk, group, async_op=True), None))
+
+
+def allreduce_grads(params, group=None, average=False, has_grad=None):
     """Sum (or average) .grad of `params` (module or iterable) across ranks.
 
     The field gradients -- 34.8 MB at 300^3, 96 MB at 500^3 -- are all-reduced IN PLACE in the flat buffer the backward
-    kernels wrote them into (one collective per field that took part in the backward, zero copies: the 19 parameter
-    gradients are views of that buffer; the d/d rays tail behind them is rank-local and is not sent).  Everything else
-    (poses, exposure, intrinsics: a few hundred bytes) travels in one small concatenated bucket together with a
-    has-gradient flag per parameter: a parameter that received no gradient on ANY rank (a view nobody sampled this
-    iteration) keeps .grad = None, so that Adam leaves it and its step counter alone exactly as in a one-rank run;
-    one that received a gradient on some rank gets the sum on every rank.  Every rank issues identical collectives.
-    Returns the number of gradient bytes reduced."""
+    kernels wrote them into (zero copies: the 19 parameter gradients are views of that buffer; the d/d rays tail behind
+    them is rank-local and is not sent), one collective per branch of the backward (_reduce_field_chunks).  Everything
+    else (poses, exposure, intrinsics: a few hundred bytes) travels in one small concatenated bucket.  A parameter that
+    received no gradient on ANY rank (a view nobody sampled this iteration) keeps .grad = None, so that Adam leaves it
+    and its step counter alone exactly as in a one-rank run; one that received a gradient on some rank gets the sum on
+    every rank.  Which is which:
+
+    * `has_grad` given (an iterable of the parameters that are differentiated on SOME rank this iteration; every rank
+      passes the same set -- e.g. localrf_amd.dist.scene_has_grad from the GLOBAL view batch every rank knows before
+      it takes its shard): no flags travel and the host never waits for the device;
+    * otherwise one has-gradient flag per parameter rides in the small bucket (MAX over ranks) and the host reads the
+      flags back -- one synchronisation per step.
+
+    Parameters of fields that sat the backward out (finished fields of a LocalTensorfs) are never touched, whatever
+    their .grad is.  Every rank issues identical collectives.  Returns the number of gradient bytes reduced."""
     module = params if isinstance(params, torch.nn.Module) else None
     if module is not None:
         params = [p for p in module.parameters() if p.requires_grad]
@@ -68,26 +106,38 @@ def allreduce_grads(params, group=None, average=False):
     if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
     world = dist.get_world_size(group)
-    nbytes, covered, works = 0, set(), []
-    for flat, held in _field_buckets(module):
-        works.append((_all_reduce(flat, group, async_op=True), flat))
+    nbytes, covered, works, flats = 0, set(), [], []
+    unbucketed = set()                                        # fresh fields whose gradients were accumulated elsewhere: small-bucket path
+    for field, flat, held in _field_buckets(module):
+        if flat is None:
+            unbucketed.add(id(field))
+            continue
+        _reduce_field_chunks(field, flat, group, works)
+        flats.append(flat)
         covered.update(id(p) for p in held)
         nbytes += sum(p.numel() for p in held) * 4
-    if module is not None:                                    # parameters of fields that sat the backward out: not ours to touch
+    if module is not None:
+        # Fields whose gradients live in a flat bucket but which took no part in this backward (every rank is in the same
+        # lifecycle state): not ours to touch, whatever .grad holds (None after append_rf, a stale buffer otherwise)
         for m in module.modules():
-            if getattr(m, "grad_bucket", None) is not None and hasattr(m, "_grad_flat"):
+            if getattr(m, "grad_bucket", None) is not None and hasattr(m, "_grad_flat") and id(m) not in unbucketed:
                 for p in m.parameters():
-                    if id(p) not in covered and p.grad is not None and m._grad_flat is not None \
-                            and p.grad.untyped_storage().data_ptr() == m._grad_flat[0].untyped_storage().data_ptr():
-                        covered.add(id(p))
+                    covered.add(id(p))
     rest = [p for p in params if id(p) not in covered]
+    if has_grad is not None:
+        want = {id(p) for p in has_grad}
+        rest = [p for p in rest if id(p) in want]
     if rest:
         dev = rest[0].device
-        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in rest], dtype=torch.float32, device=dev)
-        small = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dev, torch.float32)
-                           for p in rest] + [has])
+        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dev, torch.float32) for p in rest]
+        if has_grad is None:
+            pieces.append(torch.tensor([0.0 if p.grad is None else 1.0 for p in rest], dtype=torch.float32, device=dev))
+        small = torch.cat(pieces)
         _all_reduce(small, group)
-        any_grad = small[small.numel() - len(rest):].tolist()
+        if has_grad is None:
+            any_grad = small[small.numel() - len(rest):].tolist()     # the one host synchronisation of this path
+        else:
+            any_grad = [1.0] * len(rest)
         if average:
             small /= world
         off = 0
@@ -101,12 +151,28 @@ def allreduce_grads(params, group=None, average=False):
                     p.grad.copy_(g)
                 nbytes += n * 4
             off += n
-    for work, flat in works:
+    for work, _ in works:
         if work is not None:
             work.wait()
-        if average:
+    if average:
+        for flat in flats:
             flat /= world
     return nbytes
+
+
+def scene_has_grad(scene, global_view_ids, optimize_poses=True):
+    """The parameters of a LocalTensorfs outside its field buckets that receive a gradient on some rank when the ranks
+    together render `global_view_ids` (the batch before shard_views): rotation / translation / exposure of the sampled
+    frames and the intrinsics.  For allreduce_grads(..., has_grad=...)."""
+    views = sorted({int(v) for v in (global_view_ids.tolist() if hasattr(global_view_ids, "tolist") else global_view_ids)})
+    out = []
+    for v in views:
+        if optimize_poses:
+            out += [scene.r_c2w[v], scene.t_c2w[v]]
+        if getattr(scene, "lr_exposure_init", 0) > 0:
+            out.append(scene.exposure[v])
+    out += [p for p in (getattr(scene, "focal_offset", None), getattr(scene, "center_rel", None)) if p is not None]
+    return [p for p in out if p.requires_grad]
 
 
 def allreduce_scalar(x, group=None, average=True):

@@ -5,7 +5,7 @@ Drop-in for the reference's `models.tensoRF.TensorVMSplit` (+ `models.tensorBase
 parameter names / shapes / creation order (so `torch.manual_seed(s)` yields the same field
 and reference checkpoints load with `load_state_dict`), same `forward` signature and
 return tuple.  Behind `forward` the work of tensorBase.py:567-636 + tensoRF.py:112-196 is
-done by hand-written HIP kernels (csrc/lrf_render.hip, csrc/lrf_backward.hip) called
+done by hand-written HIP kernels (csrc/lrf_render.hip and the .inl files it includes) called
 through the C ABI in include/lrf.h.  There is no PyTorch/CPU fallback for that path: a
 missing library or a non-GPU tensor raises.
 
@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import _native as N
 
+EARLY_TERM_T_FAST = 1e-9                # TensorVMSplit.early_term_T opt-in value (north_star: "early termination")
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]     # tensorBase.py:274
 VEC_MODE = [2, 1, 0]                    # tensorBase.py:275
 
@@ -227,8 +228,10 @@ class TensorVMSplit(torch.nn.Module):
         # "f32" exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
         self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
-        # early termination of the march (LrfField.term_T in include/lrf.h): 0 = evaluate every sample
-        self.early_term_T = 1e-9
+        # early termination of the march (LrfField.term_T in include/lrf.h).  Default 0 = every sample is evaluated, the
+        # reference's arithmetic (tensorBase.py:600-610).  Opt-in: EARLY_TERM_T_FAST (1e-9) skips the density gathers of a
+        # ray once no later sample can pass rayMarch_weight_thres -- colours / acc identical, depth within 1e-6 absolute
+        self.early_term_T = 0.0
 
     # ------------------------------------------------------------------ construction
     def _check_supported(self, shadingMode, pos_pe, view_pe, fea_pe, featureC):
@@ -501,7 +504,7 @@ class TensorVMSplit(torch.nn.Module):
         flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
         grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
         g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
-        self._grad_flat = (flat, keep, offs[-2])   # see grad_bucket(): data-parallel all-reduce without copies
+        self._grad_flat = (flat, keep, offs[-2], (offs[0], offs[6], offs[12], offs[-2]))   # see grad_bucket(): data-parallel all-reduce without copies
         self._grad_fresh = True                    # written by THIS backward (localrf_amd.dist reduces fresh buckets only)
         if R == 0:
             return g_rays, grads
@@ -539,13 +542,27 @@ class TensorVMSplit(torch.nn.Module):
         gf = getattr(self, "_grad_flat", None)
         if gf is None:
             return None
-        flat, _, n_param = gf
+        flat, _, n_param = gf[:3]
         base = flat.untyped_storage().data_ptr()
         ps = [p for p in self._param_list() if p.requires_grad]
         for p in ps:
             if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
                 return None
         return flat[:n_param], ps                    # the parameter part: the d/d rays tail behind it is rank-local
+
+    def grad_segments(self):
+        """[(start, end)] float offsets into grad_bucket()'s flat buffer of the three branches of lrf_render_bwd, in the order
+        lrf_render_bwd_wait numbers them: density planes + lines, colour network (basis, three layers), appearance planes +
+        lines.  localrf_amd.dist reduces them as three collectives."""
+        gf = getattr(self, "_grad_flat", None)
+        if gf is None:
+            return None
+        d0, a0, n0, end = gf[3]
+        return [(d0, a0), (n0, end), (a0, n0)]
+
+    def _wait_bwd_bucket(self, which, stream):
+        """Make `stream` wait until bucket `which` (grad_segments order) of the last lrf_render_bwd on this device is final."""
+        N.check(N.lib().lrf_render_bwd_wait(int(which), stream.cuda_stream), "lrf_render_bwd_wait")
 
     # ------------------------------------------------------------------ sampling
     def z_schedule(self, is_train, N_samples, device):
@@ -633,6 +650,50 @@ class TensorVMSplit(torch.nn.Module):
         N.check(N.lib().lrf_app_feature(C.byref(f), N.ptr(u), u.shape[0], N.ptr(out), st),
                 "lrf_app_feature")
         return out
+
+    def compute_features(self, xyz_sampled):
+        """tensorBase.py:333-334 declares it (no body, no caller): here the pair (density feature [P], appearance feature
+        [P,27]) of normalised coordinates [P,3]."""
+        return self.compute_densityfeature(xyz_sampled), self.compute_appfeature(xyz_sampled)
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        """tensorBase.py:289-315.  Only the mode train.py runs exists in this build (see _check_supported)."""
+        self._check_supported(shadingMode, pos_pe, view_pe, fea_pe, featureC)
+        self.renderModule = MLPRender_Fea_late_view(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        self._cache_key = None
+
+    def get_arange(self, idx):
+        """tensoRF.py:14-16 (unused by the reference): the lattice coordinates along axis idx, pulled 1e-6 inside the box."""
+        lo, hi = self.aabb[0, idx] + 1e-6, self.aabb[1, idx] - 1e-6
+        step = (hi - lo) / (self.gridSize[idx] - 1)
+        return torch.arange(lo, hi + step, step, device=self.device)
+
+    def save(self, se3_poses, path):
+        """tensorBase.py:371-380 (unused by train.py, which saves through LocalTensorfs.save): kwargs + state dict, the
+        alpha mask as packed bits."""
+        import numpy as np
+        kw = self.get_kwargs()
+        kw["se3_poses"] = se3_poses
+        ckpt = {"kwargs": kw, "state_dict": self.state_dict()}
+        if self.alphaMask is not None:
+            vol = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({"alphaMask.shape": vol.shape, "alphaMask.mask": np.packbits(vol.reshape(-1)),
+                         "alphaMask.aabb": self.alphaMask.aabb.cpu()})
+        torch.save(ckpt, path)
+
+    def _not_on_the_path(self, what, where):
+        raise NotImplementedError(
+            f"localrf_amd.TensorVMSplit.{what}: {where} in the reference is not called by train.py / renderer.py / "
+            "local_tensorfs.py (SURVEY.md s0.4) and is not part of the MI355X render path; there is no fallback.")
+
+    def sample_ray_ndc(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        self._not_on_the_path("sample_ray_ndc", "tensorBase.py:382-394")
+
+    def shrink(self, new_aabb, voxel_size=None):
+        self._not_on_the_path("shrink", "tensoRF.py:236 / tensorBase.py:445")
+
+    def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        self._not_on_the_path("filtering_rays", "tensorBase.py:449-493")
 
     def feature2density(self, density_features):
         """tensorBase.py:495-499."""

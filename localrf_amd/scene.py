@@ -143,7 +143,8 @@ class LocalTensorfs(SceneLifecycle):
         per_field = max(1, chunk // len(active))
         taped = torch.is_grad_enabled() and (cam2world.requires_grad or shifts.requires_grad or any(
             p.requires_grad for rf in active for p in self.tensorfs[rf].parameters()) or any(
-            t is not None and t.requires_grad for t in (focal, center)))
+            t is not None and t.requires_grad for t in (focal, center)) or (
+            self.lr_exposure_init > 0 and not test_id and any(e.requires_grad for e in self.exposure)))
         if not taped and not is_train:                          # one native call for the whole scene forward (lrf_scene_fwd)
             return scene_forward(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole,
                                  [self.tensorfs[rf] for rf in active], white_bg, floater_thresh,

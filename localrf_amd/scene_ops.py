@@ -178,7 +178,10 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
     `fields`: the active TensorVMSplit objects; world2rf [n_rf,3].  -> (rgbs [R,3], depth [R], directions [R,3], ij [R,2])."""
     _require_gpu(ray_ids)
     dev = ray_ids.device
-    R, n_rf = int(ray_ids.shape[0]), len(fields)
+    # the kernel reads int64 ids at unit stride (as the taped path's _SceneRaysFn coerces them): an int32 or strided
+    # tensor handed over as is would be read out of bounds
+    ids = ray_ids.detach().contiguous().long()
+    R, n_rf = int(ids.shape[0]), len(fields)
     if R % per_view:
         raise ValueError("number of rays must be a multiple of the number of views")
     c2w = _f32c(cam2world[:, :3, :])
@@ -210,7 +213,7 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
     rgbs = torch.empty(R, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(R, dtype=torch.float32, device=dev)
     if R:
-        N.check(N.lib().lrf_scene_fwd(ray_ids.data_ptr(), R, int(per_view), N.ptr(c2w), N.ptr(w2rf), n_rf, N.ptr(fo), N.ptr(ce),
+        N.check(N.lib().lrf_scene_fwd(ids.data_ptr(), R, int(per_view), N.ptr(c2w), N.ptr(w2rf), n_rf, N.ptr(fo), N.ptr(ce),
                                       int(W), int(H), int(bool(fov360)), arr, float(floater_thresh), int(n_chunk),
                                       N.ptr(bw), N.ptr(ex), N.ptr(rays), N.ptr(rgb_f), N.ptr(dep_f), N.ptr(dirs), ij.data_ptr(),
                                       N.ptr(rgbs), N.ptr(depth), _stream(dev)), "lrf_scene_fwd")

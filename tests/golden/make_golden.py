@@ -317,6 +317,31 @@ def case_train_grad_big(TensorVMSplit, name, grid=(128, 128, 128), R=512, seed=5
     save(name, **arrs)
 
 
+def case_ladder(TensorVMSplit, name, seed=45, R=128):
+    """The upsample ladder of train.py (train.py:275-288 with opt.py:61-69: 64^3 -> 101, 161, 255, 404 -> 640^3,
+    resolutions through utils.N_to_reso as local_tensorfs.py:251-253 does): one seeded 64^3 field taken through
+    upsample_volume_grid five times; after every stage an eval render at that stage's own default sample count."""
+    from utils.utils import N_to_reso
+    n_list = torch.round(torch.exp(torch.linspace(np.log(64 ** 3), np.log(640 ** 3), 6))).long().tolist()[1:]
+    n_list = [round(n ** (1 / 3)) ** 3 for n in n_list]
+    f = make_field(TensorVMSplit, (64, 64, 64), seed, scale_density=3.0)
+    rays = make_rays(R, seed + 1, pinhole=True)
+    arrs = dict(rays=rays.numpy(), seed=np.array(seed), n_voxels=np.array(n_list, np.int64), scale_density=np.array(3.0, np.float32),
+                field_sum=field_checksum(f.state_dict()))
+    for i, n in enumerate(n_list):
+        reso = N_to_reso(n, f.aabb)
+        quiet(f.upsample_volume_grid, reso)
+        with torch.no_grad():
+            rgb, depth = f(rays.clone(), white_bg=True, is_train=False, N_samples=-1)
+        arrs[f"reso{i}"] = np.array(reso)
+        arrs[f"nSamples{i}"] = np.array(f.nSamples)
+        arrs[f"rgb{i}"] = rgb.numpy()
+        arrs[f"depth{i}"] = depth.numpy()
+        arrs[f"field_sum{i}"] = field_checksum(f.state_dict())
+        print("ladder stage", i, reso, f.nSamples, flush=True)
+    save(name, **arrs)
+
+
 def case_sample_ray(TensorVMSplit, name):
     """TensorBase.sample_ray (tensorBase.py:396-417; dead code on train.py's path, named by north_star)."""
     f = make_field(TensorVMSplit, (32, 32, 32), 5)
@@ -756,7 +781,10 @@ def main():
               "config3": lambda: case_config3(LocalTensorfs, "config3_4x300.npz"),
               "upsample": lambda: case_upsample(TensorVMSplit, "upsample_grid.npz"),
               "geo": lambda: case_geo_losses("geo_losses.npz"),
-              "trajectory": lambda: case_trajectory(TensorVMSplit, LocalTensorfs, "trajectory_30it.npz")}
+              "trajectory": lambda: case_trajectory(TensorVMSplit, LocalTensorfs, "trajectory_30it.npz"),
+              "train500": lambda: case_train_grad_big(TensorVMSplit, "field_500_train_grad.npz", grid=(500, 500, 500), R=512, seed=41),
+              "train640": lambda: case_train_grad_big(TensorVMSplit, "field_640_train_grad.npz", grid=(640, 640, 640), R=256, seed=43),
+              "ladder": lambda: case_ladder(TensorVMSplit, "ladder_64_to_640.npz")}
         for k in only:
             r2[k]()
         return
@@ -788,6 +816,10 @@ def main():
     case_geo_losses("geo_losses.npz")
     # round 3
     case_trajectory(TensorVMSplit, LocalTensorfs, "trajectory_30it.npz")
+    # round 4: BASELINE configs[4]'s own sizes (500^3; the reference's default end size 640^3; train.py's upsample ladder)
+    case_train_grad_big(TensorVMSplit, "field_500_train_grad.npz", grid=(500, 500, 500), R=512, seed=41)
+    case_train_grad_big(TensorVMSplit, "field_640_train_grad.npz", grid=(640, 640, 640), R=256, seed=43)
+    case_ladder(TensorVMSplit, "ladder_64_to_640.npz")
 
 
 if __name__ == "__main__":

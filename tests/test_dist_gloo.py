@@ -172,6 +172,92 @@ def test_two_rank_training_steps_match_single_rank_with_unsampled_views(tmp_path
         assert float((a - p.detach()).abs().max()) <= 1e-5 * max(float(p.detach().abs().max()), 1e-3), n
 
 
+class _BucketField(torch.nn.Module):
+    """Stand-in for a TensorVMSplit after lrf_render_bwd: all gradients are views of ONE flat buffer, in three branches
+    (density | appearance | network), exposed through grad_bucket() / grad_segments() as localrf_amd.field does."""
+
+    def __init__(self, seed, fresh=True):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.dens = torch.nn.Parameter(torch.randn(37, generator=g))
+        self.app = torch.nn.Parameter(torch.randn(101, generator=g))
+        self.net = torch.nn.Parameter(torch.randn(13, generator=g))
+        self._grad_flat, self._grad_fresh = None, False
+        if fresh:
+            self.fill(seed)
+
+    def fill(self, seed):
+        g = torch.Generator().manual_seed(1000 + seed)
+        offs = [0, 64, 192, 256]                              # 64-float aligned views, as _native_backward lays them out
+        flat = torch.zeros(offs[-1])
+        ps = [self.dens, self.app, self.net]
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()] = torch.randn(p.numel(), generator=g)
+            p.grad = flat[o:o + p.numel()].view_as(p)
+        self._grad_flat = (flat, ps, offs[-1], (0, 64, 192, 256))
+        self._grad_fresh = True
+
+    def grad_bucket(self):
+        if self._grad_flat is None:
+            return None
+        return self._grad_flat[0][:self._grad_flat[2]], [self.dens, self.app, self.net]
+
+    def grad_segments(self):
+        d0, a0, n0, end = self._grad_flat[3]
+        return [(d0, a0), (n0, end), (a0, n0)]
+
+
+class _BucketScene(torch.nn.Module):
+    def __init__(self, rank):
+        super().__init__()
+        self.done = _BucketField(5, fresh=False)              # finished field: .grad None, _grad_flat None (append_rf)
+        self.live = _BucketField(7 + rank)
+        g = torch.Generator().manual_seed(50 + rank)
+        self.poses = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(3, generator=g)) for _ in range(4)])
+        for i in ((0, 1) if rank == 0 else (1, 2)):           # view 3 is sampled by nobody
+            self.poses[i].grad = torch.randn(3, generator=g)
+
+
+def _worker_buckets(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from localrf_amd.dist import allreduce_grads
+    res = {}
+    for mode in ("flags", "hint"):
+        m = _BucketScene(rank)
+        hint = None if mode == "flags" else [m.poses[0], m.poses[1], m.poses[2]]
+        nbytes = allreduce_grads(m, has_grad=hint)
+        res[mode] = {"flat": m.live._grad_flat[0].clone(), "dens": m.live.dens.grad.clone(), "app": m.live.app.grad.clone(),
+                     "net": m.live.net.grad.clone(), "poses": [None if p.grad is None else p.grad.clone() for p in m.poses],
+                     "done": [p.grad for p in m.done.parameters()], "bytes": nbytes, "fresh": m.live._grad_fresh}
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_field_reduction_equals_the_flat_sum_and_finished_fields_are_left_alone(tmp_path):
+    """allreduce_grads reduces a field's flat gradient buffer as three collectives (density / network / appearance: the
+    branches lrf_render_bwd finishes at different times) -- the result must be the plain sum of the ranks' buffers; the
+    parameters of a finished field (no fresh bucket, .grad None) are neither reduced nor counted nor given a gradient;
+    the has_grad hint (no flag exchange, no host synchronisation) gives the same result as the flag path, and a view no
+    rank sampled keeps .grad None either way."""
+    out = str(tmp_path / "b.pt")
+    mp.spawn(_worker_buckets, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    a, b = _BucketScene(0), _BucketScene(1)
+    want_flat = a.live._grad_flat[0] + b.live._grad_flat[0]
+    for mode in ("flags", "hint"):
+        r = got[mode]
+        assert torch.equal(r["flat"], want_flat), mode
+        assert torch.equal(r["dens"], want_flat[0:37]) and torch.equal(r["app"], want_flat[64:165]) and torch.equal(r["net"], want_flat[192:205])
+        assert torch.equal(r["poses"][0], a.poses[0].grad) and torch.equal(r["poses"][2], b.poses[2].grad)
+        assert torch.allclose(r["poses"][1], a.poses[1].grad + b.poses[1].grad)
+        assert r["poses"][3] is None                          # sampled by nobody: no gradient is invented
+        assert all(g is None for g in r["done"])
+        assert r["bytes"] == 4 * (37 + 101 + 13 + 9) and r["fresh"] is False
+
+
 def test_shard_views_keeps_rays_per_view_integral():
     from localrf_amd.dist import shard_views
     ray_ids, view_ids = torch.arange(16 * 10), torch.arange(16)

@@ -35,12 +35,14 @@ def _check_rays(got, ref, tol=TOL, max_outliers=0, outlier_abs=2e-3):
         assert np.abs(got - ref).max() < outlier_abs
 
 
+@pytest.mark.parametrize("term_T", [0.0, 1e-9])          # the default (reference semantics) and the early-termination opt-in
 @pytest.mark.parametrize("engine", ["bf16x3", "f32", "valu"])
 @pytest.mark.parametrize("name", FIELD_CASES)
-def test_field_forward_vs_reference_golden(built_lib, name, engine):
+def test_field_forward_vs_reference_golden(built_lib, name, engine, term_T):
     g = load_golden(name)
     f = quiet(field_from_golden, g, DEV)
     f.mlp_engine = engine
+    f.early_term_T = term_T
     rays = torch.from_numpy(g["rays"]).to(DEV)
     with torch.no_grad():
         rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=int(g["N_samples"]),
@@ -238,7 +240,8 @@ def test_early_termination_on_a_trained_like_scene(built_lib):
     really skipped (their weights are exactly zero)."""
     f = _walls_field([96, 96, 96], 7, DEV)
     rays = make_rays(512, 8, pinhole=True).to(DEV)
-    assert f.early_term_T == 1e-9
+    assert f.early_term_T == 0.0                              # reference semantics by default; the skip is the opt-in
+    f.early_term_T = 1e-9
     with torch.no_grad():
         rgb, depth, w, acc, z = f.render_weights(rays, N_samples=600)
         f.early_term_T = 0.0
@@ -284,8 +287,9 @@ def big(built_lib):
     return f, rays
 
 
+@pytest.mark.parametrize("term_T", [0.0, 1e-9])
 @pytest.mark.parametrize("engine", ["bf16x3", "f32"])
-def test_config2_all_rays_vs_reference_golden(big, engine):
+def test_config2_all_rays_vs_reference_golden(big, engine, term_T):
     """BASELINE.json configs[1] at full size against the REFERENCE's own output for all 4096 rays
     (tests/golden/config2_300cube.npz: 300^3 field from seed 0, 512 samples).  A ray may miss the 1e-4
     bar only because a sample sits on the shading threshold weight > 1e-3 (tensorBase.py:622): at most
@@ -296,10 +300,10 @@ def test_config2_all_rays_vs_reference_golden(big, engine):
     assert np.array_equal(_np(rays), g["rays"])
     s = float(sum(v.double().abs().sum() for v in f.state_dict().values()))
     assert abs(s - float(g["field_sum"][0])) < 1e-6 * float(g["field_sum"][0])
-    f.mlp_engine = engine
+    f.mlp_engine, f.early_term_T = engine, term_T
     with torch.no_grad():
         rgb, depth, w, acc, z = f.render_weights(rays, N_samples=1536)
-    f.mlp_engine = "bf16x3"
+    f.mlp_engine, f.early_term_T = "bf16x3", 0.0
     e_rgb = (np.abs(_np(rgb) - g["rgb"]) / np.maximum(np.abs(g["rgb"]), 1e-3)).max(-1)
     e_dep = np.abs(_np(depth) - g["depth"]) / np.maximum(np.abs(g["depth"]), 1e-3)
     assert e_dep.max() < TOL, e_dep.max()
@@ -508,6 +512,63 @@ def test_backward_128cube_vs_reference_autograd_golden(built_lib):
     for n in grads:                                   # the whole tensor, through its L2 norm
         assert abs(float(grads[n].double().norm()) - float(g["gl2." + n])) <= 2e-3 * float(g["gl2." + n]), n
     print("flips", info["n_flips"], "max |pre|", info["max_pre"], "worst", {k: "%.1e" % v for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("name,min_forced", [("field_500_train_grad", 10000), ("field_640_train_grad", 5000)])
+def test_backward_at_training_sizes_vs_reference_autograd_golden(built_lib, name, min_forced):
+    """BASELINE configs[4]'s own sizes against the REFERENCE: 500^3 (512 rays) and the reference's default end size 640^3
+    (256 rays; opt.py:62), recorded by make_golden.case_train_grad_big from the real TensorVMSplit -- train-mode forward
+    with the recorded jitter at the grid's default sample count (S = 576 / 738), autograd gradients packed as a seeded
+    subset + the 2048 largest entries + max + L2 per tensor; the field is regenerated from its seed (checksum).
+    (a) every ray's colour and depth against the reference's at 1e-4 (a ray may miss only through the shading
+    threshold: at most one); (b) all 19 parameter tensors against autograd through the ATen port with the kernel's ReLU
+    masks forced: 1e-4 of each tensor's maximum, no exceptions (d/d rays: the cell-boundary bar measured in
+    test_500cube_forward_and_gradients_vs_port); (c) against the reference-recorded gradients: the density tensors,
+    which no ReLU mask touches, at 1e-4 unconditionally, every tensor at 1e-4 when the port and the kernel agree on
+    every mask, and every tensor's L2 norm at 2e-3."""
+    g = load_golden(name)
+    f = field_from_seed(g, DEV)
+    z = torch.from_numpy(oracle.z_schedule(int(g["nSamples"]), np.float32, jitter=(g["U"], g["U2"])))
+    gr, gd = torch.from_numpy(g["g_rgb"]).to(DEV), torch.from_numpy(g["g_depth"]).to(DEV)
+    rgb, depth, grads, info, worst = _grads_vs_port_with_forced_masks(f, g["rays"], z, gr, gd, tol_for={"rays": 5e-3})
+    assert info["n_forced"] > min_forced, info
+    _check_rays(_np(rgb), g["rgb"], max_outliers=1)
+    _check_rays(_np(depth), g["depth"])
+    ref = {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in grads}
+    subset = {n: torch.from_numpy(g["gidx." + n]).to(DEV) for n in grads if ("gidx." + n) in g}
+    gmax = {n: float(g["gmax." + n]) for n in grads}
+    dens = {n: v for n, v in grads.items() if n.startswith("density_")}
+    check_grads(dens, ref, 1e-4, subset=subset, gmax=gmax)
+    if info["n_flips"] == 0:
+        check_grads({n: v for n, v in grads.items() if n != "rays"}, ref, 1e-4, subset=subset, gmax=gmax)
+    for n in grads:
+        if n != "rays":
+            assert abs(float(grads[n].double().norm()) - float(g["gl2." + n])) <= 2e-3 * float(g["gl2." + n]), n
+    print(name, "flips", info["n_flips"], "max |pre|", info["max_pre"], "worst", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_upsample_ladder_vs_reference_golden(built_lib):
+    """train.py's upsample ladder (train.py:275-288 + opt.py:61-69: 64^3 -> 101 -> 161 -> 255 -> 404 -> 640^3, resolutions
+    through N_to_reso as local_tensorfs.py:251-253) recorded from the reference: one seeded 64^3 field taken through
+    upsample_volume_grid (lrf_upsample_bilinear) five times; after every stage the parameters' checksum and an eval
+    render of 128 rays at that stage's own default sample count against the reference's."""
+    from localrf_amd.rays import N_to_reso
+    from util import state_checksum
+    g = load_golden("ladder_64_to_640")
+    f = field_from_seed({"grid": np.array([64, 64, 64]), "seed": g["seed"], "scale_density": g["scale_density"],
+                         "field_sum": g["field_sum"]}, DEV)
+    rays = torch.from_numpy(g["rays"]).to(DEV)
+    for i, n in enumerate(g["n_voxels"].tolist()):
+        reso = N_to_reso(int(n), f.aabb)
+        assert list(reso) == g[f"reso{i}"].tolist(), (i, reso)
+        f.upsample_volume_grid(reso)
+        assert f.nSamples == int(g[f"nSamples{i}"])
+        got, want = state_checksum(f.state_dict()), float(g[f"field_sum{i}"][0])
+        assert abs(got - want) <= 2e-6 * want, (i, got, want)
+        with torch.no_grad():
+            rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=-1)
+        _check_rays(_np(rgb), g[f"rgb{i}"], max_outliers=1)
+        _check_rays(_np(depth), g[f"depth{i}"])
 
 
 def test_backward_accumulates_and_zero_grad_output(built_lib):

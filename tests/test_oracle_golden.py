@@ -362,6 +362,46 @@ def test_train_grad_128_port_vs_reference_golden():
     packed_grad_check(g, "rays", rays.grad.numpy(), 2e-5)
 
 
+def test_train_grad_500_port_vs_reference_golden():
+    """The ATen port (the checker of the GPU test at this size) against the reference's own 500^3 recording: colours,
+    depths and the gradients of every tensor on the packed subset, 128 of the 512 rays' worth of loss being enough to
+    keep this in the CPU suite's budget would change the gradients -- so all 512 rays are differentiated (25 s)."""
+    import torch
+    from oracle import vm_render_torch as ot
+    from util import field_from_seed, packed_grad_check
+    g = load_golden("field_500_train_grad")
+    f = field_from_seed(g)
+    fld = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    names = [k for k in fld if ("plane" in k or "line" in k or "basis" in k or "renderModule" in k)]
+    for k in names:
+        fld[k].requires_grad_(True)
+    rays = _t(g["rays"]).requires_grad_(True)
+    z = ot.z_schedule(int(g["nSamples"]), jitter=(_t(g["U"]), _t(g["U2"])))
+    rgb, depth = ot.render_field(fld, rays, z, True, 0.0)
+    assert rel_err(rgb.detach().numpy(), g["rgb"]) < 5e-6 and rel_err(depth.detach().numpy(), g["depth"]) < 5e-6
+    ((rgb * _t(g["g_rgb"])).sum() + (depth * _t(g["g_depth"])).sum()).backward()
+    for k in names:
+        packed_grad_check(g, k, fld[k].grad.numpy(), 2e-5)
+    packed_grad_check(g, "rays", rays.grad.numpy(), 2e-5)
+
+
+def test_ladder_golden_is_the_train_py_schedule():
+    """tests/golden/ladder_64_to_640.npz walks the resolutions train.py computes (train.py:275-288 with the opt.py:61-69
+    defaults) and this package's N_to_reso / update_stepSize agree with the recorded resolutions and sample counts."""
+    import torch
+    from localrf_amd.rays import N_to_reso
+    from util import make_field, quiet
+    g = load_golden("ladder_64_to_640")
+    sides = [round(float(n) ** (1 / 3)) for n in g["n_voxels"]]
+    assert sides == [101, 161, 255, 404, 640]
+    f = quiet(make_field, [8, 8, 8], "cpu", seed=1)
+    for i, n in enumerate(g["n_voxels"].tolist()):
+        reso = N_to_reso(int(n), f.aabb)
+        assert list(reso) == g[f"reso{i}"].tolist()
+        f.update_stepSize(list(reso))
+        assert f.nSamples == int(g[f"nSamples{i}"])
+
+
 @pytest.mark.parametrize("name,prior", [("local_train_3views", False), ("local_train_prior", True)])
 def test_local_seeded_goldens_regenerate_and_match_port(name, prior):
     """LocalTensorfs built by THIS package from the golden's seed has the reference's parameters
