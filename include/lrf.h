@@ -133,7 +133,7 @@ size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]);
  * per-sample state the backward needs (density features, shaded-sample lists, per-sample colours,
  * activation rows) is left in `workspace` (lrf_workspace_bytes_bwd bytes) instead of being
  * recomputed by lrf_render_bwd: pass the SAME workspace, field, rays and z to lrf_render_bwd with
- * LRF_FLAG_ROWS_SAVED set.  Memory for recompute: a 6.5 GB worst-case reservation at 4096 x 512 (2.3 GB touched when 35 % of the samples are shaded) against 288 GB of HBM. */
+ * LRF_FLAG_ROWS_SAVED set.  Memory for recompute: a 3.3 GB worst-case reservation at 4096 x 512 (1.2 GB touched when 35 % of the samples are shaded) against 288 GB of HBM. */
 int lrf_render_fwd_train(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                          uint32_t flags, float* rgb, float* depth, void* workspace, void* stream);
 
@@ -155,8 +155,9 @@ int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, con
 int lrf_render_bwd_wait(int32_t bucket, void* stream);
 
 /* Debug / parity diagnostics: byte offsets inside the training workspace of {activation rows, gradient rows,
- * rowinfo (row -> ray*S+k or ~0), toff} and the row strides / column offsets {ACT_LD, GRD_LD, ACT_H1, ACT_H2}
- * in floats, then the byte offset of the density-feature buffer [R,S] (-inf = sample not evaluated: masked,
+ * rowinfo (row -> ray*S+k or ~0), toff}, the row strides {ACT_LD, GRD_LD} in floats, the byte offset of the ReLU mask
+ * bits the training forward saved ([tile][layer 1, 2][lane s + 16 g] dwords: bit 4 t + r = unit 16 t + 4 g + r of the
+ * tile's sample s), a reserved 0, then the byte offset of the density-feature buffer [R,S] (-inf = sample not evaluated: masked,
  * last, or behind an early termination; overwritten with d(loss)/d(feature) by lrf_render_bwd).  Rows are
  * indexed tile*16 + lane; rowinfo is valid after lrf_render_bwd of the same workspace. */
 void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[9]);

@@ -7,19 +7,20 @@
 // lrf_render_bwd when the caller has no saved workspace):
 //   k_march (+feat)      density features of every sample, compaction lists (as in the forward)
 //   k_scan_tiles         tile offsets
-//   k_bwd_shade_fwd      the split-bf16 colour chain of k_shade_bf16, additionally saving per
-//                        shaded sample: rgb, the ReLU masks as bits, and the activation row
-//                        ACT = [X | feat,1 | relu(h1),1 | relu(h2), dhat,1], stored in MFMA-fragment
-//                        order (lrf_common.h: 1 KB per store instruction)
+//   k_bwd_shade_fwd      the split-bf16 colour chain (16-sample tiles on v_mfma_f32_16x16x32_bf16), additionally
+//                        saving per shaded sample: rgb, the ReLU masks of both hidden layers as bits, and the
+//                        activation row ACT = [X | feat,1] in MFMA-fragment order (lrf_common.h: 1 KB per store
+//                        instruction).  The hidden activations themselves are not stored (round 4).
 // backward (two branches on two streams, lrf_render_bwd):
 //   k_bwd_shade_dgrad    per tile: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX on TRANSPOSED
 //                        weight fragments, split-bf16 on v_mfma_f32_16x16x32_bf16 (same register-
 //                        resident trick as the forward: D layout of one layer = B operand of
 //                        the next; <false>: exact fp32 chain), ReLU masks from the saved bits,
-//                        gradient row GRD = [go | dfeat | dz1 | (dz2) | dX];
+//                        gradient row GRD = [go, dhat | dfeat | dz1 | dX];
 //                        d/d(position) of the appearance lookups -> per-tile ray partials
-//   k_wgrad_w2           dW2 = dz2^T [h1 | 1]: dz2 rebuilt from go + mask bits, split-bf16 MFMAs
-//   k_wgrad<MT,NT,KS> x3 the other weight gradients as tall-skinny GEMMs C = A^T B over the saved rows
+//   k_wgrad_w2w3         dW2 = dz2^T [relu(h1) | 1] and dW3 = go^T [relu(h2) | dhat | 1]: h1, h2 recomputed from the
+//                        saved feat rows (the forward's own MFMA chain), dz2 rebuilt from go + mask bits
+//   k_wgrad<MT,NT,KS> x2 dW1 and dbasis as tall-skinny GEMMs C = A^T B over the saved rows
 //                        (K = shaded samples) on v_mfma_f32_16x16x4_f32, per-chunk partials
 //   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts (1 launch)
 //   k_bwd_ray            one wavefront per ray: weights, d(loss)/d(w), suffix sums ->
@@ -359,10 +360,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
         h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
         m1 |= min(__float_as_uint(h1[t1][r]), 1u) << (4 * t1 + r);        // relu output: +0 or positive
       }
-      row_store(afr + 16 * (ACT_H1 + 16 * t1), h1[t1]);
     }
     relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane] = m1;
-    row_store_b<32>(afr + 16 * (ACT_H1 + 128), make_float4(g == 0 ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f));
     f32x4 h2[8];
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
@@ -386,9 +385,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
         const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
         o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
       }
-      row_store(afr + 16 * (ACT_H2 + 16 * t1), h2[t1]);
     }
-    row_store_b<32>(afr + 16 * (ACT_H2 + 128), g == 0 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane] = m2;
     o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
@@ -458,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
     float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax,
-    const uint32_t* __restrict__ relu_bits, int store_dz2) {
+    const uint32_t* __restrict__ relu_bits) {
   __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
   // Geometry of the appearance lookups, read back from LDS next to its use: as kernel arguments
   // these 30 uniform values stayed live across the MFMA phases, overflowed the SGPR file and were
@@ -514,7 +511,9 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
         go[c] = g_rgb[(size_t)ray * 3 + c] * w * r * (1.0f - r);
       }
     }
-    row_store_b<32>(gfr + 16 * GRD_GO, g == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    // go block: lane group 0 = go, lane group 1 = (dhat, 1): the view-direction and bias columns of dW3 (k_wgrad_w2w3)
+    row_store_b<32>(gfr + 16 * GRD_GO, g == 0 ? make_float4(go[0], go[1], go[2], 0.0f)
+                                     : g == 1 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
 
     // dz2 = (W3[:, :128]^T go) * [h2 > 0]
     f32x4 dz[8];
@@ -524,9 +523,8 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
       for (int r = 0; r < 4; ++r) {
         const float4 wv = *reinterpret_cast<const float4*>(&img[(BF16 ? IMTB_TAIL * 4 : IMT_W3H) + (g * 32 + t1 * 4 + r) * 4]);
         const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
-        dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);
+        dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);             // (not stored: k_wgrad_w2w3 rebuilds dz2 from go + mask bits)
       }
-      if (store_dz2) *reinterpret_cast<f32x4*>(gfr + 16 * (GRD_DZ2 + 16 * t1)) = dz[t1];   // (k_wgrad_w2 rebuilds dz2 from go + mask bits)
     }
     f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     f32x4 dxs[5];
@@ -825,32 +823,55 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   }
 }
 
-// dW2 (and db2) = dz2^T [relu(h1) | 1] without dz2 rows: dz2[u] = [h2_u > 0] * sum_c W3[c][u] go[c] is rank 3 plus a
-// mask, so the kernel rebuilds its A operand from 16 B of go and 16 B of ReLU mask bits per sample (and W3 in
-// registers) instead of reading 512 B of dz2 that k_bwd_shade_dgrad would have had to write first.  M-tiles w, w + 4 per
-// wave, 9 N-tiles of the h1 row, split-bf16 (Al Bh + Ah Bl + Ah Bh) on v_mfma_f32_16x16x32_bf16, one instruction per
-// 32-row step.  History on one box (serial trace): K = 16 instruction on a row-major fp32 staging tile, every wave
-// splitting all of B: 251-274 us (645 VALU + 108 MFMA per step in ONE wave per SIMD); this version 194 us.
-__global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /* grd + GRD_GO */, int ldg,
-                                                  const uint32_t* __restrict__ relu_bits, const float* __restrict__ w3 /* [3][131] */,
-                                                  const float* __restrict__ B, int ldb, const int* __restrict__ toff, int R,
-                                                  float* __restrict__ wpart, int wp_off) {
-  constexpr int KT = 32, NT = 9, WB = NT * 16, LD = WB + 16;     // LD = 16 (mod 32)
-  // h1 staged TRANSPOSED and already split: s_bh / s_bl [column][32 rows (+8 pad)] bf16.  A lane's B operand of one
-  // v_mfma_f32_16x16x32_bf16 (rows 8 g .. 8 g + 7 of column 16 n + i) is then one ds_read_b128 per half (column
-  // stride 80 B: the eight lanes of a read cycle cover all 32 banks), every element is split once by the thread that
-  // staged it instead of once per wave, and the K = 32 instruction runs at twice the rate of the K = 16 one.
-  constexpr int CS = KT + 8;                                     // bf16 per column
-  __shared__ __attribute__((aligned(16))) __bf16 s_bh[WB * CS];
-  __shared__ __attribute__((aligned(16))) __bf16 s_bl[WB * CS];
-  __shared__ __attribute__((aligned(16))) float s_go[KT][4];
-  __shared__ uint32_t s_m[KT][4];
+// dW2 (+ db2) = dz2^T [relu(h1) | 1] and dW3 (+ db3) = go^T [relu(h2) | dhat | 1] with NEITHER hidden activation stored.
+// Round 3 read 576 B of h1 and 576 B of h2 per shaded sample here (and the forward wrote them: 1.8 GB per step at
+// BASELINE configs[1]); both are functions of the 108 B `feat` row, so this kernel runs the forward's own chain
+// (gemm_step, the same fragments, the same order: bit-identical h1 / h2) on the rows it is about to contract:
+//   * a step is 64 rows = 4 tiles, one per wave: feat (the B operand as the forward's D registers left it) -> layer 1
+//     (W1 fragments held in registers) -> relu -> layer 2 (W2 fragments in LDS, 64 KB) -> relu;
+//   * relu(h1) goes to LDS TRANSPOSED and already split, s_bh / s_bl [column][64 rows (+8 pad)] bf16: a lane's B operand
+//     of one v_mfma_f32_16x16x32_bf16 (rows 8 g .. 8 g + 7 of column 16 n + i) is one ds_read_b128 per half;
+//   * dz2[u] = [h2_u > 0] * sum_c W3[c][u] go[c] is rank 3 plus a mask: the A operand is rebuilt from 16 B of go and 16 B
+//     of ReLU mask bits per sample (W3 in six registers per lane); M-tiles w, w + 4 per wave, 9 N-tiles, split-bf16
+//     (Al Bh + Ah Bl + Ah Bh), two K = 32 instructions per step;
+//   * relu(h2) goes to LDS as fp32 [row][unit]; thread (unit u, row half) adds go[row][c] * h2[row][u] over its 32 rows:
+//     dW3 is 3 x 132 numbers, a GEMM is not worth its operand shuffle; the view / bias columns come from the (dhat, 1)
+//     quadruple the data-gradient kernel left in the go block.
+// Rows behind the chunk's end read tile r0 again; their go is zeroed in LDS, so they contribute nothing to either product.
+constexpr int W23_KT = 64, W23_CS = W23_KT + 8, W23_NT = 9, W23_H2LD = LRF_FEATC + 4;
+constexpr size_t W23_LDS = (size_t)(32 * 128) * 16 + 256 * 4 + 2 * (size_t)(W23_NT * 16) * W23_CS * 2 + (size_t)W23_KT * W23_H2LD * 4
+                         + (size_t)W23_KT * 8 * 4 + (size_t)W23_KT * 4 * 4;
+__global__ __launch_bounds__(256) void k_wgrad_w2w3(const uint4* __restrict__ mlpb, const float* __restrict__ feat /* act + 16 * ACT_FEAT */, int lda,
+                                                    const float* __restrict__ go /* grd + 16 * GRD_GO */, int ldg,
+                                                    const uint32_t* __restrict__ relu_bits, const float* __restrict__ w3 /* [3][131] */,
+                                                    const int* __restrict__ toff, int R, float* __restrict__ wpart) {
+  constexpr int KT = W23_KT, NT = W23_NT, WB = NT * 16, CS = W23_CS, H2LD = W23_H2LD;
+  extern __shared__ uint4 s_w23[];
+  uint4* s_w2 = s_w23;                                              // W2 fragments [t' 8][ks 4][hi, lo][lane 64]
+  float* s_tail = reinterpret_cast<float*>(s_w2 + 32 * 128);        // b1[128] | b2[128]
+  __bf16* s_bh = reinterpret_cast<__bf16*>(s_tail + 256);          // [144 columns][CS rows]
+  __bf16* s_bl = s_bh + WB * CS;
+  float* s_h2 = reinterpret_cast<float*>(s_bl + WB * CS);           // [KT rows][H2LD]
+  float* s_go = s_h2 + KT * H2LD;                                   // [KT rows][go.xyz, 0, dhat.xyz, 1]
+  uint32_t* s_m = reinterpret_cast<uint32_t*>(s_go + KT * 8);      // [KT rows][4 lane groups]: layer-2 mask dwords
   const int rows = toff[R] * 16;
   const int WGRAD_CH = wgrad_chunk_rows(rows);
   const int r0 = blockIdx.x * WGRAD_CH;
   if (r0 >= rows) return;
   const int r1 = min(r0 + WGRAD_CH, rows);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  for (int q = tid; q < 32 * 128; q += 256) s_w2[q] = mlpb[IMGB_W2 + q];
+  {
+    const float* tail = reinterpret_cast<const float*>(mlpb + IMGB_TAIL);
+    s_tail[tid] = tail[tid < 128 ? TAIL_B1 + tid : TAIL_B2 + tid - 128];
+  }
+  for (int q = tid; q < 16 * CS; q += 256) {                        // the bias block of B: column 128 = 1, 129 .. 143 = 0
+    s_bh[128 * CS + q] = (__bf16)(q < CS ? 1.0f : 0.0f);
+    s_bl[128 * CS + q] = (__bf16)0.0f;
+  }
+  bf16x8 w1h[8], w1l[8];                                            // layer-1 fragments stay in registers (one wave per SIMD: 512 of them)
+#pragma unroll
+  for (int t1 = 0; t1 < 8; ++t1) { w1h[t1] = lds_frag(mlpb, IMGB_W1 / 128 + t1, 0, lane); w1l[t1] = lds_frag(mlpb, IMGB_W1 / 128 + t1, 1, lane); }
   f32x4 acc[2][NT];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -862,97 +883,143 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
     const int u = 16 * (wave + 4 * m) + i;
     wr[m] = w3[u]; wg[m] = w3[131 + u]; wb[m] = w3[262 + u];
   }
-  constexpr int NF4 = (KT / 16) * NT * 64;                 // B in fragment order, staged as in k_wgrad
-  constexpr int NQ = (NF4 + 255) / 256;
-  struct Pre { float4 b[NQ]; float4 go; uint32_t m; };
-  Pre pre0;
-  auto fetch = [&](Pre& pre, int rb) {
-#pragma unroll
-    for (int t = 0; t < NQ; ++t) {
-      const int q = threadIdx.x + 256 * t;
-      const int l = q & 63, bt = q >> 6, blk = bt % NT, th = bt / NT;
-      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      const int row = rb + 16 * th + sr;                   // (branch-free loads, zeroed in stage(): see k_wgrad)
-      const int rowc = (q < NF4 && row < r1) ? row : r0;
-      pre.b[t] = row_load4(B + (size_t)(rowc >> 4) * (size_t)(16 * ldb) + blk * 256 + ((gq * 16 + sr) << 2));
+  float a3[3] = {0.0f, 0.0f, 0.0f}, x3[3] = {0.0f, 0.0f, 0.0f};     // dW3 column (tid & 127) over this thread's row half; view / bias column
+  struct Pre { float4 f0, f1, go, dh; uint32_t m; };
+  Pre pre;
+  auto fetch = [&](Pre& p, int rb) {
+    {                                                      // feat of this wave's tile, as the forward's D registers: blocks 0, 1 of the row
+      int tile = (rb >> 4) + wave;
+      if (tile * 16 >= r1) tile = r0 >> 4;
+      const float* fp = feat + (size_t)tile * (size_t)(16 * lda) + (lane << 2);
+      p.f0 = row_load4(fp);
+      p.f1 = row_load4(fp + 256);
     }
-    {                                                      // go of row rb + tid % 32: block 0, lane group 0 (threads < KT stage it)
-      const int row = rb + (threadIdx.x & (KT - 1));
+    {                                                      // go / (dhat, 1) of row rb + tid % 64: lane groups 0 and 1 of the go block
+      const int row = rb + (tid & (KT - 1));
       const int rowc = row < r1 ? row : r0;
-      pre.go = *reinterpret_cast<const float4*>(go + (size_t)(rowc >> 4) * (size_t)(16 * ldg) + ((rowc & 15) << 2));
+      const float* gp = go + (size_t)(rowc >> 4) * (size_t)(16 * ldg) + ((rowc & 15) << 2);
+      p.go = *reinterpret_cast<const float4*>(gp);
+      p.dh = *reinterpret_cast<const float4*>(gp + 64);
     }
-    {                                                      // mask dword (row, lane group gg): tile row/16, layer 2, lane (row%16) + 16 gg
-      const int e = (threadIdx.x - KT) & (4 * KT - 1), k = e >> 2, gg = e & 3;     // threads KT .. 5 KT - 1 stage it
-      const int row = rb + k;
+    {                                                      // mask dword (row, lane group gg): tile row / 16, layer 2, lane (row % 16) + 16 gg
+      const int row = rb + (tid >> 2), gg = tid & 3;
       const int rowc = row < r1 ? row : r0;
-      pre.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * gg];
+      p.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * gg];
     }
   };
-  auto stage = [&](const Pre& pre, int rb) {
-    __syncthreads();
+  auto stage = [&](const Pre& p, int rb) {
+    __syncthreads();                                       // previous step's products and dW3 sums have read LDS
+    // ---- the forward's chain on this wave's 16 rows (k_bwd_shade_fwd: same fragments, same order)
+    f32x4 h1[8];
 #pragma unroll
-    for (int t = 0; t < NQ; ++t) {
-      const int q = threadIdx.x + 256 * t;
-      const int l = q & 63, bt = q >> 6, blk = bt % NT, th = bt / NT;
-      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      const bool ok = rb + 16 * th + sr < r1;
-      if (q < NF4) {
-        const float v[4] = {ok ? pre.b[t].x : 0.0f, ok ? pre.b[t].y : 0.0f, ok ? pre.b[t].z : 0.0f, ok ? pre.b[t].w : 0.0f};
+    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&s_tail[16 * t1 + 4 * g]);
+    {
+      const float v[8] = {p.f0.x, p.f0.y, p.f0.z, p.f0.w, p.f1.x, p.f1.y, p.f1.z, p.f1.w};
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const __bf16 h = (__bf16)v[r];
-          const int at = (16 * blk + 4 * gq + r) * CS + 16 * th + sr;
-          s_bh[at] = h;
-          s_bl[at] = (__bf16)(v[r] - (float)h);
-        }
+      for (int t0 = 0; t0 < 8; t0 += 2) {
+        mfma_bf16_acc(w1l[t0], bh, h1[t0]); mfma_bf16_acc(w1l[t0 + 1], bh, h1[t0 + 1]);
+        mfma_bf16_acc(w1h[t0], bl, h1[t0]); mfma_bf16_acc(w1h[t0 + 1], bl, h1[t0 + 1]);
+        mfma_bf16_acc(w1h[t0], bh, h1[t0]); mfma_bf16_acc(w1h[t0 + 1], bh, h1[t0 + 1]);
       }
     }
-    if (threadIdx.x < KT) *reinterpret_cast<float4*>(&s_go[threadIdx.x][0]) = rb + (int)threadIdx.x < r1 ? pre.go : make_float4(0, 0, 0, 0);
-    else if (threadIdx.x < 5 * KT) s_m[(threadIdx.x - KT) >> 2][(threadIdx.x - KT) & 3] = rb + (int)((threadIdx.x - KT) >> 2) < r1 ? pre.m : 0u;
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaxf(h1[t1][r], 0.0f);
+        h1[t1][r] = v;
+        const __bf16 h = (__bf16)v;
+        const int at = (16 * t1 + 4 * g + r) * CS + 16 * wave + i;
+        s_bh[at] = h;
+        s_bl[at] = (__bf16)(v - (float)h);
+      }
+    f32x4 h2[8];
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&s_tail[128 + 16 * t1 + 4 * g]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h1[2 * ks + (j >> 2)][j & 3];
+      bf16x8 bh, bl;
+      split8(v, bh, bl);
+      gemm_step<8>(s_w2, ks, 4, lane, bh, bl, h2);
+    }
+#pragma unroll
+    for (int t1 = 0; t1 < 8; ++t1) {
+      f32x4 v = h2[t1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+      *reinterpret_cast<f32x4*>(&s_h2[(16 * wave + i) * H2LD + 16 * t1 + 4 * g]) = v;
+    }
+    if (tid < KT) {
+      const bool ok = rb + tid < r1;
+      *reinterpret_cast<float4*>(&s_go[tid * 8]) = ok ? p.go : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *reinterpret_cast<float4*>(&s_go[tid * 8 + 4]) = p.dh;
+    }
+    s_m[tid] = rb + (tid >> 2) < r1 ? p.m : 0u;
     __syncthreads();
   };
   auto compute = [&]() {
-    bf16x8 bh[NT], bl[NT];
-    float4 gq8[8];
-    uint32_t md[8];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      bh[n] = *reinterpret_cast<const bf16x8*>(&s_bh[(16 * n + i) * CS + 8 * g]);
-      bl[n] = *reinterpret_cast<const bf16x8*>(&s_bl[(16 * n + i) * CS + 8 * g]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                        // K slot (g, j) = row 8 g + j of the step
-      gq8[j] = *reinterpret_cast<const float4*>(&s_go[8 * g + j][0]);
-      md[j] = s_m[8 * g + j][i >> 2];
-    }
-    __builtin_amdgcn_sched_barrier(0);                   // every LDS operand first: with one wave per SIMD nothing else covers the round trips
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int mt = wave + 4 * m;
-      bf16x8 ah, al;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = wr[m] * gq8[j].x + wg[m] * gq8[j].y + wb[m] * gq8[j].z;
-        const float v = relu_gate(d, md[j], 4 * mt + (i & 3));
-        const __bf16 h = (__bf16)v;
-        ah[j] = h;
-        al[j] = (__bf16)(v - (float)h);
-      }
+    for (int kk = 0; kk < KT / 32; ++kk) {
+      bf16x8 bh[NT], bl[NT];
+      float4 gq8[8];
+      uint32_t md[8];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+        bh[n] = *reinterpret_cast<const bf16x8*>(&s_bh[(16 * n + i) * CS + 32 * kk + 8 * g]);
+        bl[n] = *reinterpret_cast<const bf16x8*>(&s_bl[(16 * n + i) * CS + 32 * kk + 8 * g]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {                        // K slot (g, j) = row 32 kk + 8 g + j of the step
+        gq8[j] = *reinterpret_cast<const float4*>(&s_go[(32 * kk + 8 * g + j) * 8]);
+        md[j] = s_m[(32 * kk + 8 * g + j) * 4 + (i >> 2)];
+      }
+      __builtin_amdgcn_sched_barrier(0);                   // every LDS operand first: with one wave per SIMD nothing else covers the round trips
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int mt = wave + 4 * m;
+        bf16x8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = wr[m] * gq8[j].x + wg[m] * gq8[j].y + wb[m] * gq8[j].z;
+          const float v = relu_gate(d, md[j], 4 * mt + (i & 3));
+          const __bf16 h = (__bf16)v;
+          ah[j] = h;
+          al[j] = (__bf16)(v - (float)h);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+    {                                                      // dW3: column u over this thread's half of the step's rows
+      const int u = tid & 127, rbase = (tid >> 7) * (KT / 2);
+#pragma unroll 8
+      for (int k = 0; k < KT / 2; ++k) {
+        const float4 gk = *reinterpret_cast<const float4*>(&s_go[(rbase + k) * 8]);
+        const float hv = s_h2[(rbase + k) * H2LD + u];
+        a3[0] += gk.x * hv; a3[1] += gk.y * hv; a3[2] += gk.z * hv;
+        if (u < 4) {
+          const float dv = s_go[(rbase + k) * 8 + 4 + u];
+          x3[0] += gk.x * dv; x3[1] += gk.y * dv; x3[2] += gk.z * dv;
+        }
       }
     }
   };
-  fetch(pre0, r0);
+  fetch(pre, r0);
   for (int rb = r0; rb < r1; rb += KT) {
-    stage(pre0, rb);
-    fetch(pre0, rb + KT);
+    stage(pre, rb);
+    fetch(pre, rb + KT);
     compute();
   }
-  float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
+  float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W2;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int mt = wave + 4 * m;
@@ -960,6 +1027,20 @@ __global__ __launch_bounds__(256) void k_wgrad_w2(const float* __restrict__ go /
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * (NT * 16) + 16 * n + i] = acc[m][n][r];
+  }
+  __syncthreads();                                         // the two row halves of dW3 meet in LDS, lower half first
+  if (tid >= 128) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_h2[(tid - 128) * 8 + c] = a3[c]; s_h2[(tid - 128) * 8 + 4 + c] = x3[c]; }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    float* o3 = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      o3[c * 144 + tid] = a3[c] + s_h2[tid * 8 + c];
+      if (tid < 4) o3[c * 144 + LRF_FEATC + tid] = x3[c] + s_h2[tid * 8 + 4 + c];
+    }
   }
 }
 
@@ -1649,7 +1730,6 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 // in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
 static int g_dgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(4 | ...): data-gradient chain on the exact-fp32 MFMA path
 static int g_wgrad_split = 2;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
-static int g_wgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(2 | engine): dW2 = k_wgrad<8,9> over stored dz2 rows on fp32 MFMAs (measurement)
 static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                               const BwdWorkspace& b, hipStream_t st) {
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
@@ -1658,7 +1738,7 @@ static void launch_shade_save(const DField& d, const float* rays, const float* z
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_wgrad_bf16 = (e & 2) ? 0 : 1; lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; }
 
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
@@ -1671,7 +1751,7 @@ extern "C" void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t gri
   const BwdWorkspace b = carve_bwd(nullptr, R, S, grid);
   auto off = [](const void* p) { return (uint64_t)reinterpret_cast<uintptr_t>(p); };
   out[0] = off(b.act); out[1] = off(b.grd); out[2] = off(b.rowinfo); out[3] = off(b.fw.toff);
-  out[4] = (uint64_t)ACT_LD; out[5] = (uint64_t)GRD_LD; out[6] = (uint64_t)ACT_H1; out[7] = (uint64_t)ACT_H2;
+  out[4] = (uint64_t)ACT_LD; out[5] = (uint64_t)GRD_LD; out[6] = off(b.relu_bits); out[7] = 0;
   out[8] = off(b.feat);
 }
 
@@ -1726,6 +1806,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
       lds_attr_err[dev_id & 63] = e;
     });
     LRF_HIP(lds_attr_err[dev_id & 63]);
@@ -1778,10 +1860,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // ---- caller's stream: data gradient of the colour network
   if (g_dgrad_bf16)
     hipLaunchKernelGGL(k_bwd_shade_dgrad<true>, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, g_wgrad_bf16 ? 0 : 1);
+                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits);
   else
     hipLaunchKernelGGL(k_bwd_shade_dgrad<false>, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, g_wgrad_bf16 ? 0 : 1);
+                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits);
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));
 
   // ---- side stream: per-ray backward, density scatter
@@ -1807,18 +1889,12 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int on_a = ss ? g_wgrad_split : 4;
   if (ss && on_a < 4) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
   auto wst = [&](int idx) { return idx < on_a ? st : sb; };
-  if (g_wgrad_bf16)
-    hipLaunchKernelGGL(k_wgrad_w2, dim3(nch_max), dim3(256), 0, wst(0), b.grd + 16 * GRD_GO, GRD_LD, b.relu_bits, p->w3,
-                       b.act + 16 * ACT_H1, ACT_LD, w.toff, R, b.wpart, WP_W2);
-  else
-    hipLaunchKernelGGL((k_wgrad<8, 9, false>), dim3(nch_max), dim3(256), 0, wst(0), b.grd + 16 * GRD_DZ2, GRD_LD, b.act + 16 * ACT_H1, ACT_LD,
-                       w.toff, R, b.wpart, WP_W2);
+  hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(256), W23_LDS, wst(0), d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
+                     b.relu_bits, p->w3, w.toff, R, b.wpart);
   hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + 16 * GRD_DZ1, GRD_LD, b.act + 16 * ACT_FEAT, ACT_LD,
                      w.toff, R, b.wpart, WP_W1);
   hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(2), b.grd + 16 * GRD_DFEAT, GRD_LD, b.act + 16 * ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
-  hipLaunchKernelGGL((k_wgrad<1, 9, true>), dim3(nch_max), dim3(256), 0, wst(3), b.grd + 16 * GRD_GO, GRD_LD, b.act + 16 * ACT_H2, ACT_LD,
-                     w.toff, R, b.wpart, WP_W3);
   if (ss && on_a > 0) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream GEMMs are done behind this
   {
     WgradSegs segs;

@@ -189,7 +189,8 @@ class capture_train_ws:
 
 def kernel_relu_masks(f, rays, z, ws):
     """The ReLU masks the kernel's colour network used in the training forward that filled workspace `ws`
-    (lrf_render_fwd_train): read out of the saved activation rows (relu(h1), relu(h2) > 0), per shaded sample.
+    (lrf_render_fwd_train): the mask bits it saved for the data-gradient kernel (relu(h) > 0 per unit; the hidden
+    activations themselves are not stored since round 4), per shaded sample.
     Returns (lin, m1, m2, n_shaded): lin = ray * S + sample, sorted; m1, m2 [n,128] bool.  Call after backward (rowinfo
     is written by the data-gradient kernel)."""
     import ctypes as C
@@ -197,17 +198,20 @@ def kernel_relu_masks(f, rays, z, ws):
     R, S = rays.shape[0], z.numel()
     out = (C.c_uint64 * 9)()
     N.lib().lrf_workspace_layout_bwd(R, S, (C.c_int32 * 3)(*f._grid_host), out)
-    act_off, _, ri_off, toff_off, ACT_LD, _, ACT_H1, ACT_H2, _ = [int(v) for v in out]
+    _, _, ri_off, toff_off, _, _, bits_off, _, _ = [int(v) for v in out]
     toff = ws[toff_off:toff_off + 4 * (R + 1)].view(torch.int32)
-    rows = int(toff[R]) * 16
-    # the rows are stored in MFMA-fragment order (csrc/lrf_common.h: tile, 16-column block, lane group, sample, 4 columns)
-    act = ws[act_off:act_off + rows * ACT_LD * 4].view(torch.float32).view(rows // 16, ACT_LD // 16, 4, 16, 4)
-    act = act.permute(0, 3, 1, 2, 4).reshape(rows, ACT_LD)
+    tiles = int(toff[R])
+    rows = tiles * 16
+    # relu_bits[tile][layer][lane = s + 16 g]: bit 4 t1 + r = unit 16 t1 + 4 g + r of the tile's sample s (k_bwd_shade_fwd)
+    bits = ws[bits_off:bits_off + tiles * 2 * 64 * 4].view(torch.int32).view(tiles, 2, 4, 16)        # [tile][layer][g][s]
+    u = torch.arange(128, device=ws.device)
+    t1, gq, r = u >> 4, (u >> 2) & 3, u & 3
+    sel = bits[:, :, gq, :]                                                                           # [tile][layer][unit][s]
+    m = ((sel >> (4 * t1 + r)[None, None, :, None]) & 1).bool().permute(0, 3, 1, 2).reshape(rows, 2, 128)
     rowinfo = ws[ri_off:ri_off + rows * 4].view(torch.int32)
     valid = rowinfo >= 0
     lin = rowinfo[valid].long()
-    m1 = act[valid][:, ACT_H1:ACT_H1 + 128] > 0
-    m2 = act[valid][:, ACT_H2:ACT_H2 + 128] > 0
+    m1, m2 = m[valid][:, 0], m[valid][:, 1]
     order = torch.argsort(lin)
     return lin[order], m1[order], m2[order], int(valid.sum())
 
