@@ -40,7 +40,11 @@ extern "C" {
 #define LRF_FLAG_MLP_F32    8u   /* colour MLP on exact-fp32 MFMA (16x16x4 f32) instead of the default
                                     split-bf16 (hi+lo, 3-term) chain on v_mfma_f32_32x32x16_bf16 (k_shade3) */
 #define LRF_FLAG_ROWS_SAVED 16u  /* lrf_render_bwd only: the workspace was filled by lrf_render_fwd_train */
-#define LRF_FLAG_ALL        31u  /* any other bit is an error (a caller built against another ABI version) */
+#define LRF_FLAG_SORT_RAYS  32u  /* render the batch in direction-sorted order (cube face + Morton key of d / |d|, one small launch):
+                                    rays that march through the same texels run on the same XCD at the same time.  Results are
+                                    per-ray and do not depend on the order (bit-identical); ignored for R > 32768.  The same value
+                                    must be passed to lrf_render_fwd_train and the lrf_render_bwd that follows it. */
+#define LRF_FLAG_ALL        63u  /* any other bit is an error (a caller built against another ABI version) */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
  * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with
@@ -157,7 +161,8 @@ int lrf_render_bwd_wait(int32_t bucket, void* stream);
 /* Debug / parity diagnostics: byte offsets inside the training workspace of {activation rows, gradient rows,
  * rowinfo (row -> ray*S+k or ~0), toff}, the row strides {ACT_LD, GRD_LD} in floats, the byte offset of the ReLU mask
  * bits the training forward saved ([tile][layer 1, 2][lane s + 16 g] dwords: bit 4 t + r = unit 16 t + 4 g + r of the
- * tile's sample s), a reserved 0, then the byte offset of the density-feature buffer [R,S] (-inf = sample not evaluated: masked,
+ * tile's sample s), the byte offset of the slot -> ray permutation of LRF_FLAG_SORT_RAYS (int32 [R]; rowinfo and the feature
+ * buffer are indexed by SLOT when the batch was sorted), then the byte offset of the density-feature buffer [R,S] (-inf = sample not evaluated: masked,
  * last, or behind an early termination; overwritten with d(loss)/d(feature) by lrf_render_bwd).  Rows are
  * indexed tile*16 + lane; rowinfo is valid after lrf_render_bwd of the same workspace. */
 void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t grid[3], uint64_t out[9]);

@@ -13,6 +13,7 @@ LRF_FLAG_RELU_DENS = 2
 LRF_FLAG_MLP_VALU = 4
 LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
+LRF_FLAG_SORT_RAYS = 32
 
 _f = C.c_void_p  # device float*
 

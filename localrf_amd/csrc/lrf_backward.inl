@@ -508,7 +508,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float r = crgb[ci * 3 + c];
-        go[c] = g_rgb[(size_t)ray * 3 + c] * w * r * (1.0f - r);
+        go[c] = g_rgb[(size_t)(f.perm ? f.perm[ray] : ray) * 3 + c] * w * r * (1.0f - r);
       }
     }
     // go block: lane group 0 = go, lane group 1 = (dhat, 1): the view-direction and bias columns of dW3 (k_wgrad_w2w3)
@@ -823,67 +823,64 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   }
 }
 
-// dW2 (+ db2) = dz2^T [relu(h1) | 1] and dW3 (+ db3) = go^T [relu(h2) | dhat | 1] with NEITHER hidden activation stored.
-// Round 3 read 576 B of h1 and 576 B of h2 per shaded sample here (and the forward wrote them: 1.8 GB per step at
-// BASELINE configs[1]); both are functions of the 108 B `feat` row, so this kernel runs the forward's own chain
-// (gemm_step, the same fragments, the same order: bit-identical h1 / h2) on the rows it is about to contract:
-//   * a step is 64 rows = 4 tiles, one per wave: feat (the B operand as the forward's D registers left it) -> layer 1
-//     (W1 fragments held in registers) -> relu -> layer 2 (W2 fragments in LDS, 64 KB) -> relu;
-//   * relu(h1) goes to LDS TRANSPOSED and already split, s_bh / s_bl [column][64 rows (+8 pad)] bf16: a lane's B operand
-//     of one v_mfma_f32_16x16x32_bf16 (rows 8 g .. 8 g + 7 of column 16 n + i) is one ds_read_b128 per half;
-//   * dz2[u] = [h2_u > 0] * sum_c W3[c][u] go[c] is rank 3 plus a mask: the A operand is rebuilt from 16 B of go and 16 B
-//     of ReLU mask bits per sample (W3 in six registers per lane); M-tiles w, w + 4 per wave, 9 N-tiles, split-bf16
-//     (Al Bh + Ah Bl + Ah Bh), two K = 32 instructions per step;
-//   * relu(h2) goes to LDS as fp32 [row][unit]; thread (unit u, row half) adds go[row][c] * h2[row][u] over its 32 rows:
-//     dW3 is 3 x 132 numbers, a GEMM is not worth its operand shuffle; the view / bias columns come from the (dhat, 1)
-//     quadruple the data-gradient kernel left in the go block.
-// Rows behind the chunk's end read tile r0 again; their go is zeroed in LDS, so they contribute nothing to either product.
-constexpr int W23_KT = 64, W23_CS = W23_KT + 8, W23_NT = 9, W23_H2LD = LRF_FEATC + 4;
-constexpr size_t W23_LDS = (size_t)(32 * 128) * 16 + 256 * 4 + 2 * (size_t)(W23_NT * 16) * W23_CS * 2 + (size_t)W23_KT * W23_H2LD * 4
-                         + (size_t)W23_KT * 8 * 4 + (size_t)W23_KT * 4 * 4;
-__global__ __launch_bounds__(256) void k_wgrad_w2w3(const uint4* __restrict__ mlpb, const float* __restrict__ feat /* act + 16 * ACT_FEAT */, int lda,
+// dW2 (+ db2) = dz2^T [relu(h1) | 1] and dW3 (+ db3) = go^T [relu(h2) | dhat | 1] with NEITHER hidden activation stored
+// and without recomputing layer 2.  Round 3 read 576 B of h1 and 576 B of h2 per shaded sample here (and the forward
+// wrote them: 1.8 GB per step at BASELINE configs[1]).  With m2 = [h2 > 0] (the saved mask bits), B = [relu(h1) | 1]:
+//     T_c[u][v]  = sum_rows go[row][c] m2[row][u] B[row][v]                       (three 128 x 129 products, K = rows)
+//     dW2[u][v]  = sum_c W3[c][u] T_c[u][v],   db2[u] = sum_c W3[c][u] T_c[u][128]          (dz2 = m2 * W3^T go)
+//     dW3[c][u]  = sum_v W2[u][v] T_c[u][v] + b2[u] T_c[u][128]                   (relu(h2) = m2 * (W2 relu(h1) + b2))
+// so one GEMM family over the rows yields both gradients; relu(h1) is recomputed from the 108 B `feat` row with the
+// forward's own layer-1 fragments and order (bit-identical), and h2 never exists here.  The first version of this
+// round recomputed layer 2 as well and contracted dW3 on the VALU at one wave per SIMD: 392 us, issue-bound (1450 VALU +
+// 230 MFMA + 305 LDS instructions per 64-row step and wave, profiles/r11a).  This one:
+//   * 512 threads, two waves per SIMD; a step is 128 rows = 8 tiles, one per wave for layer 1; relu(h1) goes to LDS
+//     TRANSPOSED and already split, s_bh / s_bl [column][128 rows (+8 pad)] bf16, so a lane's B operand of one
+//     v_mfma_f32_16x16x32_bf16 (rows 8 g .. 8 g + 7 of column 16 n + i) is one ds_read_b128 per half;
+//   * wave w owns M-tile w (units 16 w .. 16 w + 15) of all three T_c: 27 accumulator tiles; its A operand
+//     go[row][c] m2[row][u] is go's pre-split halves (s_ga, one ds_read_b128 per colour and half) ANDed with a mask
+//     expanded from one byte of row bits -- the staging waves transpose the mask dwords with ballots (s_mt[unit][row]);
+//   * 81 independent MFMAs per 32 rows and wave against ~60 VALU: the matrix pipe is what the kernel waits for;
+//   * the W3 / W2 contractions of the epilogue run once per chunk, in registers; the view / bias columns of dW3 come
+//     from the (dhat, 1) quadruple the data-gradient kernel left in the go block.
+// Rows behind the chunk's end read tile r0 again; their go and mask bits are zeroed in LDS, so they contribute nothing.
+constexpr int W23_KT = 128, W23_CS = W23_KT + 8, W23_NT = 9;
+constexpr size_t W23_LDS = (size_t)(8 * 128) * 16 + 128 * 4 + 2 * (size_t)(W23_NT * 16) * W23_CS * 2 + (size_t)6 * W23_KT * 2
+                         + (size_t)LRF_FEATC * (W23_KT / 32) * 4;
+__global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ mlpb, const float* __restrict__ feat /* act + 16 * ACT_FEAT */, int lda,
                                                     const float* __restrict__ go /* grd + 16 * GRD_GO */, int ldg,
                                                     const uint32_t* __restrict__ relu_bits, const float* __restrict__ w3 /* [3][131] */,
+                                                    const float* __restrict__ w2 /* [128][128] */, const float* __restrict__ b2,
                                                     const int* __restrict__ toff, int R, float* __restrict__ wpart) {
-  constexpr int KT = W23_KT, NT = W23_NT, WB = NT * 16, CS = W23_CS, H2LD = W23_H2LD;
+  constexpr int KT = W23_KT, NT = W23_NT, WB = NT * 16, CS = W23_CS;
   extern __shared__ uint4 s_w23[];
-  uint4* s_w2 = s_w23;                                              // W2 fragments [t' 8][ks 4][hi, lo][lane 64]
-  float* s_tail = reinterpret_cast<float*>(s_w2 + 32 * 128);        // b1[128] | b2[128]
-  __bf16* s_bh = reinterpret_cast<__bf16*>(s_tail + 256);          // [144 columns][CS rows]
+  uint4* s_w1 = s_w23;                                              // W1 fragments [t' 8][hi, lo][lane 64]
+  float* s_b1 = reinterpret_cast<float*>(s_w1 + 8 * 128);
+  __bf16* s_bh = reinterpret_cast<__bf16*>(s_b1 + 128);            // [144 columns][CS rows]
   __bf16* s_bl = s_bh + WB * CS;
-  float* s_h2 = reinterpret_cast<float*>(s_bl + WB * CS);           // [KT rows][H2LD]
-  float* s_go = s_h2 + KT * H2LD;                                   // [KT rows][go.xyz, 0, dhat.xyz, 1]
-  uint32_t* s_m = reinterpret_cast<uint32_t*>(s_go + KT * 8);      // [KT rows][4 lane groups]: layer-2 mask dwords
+  __bf16* s_ga = s_bl + WB * CS;                                    // [colour 3][hi, lo][KT rows]: go, pre-split
+  uint32_t* s_mt = reinterpret_cast<uint32_t*>(s_ga + 6 * KT);     // [unit 128][KT / 32]: bit (row % 32) of dword row / 32 = m2[row][unit]
   const int rows = toff[R] * 16;
   const int WGRAD_CH = wgrad_chunk_rows(rows);
   const int r0 = blockIdx.x * WGRAD_CH;
   if (r0 >= rows) return;
   const int r1 = min(r0 + WGRAD_CH, rows);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-  for (int q = tid; q < 32 * 128; q += 256) s_w2[q] = mlpb[IMGB_W2 + q];
-  {
-    const float* tail = reinterpret_cast<const float*>(mlpb + IMGB_TAIL);
-    s_tail[tid] = tail[tid < 128 ? TAIL_B1 + tid : TAIL_B2 + tid - 128];
-  }
-  for (int q = tid; q < 16 * CS; q += 256) {                        // the bias block of B: column 128 = 1, 129 .. 143 = 0
+  for (int q = tid; q < 8 * 128; q += 512) s_w1[q] = mlpb[IMGB_W1 + q];
+  if (tid < 128) s_b1[tid] = reinterpret_cast<const float*>(mlpb + IMGB_TAIL)[TAIL_B1 + tid];
+  for (int q = tid; q < 16 * CS; q += 512) {                        // the bias block of B: column 128 = 1, 129 .. 143 = 0
     s_bh[128 * CS + q] = (__bf16)(q < CS ? 1.0f : 0.0f);
     s_bl[128 * CS + q] = (__bf16)0.0f;
   }
-  bf16x8 w1h[8], w1l[8];                                            // layer-1 fragments stay in registers (one wave per SIMD: 512 of them)
+  f32x4 acc[3][NT];
 #pragma unroll
-  for (int t1 = 0; t1 < 8; ++t1) { w1h[t1] = lds_frag(mlpb, IMGB_W1 / 128 + t1, 0, lane); w1l[t1] = lds_frag(mlpb, IMGB_W1 / 128 + t1, 1, lane); }
-  f32x4 acc[2][NT];
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < NT; ++n) acc[c][n] = f32x4{0, 0, 0, 0};
+  float xv[3][4];                                                  // threads < KT: sum over their rows of go[c] * (dhat, 1)[a]
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
-  float wr[2], wg[2], wb[2];                               // W3[:, unit] of this lane's unit in its two M-tiles
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int u = 16 * (wave + 4 * m) + i;
-    wr[m] = w3[u]; wg[m] = w3[131 + u]; wb[m] = w3[262 + u];
-  }
-  float a3[3] = {0.0f, 0.0f, 0.0f}, x3[3] = {0.0f, 0.0f, 0.0f};     // dW3 column (tid & 127) over this thread's row half; view / bias column
+    for (int a = 0; a < 4; ++a) xv[c][a] = 0.0f;
   struct Pre { float4 f0, f1, go, dh; uint32_t m; };
   Pre pre;
   auto fetch = [&](Pre& p, int rb) {
@@ -894,122 +891,110 @@ __global__ __launch_bounds__(256) void k_wgrad_w2w3(const uint4* __restrict__ ml
       p.f0 = row_load4(fp);
       p.f1 = row_load4(fp + 256);
     }
-    {                                                      // go / (dhat, 1) of row rb + tid % 64: lane groups 0 and 1 of the go block
+    {                                                      // go / (dhat, 1) of row rb + tid % 128: lane groups 0 and 1 of the go block
       const int row = rb + (tid & (KT - 1));
       const int rowc = row < r1 ? row : r0;
       const float* gp = go + (size_t)(rowc >> 4) * (size_t)(16 * ldg) + ((rowc & 15) << 2);
       p.go = *reinterpret_cast<const float4*>(gp);
       p.dh = *reinterpret_cast<const float4*>(gp + 64);
-    }
-    {                                                      // mask dword (row, lane group gg): tile row / 16, layer 2, lane (row % 16) + 16 gg
-      const int row = rb + (tid >> 2), gg = tid & 3;
-      const int rowc = row < r1 ? row : r0;
-      p.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * gg];
+      // layer-2 mask dword (row, lane group gg = tid / 128): tile row / 16, lane (row % 16) + 16 gg
+      p.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * (tid >> 7)];
     }
   };
   auto stage = [&](const Pre& p, int rb) {
-    __syncthreads();                                       // previous step's products and dW3 sums have read LDS
-    // ---- the forward's chain on this wave's 16 rows (k_bwd_shade_fwd: same fragments, same order)
+    __syncthreads();                                       // previous step's products have read LDS
+    // ---- layer 1 of the forward on this wave's 16 rows (k_bwd_shade_fwd: same fragments, same order)
     f32x4 h1[8];
 #pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&s_tail[16 * t1 + 4 * g]);
+    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&s_b1[16 * t1 + 4 * g]);
     {
       const float v[8] = {p.f0.x, p.f0.y, p.f0.z, p.f0.w, p.f1.x, p.f1.y, p.f1.z, p.f1.w};
       bf16x8 bh, bl;
       split8(v, bh, bl);
-#pragma unroll
-      for (int t0 = 0; t0 < 8; t0 += 2) {
-        mfma_bf16_acc(w1l[t0], bh, h1[t0]); mfma_bf16_acc(w1l[t0 + 1], bh, h1[t0 + 1]);
-        mfma_bf16_acc(w1h[t0], bl, h1[t0]); mfma_bf16_acc(w1h[t0 + 1], bl, h1[t0 + 1]);
-        mfma_bf16_acc(w1h[t0], bh, h1[t0]); mfma_bf16_acc(w1h[t0 + 1], bh, h1[t0 + 1]);
-      }
+      gemm_step<8>(s_w1, 0, 1, lane, bh, bl, h1);
     }
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = fmaxf(h1[t1][r], 0.0f);
-        h1[t1][r] = v;
         const __bf16 h = (__bf16)v;
         const int at = (16 * t1 + 4 * g + r) * CS + 16 * wave + i;
         s_bh[at] = h;
         s_bl[at] = (__bf16)(v - (float)h);
       }
-    f32x4 h2[8];
+    const bool ok = rb + (tid & (KT - 1)) < r1;
+    if (tid < KT) {                                        // go of row tid, split once for all eight product waves
+      const float gv[3] = {ok ? p.go.x : 0.0f, ok ? p.go.y : 0.0f, ok ? p.go.z : 0.0f};
+      const float dv[4] = {p.dh.x, p.dh.y, p.dh.z, p.dh.w};
 #pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&s_tail[128 + 16 * t1 + 4 * g]);
+      for (int c = 0; c < 3; ++c) {
+        const __bf16 h = (__bf16)gv[c];
+        s_ga[(2 * c) * KT + tid] = h;
+        s_ga[(2 * c + 1) * KT + tid] = (__bf16)(gv[c] - (float)h);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = h1[2 * ks + (j >> 2)][j & 3];
-      bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(s_w2, ks, 4, lane, bh, bl, h2);
+        for (int a = 0; a < 4; ++a) xv[c][a] += gv[c] * dv[a];
+      }
     }
+    {                                                      // mask bits, transposed: wave w holds lane group gg = w / 2 of rows 64 (w % 2) + lane
+      const uint32_t m = ok ? p.m : 0u;
+      const int gg = wave >> 1, half = wave & 1;
 #pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) {
-      f32x4 v = h2[t1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-      *reinterpret_cast<f32x4*>(&s_h2[(16 * wave + i) * H2LD + 16 * t1 + 4 * g]) = v;
+      for (int b = 0; b < 32; ++b) {                       // bit b = unit 16 (b / 4) + 4 gg + b % 4
+        const unsigned long long bal = __ballot((m >> b) & 1u);
+        if (lane == b) {
+          const int u = 16 * (b >> 2) + 4 * gg + (b & 3);
+          *reinterpret_cast<uint2*>(&s_mt[u * (KT / 32) + 2 * half]) = make_uint2((uint32_t)bal, (uint32_t)(bal >> 32));
+        }
+      }
     }
-    if (tid < KT) {
-      const bool ok = rb + tid < r1;
-      *reinterpret_cast<float4*>(&s_go[tid * 8]) = ok ? p.go : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      *reinterpret_cast<float4*>(&s_go[tid * 8 + 4]) = p.dh;
-    }
-    s_m[tid] = rb + (tid >> 2) < r1 ? p.m : 0u;
     __syncthreads();
   };
   auto compute = [&]() {
-#pragma unroll
+#pragma unroll 1
     for (int kk = 0; kk < KT / 32; ++kk) {
-      bf16x8 bh[NT], bl[NT];
-      float4 gq8[8];
-      uint32_t md[8];
+      uint4 ar[3][2];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        bh[n] = *reinterpret_cast<const bf16x8*>(&s_bh[(16 * n + i) * CS + 32 * kk + 8 * g]);
-        bl[n] = *reinterpret_cast<const bf16x8*>(&s_bl[(16 * n + i) * CS + 32 * kk + 8 * g]);
+      for (int c = 0; c < 3; ++c) {
+        ar[c][0] = *reinterpret_cast<const uint4*>(&s_ga[(2 * c) * KT + 32 * kk + 8 * g]);
+        ar[c][1] = *reinterpret_cast<const uint4*>(&s_ga[(2 * c + 1) * KT + 32 * kk + 8 * g]);
       }
+      // rows 32 kk + 8 g + j, j = 0 .. 7: bit j of this byte says whether unit 16 wave + i was active in row j
+      const uint32_t byte = (s_mt[(16 * wave + i) * (KT / 32) + kk] >> (8 * g)) & 0xffu;
+      uint32_t pm[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {                        // K slot (g, j) = row 32 kk + 8 g + j of the step
-        gq8[j] = *reinterpret_cast<const float4*>(&s_go[(32 * kk + 8 * g + j) * 8]);
-        md[j] = s_m[(32 * kk + 8 * g + j) * 4 + (i >> 2)];
+      for (int q = 0; q < 4; ++q) {                        // K slots 2 q, 2 q + 1 share a dword of the operand
+        const uint32_t lo = (uint32_t)((int32_t)(byte << (31 - 2 * q)) >> 31), hi = (uint32_t)((int32_t)(byte << (30 - 2 * q)) >> 31);
+        pm[q] = (lo & 0xffffu) | (hi & 0xffff0000u);
       }
-      __builtin_amdgcn_sched_barrier(0);                   // every LDS operand first: with one wave per SIMD nothing else covers the round trips
+      bf16x8 ah[3], al[3];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int mt = wave + 4 * m;
-        bf16x8 ah, al;
+      for (int c = 0; c < 3; ++c) {
+        ah[c] = __builtin_bit_cast(bf16x8, make_uint4(ar[c][0].x & pm[0], ar[c][0].y & pm[1], ar[c][0].z & pm[2], ar[c][0].w & pm[3]));
+        al[c] = __builtin_bit_cast(bf16x8, make_uint4(ar[c][1].x & pm[0], ar[c][1].y & pm[1], ar[c][1].z & pm[2], ar[c][1].w & pm[3]));
+      }
+      // three N-tiles at a time (24 operand registers live instead of 72), term-major over their nine accumulators:
+      // consecutive MFMAs never depend on each other
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float d = wr[m] * gq8[j].x + wg[m] * gq8[j].y + wb[m] * gq8[j].z;
-          const float v = relu_gate(d, md[j], 4 * mt + (i & 3));
-          const __bf16 h = (__bf16)v;
-          ah[j] = h;
-          al[j] = (__bf16)(v - (float)h);
+      for (int n0 = 0; n0 < NT; n0 += 3) {
+        bf16x8 bh[3], bl[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          bh[n] = *reinterpret_cast<const bf16x8*>(&s_bh[(16 * (n0 + n) + i) * CS + 32 * kk + 8 * g]);
+          bl[n] = *reinterpret_cast<const bf16x8*>(&s_bl[(16 * (n0 + n) + i) * CS + 32 * kk + 8 * g]);
         }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
-        }
-      }
-    }
-    {                                                      // dW3: column u over this thread's half of the step's rows
-      const int u = tid & 127, rbase = (tid >> 7) * (KT / 2);
-#pragma unroll 8
-      for (int k = 0; k < KT / 2; ++k) {
-        const float4 gk = *reinterpret_cast<const float4*>(&s_go[(rbase + k) * 8]);
-        const float hv = s_h2[(rbase + k) * H2LD + u];
-        a3[0] += gk.x * hv; a3[1] += gk.y * hv; a3[2] += gk.z * hv;
-        if (u < 4) {
-          const float dv = s_go[(rbase + k) * 8 + 4 + u];
-          x3[0] += gk.x * dv; x3[1] += gk.y * dv; x3[2] += gk.z * dv;
-        }
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[c][n0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[c], bh[n], acc[c][n0 + n], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[c][n0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c], bl[n], acc[c][n0 + n], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[c][n0 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c], bh[n], acc[c][n0 + n], 0, 0, 0);
       }
     }
   };
@@ -1019,29 +1004,41 @@ __global__ __launch_bounds__(256) void k_wgrad_w2w3(const uint4* __restrict__ ml
     fetch(pre, rb + KT);
     compute();
   }
-  float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W2;
+  // ---- epilogue, once per chunk: acc[c][n][r] = T_c[u = 16 wave + 4 g + r][v = 16 n + i]
+  float* o2 = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W2;
+  float* o3 = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W3;
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int mt = wave + 4 * m;
+  for (int r = 0; r < 4; ++r) {
+    const int u = 16 * wave + 4 * g + r;
+    const float w3r = w3[u], w3g = w3[131 + u], w3b = w3[262 + u];
+    float d3[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int n = 0; n < NT; ++n) {
+      o2[(size_t)u * (NT * 16) + 16 * n + i] = w3r * acc[0][n][r] + w3g * acc[1][n][r] + w3b * acc[2][n][r];
+      const float wv = n < 8 ? w2[u * LRF_FEATC + 16 * n + i] : (i == 0 ? b2[u] : 0.0f);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * (NT * 16) + 16 * n + i] = acc[m][n][r];
-  }
-  __syncthreads();                                         // the two row halves of dW3 meet in LDS, lower half first
-  if (tid >= 128) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { s_h2[(tid - 128) * 8 + c] = a3[c]; s_h2[(tid - 128) * 8 + 4 + c] = x3[c]; }
-  }
-  __syncthreads();
-  if (tid < 128) {
-    float* o3 = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W3;
+      for (int c = 0; c < 3; ++c) d3[c] += wv * acc[c][n][r];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      o3[c * 144 + tid] = a3[c] + s_h2[tid * 8 + c];
-      if (tid < 4) o3[c * 144 + LRF_FEATC + tid] = x3[c] + s_h2[tid * 8 + 4 + c];
+#pragma unroll
+      for (int dd = 1; dd < 16; dd <<= 1) d3[c] += __shfl_xor(d3[c], dd, 64);
+      if (i == 0) o3[c * 144 + u] = d3[c];
     }
   }
+  __syncthreads();                                         // the view / bias columns: 128 row threads -> 12 sums (LDS reused)
+  float* s_x = reinterpret_cast<float*>(s_bh);
+  if (tid < KT) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float v = wave_sum(xv[c][a]);
+        if (lane == 0) s_x[wave * 12 + 4 * c + a] = v;
+      }
+  }
+  __syncthreads();
+  if (tid < 12) o3[(tid >> 2) * 144 + LRF_FEATC + (tid & 3)] = s_x[tid] + s_x[12 + tid];
 }
 
 // dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in a fixed order) for
@@ -1093,9 +1090,10 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
   const bool relu = flags & LRF_FLAG_RELU_DENS;
   const float white = (flags & LRF_FLAG_WHITE_BG) ? 1.0f : 0.0f;
-  const float gr[3] = {g_rgb[(size_t)ray * 3], g_rgb[(size_t)ray * 3 + 1], g_rgb[(size_t)ray * 3 + 2]};
+  const int oray = f.perm ? f.perm[ray] : ray;              // the caller's index of this slot (ray sorting)
+  const float gr[3] = {g_rgb[(size_t)oray * 3], g_rgb[(size_t)oray * 3 + 1], g_rgb[(size_t)oray * 3 + 2]};
   const float gsum = (gr[0] + gr[1] + gr[2]) * white;
-  const float gd = g_depth[ray];
+  const float gd = g_depth[oray];
   const int nchunk = (S + 63) >> 6;
   const int nsh = ncomp[ray];
 
@@ -1243,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
     // dhat = d / n (tensorBase.py:578-580); depth = sum(w z) / n (:615)
     const float dot = dh[0] * gdh[0] + dh[1] * gdh[1] + dh[2] * gdh[2];
     const float depth = dsum / dn;
-    float* gp = g_rays + (size_t)ray * 6;
+    float* gp = g_rays + (size_t)oray * 6;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       gp[a] = go3[a];
@@ -1255,7 +1253,8 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
 // d(loss)/d(rays) += the appearance lookups' position gradients (per-tile partials of k_bwd_shade_dgrad): the tail of
 // k_bwd_ray as its own launch, linear in the partial sums: g_o += sum go, g_d += (I - dhat dhat^T) sum gdh / |d|.
 __global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict__ rays, int R, const int* __restrict__ ncomp,
-                                                        const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays) {
+                                                        const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays,
+                                                        const int* __restrict__ perm) {
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
   if (ray >= R) return;
   const int nt = (ncomp[ray] + ITEM - 1) / ITEM;
@@ -1270,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict_
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
   const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
   const float dot = dh[0] * gdh[0] + dh[1] * gdh[1] + dh[2] * gdh[2];
-  float* gp = g_rays + (size_t)ray * 6;
+  float* gp = g_rays + (size_t)(perm ? perm[ray] : ray) * 6;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     gp[a] += go3[a];
@@ -1751,7 +1750,7 @@ extern "C" void lrf_workspace_layout_bwd(int32_t R, int32_t S, const int32_t gri
   const BwdWorkspace b = carve_bwd(nullptr, R, S, grid);
   auto off = [](const void* p) { return (uint64_t)reinterpret_cast<uintptr_t>(p); };
   out[0] = off(b.act); out[1] = off(b.grd); out[2] = off(b.rowinfo); out[3] = off(b.fw.toff);
-  out[4] = (uint64_t)ACT_LD; out[5] = (uint64_t)GRD_LD; out[6] = off(b.relu_bits); out[7] = 0;
+  out[4] = (uint64_t)ACT_LD; out[5] = (uint64_t)GRD_LD; out[6] = off(b.relu_bits); out[7] = off(b.fw.perm);
   out[8] = off(b.feat);
 }
 
@@ -1765,14 +1764,15 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
     return set_err("lrf_render_fwd_train: the row-saving forward runs the split-bf16 engine only");
   if (flags & ~LRF_FLAG_ALL) return set_err("lrf_render_fwd_train: unknown flag bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const DField d = make_dfield(f);
+  DField d = make_dfield(f);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
+  rays = sort_rays_if_asked(d, rays, R, flags, w, st);
   launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
   launch_shade_save(d, rays, z, S, R, w, b, st);
   hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
-                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr);
+                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr, d.perm);
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1787,11 +1787,16 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     return set_err("lrf_render_bwd: need R > 0 and 2 <= S <= LRF_MAX_S_TRAIN (2048: the per-ray backward keeps 16 B per sample in LDS)");
   if (flags & ~LRF_FLAG_ALL) return set_err("lrf_render_bwd: unknown flag bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const DField d = make_dfield(f);
+  DField d = make_dfield(f);
   const Layout L = make_layout(f->grid);
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
   const int cus = device_cus();
+  if (flags & LRF_FLAG_ROWS_SAVED) {                       // lrf_render_fwd_train sorted (or not) with the same flags: same workspace
+    if ((flags & LRF_FLAG_SORT_RAYS) && R <= LRF_SORT_MAX_R && R >= 2) { d.perm = w.perm; rays = w.rays_s; }
+  } else {
+    rays = sort_rays_if_asked(d, rays, R, flags, w, st);
+  }
   {
     static std::once_flag lds_attr_once[64];   // dynamic LDS above 64 KB has to be opted into once per device
     static hipError_t lds_attr_err[64];
@@ -1889,8 +1894,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int on_a = ss ? g_wgrad_split : 4;
   if (ss && on_a < 4) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
   auto wst = [&](int idx) { return idx < on_a ? st : sb; };
-  hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(256), W23_LDS, wst(0), d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
-                     b.relu_bits, p->w3, w.toff, R, b.wpart);
+  hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, wst(0), d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
+                     b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
   hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + 16 * GRD_DZ1, GRD_LD, b.act + 16 * ACT_FEAT, ACT_LD,
                      w.toff, R, b.wpart, WP_W1);
   hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(2), b.grd + 16 * GRD_DFEAT, GRD_LD, b.act + 16 * ACT_X, ACT_LD,
@@ -1930,7 +1935,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
 
   // ---- join: both branches done
   if (ss) LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
-  hipLaunchKernelGGL(k_rays_add_rpart, dim3((R + 255) / 256), dim3(256), 0, st, rays, R, w.ncomp, b.rpart, w.pmax, g_rays);
+  hipLaunchKernelGGL(k_rays_add_rpart, dim3((R + 255) / 256), dim3(256), 0, st, rays, R, w.ncomp, b.rpart, w.pmax, g_rays, d.perm);
   hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 6), dim3(128), 0, st, tab_a);
   if (sx) { LRF_HIP(hipEventRecord(sx->bucket[2], st)); sx->bucket_set = true; }
   LRF_HIP(hipGetLastError());

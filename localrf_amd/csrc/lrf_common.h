@@ -168,7 +168,8 @@ struct DField {
   const float* w3; const float* b3;
   float* dump;                 // test hook: s_memtime totals of k_shade3<TIMED> (lrf_debug_set_dump), else null
   float* rdir;                 // k_march -> k_shade3: per ray (d / |d|, |d|), or null
-};
+  const int* perm;             // ray sorting (LRF_FLAG_SORT_RAYS): slot -> the caller's ray index for everything indexed by the
+};                             // caller (rgb, depth, weights, g_rgb, g_depth, g_rays); null = identity.  `rays` is then the sorted copy
 
 // ------------------------------------------------------------------ geometry
 // utils/ray_utils.py:9-12

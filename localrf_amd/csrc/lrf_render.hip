@@ -254,6 +254,7 @@ __global__ __launch_bounds__(1024) void k_march(
   }
   if (ray >= R) return;
   float* s_alpha = s_alpha_all + (size_t)wave * S;
+  const int oray = f.perm ? f.perm[ray] : ray;             // where the caller sees this ray (ray sorting)
 
   const float* rp = rays + (size_t)ray * 6;
   const float o[3] = {rp[0], rp[1], rp[2]};
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_march(
         a_k += w * (float)k;
       }
       if (emit) {
-        if (w_all && k < S) w_all[(size_t)ray * S + k] = w;
+        if (w_all && k < S) w_all[(size_t)oray * S + k] = w;
         const bool sh = (k < S) && (w > f.weight_thres);                            // :622
         const unsigned long long m = __ballot(sh);
         if (sh) {
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(1024) void k_march(
     }
   }
   if (lane == 0) {
-    depth[ray] = dsum / dn;                                                         // :615
+    depth[oray] = dsum / dn;                                                        // :615
     acc_ws[ray] = acc;
     ncomp[ray] = nsh;
     if (f.rdir) *reinterpret_cast<float4*>(f.rdir + (size_t)ray * 4) = make_float4(dh[0], dh[1], dh[2], dn);
@@ -716,9 +717,10 @@ __global__ __launch_bounds__(64) void k_shade_valu(
 // rgb_map = sum_k w_k rgb_k (+ 1 - acc)                        (tensorBase.py:632-634)
 __global__ void k_finalize(int R, int pmax, uint32_t flags, const int* __restrict__ ncomp,
                            const float* __restrict__ acc, const float* __restrict__ part,
-                           float* __restrict__ rgb, float* __restrict__ acc_out) {
+                           float* __restrict__ rgb, float* __restrict__ acc_out, const int* __restrict__ perm) {
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
   if (ray >= R) return;
+  const int oray = perm ? perm[ray] : ray;
   const int nit = (ncomp[ray] + ITEM - 1) / ITEM;
   float r = 0.0f, g = 0.0f, b = 0.0f;
   for (int i = 0; i < nit; ++i) {
@@ -729,8 +731,56 @@ __global__ void k_finalize(int R, int pmax, uint32_t flags, const int* __restric
     const float bg = 1.0f - acc[ray];
     r += bg; g += bg; b += bg;
   }
-  rgb[(size_t)ray * 3 + 0] = r; rgb[(size_t)ray * 3 + 1] = g; rgb[(size_t)ray * 3 + 2] = b;
-  if (acc_out) acc_out[ray] = acc[ray];
+  rgb[(size_t)oray * 3 + 0] = r; rgb[(size_t)oray * 3 + 1] = g; rgb[(size_t)oray * 3 + 2] = b;
+  if (acc_out) acc_out[oray] = acc[ray];
+}
+
+// ---------------------------------------------------------------------------- ray sorting (LRF_FLAG_SORT_RAYS)
+// Rays are independent, so the batch may be rendered in any order; the caller's order is usually the worst one (random
+// pixels of a few views; random directions in the benchmark): the 256 CUs then gather from everywhere at once and an
+// XCD's 4 MB L2 sees the whole 35-160 MB field.  One 1024-thread workgroup sorts the batch by a 15-bit direction key
+// (cube face of d / |d|, then the Morton code of the two in-face coordinates at 6 bits each) with a bitonic network on
+// (key << 16 | index) words in LDS, writes the sorted copy of the rays and the slot -> ray permutation.  Everything after
+// it indexes rays by slot; only what the caller sees (rgb, depth, weights, g_rgb, g_depth, g_rays) goes through `perm`.
+// With the XCD-aware block order of the kernels, an XCD then renders one contiguous eighth of the direction sphere.
+__device__ __forceinline__ uint32_t ray_dir_key(const float* __restrict__ rp) {
+  const float x = rp[3], y = rp[4], z = rp[5];
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  int face; float m, u, v;
+  if (ax >= ay && ax >= az) { face = x < 0.0f ? 1 : 0; m = ax; u = y; v = z; }
+  else if (ay >= az)        { face = y < 0.0f ? 3 : 2; m = ay; u = x; v = z; }
+  else                      { face = z < 0.0f ? 5 : 4; m = az; u = x; v = y; }
+  m = fmaxf(m, 1e-30f);
+  const int iu = min(63, max(0, (int)((u / m * 0.5f + 0.5f) * 64.0f)));
+  const int iv = min(63, max(0, (int)((v / m * 0.5f + 0.5f) * 64.0f)));
+  uint32_t mort = 0;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) mort |= (uint32_t)((iu >> b) & 1) << (2 * b) | (uint32_t)((iv >> b) & 1) << (2 * b + 1);
+  return ((uint32_t)face << 12) | mort;
+}
+__global__ __launch_bounds__(1024) void k_sort_rays(const float* __restrict__ rays, int R, int N /* pow2 >= R */,
+                                                    float* __restrict__ rays_s, int* __restrict__ perm) {
+  extern __shared__ uint32_t s_key[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N; i += 1024) s_key[i] = i < R ? (ray_dir_key(rays + (size_t)i * 6) << 16) | (uint32_t)i : 0xffffffffu;
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < N / 2; t += 1024) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;        // the pair (lo, lo + j)
+        const uint32_t a = s_key[lo], b = s_key[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < R; i += 1024) {
+    const int src = (int)(s_key[i] & 0xffffu);
+    perm[i] = src;
+    const float2* sp = reinterpret_cast<const float2*>(rays + (size_t)src * 6);
+    float2* dp = reinterpret_cast<float2*>(rays_s + (size_t)i * 6);
+    dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
+  }
 }
 
 // ----------------------------------------------------------------- stand-alone pieces
@@ -839,6 +889,7 @@ static DField make_dfield(const LrfField* f) {
   d.term_T = f->term_T > 0.0f ? f->term_T : 0.0f;
   d.dump = nullptr;
   d.rdir = nullptr;
+  d.perm = nullptr;
   d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
   return d;
 }
@@ -846,6 +897,7 @@ static DField make_dfield(const LrfField* f) {
 struct Workspace {
   int* toff; int* ncomp; float* acc; uint16_t* cidx; float* cw; float* part;
   float* rdir;             // k_march -> k_shade3: unit direction and length per ray
+  int* perm; float* rays_s;  // ray sorting: slot -> ray, sorted copy of the rays
   int pmax; size_t bytes;
 };
 static size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -861,6 +913,8 @@ static Workspace carve(void* ws, int R, int S) {
   w.cw    = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * S * 4);
   w.part  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * w.pmax * 12);
   w.rdir  = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 16);
+  w.perm  = reinterpret_cast<int*>(p + off);       off += up256((size_t)R * 4);
+  w.rays_s = reinterpret_cast<float*>(p + off);    off += up256((size_t)R * 24);
   w.bytes = off;
   return w;
 }
@@ -904,6 +958,27 @@ static SideStream* side_stream() {
   }
   return &x;
 }
+// LRF_FLAG_SORT_RAYS: sort the batch by direction (k_sort_rays) into the workspace; returns the rays the kernels should read
+// and sets d.perm.  Batches beyond the 16-bit index of the sort words are rendered in the caller's order.
+constexpr int LRF_SORT_MAX_R = 32768;
+static const float* sort_rays_if_asked(DField& d, const float* rays, int R, uint32_t flags, const Workspace& w, hipStream_t st) {
+  d.perm = nullptr;
+  if (!(flags & LRF_FLAG_SORT_RAYS) || R > LRF_SORT_MAX_R || R < 2) return rays;
+  int N = 2;
+  while (N < R) N <<= 1;
+  if ((size_t)N * 4 > 64 * 1024) {
+    static std::once_flag once[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess)
+      std::call_once(once[dev & 63], [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rays), hipFuncAttributeMaxDynamicSharedMemorySize, LRF_SORT_MAX_R * 4);
+      });
+  }
+  hipLaunchKernelGGL(k_sort_rays, dim3(1), dim3(1024), (size_t)N * 4, st, rays, R, N, w.rays_s, w.perm);
+  d.perm = w.perm;
+  return w.rays_s;
+}
+
 // k_march launch: lines in LDS when the three of them (+ the alpha slices) leave four workgroups per CU
 static void launch_march(const DField& d, const float* rays, const float* z, int R, int S, uint32_t flags, float floater,
                          float* depth, float* acc, float* w_all, int* ncomp, uint16_t* cidx, float* cw, float* feat,
@@ -1010,6 +1085,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   DField d = make_dfield(f);
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
+  rays = sort_rays_if_asked(d, rays, R, flags, w, st);
   if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))) {
     // Default engine: k_march -> k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16, lrf_shade3.inl); the tile
     // offsets are scanned inside the colour kernel when they fit in LDS beside the image, by k_scan_tiles_n otherwise.
@@ -1056,7 +1132,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
     hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
   }
   if (ev) LRF_HIP(hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, acc_out);
+  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, acc_out, d.perm);
   if (ev) LRF_HIP(hipEventRecord(ev[3], st));
   LRF_HIP(hipGetLastError());
   return 0;

@@ -147,7 +147,7 @@ struct Hdr3 {
 // NW waves per workgroup (one workgroup per CU).  LDSTOFF: the tile offsets are scanned by every workgroup itself into
 // LDS (R + 1 ints beside the image: two launches per render, k_march -> k_shade3); otherwise k_scan_tiles_n<32> ran before
 // and toff_g holds them.
-// TIMED (debug, lrf_debug_set_dump + lrf_debug_set_mlp_policy(10)): s_memtime totals per wave -> dump[block][wave][8] =
+// TIMED (debug, lrf_debug_set_dump): s_memtime totals per wave -> dump[block][wave][8] =
 // {rest of the prologue, header + position, gather + split, image copy, scan, chain, tiles, finalize}
 template <int NW, bool LDSTOFF, bool TIMED = false>
 __global__ __launch_bounds__(NW * 64) void k_shade3(
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   // waves share one L1 and these lines were never read before in this launch; the stores only have to be acknowledged.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int r = ra + tid; r < rb; r += NT) finalize_ray<false>(r, (int)toff[r + 1] - (int)toff[r], pmax, flags, acc, part, rgb_out, acc_out);
+  for (int r = ra + tid; r < rb; r += NT) finalize_ray<false>(r, (int)toff[r + 1] - (int)toff[r], pmax, flags, acc, part, rgb_out, acc_out, f.perm ? f.perm[r] : r);
   LRF_TICK(7);
   if (TIMED && f.dump && lane == 0) {
     unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * NW + wave) * 8;

@@ -92,7 +92,7 @@ __device__ __forceinline__ void gather_app6_plane32(const DField& f, const AxisT
 struct St16 { __device__ __forceinline__ void operator()(float* p, float4 q) const { *reinterpret_cast<float4*>(p) = q; } };
 template <bool COHERENT>
 __device__ __forceinline__ void finalize_ray(int ray, int nit, int pmax, uint32_t flags, const float* __restrict__ acc,
-                                             const float* part, float* __restrict__ rgb, float* __restrict__ acc_out) {
+                                             const float* part, float* __restrict__ rgb, float* __restrict__ acc_out, int oray) {
   const float* pp = part + (size_t)ray * pmax * 3;
   float r = 0.0f, g = 0.0f, b = 0.0f;
   for (int i0 = 0; i0 < nit; i0 += 8) {                         // 8 tiles' partials in flight, summed in tile order
@@ -112,8 +112,8 @@ __device__ __forceinline__ void finalize_ray(int ray, int nit, int pmax, uint32_
     const float bg = 1.0f - a;
     r += bg; g += bg; b += bg;
   }
-  rgb[(size_t)ray * 3 + 0] = r; rgb[(size_t)ray * 3 + 1] = g; rgb[(size_t)ray * 3 + 2] = b;
-  if (acc_out) acc_out[ray] = a;
+  rgb[(size_t)oray * 3 + 0] = r; rgb[(size_t)oray * 3 + 1] = g; rgb[(size_t)oray * 3 + 2] = b;     // oray: the caller's index of slot `ray`
+  if (acc_out) acc_out[oray] = a;
 }
 
 }  // namespace lrf

@@ -393,6 +393,43 @@ def test_full_size_properties(big):
     assert rel_err(_np(outs["bf16x3"]), _np(outs["valu"])) < 3e-5
 
 
+def test_ray_sorting_is_invisible_to_the_caller(big):
+    """LRF_FLAG_SORT_RAYS renders the batch in direction-sorted order; rays are independent and every per-ray sum keeps its
+    order, so colours, depths, weights and acc must be BIT-identical to the unsorted render, in the caller's order; the
+    gradients agree to the order of the scatter kernels' LDS adds."""
+    f, rays = big
+    outs = {}
+    for srt in (False, True):
+        f.sort_rays = srt
+        with torch.no_grad():
+            outs[srt] = f.render_weights(rays[:1500], N_samples=1536)[:4]
+            f.mlp_engine = "f32"
+            outs[srt] += f(rays[:700], white_bg=False, is_train=False, N_samples=-1)
+            f.mlp_engine = "bf16x3"
+    f.sort_rays = False
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    small = quiet(make_field, [40, 36, 44], "cpu", seed=3).to(DEV)
+    with torch.no_grad():
+        for p in small.density_plane:
+            p.mul_(3.0)
+    r0 = make_rays(333, 5, pinhole=True).to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    gr, gd = torch.randn(333, 3, generator=gen).to(DEV), torch.randn(333, generator=gen).to(DEV)
+    res = {}
+    for srt in (False, True):
+        small.sort_rays = srt
+        for p in small.parameters():
+            p.grad = None
+        r = r0.clone().requires_grad_(True)
+        rgb, depth = small(r, is_train=False, N_samples=96)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+        res[srt] = (rgb.detach(), depth.detach(), [p.grad.clone() for p in small.parameters() if p.grad is not None] + [r.grad.clone()])
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    for x, y in zip(res[False][2], res[True][2]):
+        assert float((x - y).abs().max()) <= 1e-5 * max(float(y.abs().max()), 1e-12)
+
+
 @pytest.mark.parametrize("engine", ["bf16x3", "f32"])
 def test_repeat_runs_are_bitwise_identical(big, engine):
     """200 renders of the same 4096 x 512 batch, with a foreign kernel (a sort) thrown in between: every render must

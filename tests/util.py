@@ -198,7 +198,7 @@ def kernel_relu_masks(f, rays, z, ws):
     R, S = rays.shape[0], z.numel()
     out = (C.c_uint64 * 9)()
     N.lib().lrf_workspace_layout_bwd(R, S, (C.c_int32 * 3)(*f._grid_host), out)
-    _, _, ri_off, toff_off, _, _, bits_off, _, _ = [int(v) for v in out]
+    _, _, ri_off, toff_off, _, _, bits_off, perm_off, _ = [int(v) for v in out]
     toff = ws[toff_off:toff_off + 4 * (R + 1)].view(torch.int32)
     tiles = int(toff[R])
     rows = tiles * 16
@@ -211,6 +211,9 @@ def kernel_relu_masks(f, rays, z, ws):
     rowinfo = ws[ri_off:ri_off + rows * 4].view(torch.int32)
     valid = rowinfo >= 0
     lin = rowinfo[valid].long()
+    if getattr(f, "sort_rays", False) and 2 <= R <= 32768:                # rows are indexed by SLOT of the direction-sorted batch
+        perm = ws[perm_off:perm_off + 4 * R].view(torch.int32).long()
+        lin = perm[lin // S] * S + lin % S
     m1, m2 = m[valid][:, 0], m[valid][:, 1]
     order = torch.argsort(lin)
     return lin[order], m1[order], m2[order], int(valid.sum())
