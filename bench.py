@@ -21,7 +21,8 @@ Prints ONE JSON line on rank 0 (see the task contract) with
   train_step    forward with a graph + backward + (N>1) the gradient all-reduce over RCCL + FusedAdam, on every
                 N -- the design's only collective is inside this timed region
   workloads     N=1 only: the exact-fp32 colour engine, a trained-like scene (walls + rebuilt alpha mask:
-                early termination), BASELINE configs[2] (4 blended 300^3 fields)
+                early termination), BASELINE configs[2] (4 blended 300^3 fields), and BASELINE configs[4]'s sizes:
+                fwd_500, fwd_640 (eval forward) and train_500 (training step), each with its own PMC traffic / L2 hit rate
 """
 import argparse
 import contextlib
@@ -154,6 +155,106 @@ def torch_rocm_baseline(field_sd, rays, iters=5):
     return out
 
 
+def torch_rocm_train_baseline(field_sd, rays, g_rgb, g_depth, iters=3):
+    """One training step (forward with a graph + backward + Adam) of the reference path under stock PyTorch-ROCm on this GPU:
+    the reference module when importable, else its ATen op chain -- same batch, same loss, same optimiser groups."""
+    RefVM, why = import_reference()
+    if RefVM is not None:
+        f = _ref_field(RefVM, {k: v.detach() for k, v in field_sd.items()}, rays.device)
+        opt = torch.optim.Adam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        render = lambda: f(rays, white_bg=True, is_train=True, N_samples=N_SAMPLES_ARG)      # noqa: E731
+        kind = "reference"
+    else:
+        from oracle import vm_render_torch as ot
+        fld = {k: v.detach().clone() for k, v in field_sd.items()}
+        leaves = [k for k in fld if fld[k].dtype.is_floating_point and ("plane" in k or "line" in k or "basis" in k or "renderModule" in k)]
+        for k in leaves:
+            fld[k].requires_grad_(True)
+        opt = torch.optim.Adam([fld[k] for k in leaves], lr=0.02, betas=(0.9, 0.99))
+        z = ot.z_schedule(N_SAMPLES_ARG, device=rays.device)
+        render = lambda: ot.render_field(fld, rays, z)                                       # noqa: E731
+        kind = "port"
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        rgb, depth = render()
+        ((rgb * g_rgb).sum() + (depth * g_depth).sum()).backward()
+        opt.step()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    out = {"ms_per_step": dt * 1e3, "rays_per_s": rays.shape[0] / dt, "kind": kind,
+           "what": ("the reference module" if kind == "reference" else "oracle/vm_render_torch.py (the reference's ATen op chain)")
+                   + " on cuda:0: forward with a graph + autograd backward + torch.optim.Adam, fp32, 4096 rays x 512 samples"}
+    if why:
+        out["why_port"] = why
+    return out
+
+
+def size_workloads(dev, sync, use_pmc):
+    """BASELINE configs[4]'s own sizes in the bench line: the eval forward at 500^3 and 640^3 (the reference's default end
+    size, opt.py:62) and the training step at 500^3, 4096 rays at each grid's default sample count (S = 576 / 738, what
+    train.py runs), each with per-kernel HIP-event times, HBM-side PMC traffic and L2 hit rate of ITS OWN run -- at these
+    sizes the field (96 / 158 MB) no longer fits the 32 MB of aggregate L2."""
+    from localrf_amd import FusedAdam, TensorVMSplit
+    out = {}
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    rays = make_rays(R_PER_GPU, 1).to(dev)
+    for g in (500, 640):
+        torch.manual_seed(0)
+        f = TensorVMSplit(torch.device("cpu"), aabb, [g] * 3, **FIELD_KW).to(dev)
+        z = f.z_schedule(False, -1, dev).contiguous()
+        S = int(z.shape[0])
+        with torch.no_grad():                                    # two timed blocks, the faster one: the first block after a new 100-MB-class
+            fwd_g = lambda: f(rays, white_bg=True, is_train=False, N_samples=-1)   # noqa: E731  field is built has been seen 8 x slow
+            d = min(timed(fwd_g, 20, 10, sync), timed(fwd_g, 20, 0, sync))
+        prof = kernel_profile(f, rays, z)
+        n_par = sum(p.numel() for p in f.parameters())
+        rec = {"what": f"single {g}^3 TensorVMSplit ({n_par * 4 / 1e6:.0f} MB of parameters), 4096 rays x {S} samples (the grid's default), eval forward",
+               "rays_per_s": R_PER_GPU * 20 / d, "ms_per_step": d / 20 * 1e3, "samples_per_ray": S,
+               "k_march_ms": prof["march_ms"], "k_shade3_ms": prof["shade_ms"], "shaded_fraction": prof["n_shaded"] / (R_PER_GPU * S),
+               "alg_bytes": R_PER_GPU * S * DENS_BYTES_PER_SAMPLE + prof["n_shaded"] * APP_BYTES_PER_SAMPLE}
+        if use_pmc:
+            tr, src = pmc_traffic(mode="fwd", grid=g, n_samples=-1, steps=5)
+            rec["traffic_source"] = src
+            if tr:
+                rec["kernels"] = {k: {"traffic_bytes": v["traffic_bytes"], "l2_hit_rate": v["l2_hit_rate"], "profiled_us": v["profiled_us"]}
+                                  for k, v in tr.items() if k in ("k_march", "k_shade3")}
+                rec["traffic"] = sum(v["traffic_bytes"] for v in rec["kernels"].values())
+        out[f"fwd_{g}"] = rec
+        if g == 500:
+            opt = FusedAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+            gr, gd = torch.randn(R_PER_GPU, 3, device=dev), torch.randn(R_PER_GPU, device=dev)
+
+            def step():
+                opt.zero_grad()
+                rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=-1)
+                ((rgb * gr).sum() + (depth * gd).sum()).backward()
+                opt.step()
+            dtt = min(timed(step, 10, 3, sync), timed(step, 10, 0, sync))
+            rt = {"what": f"training step at 500^3: lrf_render_fwd_train + lrf_render_bwd + FusedAdam ({n_par * 4 / 1e6:.0f} MB of parameters, "
+                          f"m, v), 4096 rays x {S} jittered samples", "ms_per_step": dtt / 10 * 1e3, "rays_per_s": R_PER_GPU * 10 / dtt}
+            if use_pmc:
+                tr, src = pmc_traffic(mode="train", grid=g, n_samples=-1, steps=5)
+                rt["traffic_source"] = src
+                if tr:
+                    n_steps = 3 + 5                                          # the child runs 3 warm-up + 5 timed training steps
+                    tab = {k: {"traffic_bytes_per_step": v["traffic_bytes"] * v["launches"] / n_steps, "l2_hit_rate": v["l2_hit_rate"],
+                               "profiled_us": v["profiled_us"], "launches_per_step": v["launches"] / n_steps} for k, v in tr.items()}
+                    rt["kernels"] = dict(sorted(tab.items(), key=lambda kv: -kv[1]["traffic_bytes_per_step"]))
+                    rt["traffic"] = sum(v["traffic_bytes_per_step"] for v in tab.values())
+                    rt["hbm_frac"] = rt["traffic"] / (dtt / 10) / 1e9 / HBM_PEAK_GBS
+            out["train_500"] = rt
+            del opt
+        del f
+        torch.cuda.empty_cache()
+    return out
+
+
 def geometric_losses_workload(dev, V=16, n=256, Fr=20, W=640, H=480, iters=100):
     """the flow + depth losses of train.py:385-423 on a 4096-ray batch (16 views), forward + backward:
     localrf_amd.losses (HIP) and, beside it, the ATen op chain (oracle/vm_render_torch.py: baseline leg only)."""
@@ -234,7 +335,7 @@ def kernel_profile(field, rays, z, reps=5):
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"))
 
 
-def pmc_traffic(timeout_s=240, mode="fwd"):
+def pmc_traffic(timeout_s=240, mode="fwd", grid=GRID, n_samples=N_SAMPLES_ARG, steps=10):
     """HBM-side bytes per launch of every lrf kernel, measured now: one rocprofv3 --kernel-trace --pmc
     child per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass), each re-running this script
     for a few steps.  traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE reports half the bytes
@@ -245,7 +346,8 @@ def pmc_traffic(timeout_s=240, mode="fwd"):
     for ctrs in PMC_PASSES:
         d = tempfile.mkdtemp(prefix="lrf_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "-d", d, "-o", "pmc", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--child", mode]
+               os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "2", "--child", mode,
+               "--grid", str(grid), "--n-samples", str(n_samples)]
         if mode == "train":
             cmd += ["--preroll-ms", "0"]                         # no eval renders in the counted run
         try:
@@ -265,6 +367,10 @@ def pmc_traffic(timeout_s=240, mode="fwd"):
             for (k, ctr), vals in acc.items():
                 per.setdefault(k, {})[ctr] = sum(vals) / len(vals)
                 per[k]["launches"] = len(vals)
+            for name, n, avg in db.execute("select name, count(*), avg(duration) from kernels group by name"):
+                short = name.split("(")[0].replace("lrf::", "").replace("void ", "")
+                if short.startswith("k_"):                      # (durations under counter collection: serialised, slightly inflated)
+                    per.setdefault(short.split("<")[0], {})["profiled_us"] = avg / 1e3
         except Exception as e:                               # noqa: BLE001
             return None, f"rocprofv3 pass {ctrs}: {e!r}"
         finally:
@@ -273,7 +379,8 @@ def pmc_traffic(timeout_s=240, mode="fwd"):
     for k, c in per.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             out[k] = {"traffic_bytes": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024, "launches": c.get("launches", 0),
-                      "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0)}
+                      "l2_hit_rate": c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0),
+                      "profiled_us": c.get("profiled_us")}
     return out, "rocprofv3 --kernel-trace --pmc, 2 passes of this run; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"
 
 
@@ -398,7 +505,12 @@ def main():
     ap.add_argument("--child", nargs="?", const="fwd", default=None, choices=("fwd", "train"),
                     help="(internal) the timed loop only: what the PMC passes profile (fwd: eval forward; train: training step)")
     ap.add_argument("--preroll-ms", type=float, default=150.0, help="untimed GPU clock ramp before the warm-up steps")
+    ap.add_argument("--grid", type=int, default=GRID, help="(internal, with --child) grid size of the profiled workload")
+    ap.add_argument("--n-samples", type=int, default=N_SAMPLES_ARG, help="(internal, with --child) N_samples argument (-1 = the grid's default)")
     args = ap.parse_args()
+    if not args.child and (args.grid != GRID or args.n_samples != N_SAMPLES_ARG):
+        raise SystemExit("--grid / --n-samples are for the PMC child runs; the headline workload is BASELINE configs[1]")
+    grid, ns_arg = args.grid, args.n_samples
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -430,7 +542,7 @@ def main():
 
     torch.manual_seed(0)                                      # identical replica on every rank
     aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
-    field = TensorVMSplit(torch.device("cpu"), aabb, [GRID] * 3, **FIELD_KW).to(dev)
+    field = TensorVMSplit(torch.device("cpu"), aabb, [grid] * 3, **FIELD_KW).to(dev)
     rays_cpu = make_rays(R_PER_GPU, 1 + rank)                 # this rank's shard
     rays = rays_cpu.to(dev)
 
@@ -441,7 +553,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     def fwd():
-        return field(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
+        return field(rays, white_bg=True, is_train=False, N_samples=ns_arg)
 
     with torch.no_grad():
         # clock ramp: the first ~10 ms of work after an idle period run at a lower GPU clock; render untimed
@@ -470,7 +582,7 @@ def main():
 
     def train_step():
         opt.zero_grad()
-        rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=N_SAMPLES_ARG)
+        rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=ns_arg)
         ((rgb * gr).sum() + (depth * gd).sum()).backward()
         if ddp:
             reduced[0] = allreduce_grads(field)
@@ -502,11 +614,13 @@ def main():
         n_sh = prof["n_shaded"]
         rows = ((n_sh + 15) // 16) * 16
         # bytes the training step moves through HBM-side memory by construction: the saved activation /
-        # gradient rows (ACT 400 + GRD 384 floats per row: written once, read once by the weight-gradient GEMMs; the
-        # data gradient takes its ReLU masks from 32 B per sample), the density features (R*S floats, written + read twice), gradient images + reference-layout
+        # gradient rows (ACT 112 + GRD 256 floats per row since round 4 -- the hidden activations are recomputed, not stored;
+        # the data gradient takes its ReLU masks from 32 B per sample), the density features (R*S floats, written + read twice), gradient images + reference-layout
         # gradients (3 x 35 MB) + Adam (param, m, v read+write) -- cache-served gathers not counted
         n_par = sum(p.numel() for p in field.parameters() if p.requires_grad)
-        train_bytes = rows * (4 * (400 * 2 + (384 - 128) * 2) + 32 * 3) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)   # dz2 (128 floats) is never materialised
+        # per row: written ACT 448 B + GRD 1024 B + mask bits 32 B + rgb / rowinfo 16 B; read: k_wgrad_w2w3 feat + go + bits 176 B,
+        # dW1 dz1 + feat 640 B, dbasis dfeat + X 448 B, the data gradient bits + rgb 48 B, the scatters dX twice + ids 584 B
+        train_bytes = rows * ((448 + 1024 + 32 + 16) + (176 + 640 + 448 + 48 + 584)) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
         train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
                  "what": "lrf_render_fwd_train + lrf_render_bwd + "
                          + (f"allreduce_grads over RCCL ({reduced[0] / 1e6:.1f} MB in place) + " if ddp else "")
@@ -609,12 +723,21 @@ def main():
             except Exception as e:                           # noqa: BLE001
                 work["config3_4x300"] = {"error": repr(e)}
             try:
+                work.update(size_workloads(dev, sync, use_pmc=not args.no_pmc))
+            except Exception as e:                           # noqa: BLE001
+                work["fwd_500"] = {"error": repr(e)}
+            try:
                 work["geometric_losses"] = geometric_losses_workload(dev)
             except Exception as e:                           # noqa: BLE001
                 work["geometric_losses"] = {"error": repr(e)}
             out["workloads"] = work
             sd = field.state_dict()
             out["torch_rocm_baseline"] = torch_rocm_baseline(sd, rays)
+            try:
+                out["torch_rocm_baseline"]["train_step"] = torch_rocm_train_baseline(sd, rays, gr, gd)
+                out["train_step"]["speedup_vs_torch_rocm"] = out["torch_rocm_baseline"]["train_step"]["ms_per_step"] / out["train_step"]["ms_per_step"]
+            except Exception as e:                           # noqa: BLE001
+                out["torch_rocm_baseline"]["train_step"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline(sd, rays_cpu)
             out["speedup_vs_torch_rocm"] = value / world / out["torch_rocm_baseline"]["value"]
         print(json.dumps(out), flush=True)
