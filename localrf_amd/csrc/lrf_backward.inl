@@ -30,7 +30,6 @@
 //   k_scatter_plane/line plane / line gradients accumulated per workgroup in LDS (CAS-loop fp32
 //                        adds; ds_add_f32 is 30x slower on this chip), runs of consecutive
 //                        same-cell entries merged in registers first
-//   k_unpack_grads       channel-last gradient images -> += the reference's layouts (1 launch)
 #pragma once
 
 namespace lrf {
@@ -1433,13 +1432,23 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
 // Plane gradients.  The entry lists are sorted by tile; workgroup w owns the w-th equal share
 // of the concatenated list (a few tiles hold 12 % of all samples each, so one workgroup per
 // tile is badly unbalanced), accumulates tile by tile in LDS and flushes each tile once.
-template <int C, bool APP, int NT>
-__global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layout L, const float* __restrict__ rays,
+// LINES: the gradient of line p is accumulated by the same pass over plane p's entries, in a second LDS array behind the
+// tile ([L_p][C], flushed when the workgroup's share leaves the plane): an entry's position, taps and dX row are then
+// read once instead of once per kernel, and the separate line kernel (which re-derives all of that to gather the four
+// plane taps) disappears.  Round 3 measured this fusion as a no-op in a step bound by 7.3 GB of row traffic; with 1.8 GB
+// of rows gone (round 4) the 0.15 ms of kernel time it removes show.  Falls back to the two-kernel form (lrf_render_bwd)
+// when tile + line accumulators exceed the CU's LDS (appearance at 640^3).
+// The accumulated tiles / lines are added straight into the reference's gradient tensors ([C][H][W] planes, [C][L] lines:
+// ScatterDst), x fastest; round 3 flushed into a channel-last gradient image that one more kernel unpacked (a 35-70 MB
+// memset + read + transpose per step).
+struct ScatterDst { float* plane[3]; float* line[3]; };
+template <int C, bool APP, int NT, bool LINES>
+__global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, ScatterDst dst, const float* __restrict__ rays,
                                                        const float* __restrict__ z, int S, const int* __restrict__ offs,
                                                        const uint32_t* __restrict__ list, const float* __restrict__ gf,
-                                                       const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
-                                                       float* __restrict__ gcache) {
-  extern __shared__ float s_acc[];                     // [BCELL*BCELL][C]
+                                                       const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd) {
+  extern __shared__ float s_acc[];                     // [BCELL*BCELL][C], then (LINES) [L_p][C]
+  float* s_lacc = s_acc + BCELL * BCELL * C;
   const long long E = offs[bg.total];
   int a = (int)(E * blockIdx.x / gridDim.x);
   const int b = (int)(E * (blockIdx.x + 1) / gridDim.x);
@@ -1447,15 +1456,33 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
   int lo = 0, hi = bg.total;                           // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
   int bin = lo;
+  int lplane = -1;                                     // plane whose line gradient s_lacc currently holds (LINES)
+  auto flush_line = [&]() {                            // whole workgroup; s_lacc -> += the gradient of line `lplane` ([C][L])
+    __syncthreads();
+    float* gln = dst.line[lplane];
+    const int ll = f.ll[lplane], nl = ll * C;
+    for (int i = threadIdx.x; i < nl; i += NT) {
+      const int c = i / ll, l = i % ll;
+      const float v = s_lacc[l * C + c];
+      if (v != 0.0f) atomic_add_f32(gln + i, v);
+    }
+    __syncthreads();
+  };
   while (a < b) {
     while (offs[bin + 1] <= a) ++bin;
     const int seg_end = min(b, offs[bin + 1]);
     const int p = bin >= bg.base[2] ? 2 : (bin >= bg.base[1] ? 1 : 0);
     const int t = bin - bg.base[p];
     const int tx0 = (t % bg.tx[p]) * BTILE, ty0 = (t / bg.tx[p]) * BTILE;
+    if (LINES && p != lplane) {
+      if (lplane >= 0) flush_line();
+      lplane = p;
+      for (int i = threadIdx.x; i < f.ll[p] * C; i += NT) s_lacc[i] = 0.0f;
+    }
     for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) s_acc[i] = 0.0f;
     __syncthreads();
     const float* lnp = APP ? f.aline[p] : f.dline[p];
+    const float* plp = APP ? f.aplane[p] : f.dplane[p];
     // Two phases per 64 entries of a wave.  A: lane = entry -- list / row lookup, sample position,
     // taps (one dependent-load chain per 64 entries instead of one per 8).  B: the 8-lane groups
     // take the entries 8 at a time, fetch the packed taps of theirs with a cross-lane read, and each
@@ -1463,7 +1490,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int e0 = a + wv * 64; e0 < seg_end; e0 += NT) {
       const int e = e0 + lane;
-      int i_row = 0, c00 = 0, lpk = 0;
+      int i_row = 0, c00 = 0, lpk = 0, ppk = 0;
       float tx = 0.0f, ty = 0.0f, tl = 0.0f;
       if (e < seg_end) {
         const uint32_t i = list[e];
@@ -1477,6 +1504,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
         i_row = (int)i;
         c00 = (((y0 - ty0) * BCELL + (x0 - tx0)) << 2) | ((y1 - y0) << 1) | (x1 - x0);   // +1 taps are clamped: step 0 or 1
         lpk = (l0 << 1) | (l1 - l0);
+        ppk = y0 * f.pw[p] + x0;                       // (LINES) texel index of the base tap in the plane itself
       }
       const int n_here = min(64, seg_end - e0);
       // A group of LPE lanes takes LPE consecutive entries IN LIST ORDER: the list keeps consecutive
@@ -1486,12 +1514,15 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
       // 6 channels 6s..6s+5 (two float4 of the padded texel per tap -- the texture path retires one
       // wave-level load per ~16 cycles whatever its width, so wide loads are what counts);
       // density: 8 lanes per entry, one channel each.
+      // (density with 2 lanes per entry and float4 taps -- 3.5 x fewer gather instructions -- was measured in round 4: 244 ->
+      // 640-800 us.  Thirty-two lane pairs then work on 64 CONSECUTIVE samples of a ray at once, which share their cells, and
+      // their same-address CAS adds serialise; with 8 lanes per entry a group merges 8 consecutive samples in registers.)
       constexpr int LPE = APP ? 4 : 8, CPL = C / LPE;
       const int sub = lane % LPE, grp = lane / LPE;
-      int cur = -1;
-      float acc[4][CPL];
+      int cur = -1, curl = -1;
+      float acc[4][CPL], lac[2][CPL];
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f; }
+      for (int j = 0; j < CPL; ++j) { acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f; lac[0][j] = 0.0f; lac[1][j] = 0.0f; }
       auto flush = [&](int cp) {
         const int b00 = (cp >> 2) * C + CPL * sub, b10 = b00 + (cp & 1) * C, b01 = b00 + ((cp >> 1) & 1) * BCELL * C, b11 = b01 + (cp & 1) * C;
 #pragma unroll
@@ -1501,21 +1532,39 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
           acc[0][j] = 0.0f; acc[1][j] = 0.0f; acc[2][j] = 0.0f; acc[3][j] = 0.0f;
         }
       };
+      auto flushl = [&](int lp) {                      // two channels' pairs of cells per call: four CAS round trips overlapped
+        const int c0 = (lp >> 1) * C + CPL * sub, c1 = c0 + (lp & 1) * C;
+#pragma unroll
+        for (int j = 0; j + 1 < CPL; j += 2) {
+          lds_add4_f32(&s_lacc[c0 + j], lac[0][j], &s_lacc[c1 + j], lac[1][j], &s_lacc[c0 + j + 1], lac[0][j + 1], &s_lacc[c1 + j + 1], lac[1][j + 1]);
+          lac[0][j] = 0.0f; lac[1][j] = 0.0f; lac[0][j + 1] = 0.0f; lac[1][j + 1] = 0.0f;
+        }
+        if (CPL & 1) {
+          lds_add_f32(&s_lacc[c0 + CPL - 1], lac[0][CPL - 1]); lds_add_f32(&s_lacc[c1 + CPL - 1], lac[1][CPL - 1]);
+          lac[0][CPL - 1] = 0.0f; lac[1][CPL - 1] = 0.0f;
+        }
+      };
 #pragma unroll 1
       for (int q = 0; q < LPE; ++q) {
         const int src = LPE * grp + q;
         const int ir = __shfl(i_row, src, 64), cp = __shfl(c00, src, 64), lp = __shfl(lpk, src, 64);
+        const int pp = LINES ? __shfl(ppk, src, 64) : 0;
         const float sx = __shfl(tx, src, 64), sy = __shfl(ty, src, 64), sl = __shfl(tl, src, 64);
         if (src >= n_here) continue;
         if (cp != cur) {
           if (cur >= 0) flush(cur);
           cur = cp;
         }
+        if (LINES && lp != curl) {
+          if (curl >= 0) flushl(curl);
+          curl = lp;
+        }
         const float w00 = (1.0f - sx) * (1.0f - sy), w10 = sx * (1.0f - sy), w01 = (1.0f - sx) * sy, w11 = sx * sy;
         constexpr int CS = APP ? LRF_CAS : C;               // channel stride of the cache / gradient image
         const float* r0 = lnp + (size_t)(lp >> 1) * CS;
         const float* r1 = r0 + (size_t)(lp & 1) * CS;
         float e0v[8], e1v[8], dv[6];
+        float v00[8], v10[8], v01[8], v11[8];
         if (APP) {
           ld4g(r0 + 8 * sub, e0v); ld4g(r0 + 8 * sub + 4, e0v + 4);
           ld4g(r1 + 8 * sub, e1v); ld4g(r1 + 8 * sub + 4, e1v + 4);
@@ -1523,36 +1572,58 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Layo
         } else {
           e0v[0] = r0[sub]; e1v[0] = r1[sub]; dv[0] = gf[ir];
         }
+        if (LINES) {                                   // the plane's own four taps: what the line gradient multiplies dX with
+          const float* q00 = plp + (size_t)pp * CS;
+          const float* q10 = q00 + (size_t)(cp & 1) * CS;
+          const float* q01 = q00 + (size_t)((cp >> 1) & 1) * f.pw[p] * CS;
+          const float* q11 = q01 + (size_t)(cp & 1) * CS;
+          if (APP) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              ld4g(q00 + 8 * sub + 4 * h, v00 + 4 * h); ld4g(q10 + 8 * sub + 4 * h, v10 + 4 * h);
+              ld4g(q01 + 8 * sub + 4 * h, v01 + 4 * h); ld4g(q11 + 8 * sub + 4 * h, v11 + 4 * h);
+            }
+          } else {
+            v00[0] = q00[sub]; v10[0] = q10[sub]; v01[0] = q01[sub]; v11[0] = q11[sub];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           const float Lv = e0v[j] * (1.0f - sl) + e1v[j] * sl;
           const float dP = dv[j] * Lv;
           acc[0][j] += dP * w00; acc[1][j] += dP * w10; acc[2][j] += dP * w01; acc[3][j] += dP * w11;
+          if (LINES) {
+            const float P = v00[j] * w00 + v10[j] * w10 + v01[j] * w01 + v11[j] * w11;
+            const float dL = dv[j] * P;
+            lac[0][j] += dL * (1.0f - sl);
+            lac[1][j] += dL * sl;
+          }
         }
       }
       if (cur >= 0) flush(cur);
+      if (LINES && curl >= 0) flushl(curl);
     }
     __syncthreads();
-    float* gpl = gcache + (APP ? L.aplane[p] : L.dplane[p]);
-    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) {
-      const float v = s_acc[i];
+    float* gpl = dst.plane[p];
+    for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) {       // x fastest: 33 consecutive floats of one channel row
+      const int c = i / (BCELL * BCELL), cell = i % (BCELL * BCELL);
+      const float v = s_acc[cell * C + c];
       if (v == 0.0f) continue;
-      const int cell = i / C, c = i % C;
       const int x = tx0 + cell % BCELL, y = ty0 + cell / BCELL;
       if (x < f.pw[p] && y < f.ph[p])
-        atomic_add_f32(gpl + ((size_t)y * f.pw[p] + x) * (APP ? LRF_CAS : C) + (APP ? app_pc(c) : c), v);
+        atomic_add_f32(gpl + ((size_t)c * f.ph[p] + y) * f.pw[p] + x, v);
     }
     __syncthreads();
     a = seg_end;
   }
+  if (LINES && lplane >= 0) flush_line();
 }
 
 // line gradients: LINE_WGS workgroups per line, each accumulates its slice of the entries
 template <int C, bool APP, int NT>
-__global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const float* __restrict__ rays, const float* __restrict__ z,
+__global__ __launch_bounds__(NT) void k_scatter_line(DField f, ScatterDst dst, const float* __restrict__ rays, const float* __restrict__ z,
                                                       int R, int S, const int* __restrict__ toff, const float* __restrict__ gf,
-                                                      const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
-                                                      float* __restrict__ gcache) {
+                                                      const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd) {
   extern __shared__ float s_acc[];                     // [L_p][C]
   const int p = blockIdx.x / LINE_WGS, wg = blockIdx.x % LINE_WGS;
   const int nl = f.ll[p] * C;
@@ -1641,52 +1712,24 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, Layout L, const f
     if (cur >= 0) flush(cur);
   }
   __syncthreads();
-  float* gln = gcache + (APP ? L.aline[p] : L.dline[p]);
+  float* gln = dst.line[p];
+  const int ll = f.ll[p];
   for (int i = threadIdx.x; i < nl; i += NT) {
-    const float v = s_acc[i];
-    const int l = i / C, c = i % C;
-    if (v != 0.0f) atomic_add_f32(gln + (size_t)l * (APP ? LRF_CAS : C) + (APP ? app_pc(c) : c), v);
+    const int c = i / ll, l = i % ll;
+    const float v = s_acc[l * C + c];
+    if (v != 0.0f) atomic_add_f32(gln + i, v);
   }
-}
-
-// channel-last gradient images -> += the reference layouts ([C,H,W] planes, [C,L] lines taken as
-// H = 1), all twelve tensors in one launch: blockIdx.z selects the tensor.
-struct UnpackSeg { const float* src; float* dst; int C, H, W, CS, app; };
-struct UnpackTab { UnpackSeg s[6]; };
-__global__ __launch_bounds__(128) void k_unpack_grads(UnpackTab tab) {
-  // a block takes 128 consecutive texels of one row: their CS-float records are one contiguous span of the image, read
-  // as float4 into LDS (the per-texel reads of the straightforward loop were 4 bytes at a 32- or 128-byte stride), then
-  // written out channel by channel, 128 consecutive floats each
-  __shared__ __attribute__((aligned(16))) float s_t[128 * (LRF_CAS + 1)];
-  const UnpackSeg sg = tab.s[blockIdx.z];
-  const int x0 = blockIdx.x * 128, y = blockIdx.y;
-  if (x0 >= sg.W || y >= sg.H) return;
-  const int nx = min(128, sg.W - x0);
-  const int ld = sg.CS + 1;                                 // odd stride: the channel reads below hit distinct banks
-  const float4* src = reinterpret_cast<const float4*>(sg.src + ((size_t)y * sg.W + x0) * sg.CS);
-  const int n4 = nx * sg.CS / 4;
-  for (int i = threadIdx.x; i < n4; i += 128) {
-    const float4 v = src[i];
-    const int t = (4 * i) / sg.CS, c = (4 * i) % sg.CS;
-    float* d = &s_t[t * ld + c];
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
-  __syncthreads();
-  const int t = threadIdx.x;
-  if (t >= nx) return;
-  for (int c = 0; c < sg.C; ++c)
-    sg.dst[((size_t)c * sg.H + y) * sg.W + x0 + t] += s_t[t * ld + (sg.app ? app_pc(c) : c)];
 }
 
 struct BwdWorkspace {
   Workspace fw;
-  float* feat; float* crgb; float* gcache; float* imt; float* act; float* grd; float* rpart; float* wpart;
+  float* feat; float* crgb; float* imt; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
   uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_bwd_shade_fwd -> k_bwd_shade_dgrad
   uint16_t* tid2; int* hist2; int* offs2; int* cursor2; uint32_t* list2;   // bins of the appearance scatter (runs beside the density scatter)
   uint32_t nmax;
-  size_t gcache_floats, bytes;
+  size_t bytes;
 };
 static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   BwdWorkspace b;
@@ -1696,11 +1739,9 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   const Layout L = make_layout(grid);
   const size_t rows = (size_t)R * b.fw.pmax * 16;
   const size_t nch = WGRAD_MAXCH;
-  b.gcache_floats = L.mlp;
   auto take = [&](size_t nfloat) { float* q = reinterpret_cast<float*>(p + off); off += up256(nfloat * 4); return q; };
   b.feat = take((size_t)R * S);
   b.crgb = take((size_t)R * S * 3);
-  b.gcache = take(L.mlp);
   b.imt = take(IMT_FLOATS);
   b.act = take(rows * ACT_LD);
   b.grd = take(rows * GRD_LD);
@@ -1727,8 +1768,9 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 
 // The row-saving colour kernel of the training forward is k_bwd_shade_fwd behind k_scan_tiles.  (Round 2 also built it
 // in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
+static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
 static int g_dgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(4 | ...): data-gradient chain on the exact-fp32 MFMA path
-static int g_wgrad_split = 2;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
+static int g_wgrad_split = 3;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
 static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                               const BwdWorkspace& b, hipStream_t st) {
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
@@ -1737,7 +1779,7 @@ static void launch_shade_save(const DField& d, const float* rays, const float* z
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; lrf::g_scatter_fused = (e & 8) ? 0 : 1; }
 
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
@@ -1803,8 +1845,12 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     int dev_id = 0;
     LRF_HIP(hipGetDevice(&dev_id));
     std::call_once(lds_attr_once[dev_id & 63], [dev_id] {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CD, false, 512, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CA, true, 1024>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
@@ -1817,7 +1863,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     });
     LRF_HIP(lds_attr_err[dev_id & 63]);
   }
-  LRF_HIP(hipMemsetAsync(b.gcache, 0, b.gcache_floats * sizeof(float), st));
   if (g_dgrad_bf16) hipLaunchKernelGGL(k_pack_mlp_bf16_t, dim3((IMTB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
   else hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
@@ -1839,17 +1884,12 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // device take turns (enqueueing is ~0.3 ms of host time; the kernels themselves still overlap on the GPU)
   std::unique_lock<std::mutex> side_lock;
   if (sx) side_lock = std::unique_lock<std::mutex>(sx->mu);
-  // gradient images -> += the reference's layouts, per branch: the density tensors are final as soon as the per-ray
-  // branch is through (bucket 0), the appearance tensors at the very end (bucket 2)
-  UnpackTab tab_d, tab_a;
-  int wmax = 1, hmax = 1;
+  // the scatter kernels add straight into the reference-layout gradients: the density tensors are final as soon as the
+  // per-ray branch is through (bucket 0), the appearance tensors at the very end (bucket 2)
+  ScatterDst dst_d, dst_a;
   for (int q = 0; q < 3; ++q) {
-    tab_d.s[2 * q + 0] = UnpackSeg{b.gcache + L.dplane[q], g->density_plane[q], LRF_CD, L.ph[q], L.pw[q], LRF_CD, 0};
-    tab_d.s[2 * q + 1] = UnpackSeg{b.gcache + L.dline[q], g->density_line[q], LRF_CD, 1, L.ll[q], LRF_CD, 0};
-    tab_a.s[2 * q + 0] = UnpackSeg{b.gcache + L.aplane[q], g->app_plane[q], LRF_CA, L.ph[q], L.pw[q], LRF_CAS, 1};
-    tab_a.s[2 * q + 1] = UnpackSeg{b.gcache + L.aline[q], g->app_line[q], LRF_CA, 1, L.ll[q], LRF_CAS, 1};
-    wmax = max(wmax, max(L.pw[q], L.ll[q]));
-    hmax = max(hmax, L.ph[q]);
+    dst_d.plane[q] = g->density_plane[q]; dst_d.line[q] = g->density_line[q];
+    dst_a.plane[q] = g->app_plane[q]; dst_a.line[q] = g->app_line[q];
   }
   hipStream_t sb = st;
   if (ss) {
@@ -1879,12 +1919,20 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL((k_bin_hist<false>), dim3(nblk), dim3(256), 0, sb, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, sb, b.hist, bg.total, b.offs, b.cursor);
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.cursor, b.list);
-  hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512>), dim3(cus * LRF_DPLANE_MULT), dim3(512), sizeof(float) * BCELL * BCELL * LRF_CD, sb,
-                     d, bg, L, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, b.gcache);
-  hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024),
-                     sizeof(float) * LRF_CD * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), sb,
-                     d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
-  hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 6), dim3(128), 0, sb, tab_d);
+  const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
+  // line gradients ride on the plane pass when tile + line accumulators fit in LDS (g_scatter_fused; appearance at 640^3 does not)
+  const size_t lds_dp = sizeof(float) * BCELL * BCELL * LRF_CD, lds_dl = sizeof(float) * LRF_CD * ll_max;
+  const size_t lds_ap = sizeof(float) * BCELL * BCELL * LRF_CA, lds_al = sizeof(float) * LRF_CA * ll_max;
+  const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024, fuse_a = g_scatter_fused && lds_ap + lds_al <= 158 * 1024;
+  if (fuse_d) {
+    hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512, true>), dim3(cus * LRF_DPLANE_MULT), dim3(512), lds_dp + lds_dl, sb,
+                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd);
+  } else {
+    hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512, false>), dim3(cus * LRF_DPLANE_MULT), dim3(512), lds_dp, sb,
+                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd);
+    hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_dl, sb,
+                       d, dst_d, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd);
+  }
   if (sx) LRF_HIP(hipEventRecord(sx->bucket[0], sb));
 
   // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
@@ -1927,16 +1975,19 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL((k_bin_hist<true>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid2, b.hist2);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist2, bg.total, b.offs2, b.cursor2);
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.cursor2, b.list2);
-  hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024>), dim3(cus), dim3(1024), sizeof(float) * BCELL * BCELL * LRF_CA, st,
-                     d, bg, L, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, b.gcache);
-  hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024),
-                     sizeof(float) * LRF_CA * (size_t)max(L.ll[0], max(L.ll[1], L.ll[2])), st,
-                     d, L, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd, b.gcache);
+  if (fuse_a) {
+    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024, true>), dim3(cus), dim3(1024), lds_ap + lds_al, st,
+                       d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
+  } else {
+    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024, false>), dim3(cus), dim3(1024), lds_ap, st,
+                       d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
+    hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_al, st,
+                       d, dst_a, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd);
+  }
 
   // ---- join: both branches done
   if (ss) LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   hipLaunchKernelGGL(k_rays_add_rpart, dim3((R + 255) / 256), dim3(256), 0, st, rays, R, w.ncomp, b.rpart, w.pmax, g_rays, d.perm);
-  hipLaunchKernelGGL(k_unpack_grads, dim3((wmax + 127) / 128, hmax, 6), dim3(128), 0, st, tab_a);
   if (sx) { LRF_HIP(hipEventRecord(sx->bucket[2], st)); sx->bucket_set = true; }
   LRF_HIP(hipGetLastError());
   return 0;
