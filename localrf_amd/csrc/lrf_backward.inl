@@ -12,7 +12,7 @@
 //                        activation row ACT = [X | feat,1] in MFMA-fragment order (lrf_common.h: 1 KB per store
 //                        instruction).  The hidden activations themselves are not stored (round 4).
 // backward (two branches on two streams, lrf_render_bwd):
-//   k_bwd_shade_dgrad    per tile: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX on TRANSPOSED
+//   k_train_dgrad3       (lrf_train32.inl) per pair of tiles: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX on TRANSPOSED
 //                        weight fragments, split-bf16 on v_mfma_f32_16x16x32_bf16 (same register-
 //                        resident trick as the forward: D layout of one layer = B operand of
 //                        the next; <false>: exact fp32 chain), ReLU masks from the saved bits,
@@ -34,13 +34,6 @@
 
 namespace lrf {
 
-// ---- saved rows (floats): ACT_* / GRD_* column offsets and the fragment-order address functions are in lrf_common.h
-// transposed fp32 fragment image for the dgrad chain
-constexpr int IMT_W2T = 0;                          // [t'8][t8][lane64][4]  W2[16t+4g+r][16t'+i]
-constexpr int IMT_W1T = IMT_W2T + 8 * 8 * 256;      // [t'2][t8][lane64][4]  W1[16t+4g+r][16t'+i]
-constexpr int IMT_BT  = IMT_W1T + 2 * 8 * 256;      // [t'5][t2][lane64][4]  basis[16t+4g+r][phi(i>>2, 4t'+(i&3))]
-constexpr int IMT_W3H = IMT_BT + 5 * 2 * 256;       // [g4][f32][4]          as IMG_W3H
-constexpr int IMT_FLOATS = IMT_W3H + 512;           // 23552 floats = 94,208 B
 // weight-gradient partial block per K-chunk (floats)
 constexpr int WP_W2 = 0;                            // [128][144]  dz2^T [h1r | 1]
 constexpr int WP_W1 = WP_W2 + 128 * 144;            // [128][32]   dz1^T [feat | 1]
@@ -54,83 +47,6 @@ constexpr int WGRAD_MAXCH = 264;
 __host__ __device__ inline int wgrad_chunk_rows(int rows) {
   const int per = (rows + 255) / 256;                      // rows / 256 chunks
   return max(512, (per + 255) / 256 * 256);
-}
-
-// Split-bf16 image of the TRANSPOSED colour network for the data-gradient chain (same fragment format as IMGB_* in
-// lrf_common.h: [frag][hi, lo][lane 64][8 bf16], A operand row 16 t' + i, K slot (g, j) = feature 16 (2 ks + (j >> 2)) +
-// 4 g + (j & 3) of the previous layer's D registers), then the fp32 W3 block the dz2 step reads:
-//   W2^T  frags [t' 8][ks 4]   A[v][u] = W2[u][v]
-//   W1^T  frags [t' 2][ks 4]   A[f][v] = W1[v][f]   (f < 27)
-//   B^T   frags [t' 5][ks 1]   A[rho][f] = basis[f][ch(rho)]: row rho = 16 t' + 4 gp + r is slot q = 4 t' + r of lane
-//                              group gp = channel (q / 6) * 24 + 6 gp + q % 6 (the gather layout), q < 18
-constexpr int IMTB_W2T = 0;
-constexpr int IMTB_W1T = IMTB_W2T + 32 * 128;
-constexpr int IMTB_BT = IMTB_W1T + 8 * 128;
-constexpr int IMTB_TAIL = IMTB_BT + 5 * 128;          // uint4 index of the fp32 W3H block ([g4][f32][4] floats, as IMT_W3H)
-constexpr int IMTB_U4 = IMTB_TAIL + 128;              // 5888 uint4 = 94,208 B (= IMT_FLOATS floats)
-static_assert(IMTB_U4 * 4 == IMT_FLOATS, "the two transposed images share one buffer and one LDS array");
-__global__ void k_pack_mlp_bf16_t(LrfParams p, uint32_t* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= IMTB_U4 * 4) return;
-  if (idx >= IMTB_TAIL * 4) {
-    const int e = idx - IMTB_TAIL * 4, o = e & 3, fidx = (e >> 2) & 31, g = e >> 7;
-    const int feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3);
-    img[idx] = __float_as_uint(o < 3 ? p.w3[o * (LRF_FEATC + 3) + feat] : 0.0f);
-    return;
-  }
-  const int u4 = idx >> 2, wj = idx & 3;
-  const int lane = u4 & 63, part = (u4 >> 6) & 1, frag = u4 >> 7;
-  const int i = lane & 15, g = lane >> 4;
-  unsigned short out[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int j = 2 * wj + h;
-    float v = 0.0f;
-    if (frag < 32) {                                           // W2^T: frag = t' * 4 + ks
-      const int t1 = frag >> 2, ks = frag & 3;
-      const int u = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3);
-      v = p.w2[u * LRF_FEATC + 16 * t1 + i];
-    } else if (frag < 40) {                                    // W1^T: frag - 32 = t' * 4 + ks
-      const int t1 = (frag - 32) >> 2, ks = (frag - 32) & 3;
-      const int vv = 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3), f = 16 * t1 + i;
-      if (f < LRF_APP_DIM) v = p.w1[vv * LRF_APP_DIM + f];
-    } else {                                                   // basis^T: frag - 40 = t'
-      const int t1 = frag - 40;
-      const int f = 16 * (j >> 2) + 4 * g + (j & 3);           // dfeat feature of this K slot
-      const int q = 4 * t1 + (i & 3), gp = i >> 2;             // output slot q of lane group gp
-      if (f < LRF_APP_DIM && q < 18) v = p.basis[f * 72 + (q / 6) * LRF_CA + 6 * gp + (q % 6)];
-    }
-    const unsigned short hi = bf16_bits(v);
-    out[h] = part ? bf16_bits(v - bf16_val(hi)) : hi;
-  }
-  img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
-}
-
-__global__ void k_pack_mlp_t(LrfParams p, float* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= IMT_FLOATS) return;
-  float v = 0.0f;
-  if (idx < IMT_W1T) {
-    const int e = idx - IMT_W2T, r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
-    const int t1 = tt >> 3, t0 = tt & 7;
-    v = p.w2[(16 * t0 + 4 * (lane >> 4) + r) * LRF_FEATC + 16 * t1 + (lane & 15)];
-  } else if (idx < IMT_BT) {
-    const int e = idx - IMT_W1T, r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
-    const int t1 = tt >> 3, t0 = tt & 7;
-    const int col = 16 * t1 + (lane & 15);
-    if (col < LRF_APP_DIM) v = p.w1[(16 * t0 + 4 * (lane >> 4) + r) * LRF_APP_DIM + col];
-  } else if (idx < IMT_W3H) {
-    const int e = idx - IMT_BT, r = e & 3, lane = (e >> 2) & 63, tt = e >> 8;
-    const int t1 = tt >> 1, t0 = tt & 1;
-    const int i = lane & 15, row = 16 * t0 + 4 * (lane >> 4) + r;    // basis row (feat index)
-    const int q = 4 * t1 + (i & 3), gp = i >> 2;                     // output slot q of lane group gp
-    if (row < LRF_APP_DIM && q < 18) v = p.basis[row * 72 + (q / 6) * LRF_CA + 6 * gp + (q % 6)];
-  } else {
-    const int e = idx - IMT_W3H, o = e & 3, fidx = (e >> 2) & 31, g = e >> 7;
-    const int feat = 16 * (fidx >> 2) + 4 * g + (fidx & 3);
-    if (o < 3) v = p.w3[o * (LRF_FEATC + 3) + feat];
-  }
-  img[idx] = v;
 }
 
 // tap1d + d(ix)/d(u): (size-1)/2 inside, 0 where ATen's clip_coordinates_set_grad zeroes it
@@ -274,7 +190,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
     float* __restrict__ crgb, float* __restrict__ act,
     const float* __restrict__ cw /* with part: also emit the per-tile weighted colours of k_shade_bf16 */,
-    float* __restrict__ part, int pmax, uint32_t* __restrict__ relu_bits) {
+    float* __restrict__ part, int pmax, uint32_t* __restrict__ relu_bits, int4* __restrict__ tileinfo) {
   __shared__ uint4 img[IMGB_U4];
   for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
   __syncthreads();
@@ -291,6 +207,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
     const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
     const int cnt = min(ITEM, ncomp[ray] - j0);
+    if (lane == 0) tileinfo[tw.t] = make_int4(ray, j0, cnt, j0 / ITEM);          // for k_train_dgrad3: no tile walk there
     const float* rp = rays + (size_t)ray * 6;
     const float o[3] = {rp[0], rp[1], rp[2]};
     const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
@@ -411,7 +328,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
   }
 }
 
-// ---------------------------------------------------------------- colour chain, data gradient
+// ---------------------------------------------------------------- helpers of the data-gradient / scatter kernels
 // aligned 16-byte load from a pointer known to be global memory
 __device__ __forceinline__ void ld4g(const float* p, float* out) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -426,271 +343,6 @@ __device__ __forceinline__ void ld4g(const float* p, float* out) {
 __device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
   return __uint_as_float(__float_as_uint(x) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, k, 1));
 }
-// the lane's 6 live channels of a padded texel: one 16-byte and one 8-byte load at a 32-bit byte offset from a
-// wave-uniform base.  The base comes out of LDS here, so the loads are pinned to the global address space by hand
-// (a generic pointer would make them flat_load).
-__device__ __forceinline__ void ld6b(const float* base, unsigned off, float out[6]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef char __attribute__((address_space(1))) gchar;
-  typedef f32x4 __attribute__((address_space(1))) gf32x4;
-  typedef f32x2 __attribute__((address_space(1))) gf32x2;
-  const gchar* b = (const gchar*)base + off;
-  const f32x4 a = *(const gf32x4*)b;
-  const f32x2 c = *(const gf32x2*)(b + 16);
-#else
-  const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
-  const f32x2 c = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(base) + off + 16);
-#endif
-  out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3]; out[4] = c[0]; out[5] = c[1];
-}
-struct AppGeo { const float* pl[3]; const float* ln[3]; int pw[3], ph[3], ll[3]; float lo[3], inv[3]; };
-// BF16: the chain dz2 -> dz1 -> dfeat -> dX on split-bf16 MFMAs (IMTB_* image, hand-issued as in the forward: the
-// kernel also gathers) instead of v_mfma_f32_16x16x4_f32 on the fp32 image: 135 instead of 360 MFMAs per tile at
-// half the cycles each (the fp32 chain kept the matrix pipe 51 % busy in a 441 us kernel).
-template <bool BF16>
-__global__ __launch_bounds__(1024) void k_bwd_shade_dgrad(
-    DField f, const float* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int* __restrict__ toff, int R,
-    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
-    const float* __restrict__ crgb, const float* __restrict__ act, const float* __restrict__ g_rgb,
-    float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax,
-    const uint32_t* __restrict__ relu_bits) {
-  __shared__ __attribute__((aligned(16))) float img[IMT_FLOATS];
-  // Geometry of the appearance lookups, read back from LDS next to its use: as kernel arguments
-  // these 30 uniform values stayed live across the MFMA phases, overflowed the SGPR file and were
-  // spilled to scratch through VGPRs (47 stores up front, ~70 reloads per tile).
-  __shared__ AppGeo geo;
-  if (threadIdx.x == 0) {
-    for (int p = 0; p < 3; ++p) {
-      geo.pl[p] = f.aplane[p]; geo.ln[p] = f.aline[p];
-      geo.pw[p] = f.pw[p]; geo.ph[p] = f.ph[p]; geo.ll[p] = f.ll[p];
-      geo.lo[p] = f.lo[p]; geo.inv[p] = f.inv[p];
-    }
-  }
-  {
-    const float4* src = reinterpret_cast<const float4*>(imt);
-    float4* dst = reinterpret_cast<float4*>(img);
-    for (int i = threadIdx.x; i < IMT_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
-  }
-  __syncthreads();
-  TileWalk tw = tile_walk_begin(toff, R);
-  for (; tw.t < tw.t_end; ++tw.t) {
-    asm volatile("" ::: "memory");
-    // the lane's coordinates are re-derived per tile (two instructions) instead of being kept -- and spilled -- across the
-    // 1800-instruction loop body
-    int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    const int s = lane & 15, g = lane >> 4;
-    tile_walk_seek(tw, toff);
-    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
-    const int tile = tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM);
-    const int j0 = tile * ITEM;
-    const int cnt = min(ITEM, ncomp[ray] - j0);
-    const float* rp = rays + (size_t)ray * 6;
-    const float o[3] = {rp[0], rp[1], rp[2]};
-    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
-    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
-    const bool valid = s < cnt;
-    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
-    const int k = cidx[ci];
-    const float zk = z[k];
-    const size_t row = (size_t)tw.t * 16 + s;
-    float* gfr = frag_lane_base(grd, (size_t)tw.t, GRD_LD, s, g);
-    float* gdx = grd + (size_t)tw.t * (16 * GRD_LD) + GRD_DX * 16 + s * (GRD_LD - GRD_DX);   // row-major dX block (grd_dx_row)
-    const uint32_t m1 = relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane];       // ReLU masks saved by k_bwd_shade_fwd
-    const uint32_t m2 = relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane];
-
-    // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k  (tensorBase.py:632-633)
-    float go[3] = {0.0f, 0.0f, 0.0f};
-    if (valid) {
-      const float w = cw[ci];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float r = crgb[ci * 3 + c];
-        go[c] = g_rgb[(size_t)(f.perm ? f.perm[ray] : ray) * 3 + c] * w * r * (1.0f - r);
-      }
-    }
-    // go block: lane group 0 = go, lane group 1 = (dhat, 1): the view-direction and bias columns of dW3 (k_wgrad_w2w3)
-    row_store_b<32>(gfr + 16 * GRD_GO, g == 0 ? make_float4(go[0], go[1], go[2], 0.0f)
-                                     : g == 1 ? make_float4(dh[0], dh[1], dh[2], 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-
-    // dz2 = (W3[:, :128]^T go) * [h2 > 0]
-    f32x4 dz[8];
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float4 wv = *reinterpret_cast<const float4*>(&img[(BF16 ? IMTB_TAIL * 4 : IMT_W3H) + (g * 32 + t1 * 4 + r) * 4]);
-        const float d = wv.x * go[0] + wv.y * go[1] + wv.z * go[2];
-        dz[t1][r] = relu_gate(d, m2, 4 * t1 + r);             // (not stored: k_wgrad_w2w3 rebuilds dz2 from go + mask bits)
-      }
-    }
-    f32x4 df[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    f32x4 dxs[5];
-#pragma unroll
-    for (int t1 = 0; t1 < 5; ++t1) dxs[t1] = f32x4{0, 0, 0, 0};
-    if constexpr (BF16) {
-      const uint4* imgb = reinterpret_cast<const uint4*>(img);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no global load in flight under the hand-issued chain
-      f32x4 d1[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) d1[q] = f32x4{0, 0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(d1[q]));
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {                       // dz1 = W2^T dz2
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = dz[2 * ks + (j >> 2)][j & 3];
-        bf16x8 bh, bl;
-        split8(v, bh, bl);
-        gemm_step<8>(imgb, IMTB_W2T / 128 + ks, 4, lane, bh, bl, d1);
-      }
-      settle<8>(d1);
-#pragma unroll
-      for (int t1 = 0; t1 < 8; ++t1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d1[t1][r] = relu_gate(d1[t1][r], m1, 4 * t1 + r);
-        row_store(gfr + 16 * (GRD_DZ1 + 16 * t1), d1[t1]);
-      }
-      asm volatile("" : "+v"(df[0]), "+v"(df[1]));
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {                       // dfeat = W1^T dz1
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = d1[2 * ks + (j >> 2)][j & 3];
-        bf16x8 bh, bl;
-        split8(v, bh, bl);
-        gemm_step<2>(imgb, IMTB_W1T / 128 + ks, 4, lane, bh, bl, df);
-      }
-      settle<2>(df);
-      {                                                      // dX = basis^T dfeat
-        const float v[8] = {df[0][0], df[0][1], df[0][2], df[0][3], df[1][0], df[1][1], df[1][2], df[1][3]};
-        bf16x8 bh, bl;
-        split8(v, bh, bl);
-#pragma unroll
-        for (int t1 = 0; t1 < 5; ++t1) asm volatile("" : "+v"(dxs[t1]));
-        gemm_step<5>(imgb, IMTB_BT / 128, 1, lane, bh, bl, dxs);
-        settle<5>(dxs);
-      }
-    } else {
-    // dz1 = (W2^T dz2) * [h1 > 0]      (exact fp32 MFMA, transposed fragments), one output tile at
-    // a time; each finished tile is masked, stored and consumed at once as k-step t1 of
-    // dfeat = W1^T dz1, so only dz2 (32 registers) stays live across the loop -- the 8x8 loop nest with
-    // all of dz1 live spilled 544 B per lane.  Summation order is unchanged.
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) {
-      asm volatile("" ::: "memory");             // keep each tile's row / fragment loads next to their use
-      f32x4 d1 = {0, 0, 0, 0};
-#pragma unroll
-      for (int t0 = 0; t0 < 8; ++t0) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W2T + ((t1 * 8 + t0) * 64 + lane) * 4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d1 = mfma4(a[r], dz[t0][r], d1);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d1[r] = relu_gate(d1[r], m1, 4 * t1 + r);
-      row_store(gfr + 16 * (GRD_DZ1 + 16 * t1), d1);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_W1T + ((t2 * 8 + t1) * 64 + lane) * 4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) df[t2] = mfma4(a[r], d1[r], df[t2]);
-      }
-    }
-    // dX = basis^T dfeat, delivered in the gather layout: slot q = 4t'+r of lane (s,g) is
-    // channel (p = q/6, 6g + q%6)
-#pragma unroll
-    for (int t0 = 0; t0 < 2; ++t0) {
-#pragma unroll
-      for (int t1 = 0; t1 < 5; ++t1) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&img[IMT_BT + ((t1 * 2 + t0) * 64 + lane) * 4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dxs[t1] = mfma4(a[r], df[t0][r], dxs[t1]);
-      }
-    }
-    }
-    row_store_b<32>(gfr + 16 * GRD_DFEAT, make_float4(df[0][0], df[0][1], df[0][2], df[0][3]));
-    row_store_b<32>(gfr + 16 * (GRD_DFEAT + 16), make_float4(df[1][0], df[1][1], df[1][2], df[1][3]));
-    float dX[18];
-#pragma unroll
-    for (int q = 0; q < 18; ++q) dX[q] = dxs[q >> 2][q & 3];
-    // dX row (natural channel order) + sample id for the binned plane/line scatter kernels
-#pragma unroll
-    for (int pq = 0; pq < 3; ++pq)
-#pragma unroll
-      for (int h = 0; h < 3; ++h)
-        row_store2<8>(gdx + pq * LRF_CA + 6 * g + 2 * h, dX[pq * 6 + 2 * h], dX[pq * 6 + 2 * h + 1]);
-    if (g == 0) rowinfo[row] = valid ? (uint32_t)((size_t)ray * S + k) : 0xffffffffu;
-
-    // d/d(position) from the appearance lookups
-    float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
-    float xc[3] = {xr[0], xr[1], xr[2]};
-    contract3(xc[0], xc[1], xc[2]);
-    float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - geo.lo[a]) * geo.inv[a] - 1.0f;
-    if (valid) {
-      // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps, lrf_common.h): three tap computations serve the
-      // nine lookups; byte offsets are 32-bit (ld4b / ld2b), the pad slots 6, 7 of the lane's 8 are not fetched
-      int ai0[3], ai1[3]; float at[3], ag[3];
-      tap1d_g(u[0], geo.pw[0], ai0[0], ai1[0], at[0], ag[0]);
-      tap1d_g(u[1], geo.ph[0], ai0[1], ai1[1], at[1], ag[1]);
-      tap1d_g(u[2], geo.ll[0], ai0[2], ai1[2], at[2], ag[2]);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        asm volatile("" ::: "memory");           // one plane's 12 gathers in flight at a time
-        const int x0 = ai0[MAT0[p]], x1 = ai1[MAT0[p]], y0 = ai0[MAT1[p]], y1 = ai1[MAT1[p]];
-        const int l0 = ai0[VEC[p]], l1 = ai1[VEC[p]];
-        const float tx = at[MAT0[p]], ty = at[MAT1[p]], tl = at[VEC[p]];
-        const float gx = ag[MAT0[p]], gy = ag[MAT1[p]], gl = ag[VEC[p]];
-        const unsigned gb = 32u * (unsigned)g;
-        const unsigned pw = (unsigned)geo.pw[p];
-        const unsigned row0 = (unsigned)y0 * pw, row1 = (unsigned)y1 * pw;
-        const unsigned o00 = (row0 + x0) * (LRF_CAS * 4u) + gb, o10 = (row0 + x1) * (LRF_CAS * 4u) + gb;
-        const unsigned o01 = (row1 + x0) * (LRF_CAS * 4u) + gb, o11 = (row1 + x1) * (LRF_CAS * 4u) + gb;
-        const unsigned q0 = (unsigned)l0 * (LRF_CAS * 4u) + gb, q1 = (unsigned)l1 * (LRF_CAS * 4u) + gb;
-        const float* pl = geo.pl[p];
-        const float* ln = geo.ln[p];
-        float v00[6], v10[6], v01[6], v11[6], e0[6], e1[6];
-        ld6b(pl, o00, v00); ld6b(pl, o10, v10); ld6b(pl, o01, v01); ld6b(pl, o11, v11);
-        ld6b(ln, q0, e0);   ld6b(ln, q1, e1);
-        float gix = 0.0f, giy = 0.0f, gil = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const float P = (v00[c] * (1.0f - tx) + v10[c] * tx) * (1.0f - ty) + (v01[c] * (1.0f - tx) + v11[c] * tx) * ty;
-          const float Lv = e0[c] * (1.0f - tl) + e1[c] * tl;
-          const float d = dX[p * 6 + c];
-          const float dP = d * Lv, dL = d * P;
-          gix += dP * ((v10[c] - v00[c]) * (1.0f - ty) + (v11[c] - v01[c]) * ty);
-          giy += dP * ((v01[c] - v00[c]) * (1.0f - tx) + (v11[c] - v10[c]) * tx);
-          gil += dL * (e1[c] - e0[c]);
-        }
-        gu[MAT0[p]] += gix * gx; gu[MAT1[p]] += giy * gy; gu[VEC[p]] += gil * gl;
-      }
-    }
-    // sum the four channel groups of a sample, go back through normalise + contraction
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      gu[a] += __shfl_xor(gu[a], 16, 64);
-      gu[a] += __shfl_xor(gu[a], 32, 64);
-    }
-    float gx3[3] = {gu[0] * geo.inv[0], gu[1] * geo.inv[1], gu[2] * geo.inv[2]};
-    contract3_bwd(xr, gx3);
-    float pr[6] = {gx3[0], gx3[1], gx3[2], gx3[0] * zk, gx3[1] * zk, gx3[2] * zk};
-    if (!valid) { pr[0] = pr[1] = pr[2] = pr[3] = pr[4] = pr[5] = 0.0f; }
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-      for (int dd = 1; dd < 16; dd <<= 1) pr[q] += __shfl_xor(pr[q], dd, 64);
-    if (lane == 0) {
-      float* rpp = rpart + ((size_t)ray * pmax + tile) * 8;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) rpp[q] = pr[q];
-    }
-  }
-}
-
 // ---------------------------------------------------------------- weight gradients
 // C[M x N] partial = A[rows, M]^T  B[rows, N] over one K-chunk of saved rows.
 // 4 waves; wave w owns M-tiles w, w+4, ...; every wave sweeps all NT N-tiles.  Rows are staged
@@ -1042,7 +694,7 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
 
 // dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in a fixed order) for
 // the seven weight / bias tensors in one launch: 16 lanes per output element.
-struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem, x_slots; float* dst; };   // x_slots: source column of n is x_slot_col(n)
+struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem, x_slots, nch; float* dst; };   // x_slots: source column of n is x_slot_col(n); nch: partial blocks (0: one per K-chunk of rows)
 struct WgradSegs { WgradSeg s[7]; int total_elems; };
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
                                                       WgradSegs segs) {
@@ -1055,7 +707,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   const int e = ok ? idx - sg.first_elem : 0;
   const int m = e / sg.n_count, n = e % sg.n_count;
   const int WGRAD_CH = wgrad_chunk_rows(toff[R] * 16);
-  const int nch = (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
+  const int nch = sg.nch ? sg.nch : (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
   float acc = 0.0f;
   const int src = sg.off + m * sg.ld + sg.n_off + (sg.x_slots ? x_slot_col(n) : n);
   for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + src];
@@ -1721,12 +1373,15 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, ScatterDst dst, c
   }
 }
 
+#include "lrf_train32.inl"
+
 struct BwdWorkspace {
   Workspace fw;
   float* feat; float* crgb; float* imt; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
   uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_bwd_shade_fwd -> k_bwd_shade_dgrad
+  int4* tileinfo;            // [tile] (ray, j0, count, tile in ray), k_bwd_shade_fwd -> k_train_dgrad3
   uint16_t* tid2; int* hist2; int* offs2; int* cursor2; uint32_t* list2;   // bins of the appearance scatter (runs beside the density scatter)
   uint32_t nmax;
   size_t bytes;
@@ -1742,7 +1397,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   auto take = [&](size_t nfloat) { float* q = reinterpret_cast<float*>(p + off); off += up256(nfloat * 4); return q; };
   b.feat = take((size_t)R * S);
   b.crgb = take((size_t)R * S * 3);
-  b.imt = take(IMT_FLOATS);
+  b.imt = take(W32T_ALL_U4 * 4);
   b.act = take(rows * ACT_LD);
   b.grd = take(rows * GRD_LD);
   b.rpart = take((size_t)R * b.fw.pmax * 8);
@@ -1757,6 +1412,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   b.cursor = reinterpret_cast<int*>(take(BIN_MAX));
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.relu_bits = reinterpret_cast<uint32_t*>(take(rows / 16 * 128));
+  b.tileinfo = reinterpret_cast<int4*>(take(rows / 16 * 4));
   b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
   b.hist2 = reinterpret_cast<int*>(take(BIN_MAX));
   b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
@@ -1768,18 +1424,18 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 
 // The row-saving colour kernel of the training forward is k_bwd_shade_fwd behind k_scan_tiles.  (Round 2 also built it
 // in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
+static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 without row stores / position gradient / products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
-static int g_dgrad_bf16 = 1;        // lrf_debug_set_train_fwd_engine(4 | ...): data-gradient chain on the exact-fp32 MFMA path
 static int g_wgrad_split = 3;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
 static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                               const BwdWorkspace& b, hipStream_t st) {
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                     b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits);
+                     b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits, b.tileinfo);
 }
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_dgrad_bf16 = (e & 4) ? 0 : 1; lrf::g_scatter_fused = (e & 8) ? 0 : 1; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_dgrad_dbg = (e >> 5) & 7; }
 
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
@@ -1857,14 +1513,15 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_dgrad3<8>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
       lds_attr_err[dev_id & 63] = e;
     });
     LRF_HIP(lds_attr_err[dev_id & 63]);
   }
-  if (g_dgrad_bf16) hipLaunchKernelGGL(k_pack_mlp_bf16_t, dim3((IMTB_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
-  else hipLaunchKernelGGL(k_pack_mlp_t, dim3((IMT_FLOATS + 255) / 256), dim3(256), 0, st, *p, b.imt);
+  hipLaunchKernelGGL(k_pack_mlp_w32_t, dim3((W32T_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
@@ -1903,12 +1560,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
 
   // ---- caller's stream: data gradient of the colour network
-  if (g_dgrad_bf16)
-    hipLaunchKernelGGL(k_bwd_shade_dgrad<true>, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits);
-  else
-    hipLaunchKernelGGL(k_bwd_shade_dgrad<false>, dim3(cus), dim3(1024), 0, st, d, b.imt, rays, z, S, w.toff, R, w.ncomp,
-                       w.cidx, w.cw, b.crgb, b.act, g_rgb, b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits);
+  const int n_dgrad_wg = min(cus, WGRAD_MAXCH);            // one dW1 partial block per workgroup (k_wgrad_reduce: fixed count)
+  hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16 + (size_t)S * 4, st, d,
+                     reinterpret_cast<const uint4*>(b.imt), rays, z, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
+                     b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, b.act, b.wpart, g_dgrad_dbg);
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));
 
   // ---- side stream: per-ray backward, density scatter
@@ -1944,22 +1599,20 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   auto wst = [&](int idx) { return idx < on_a ? st : sb; };
   hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, wst(0), d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
                      b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
-  hipLaunchKernelGGL((k_wgrad<8, 2, false>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + 16 * GRD_DZ1, GRD_LD, b.act + 16 * ACT_FEAT, ACT_LD,
-                     w.toff, R, b.wpart, WP_W1);
-  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(2), b.grd + 16 * GRD_DFEAT, GRD_LD, b.act + 16 * ACT_X, ACT_LD,
+  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + 16 * GRD_DFEAT, GRD_LD, b.act + 16 * ACT_X, ACT_LD,
                      w.toff, R, b.wpart, WP_BAS);
   if (ss && on_a > 0) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream GEMMs are done behind this
   {
     WgradSegs segs;
     int nseg = 0, elems = 0;
-    auto seg = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld, int x_slots = 0) {
-      segs.s[nseg++] = WgradSeg{off, ld, n_off, m, n, dst_ld, elems, x_slots, dst};
+    auto seg = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld, int x_slots = 0, int nch = 0) {
+      segs.s[nseg++] = WgradSeg{off, ld, n_off, m, n, dst_ld, elems, x_slots, nch, dst};
       elems += m * n;
     };
     seg(WP_W2, 144, 0, 128, 128, g->w2, 128);
     seg(WP_W2, 144, 128, 128, 1, g->b2, 1);
-    seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM);
-    seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1);
+    seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM, 0, n_dgrad_wg);     // accumulated by k_train_dgrad3: one block per workgroup
+    seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1, 0, n_dgrad_wg);
     seg(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72, 1);               // the X block is in slot order
     seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
     seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);

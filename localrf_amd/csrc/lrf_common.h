@@ -103,10 +103,11 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
 // Device-side view of a field, passed by value to kernels.
 // ---- rows the training forward saves per shaded sample for the backward (floats; lrf_backward.inl) --------------
 //   ACT row: X[18 slots x 4 lane groups] (+8 pad) | feat[27], 1 (+pad)                        448 B
-//   GRD row: go[3], 0, dhat[3], 1 (+pad) | dfeat | dz1 | dX                                  1024 B
+//   GRD row: go[3], 0, dhat[3], 1 (+pad) | dfeat | dX                                         512 B
 // The hidden activations are NOT rows (round 4): relu(h1) and relu(h2) are recomputed from `feat` by the one kernel that
 // needs them as GEMM operands (k_wgrad_w2w3: dW2 = dz2^T relu(h1), dW3 = go^T relu(h2)); the data-gradient kernel needs
-// only their signs (relu_bits, 32 B per sample).  That removed 1.15 KB written + 1.15 KB read per shaded sample.
+// only their signs (relu_bits, 32 B per sample).  That removed 1.15 KB written + 1.15 KB read per shaded sample.  dz1 is not
+// a row either: dW1 = dz1^T [feat | 1] is accumulated inside the data-gradient kernel (lrf_train32.inl), 0.5 + 0.5 KB more.
 // Layout in memory: MFMA-fragment order, not row-major.  The 16 rows of a tile are stored together; inside a tile every
 // 16-column block is the 1 KB a wave holds for it, [lane group g][sample s][4 columns]: column c of row s of tile t is at
 //   t * 16 * LD + (c / 16) * 256 + ((c / 4 % 4) * 16 + s) * 4 + c % 4            (frag_off below)
@@ -114,12 +115,12 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
 // instead of sixteen 64-byte pieces 1600 B apart, and the weight-gradient GEMMs stage whole blocks with contiguous
 // loads.  The X block is in the gather's slot order: slot q = 6 p + c (plane p, c < 6) of lane group g is column
 // 16 (q / 4) + 4 g + q % 4 and stands for appearance channel 24 p + 6 g + c (x_slot_col); slots 18, 19 are zero.
-// Exception: the dX block of a GRD tile is row-major inside the tile (16 rows x 80 floats behind the 11 fragment
+// Exception: the dX block of a GRD tile is row-major inside the tile (16 rows x 80 floats behind the 3 fragment
 // blocks, natural channel order): the binned scatter kernels read it one row at a time (grd_dx_row).
 constexpr int ACT_X = 0, ACT_FEAT = 80, ACT_LD = 112;
-constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DZ1 = 48, GRD_DX = 176, GRD_LD = 256;
+constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DX = 48, GRD_LD = 128;
 static_assert(ACT_FEAT % 16 == 0 && ACT_LD % 16 == 0, "fragment blocks are 16 columns");
-static_assert(GRD_DFEAT % 16 == 0 && GRD_DZ1 % 16 == 0 && GRD_DX % 16 == 0 && GRD_LD % 16 == 0 && GRD_LD - GRD_DX == 80, "fragment blocks are 16 columns");
+static_assert(GRD_DFEAT % 16 == 0 && GRD_DX % 16 == 0 && GRD_LD % 16 == 0 && GRD_LD - GRD_DX == 80, "fragment blocks are 16 columns");
 __host__ __device__ inline size_t frag_off(size_t row, int col, int ld) {
   return (row >> 4) * (size_t)(16 * ld) + (size_t)((col >> 4) * 256 + ((((col >> 2) & 3) * 16 + (int)(row & 15)) << 2) + (col & 3));
 }

@@ -1,0 +1,394 @@
+// lrf_train32.inl -- the data-gradient kernel of the training step on the k_shade3 skeleton (round 4): 32 samples per wave on
+// v_mfma_f32_32x32x16_bf16, 512-thread workgroups, compiler-scheduled term-major chain.  Included by lrf_backward.inl.
+//
+// k_bwd_shade_dgrad (16 samples per wave on v_mfma_f32_16x16x32_bf16, 1024-thread workgroups, 128 registers) issued ~1650
+// VALU + 143 MFMA + 179 LDS instructions per 16-sample tile and spent half its wave-cycles in issue stalls
+// (profiles/r11a: 320-330 us).  Here a wave takes two consecutive 16-row tiles of the saved rows (lane n = lane & 31 is
+// row 16 (n >> 4) + (n & 15) of the pair, h = lane >> 5 the K half), so every A fragment feeds 32 columns and the
+// D registers of a product are again the B operand of the next one:
+//   go -> dz2 (VALU: rank 3, gated by the saved layer-2 mask bits) -> dz1 = W2^T dz2 (4 x 8 x 3 MFMAs, gated by the layer-1
+//   bits) -> dfeat = W1^T dz1 (8 x 3) -> dX = basis^T dfeat (3 x 2 x 3), delivered per lane for exactly the channels its
+//   half gathers (12 h .. 12 h + 11 of each plane, the dense 24-channel texels of k_shade3), so the position gradient of
+//   the appearance lookups re-uses the forward's gather code.
+// The transposed network is packed per backward into the same fragment format as the forward image (k_pack_mlp_w32_t).
+// Rows are written in the 16-row fragment order the weight-gradient GEMMs and the scatter kernels read (lrf_common.h);
+// dX goes out as three 48-byte pieces per lane (round 3: nine 8-byte stores).
+//
+// dW1 (+ db1) = dz1^T [feat | 1] is accumulated HERE, so dz1 is never a row (512 B written + read per shaded sample: with
+// them the kernel ran 310-430 us against 160 us without any row store -- it was bound by its own stores).  The product
+// contracts over samples, which sit in the lane dimension of the chain's registers; both operands are therefore
+// TRANSPOSED ON THE MATRIX PIPE, by multiplying with a 0/1 selector: with the sample-major fragment as A and a selector
+// as B, D[sample][unit] arrives with lane = unit and registers = samples -- exactly an A / B operand over K = samples
+// (the K order is again folded into w32_unit).  dz1's split halves exist anyway (B operand of the dfeat product): the
+// transpose costs 2 x 8 MFMAs, feat's 2 x 2, the product 4 x 2 x 3; selectors are exact in bf16, so the transposed value
+// is hi + lo of the original (what a split product sees anyway).  64 accumulator registers per wave, reduced over the
+// workgroup's waves once at the end -> one partial block per workgroup (WP_W1), summed by k_wgrad_reduce.
+// (included inside namespace lrf)
+#pragma once
+
+// ---- transposed w32 image: fragments [part hi, lo][lane 64][8 bf16], slot j of lane (n, h) = A[n][8 h + j]
+//   frag 8 m + ks        (0..31)  W2^T:    A[n][slot] = W2[u = 16 ks + 8 h + j][v = 32 m + n]
+//   frag 32 + 2 m + q    (32..39) W1^T:    A[n][slot] = W1[v = w32_unit(m, q, h, j)][f = n]          (rows n >= 27 zero)
+//   frag 40 + 2 mt + q   (40..45) basis^T: A[n][slot] = basis[f = w32_unit(0, q, h, j)][channel of row n of tile mt]
+//                                          row n <-> (half hr = (n >> 2) & 1, value vv = 16 mt + 4 (n >> 3) + (n & 3)):
+//                                          channel w32_chan(hr, vv), zero rows for vv >= 36
+// then an fp32 tail: mlp_view.0.weight[c][0..127] padded to 132 per colour.
+constexpr int W32T_W2 = 0, W32T_W1 = 32, W32T_BAS = 40, W32T_NFRAG = 46;
+constexpr int W32T_U4 = W32T_NFRAG * 128;                        // 5888 uint4 = 94,208 B
+constexpr int W32T_T_W3 = 0, W32T_T_W3_LD = 132, W32T_T_FLOATS = 400;
+constexpr int W32T_ALL_U4 = W32T_U4 + W32T_T_FLOATS / 4;         // 5988 uint4 = 95,808 B
+
+__global__ void k_pack_mlp_w32_t(LrfParams p, uint32_t* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W32T_ALL_U4 * 4) return;
+  if (idx >= W32T_U4 * 4) {
+    const int e = idx - W32T_U4 * 4, c = e / W32T_T_W3_LD, u = e % W32T_T_W3_LD;
+    img[idx] = __float_as_uint(c < 3 && u < LRF_FEATC ? p.w3[c * (LRF_FEATC + 3) + u] : 0.0f);
+    return;
+  }
+  const int u4 = idx >> 2, wj = idx & 3;
+  const int lane = u4 & 63, part = (u4 >> 6) & 1, frag = u4 >> 7;
+  const int n = lane & 31, h = lane >> 5;
+  unsigned short out[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int j = 2 * wj + e;
+    float v = 0.0f;
+    if (frag < W32T_W1) {
+      const int m = frag >> 3, ks = frag & 7;
+      v = p.w2[(16 * ks + 8 * h + j) * LRF_FEATC + 32 * m + n];
+    } else if (frag < W32T_BAS) {
+      const int m = (frag - W32T_W1) >> 1, q = (frag - W32T_W1) & 1;
+      if (n < LRF_APP_DIM) v = p.w1[w32_unit(m, q, h, j) * LRF_APP_DIM + n];
+    } else {
+      const int mt = (frag - W32T_BAS) >> 1, q = (frag - W32T_BAS) & 1;
+      const int hr = (n >> 2) & 1, vv = 16 * mt + 4 * (n >> 3) + (n & 3);
+      const int ch = vv < 36 ? w32_chan(hr, vv) : -1;
+      const int f = w32_unit(0, q, h, j);
+      if (ch >= 0 && f < LRF_APP_DIM) v = p.basis[f * 72 + ch];
+    }
+    const unsigned short hi = bf16_bits(v);
+    out[e] = part ? bf16_bits(v - bf16_val(hi)) : hi;
+  }
+  img[idx] = (uint32_t)out[0] | ((uint32_t)out[1] << 16);
+}
+
+// position-gradient terms of plane p for lane half h: channels 12 h .. 12 h + 11 of the dense texels (gather_app12's taps),
+// dX[12] = d(loss)/d(X) of those channels.  Adds to gu[] the derivative with respect to the three normalised coordinates.
+template <int p>
+__device__ __forceinline__ void app12_position_grad(const DField& f, const int i0[3], const int i1[3], const float t[3],
+                                                    const float gm[3], int h, const float dX[12], float gu[3]) {
+  const int x0 = i0[MAT0[p]], x1 = i1[MAT0[p]], y0 = i0[MAT1[p]], y1 = i1[MAT1[p]];
+  const int l0 = i0[VEC[p]], l1 = i1[VEC[p]];
+  const float tx = t[MAT0[p]], ty = t[MAT1[p]], tl = t[VEC[p]];
+  const unsigned hb = 48u * (unsigned)h;
+  const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
+  const unsigned o00 = (row0 + x0) * (LRF_CA * 4u) + hb, o10 = (row0 + x1) * (LRF_CA * 4u) + hb;
+  const unsigned o01 = (row1 + x0) * (LRF_CA * 4u) + hb, o11 = (row1 + x1) * (LRF_CA * 4u) + hb;
+  const unsigned q0 = (unsigned)l0 * (LRF_CA * 4u) + hb, q1 = (unsigned)l1 * (LRF_CA * 4u) + hb;
+  float gix = 0.0f, giy = 0.0f, gil = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float4 a4 = ld4b(f.aplane2[p], o00 + 16 * i), b4 = ld4b(f.aplane2[p], o10 + 16 * i);
+    const float4 c4 = ld4b(f.aplane2[p], o01 + 16 * i), d4 = ld4b(f.aplane2[p], o11 + 16 * i);
+    const float4 e4 = ld4b(f.aline2[p], q0 + 16 * i), g4 = ld4b(f.aline2[p], q1 + 16 * i);
+    const float va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float vc[4] = {c4.x, c4.y, c4.z, c4.w}, vd[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float ve[4] = {e4.x, e4.y, e4.z, e4.w}, vg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v00 = va[c], v10 = vb[c], v01 = vc[c], v11 = vd[c], e0 = ve[c], e1 = vg[c];
+      const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
+      const float Lv = e0 * (1.0f - tl) + e1 * tl;
+      const float d = dX[4 * i + c];
+      const float dP = d * Lv, dL = d * P;
+      gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
+      giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
+      gil += dL * (e1 - e0);
+    }
+  }
+  gu[MAT0[p]] += gix * gm[MAT0[p]]; gu[MAT1[p]] += giy * gm[MAT1[p]]; gu[VEC[p]] += gil * gm[VEC[p]];
+}
+
+// plain (temporal) 16-byte row store: for this kernel's 512-byte segments the `nt` hint of the 16-sample kernels costs time
+// (1 KB rows: 411 us with nt, 312 us without, profiles/r11c)
+__device__ __forceinline__ void row_store_plain(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// tileinfo[t] = (ray, first compact sample j0, samples in the tile, tile number inside the ray), written by k_bwd_shade_fwd
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
+    DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff, int R, const int4* __restrict__ tileinfo,
+    const uint16_t* __restrict__ cidx, const float* __restrict__ cw, const float* __restrict__ crgb,
+    const float* __restrict__ g_rgb, float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax,
+    const uint32_t* __restrict__ relu_bits, const float* __restrict__ act /* saved feat rows */, float* __restrict__ wpart,
+    int dbg /* timing experiments: 1 no row stores, 2 no position gradient, 4 no products */) {
+  constexpr int NT = NW * 64;
+  extern __shared__ uint4 s_dyn3[];
+  uint4* img = s_dyn3;
+  float* tail = reinterpret_cast<float*>(s_dyn3 + W32T_U4);
+  float* s_z = tail + W32T_T_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5, s = n & 15;
+  {
+    const int rot = (int)((blockIdx.x * 37u) % 93u) * 64;     // every workgroup starts its copy somewhere else (finding 18)
+    for (int i = tid; i < W32T_ALL_U4; i += NT) { int j = i + rot; if (j >= W32T_ALL_U4) j -= W32T_ALL_U4; img[j] = imt[j]; }
+  }
+  for (int i = tid; i < S; i += NT) s_z[i] = z[i];
+  __syncthreads();
+  const int T = toff[R];
+  const int P = (T + 1) >> 1;                                 // pairs of 16-row tiles
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;   // XCD-aware order
+  const long long wid = (long long)lb * NW + wave, waves = (long long)nb * NW;
+  const int p_beg = (int)(wid * P / waves), p_end = (int)((wid + 1) * P / waves);
+  f32x16 w1acc[4];                                             // dW1 partial of this wave: [v = 32 m + 8 (r >> 2) + 4 h + (r & 3)][f = n]
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w1acc[m][r] = 0.0f;
+  // 0 / 1 selectors (B operands of the transposing products): slot j of lane (n, h) is 1 where the K index of the slot
+  // equals the lane's column.  sel_u[q]: K index = unit 16 q + 8 (j >> 2) + 4 h + (j & 3) of a 32-unit M-tile (dz1's
+  // D-register order); sel_f[ks]: K index = feature 16 ks + 8 h + j (the order the feat row is loaded in).
+  auto selector = [&](auto key) {
+    uint32_t wds[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2)
+      wds[q2] = (key(2 * q2) == n ? 0x3f80u : 0u) | (key(2 * q2 + 1) == n ? 0x3f800000u : 0u);
+    return __builtin_bit_cast(bf16x8, make_uint4(wds[0], wds[1], wds[2], wds[3]));
+  };
+  for (int pr = p_beg; pr < p_end; ++pr) {
+    asm volatile("" ::: "memory");                             // keep the LDS fragment reads inside the loop
+    const int tile = 2 * pr + (n >> 4);
+    const bool have_t = tile < T;
+    const bool have = have_t && !(dbg & 1);                    // (`have` guards the row stores)
+    const int4 ti = tileinfo[have_t ? tile : 2 * pr];
+    const int ray = ti.x, j0 = ti.y, cnt = ti.z;
+    const bool valid = have_t && s < cnt;
+    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
+    const int k = cidx[ci];
+    const size_t trow = (size_t)tile * (size_t)(16 * GRD_LD);   // this lane's 16-row tile of the gradient rows
+    const uint32_t* rb = relu_bits + (size_t)tile * 128 + s;
+    uint32_t m2a = 0, m2b = 0, m1a = 0, m1b = 0;
+    float go[3] = {0.0f, 0.0f, 0.0f};
+    if (have_t) {
+      m1a = rb[16 * h]; m1b = rb[16 * (2 + h)];               // layer 1: lane groups h, 2 + h of the 16-sample layout
+      m2a = rb[64 + 16 * (2 * h)]; m2b = rb[64 + 16 * (2 * h + 1)];   // layer 2: lane groups 2 h, 2 h + 1
+    }
+    const float* rp = rays + (size_t)ray * 6;
+    const float o[3] = {rp[0], rp[1], rp[2]};
+    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+    if (valid) {                                               // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k (tensorBase.py:632-633)
+      const float w = cw[ci];
+      const int oray = f.perm ? f.perm[ray] : ray;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float r = crgb[ci * 3 + c];
+        go[c] = g_rgb[(size_t)oray * 3 + c] * w * r * (1.0f - r);
+      }
+    }
+    if (have) {                                                // go block: lane group 0 = go, lane group 1 = (dhat, 1) (k_wgrad_w2w3)
+      float* gp = grd + trow + 16 * GRD_GO + ((16 * h + s) << 2);
+      row_store_plain(gp, h == 0 ? make_float4(go[0], go[1], go[2], 0.0f) : make_float4(dh[0], dh[1], dh[2], 1.0f));
+      if (h == 0) rowinfo[(size_t)tile * 16 + s] = valid ? (uint32_t)((size_t)ray * S + k) : 0xffffffffu;
+    }
+    __builtin_amdgcn_iglp_opt(0);
+    // ---- dz1 = (W2^T dz2) * [h1 > 0], dz2 = (W3[:, :128]^T go) * [h2 > 0] formed K-step by K-step on the VALU
+    f32x16 d1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d1[m][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                            // K slots j = 4 q .. 4 q + 3: units 16 ks + 8 h + j
+        const int u = 16 * ks + 8 * h + 4 * q;
+        const float4 w0 = *reinterpret_cast<const float4*>(&tail[W32T_T_W3 + u]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&tail[W32T_T_W3 + W32T_T_W3_LD + u]);
+        const float4 w2 = *reinterpret_cast<const float4*>(&tail[W32T_T_W3 + 2 * W32T_T_W3_LD + u]);
+        const uint32_t mb = q ? m2b : m2a;
+        v[4 * q]     = relu_gate(w0.x * go[0] + w1.x * go[1] + w2.x * go[2], mb, 4 * ks);
+        v[4 * q + 1] = relu_gate(w0.y * go[0] + w1.y * go[1] + w2.y * go[2], mb, 4 * ks + 1);
+        v[4 * q + 2] = relu_gate(w0.z * go[0] + w1.z * go[1] + w2.z * go[2], mb, 4 * ks + 2);
+        v[4 * q + 3] = relu_gate(w0.w * go[0] + w1.w * go[1] + w2.w * go[2], mb, 4 * ks + 3);
+      }
+      bf16x8 bh, bl;
+      split8c(v, bh, bl);
+      if (!(dbg & 4)) {                                        // two M-tiles at a time: 16 fragment registers live instead of 32
+        mma3_step<2>(img, W32T_W2 + ks, 8, lane, bh, bl, d1);
+        mma3_step<2>(img, W32T_W2 + 16 + ks, 8, lane, bh, bl, d1 + 2);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                            // registers 4 q .. 4 q + 3: units 32 m + 8 q + 4 h + r
+        const uint32_t mb = (q & 1) ? m1b : m1a;
+        const int b0 = 4 * (2 * m + (q >> 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[m][4 * q + r] = relu_gate(d1[m][4 * q + r], mb, b0 + r);
+      }
+    // ---- feat^T: this lane's sample as a row of A (features 16 ks + 8 h + j), selector as B -> lane = feature, registers = samples
+    bf16x8 Fh[2], Fl[2];
+    {
+      const float* fp = act + (size_t)(have_t ? tile : 2 * pr) * (size_t)(16 * ACT_LD) + 16 * ACT_FEAT + (s << 2);
+      f32x16 ft;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ft[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4 a = row_load4(fp + ks * 256 + ((2 * h) * 16 << 2)), b = row_load4(fp + ks * 256 + ((2 * h + 1) * 16 << 2));
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bf16x8 fh, fl;
+        split8c(v, fh, fl);
+        const bf16x8 sel = selector([&](int j) { return 16 * ks + 8 * h + j; });
+        ft = mfma32(fh, sel, ft);
+        ft = mfma32(fl, sel, ft);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ft[8 * q + j];
+        split8c(v, Fh[q], Fl[q]);
+      }
+    }
+    // ---- dfeat = W1^T dz1
+    f32x16 df;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) df[r] = 0.0f;
+    {                                                          // (one accumulator per product: the kernel lives at the 256-register limit)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        f32x16 dzt;                                            // dz1^T of M-tile m: lane = unit 32 m + n, registers = samples
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dzt[r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = d1[m][8 * q + j];
+          bf16x8 bh, bl;
+          split8c(v, bh, bl);
+          const bf16x8 ah = w32_frag(img, W32T_W1 + 2 * m + q, 0, lane), al = w32_frag(img, W32T_W1 + 2 * m + q, 1, lane);
+          const bf16x8 sel = selector([&](int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); });
+          df = mfma32(al, bh, df);
+          dzt = mfma32(bh, sel, dzt);                          // the same split halves as A: transposed by the selector
+          df = mfma32(ah, bl, df);
+          dzt = mfma32(bl, sel, dzt);
+          df = mfma32(ah, bh, df);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                          // dW1[32 m + ..][f] += sum over samples 8 (2 q + (j >> 2)) + 4 h + (j & 3)
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = dzt[8 * q + j];
+          bf16x8 th, tl;
+          split8c(v, th, tl);
+          w1acc[m] = mfma32(tl, Fh[q], w1acc[m]);
+          w1acc[m] = mfma32(th, Fl[q], w1acc[m]);
+          w1acc[m] = mfma32(th, Fh[q], w1acc[m]);
+        }
+      }
+    }
+    if (have) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        row_store_plain(grd + trow + (GRD_DFEAT / 16 + (q >> 1)) * 256 + (((2 * (q & 1) + h) * 16 + s) << 2),
+                        make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]));
+    }
+    // ---- dX = basis^T dfeat: register r of tile mt = value 16 mt + r of this lane half = channel w32_chan(h, 16 mt + r)
+    f32x16 dx[3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[mt][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = df[8 * q + j];
+      bf16x8 bh, bl;
+      split8c(v, bh, bl);
+      mma3_step<3>(img, W32T_BAS + q, 2, lane, bh, bl, dx);
+    }
+    float dX[36];
+#pragma unroll
+    for (int vv = 0; vv < 36; ++vv) dX[vv] = dx[vv >> 4][vv & 15];
+    if (have) {                                                // dX row, natural channel order: 48 contiguous bytes per plane and lane half
+      float* gdx = grd + trow + GRD_DX * 16 + s * (GRD_LD - GRD_DX) + 12 * h;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          row_store_plain(gdx + p * LRF_CA + 4 * i, make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]));
+    }
+    // ---- d/d(position) from the appearance lookups
+    const float zk = s_z[k];
+    float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
+    float xc[3] = {xr[0], xr[1], xr[2]};
+    contract3(xc[0], xc[1], xc[2]);
+    float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - f.lo[a]) * f.inv[a] - 1.0f;
+    if (valid && !(dbg & 2)) {
+      int i0[3], i1[3]; float t[3], gm[3];
+      tap1d_g(u[0], f.pw[0], i0[0], i1[0], t[0], gm[0]);       // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps)
+      tap1d_g(u[1], f.ph[0], i0[1], i1[1], t[1], gm[1]);
+      tap1d_g(u[2], f.ll[0], i0[2], i1[2], t[2], gm[2]);
+      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu);
+      __builtin_amdgcn_sched_barrier(0);                       // one plane's 18 gathers in flight at a time: the dW1 accumulators stay resident
+      app12_position_grad<1>(f, i0, i1, t, gm, h, dX + 12, gu);
+      __builtin_amdgcn_sched_barrier(0);
+      app12_position_grad<2>(f, i0, i1, t, gm, h, dX + 24, gu);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gu[a] += __shfl_xor(gu[a], 32, 64);      // the two channel halves of a sample
+    float gx3[3] = {gu[0] * f.inv[0], gu[1] * f.inv[1], gu[2] * f.inv[2]};
+    contract3_bwd(xr, gx3);
+    float prt[6] = {gx3[0], gx3[1], gx3[2], gx3[0] * zk, gx3[1] * zk, gx3[2] * zk};
+    if (!valid) { prt[0] = prt[1] = prt[2] = prt[3] = prt[4] = prt[5] = 0.0f; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int dd = 1; dd < 16; dd <<= 1) prt[q] += __shfl_xor(prt[q], dd, 64);       // over the 16 samples of the lane's tile
+    if (have_t && s == 0 && h == 0) {
+      float* rpp = rpart + ((size_t)ray * pmax + ti.w) * 8;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rpp[q] = prt[q];
+    }
+  }
+  // ---- dW1 partial of the workgroup: the waves' accumulators meet in LDS (the image is no longer needed), upper half of the
+  // remaining waves into the lower half, in a fixed order; wave 0 writes the block
+  f32x4* s_red = reinterpret_cast<f32x4*>(s_dyn3);           // [wave slot][16 float4 of the 64 accumulator registers][lane]
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (wave >= half && wave < 2 * half) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          s_red[((wave - half) * 16 + 4 * m + q) * 64 + lane] = f32x4{w1acc[m][4 * q], w1acc[m][4 * q + 1], w1acc[m][4 * q + 2], w1acc[m][4 * q + 3]};
+    }
+    __syncthreads();
+    if (wave < half) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o4 = s_red[(wave * 16 + 4 * m + q) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w1acc[m][4 * q + r] += o4[r];
+        }
+    }
+  }
+  if (wave == 0) {
+    float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W1;           // [128 units][32 features (27 = the bias column)]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * 32 + n] = w1acc[m][r];
+  }
+}

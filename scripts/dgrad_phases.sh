@@ -1,0 +1,7 @@
+#!/bin/bash
+# k_train_dgrad3 with phases switched off (results wrong by construction; only the times mean something)
+export TMPDIR=/tmp
+for e in 1 33 65 129; do
+  TRAIN_ENG=$e bash scripts/serial_trace.sh dg$e > /dev/null 2>&1
+  echo "TRAIN_ENG=$e: $(grep -E 'k_train_dgrad3' gpurun_out/serial_dg$e.md | cut -d'|' -f2-7) $(grep 'fwd+bwd' gpurun_out/serial_dg$e.log)"
+done

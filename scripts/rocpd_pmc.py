@@ -5,7 +5,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-KEEP = ("k_march", "k_shade", "k_app", "k_mlp", "k_dense", "k_alpha", "k_finalize", "k_scan", "k_bwd", "k_pack", "k_scatter", "k_wgrad", "k_bin", "k_scene")
+KEEP = ("k_train", "k_sort", "k_march", "k_shade", "k_app", "k_mlp", "k_dense", "k_alpha", "k_finalize", "k_scan", "k_bwd", "k_pack", "k_scatter", "k_wgrad", "k_bin", "k_scene")
 rows = defaultdict(dict)
 dur = {}
 for path in sys.argv[1:]:

@@ -213,7 +213,7 @@ def test_saved_row_layout_is_a_bijection_and_matches_the_test_reader(built_lib):
     1 KB, the dX block is row-major, the X-block slot columns are a bijection of the 72 channels -- and the
     permute that tests/util.py::relu_flip_report uses to read the rows agrees with it."""
     off = built_lib.lrf_debug_saved_row_offset
-    for buf, ld in ((0, 112), (1, 256)):
+    for buf, ld in ((0, 112), (1, 128)):
         assert off(buf, 0, ld) == -1 and off(buf, 0, -1) == -1
         rows = list(range(0, 48)) + [16 * 1000 + 5]
         seen = set()
@@ -223,15 +223,15 @@ def test_saved_row_layout_is_a_bijection_and_matches_the_test_reader(built_lib):
                 assert (r // 16) * 16 * ld <= o < (r // 16 + 1) * 16 * ld          # inside the row's tile
                 assert o not in seen
                 seen.add(o)
-        nfrag = ld if buf == 0 else 176                                            # GRD: columns 176.. are the dX block
+        nfrag = ld if buf == 0 else 48                                             # GRD: columns 48.. are the dX block
         for c in range(0, nfrag, 4):                                               # a lane's float4
             assert [off(buf, 7, c + k) - off(buf, 7, c) for k in range(4)] == [0, 1, 2, 3]
         for blk in range(nfrag // 16):                                             # a wave's store: lanes (s, g) -> 1 KB
             base = off(buf, 0, 16 * blk)
             got = sorted(off(buf, s, 16 * blk + 4 * g) - base for s in range(16) for g in range(4))
             assert got == list(range(0, 256, 4))
-    assert [off(1, 3, 176 + k) - off(1, 3, 176) for k in range(80)] == list(range(80))   # dX: row-major inside the tile
-    assert off(1, 4, 176) - off(1, 3, 176) == 80
+    assert [off(1, 3, 48 + k) - off(1, 3, 48) for k in range(80)] == list(range(80))     # dX: row-major inside the tile
+    assert off(1, 4, 48) - off(1, 3, 48) == 80
     cols = [off(2, ch, ch) for ch in range(72)]
     assert off(2, 0, 72) == -1 and len(set(cols)) == 72 and all(0 <= c < 80 for c in cols)
     for p in range(3):                                                             # lane group g, slot q = 6 p + c

@@ -9,8 +9,8 @@ __graft_entry__.build() compiles it and the device assembly is inspected.
    was the cause of the run-to-run differences of rounds 1-2 (DESIGN.md finding 17).
 2. k_shade3 (the default colour kernel): 135 v_mfma_f32_32x32x16_bf16 per tile (15 basis + 24 layer 1 + 96 layer 2),
    no scratch, at most 256 registers (two waves per SIMD).
-3. k_march and the two row kernels of the training step (k_bwd_shade_fwd, k_bwd_shade_dgrad) use no scratch (round 2:
-   80 and 52 bytes per lane); the weight-gradient GEMMs keep their shape.
+3. k_march and the row-saving forward of the training step (k_bwd_shade_fwd) use no scratch, the 32-sample data-gradient
+   kernel (k_train_dgrad3) at most two spilled addresses; the weight-gradient GEMMs keep their shape.
 """
 import os
 import re
@@ -94,8 +94,10 @@ def test_shade3_shape(asm):
 
 
 def test_scratch_use_is_bounded(asm):
+    # (k_train_dgrad3 lives at the 256-register limit of two waves per SIMD with its 64 dW1 accumulators: two 8-byte address
+    # spills per pair of tiles are tolerated, nothing more)
     for pat, limit in ((r"k_marchILb1EE", 0), (r"k_marchILb0EE", 0), (r"k_bwd_shade_fwdE", 0),
-                       (r"k_bwd_shade_dgradILb1EE", 0)):
+                       (r"k_train_dgrad3ILi8EE", 32)):
         for name, _ in _body(asm, pat):
             meta = asm[asm.index(".amdhsa_kernel " + name):]
             meta = meta[:meta.index(".end_amdhsa_kernel")]
@@ -103,7 +105,7 @@ def test_scratch_use_is_bounded(asm):
             assert priv and int(priv[1]) <= limit, (name, priv and priv[1])
 
 
-WGRAD = ("k_wgrad_w2w3E", "k_wgradILi8ELi2ELb0EE", "k_wgradILi2ELi5ELb1EE")
+WGRAD = ("k_wgrad_w2w3E", "k_wgradILi2ELi5ELb1EE")
 
 
 def test_weight_gradient_gemms(asm):
