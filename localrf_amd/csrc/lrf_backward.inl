@@ -1166,6 +1166,9 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
       // 6 channels 6s..6s+5 (two float4 of the padded texel per tap -- the texture path retires one
       // wave-level load per ~16 cycles whatever its width, so wide loads are what counts);
       // density: 8 lanes per entry, one channel each.
+      // (density taps fetched as float4 by the group and redistributed through 192 bytes of LDS per group -- 2 gather
+      // instructions + 8 LDS operations instead of 7 dword gathers per entry -- was measured too: 258 -> 306 us; the kernel is
+      // bound by its LDS adds, not by the texture path.)
       // (density with 2 lanes per entry and float4 taps -- 3.5 x fewer gather instructions -- was measured in round 4: 244 ->
       // 640-800 us.  Thirty-two lane pairs then work on 64 CONSECUTIVE samples of a ray at once, which share their cells, and
       // their same-address CAS adds serialise; with 8 lanes per entry a group merges 8 consecutive samples in registers.)
