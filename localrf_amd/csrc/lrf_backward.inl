@@ -494,6 +494,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 //   * the W3 / W2 contractions of the epilogue run once per chunk, in registers; the view / bias columns of dW3 come
 //     from the (dhat, 1) quadruple the data-gradient kernel left in the go block.
 // Rows behind the chunk's end read tile r0 again; their go and mask bits are zeroed in LDS, so they contribute nothing.
+// (Measured and dropped: 64-row steps double-buffered in LDS, four alternating waves staging step i + 1 while all eight
+// multiply step i, one barrier per step -- 228 us against 200 us: twice the barriers, and the staging waves hold the others up.)
 constexpr int W23_KT = 128, W23_CS = W23_KT + 8, W23_NT = 9;
 constexpr size_t W23_LDS = (size_t)(8 * 128) * 16 + 128 * 4 + 2 * (size_t)(W23_NT * 16) * W23_CS * 2 + (size_t)6 * W23_KT * 2
                          + (size_t)LRF_FEATC * (W23_KT / 32) * 4;
