@@ -13,23 +13,24 @@
 //                        instruction).  The hidden activations themselves are not stored (round 4).
 // backward (two branches on two streams, lrf_render_bwd):
 //   k_train_dgrad3       (lrf_train32.inl) per pair of tiles: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX on TRANSPOSED
-//                        weight fragments, split-bf16 on v_mfma_f32_16x16x32_bf16 (same register-
-//                        resident trick as the forward: D layout of one layer = B operand of
-//                        the next; <false>: exact fp32 chain), ReLU masks from the saved bits,
-//                        gradient row GRD = [go, dhat | dfeat | dz1 | dX];
-//                        d/d(position) of the appearance lookups -> per-tile ray partials
-//   k_wgrad_w2w3         dW2 = dz2^T [relu(h1) | 1] and dW3 = go^T [relu(h2) | dhat | 1]: h1, h2 recomputed from the
-//                        saved feat rows (the forward's own MFMA chain), dz2 rebuilt from go + mask bits
-//   k_wgrad<MT,NT,KS> x2 dW1 and dbasis as tall-skinny GEMMs C = A^T B over the saved rows
-//                        (K = shaded samples) on v_mfma_f32_16x16x4_f32, per-chunk partials
+//                        weight fragments, split-bf16 on v_mfma_f32_32x32x16_bf16, 32 samples per wave (same register-
+//                        resident trick as k_shade3: D layout of one product = B operand of the next), ReLU masks
+//                        from the saved bits; dW1 / db1 accumulated in-kernel (transposes on the matrix pipe);
+//                        gradient row GRD = [go, dhat | dfeat | dX]; d/d(position) of the appearance lookups ->
+//                        per-tile ray partials
+//   k_wgrad_w2w3         dW2 = dz2^T [relu(h1) | 1] and dW3 = go^T [relu(h2) | dhat | 1] from three masked products over
+//                        relu(h1) recomputed from the saved feat rows; no h1 / h2 / dz2 rows
+//   k_wgrad<2,5,KSPLIT>  dbasis as a tall-skinny GEMM C = A^T B over the saved rows (K = shaded samples) on
+//                        v_mfma_f32_16x16x4_f32, per-chunk partials
 //   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts (1 launch)
 //   k_bwd_ray            one wavefront per ray: weights, d(loss)/d(w), suffix sums ->
 //                        d/d(alpha) -> d/d(density feature); position gradients through
 //                        normalise / contraction to d(loss)/d(rays)
 //   k_bin_hist/scan/fill counting sort of the (sample, plane) entries by 32x32-texel tile
-//   k_scatter_plane/line plane / line gradients accumulated per workgroup in LDS (CAS-loop fp32
-//                        adds; ds_add_f32 is 30x slower on this chip), runs of consecutive
-//                        same-cell entries merged in registers first
+//   k_scatter_plane      plane AND line gradients of one pass over the binned entries, accumulated per workgroup in
+//                        LDS (CAS-loop fp32 adds; ds_add_f32 is 30x slower on this chip), runs of consecutive
+//                        same-cell entries merged in registers first, tiles added straight into the reference layout
+//                        (k_scatter_line: the fallback where tile + line accumulators exceed LDS)
 #pragma once
 
 namespace lrf {
@@ -169,10 +170,10 @@ __device__ __forceinline__ void save_x_plane(float* afr, const float v[8], float
 }
 
 // dX of (row, plane p, lane group sub): six channels 24 p + 6 sub .. + 5 from the GRD tile's row-major dX block.
-// (Slot order like the X block -- five coalesced float4 stores per lane in k_bwd_shade_dgrad instead of nine 8-byte
+// (Round 2, 16-sample data-gradient kernel: slot order like the X block -- five coalesced float4 stores per lane instead of nine 8-byte
 // ones -- was measured: dgrad 282 -> 262 us, but k_scatter_line<24> 178 -> 256 us, whose lanes walk the rows in
 // order and then read 24 B out of every 1 KB block; forward+backward 1.99 vs 1.94 ms.  Not adopted.)
-// (Also measured: k_bwd_shade_dgrad storing dX * L and dX * P -- it holds both factors when it forms the position
+// (Also measured in round 2: the data-gradient kernel storing dX * L and dX * P -- it holds both factors when it forms the position
 // gradient -- so that the appearance scatter kernels need not re-gather the other factor's taps: 288 B more per row,
 // gradients unchanged (74 tests), forward+backward 1.94 vs 1.79 ms.  The scatters are bound by their LDS adds, not by
 // those gathers.  Not adopted.)
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
 #pragma unroll
     for (int a = 0; a < 3; ++a) { go3[a] += gx3[a]; gdh[a] += gx3[a] * zk; }
   }
-  // appearance partials of this ray's tiles (written by k_bwd_shade_dgrad); with rpart == null they are added
+  // appearance partials of this ray's tiles (written by k_train_dgrad3); with rpart == null they are added
   // afterwards by k_rays_add_rpart, so that this kernel does not have to wait for the data-gradient kernel
   const int nt = rpart ? (nsh + ITEM - 1) / ITEM : 0;
   for (int t = lane; t < nt; t += 64) {
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   }
 }
 
-// d(loss)/d(rays) += the appearance lookups' position gradients (per-tile partials of k_bwd_shade_dgrad): the tail of
+// d(loss)/d(rays) += the appearance lookups' position gradients (per-tile partials of k_train_dgrad3): the tail of
 // k_bwd_ray as its own launch, linear in the partial sums: g_o += sum go, g_d += (I - dhat dhat^T) sum gdh / |d|.
 __global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict__ rays, int R, const int* __restrict__ ncomp,
                                                         const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays,
@@ -1385,7 +1386,7 @@ struct BwdWorkspace {
   float* feat; float* crgb; float* imt; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
-  uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_bwd_shade_fwd -> k_bwd_shade_dgrad
+  uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_bwd_shade_fwd -> k_train_dgrad3, k_wgrad_w2w3
   int4* tileinfo;            // [tile] (ray, j0, count, tile in ray), k_bwd_shade_fwd -> k_train_dgrad3
   uint16_t* tid2; int* hist2; int* offs2; int* cursor2; uint32_t* list2;   // bins of the appearance scatter (runs beside the density scatter)
   uint32_t nmax;
@@ -1533,7 +1534,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     launch_shade_save(d, rays, z, S, R, w, b, st);
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
-  //   caller's stream: k_bwd_shade_dgrad -> k_wgrad_w2 (dW2) -> appearance bins + scatter                  [-> join] -> ray partials, unpack
+  //   caller's stream: k_train_dgrad3 -> the weight-gradient kernels (g_wgrad_split of them) -> appearance bins + scatter   [-> join] -> ray partials
   //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) k_wgrad (dW1, dbasis, dW3) -> (dW2 done) reduce
   // (how many of the four GEMMs stay on the caller's stream is g_wgrad_split: 0..4 measured 2.53 / 2.45 / 2.53 / 2.57 / 2.59 ms in
   // round 2; 2.00 / 1.90 / 1.86 / 1.92 / 2.01 ms with the round-3 kernels, 2.20 ms on one stream: two stay)

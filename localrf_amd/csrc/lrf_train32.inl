@@ -1,7 +1,7 @@
 // lrf_train32.inl -- the data-gradient kernel of the training step on the k_shade3 skeleton (round 4): 32 samples per wave on
 // v_mfma_f32_32x32x16_bf16, 512-thread workgroups, compiler-scheduled term-major chain.  Included by lrf_backward.inl.
 //
-// k_bwd_shade_dgrad (16 samples per wave on v_mfma_f32_16x16x32_bf16, 1024-thread workgroups, 128 registers) issued ~1650
+// The round-3 kernel it replaces (16 samples per wave on v_mfma_f32_16x16x32_bf16, 1024-thread workgroups, 128 registers) issued ~1650
 // VALU + 143 MFMA + 179 LDS instructions per 16-sample tile and spent half its wave-cycles in issue stalls
 // (profiles/r11a: 320-330 us).  Here a wave takes two consecutive 16-row tiles of the saved rows (lane n = lane & 31 is
 // row 16 (n >> 4) + (n & 15) of the pair, h = lane >> 5 the K half), so every A fragment feeds 32 columns and the
