@@ -1433,10 +1433,11 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 without row stores / position gradient / products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
 static int g_wgrad_split = 3;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
-static void launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
-                              const BwdWorkspace& b, hipStream_t st) {
+static int launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
+                             const BwdWorkspace& b, hipStream_t st) {
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
                      b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits, b.tileinfo);
+  return 0;
 }
 
 }  // namespace lrf
@@ -1474,7 +1475,7 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   rays = sort_rays_if_asked(d, rays, R, flags, w, st);
   launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-  launch_shade_save(d, rays, z, S, R, w, b, st);
+  if (launch_shade_save(d, rays, z, S, R, w, b, st)) return 1;
   hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
                      R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr, d.perm);
   LRF_HIP(hipGetLastError());
@@ -1531,7 +1532,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-    launch_shade_save(d, rays, z, S, R, w, b, st);
+    if (launch_shade_save(d, rays, z, S, R, w, b, st)) return 1;
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
   //   caller's stream: k_train_dgrad3 -> the weight-gradient kernels (g_wgrad_split of them) -> appearance bins + scatter   [-> join] -> ray partials

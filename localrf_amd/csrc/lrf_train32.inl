@@ -392,3 +392,9 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
       for (int r = 0; r < 16; ++r) out[(32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * 32 + n] = w1acc[m][r];
   }
 }
+
+// (Round 4 also built the ROW-SAVING FORWARD on this skeleton -- k_shade3's gather and chain on a pair of 16-row tiles per
+// wave, X block / feat / mask dwords / rgb / partials written in the 16-row fragment order -- and measured it: correct on
+// all 103 GPU tests, 318-338 us against 175-179 us for k_bwd_shade_fwd.  Without k_shade3's tile queue and one-tile-ahead
+// header prefetch the dependent chain toff -> ncomp -> cidx -> z -> gathers is exposed at two waves per SIMD, and the
+// extra per-lane state pushed the chain into 95 spilled registers.  Not kept; profiles/r11 s7.)
