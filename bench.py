@@ -580,23 +580,32 @@ def main():
     gd = torch.randn(R_PER_GPU, device=dev)
     reduced = [0]
 
+    comm = [True]
+
     def train_step():
         opt.zero_grad()
         rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=ns_arg)
         ((rgb * gr).sum() + (depth * gd).sum()).backward()
-        if ddp:
+        if ddp and comm[0]:
             reduced[0] = allreduce_grads(field)
         opt.step()
     t_steps = max(5, min(args.steps, 20))
+    dtt_nocomm = None
+    if ddp and world > 1:                                    # the same step without the collective: what the all-reduce costs on this N
+        comm[0] = False
+        dtt_nocomm = timed(train_step, t_steps, 3, sync)
+        comm[0] = True
     dtt = timed(train_step, t_steps, 3, sync)
     if args.child == "train":                                 # the PMC passes count exactly (3 + t_steps) training steps
         return
     field.load_state_dict(sd_init)
     del sd_init
-    tmax = torch.tensor([dtt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dtt, dtt_nocomm if dtt_nocomm is not None else 0.0], device=dev, dtype=torch.float64)
     if ddp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dtt = float(tmax.item())
+    dtt = float(tmax[0].item())
+    if dtt_nocomm is not None:
+        dtt_nocomm = float(tmax[1].item())
 
     if rank == 0:
         z = field.z_schedule(False, N_SAMPLES_ARG, dev).contiguous()
@@ -622,6 +631,7 @@ def main():
         # dW1 dz1 + feat 640 B, dbasis dfeat + X 448 B, the data gradient bits + rgb 48 B, the scatters dX twice + ids 584 B
         train_bytes = rows * ((448 + 1024 + 32 + 16) + (176 + 640 + 448 + 48 + 584)) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
         train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
+                 "ms_per_step_without_allreduce": (dtt_nocomm / t_steps * 1e3 if dtt_nocomm is not None else None),
                  "what": "lrf_render_fwd_train + lrf_render_bwd + "
                          + (f"allreduce_grads over RCCL ({reduced[0] / 1e6:.1f} MB in place) + " if ddp else "")
                          + "FusedAdam, 4096 rays x 512 samples per GPU, jittered samples",

@@ -961,3 +961,40 @@ def test_scene_forward_single_native_call_equals_the_per_field_path(chunk, min_c
         assert torch.equal(a, b), name
     if test_id:                                                 # and the reference's own values for this call
         assert np.abs(native[0].cpu().numpy() - g["rgbs_testid"]).max() < 1e-4
+
+
+def test_gradient_buckets_become_final_in_order_and_can_be_awaited_separately(built_lib):
+    """lrf_render_bwd_wait (the hand-off localrf_amd.dist uses to start the density all-reduce while the rest of the
+    backward runs): after a backward, a side stream that waits for bucket k only must see that bucket's gradients final --
+    equal to what the caller's stream sees at the end -- for k = 0 (density), 1 (colour network), 2 (appearance); the
+    segments of grad_bucket() tile the flat buffer in that order; the chunked single-process 'reduction' of
+    localrf_amd.dist._reduce_field_chunks touches every byte once.  Bad bucket ids fail loudly."""
+    import ctypes as C
+    from localrf_amd import _native as N
+    from util import make_field, make_rays
+    f = quiet(make_field, [48, 40, 44], "cpu", seed=7).to(DEV)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(3.0)
+    rays = make_rays(700, 9, pinhole=True).to(DEV)
+    g = torch.Generator().manual_seed(10)
+    gr, gd = torch.randn(700, 3, generator=g).to(DEV), torch.randn(700, generator=g).to(DEV)
+    rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=120)
+    ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    flat, held = f.grad_bucket()
+    segs = f.grad_segments()
+    assert len(segs) == 3 and sorted(segs)[0][0] == 0 and sorted(segs)[-1][1] == flat.numel()
+    covered = sorted(segs)
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(2))          # the three buckets tile the parameter part
+    side = torch.cuda.Stream(DEV)
+    snaps = []
+    for which, (a, b) in enumerate(segs):
+        f._wait_bwd_bucket(which, side)
+        with torch.cuda.stream(side):
+            snaps.append(flat[a:b].clone())
+    torch.cuda.synchronize()
+    for (a, b), snap in zip(segs, snaps):
+        assert torch.equal(snap, flat[a:b])
+        assert float(snap.abs().max()) > 0
+    assert N.lib().lrf_render_bwd_wait(3, C.c_void_p(side.cuda_stream)) != 0
+    assert b"bucket" in N.lib().lrf_last_error()
