@@ -622,14 +622,15 @@ def main():
         roofline = roofline_object(prof, S, traffic or {}, traffic_src, cus=torch.cuda.get_device_properties(dev).multi_processor_count)
         n_sh = prof["n_shaded"]
         rows = ((n_sh + 15) // 16) * 16
-        # bytes the training step moves through HBM-side memory by construction: the saved activation /
-        # gradient rows (ACT 112 + GRD 256 floats per row since round 4 -- the hidden activations are recomputed, not stored;
-        # the data gradient takes its ReLU masks from 32 B per sample), the density features (R*S floats, written + read twice), gradient images + reference-layout
-        # gradients (3 x 35 MB) + Adam (param, m, v read+write) -- cache-served gathers not counted
+        # bytes the training step moves through HBM-side memory by construction: the saved activation / gradient rows
+        # (ACT 32 + GRD 128 floats per row since round 4 -- hidden activations and the plane x line products are recomputed, not
+        # stored; dW1 and dbasis are accumulated in the kernels that hold their operands), the density features (R*S floats,
+        # written + read twice), reference-layout gradients + Adam (param, m, v read+write) -- cache-served gathers not counted
         n_par = sum(p.numel() for p in field.parameters() if p.requires_grad)
-        # per row: written ACT 448 B + GRD 1024 B + mask bits 32 B + rgb / rowinfo 16 B; read: k_wgrad_w2w3 feat + go + bits 176 B,
-        # dW1 dz1 + feat 640 B, dbasis dfeat + X 448 B, the data gradient bits + rgb 48 B, the scatters dX twice + ids 584 B
-        train_bytes = rows * ((448 + 1024 + 32 + 16) + (176 + 640 + 448 + 48 + 584)) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
+        # per row: written feat 128 B + GRD 512 B (go block 64, dfeat 128, dX 320) + mask bits 32 B + rgb / rowinfo 16 B;
+        # read: k_wgrad_w2w3 feat + go + bits 224 B, k_train_dgrad3 bits + rgb + feat 172 B, k_train_app3 dfeat 128 B,
+        # the appearance scatter dX + ids 304 B
+        train_bytes = rows * ((128 + 512 + 32 + 16) + (224 + 172 + 128 + 304)) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
         train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
                  "ms_per_step_without_allreduce": (dtt_nocomm / t_steps * 1e3 if dtt_nocomm is not None else None),
                  "what": "lrf_render_fwd_train + lrf_render_bwd + "

@@ -35,11 +35,11 @@
 
 namespace lrf {
 
-// weight-gradient partial block per K-chunk (floats)
+// weight-gradient partial block per K-chunk of rows (W2, W3: k_wgrad_w2w3) / per workgroup (W1: k_train_dgrad3, BAS: k_train_app3), floats
 constexpr int WP_W2 = 0;                            // [128][144]  dz2^T [h1r | 1]
 constexpr int WP_W1 = WP_W2 + 128 * 144;            // [128][32]   dz1^T [feat | 1]
-constexpr int WP_BAS = WP_W1 + 128 * 32;            // [32][80]    dfeat^T X
-constexpr int WP_W3 = WP_BAS + 32 * 80;             // [16][144]   go^T [h2r | dhat | 1]
+constexpr int WP_BAS = WP_W1 + 128 * 32;            // [32][96]    dfeat^T X, plane p's 24 channels in columns 32 p .. 32 p + 23
+constexpr int WP_W3 = WP_BAS + 32 * 96;             // [16][144]   go^T [h2r | dhat | 1]
 constexpr int WP_FLOATS = WP_W3 + 16 * 144;
 // rows per K-chunk of the weight-gradient GEMMs: about one chunk per CU (a multiple of 256 rows, at least 512), from
 // the number of rows the forward actually produced -- at configs[1] 768 K rows -> 3072: fixed chunk sizes measured
@@ -164,11 +164,6 @@ __device__ __forceinline__ float4 row_load4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 #endif
 }
-template <int P>
-__device__ __forceinline__ void save_x_plane(float* afr, const float v[8], float xc[2]) {
-  save_x_plane_with<P>(afr, v, xc, [](float* p, float4 q) { row_store_b<2>(p, q); });
-}
-
 // dX of (row, plane p, lane group sub): six channels 24 p + 6 sub .. + 5 from the GRD tile's row-major dX block.
 // (Round 2, 16-sample data-gradient kernel: slot order like the X block -- five coalesced float4 stores per lane instead of nine 8-byte
 // ones -- was measured: dgrad 282 -> 262 us, but k_scatter_line<24> 178 -> 256 us, whose lanes walk the rows in
@@ -224,26 +219,23 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
     const int k = cidx[ci];
     float x[3], u[3];
     sample_point(f, o, dh, z[k], x, u);
-    float* afr = frag_lane_base(act, (size_t)tw.t, ACT_LD, s, g);      // + 16 * COL: this lane's float4 of block column COL
 
     f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
     {
       float v[8];
       bf16x8 bh, bl;
-      const AxisTaps at = axis_taps(f.pw[0], f.ph[0], f.ll[0], u);   // 32-bit gathers, taps once per axis
-      float xc[2];
+      int gx = f.pw[0], gy = f.ph[0], gz = f.ll[0];
+      asm volatile("" : "+s"(gx), "+s"(gy), "+s"(gz));               // (float)(size - 1) re-formed per tile: hoisted, the three values are spilled at 128 registers
+      const AxisTaps at = axis_taps(gx, gy, gz, u);                  // 32-bit gathers, taps once per axis
       gather_app6_plane32<0>(f, at, g, v);
-      save_x_plane<0>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
       gather_app6_plane32<1>(f, at, g, v);
-      save_x_plane<1>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
       __builtin_amdgcn_sched_barrier(0);                 // the third plane's gathers stay behind the second's products: with all three
       gather_app6_plane32<2>(f, at, g, v);               // in flight at once the kernel spilled 8 registers per tile (same speed)
-      save_x_plane<2>(afr, v, xc);
       split8(v, bh, bl);
       gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
       settle<2>(fe);
@@ -254,6 +246,7 @@ __global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
       float4 b = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
       if (g == 2) b.w = 1.0f;                        // column 27 = bias column of the dW1 GEMM
       if (g == 3) b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float* afr = frag_lane_base(act, (size_t)tw.t, ACT_LD, s, g);      // + 16 * COL: this lane's float4 of block column COL
       row_store_b<32>(afr + 16 * ACT_FEAT, a);
       row_store_b<32>(afr + 16 * (ACT_FEAT + 16), b);
     }
@@ -345,136 +338,6 @@ __device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
   return __uint_as_float(__float_as_uint(x) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, k, 1));
 }
 // ---------------------------------------------------------------- weight gradients
-// C[M x N] partial = A[rows, M]^T  B[rows, N] over one K-chunk of saved rows.
-// 4 waves; wave w owns M-tiles w, w+4, ...; every wave sweeps all NT N-tiles.  Rows are staged
-// 32 at a time through LDS with coalesced float4 loads (the first version fetched MFMA fragments
-// straight from global memory, one predicated dword per lane and k-step: 1.3 TB/s); the LDS row
-// stride is = 16 (mod 32) so the four 16-lane groups of a fragment read hit disjoint banks.
-// KSPLIT = false: wave w owns M-tiles w, w+4, ... (the 128 x 144 product: 18 accumulator tiles per
-// wave).  KSPLIT = true, for the narrow products (M-tiles < 4 would leave waves idle, and one
-// M-tile per wave means one LDS read per MFMA): every wave holds ALL MT x NT accumulator tiles and
-// takes every fourth k-step; the four partial sums meet in LDS at the end, in wave order.
-template <int MT, int NT, bool KSPLIT>
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                               const int* __restrict__ toff, int R, float* __restrict__ wpart, int wp_off) {
-  constexpr int KT = 32, WA = MT * 16, WB = NT * 16;
-  constexpr int LD = ((WA + WB) % 32 == 16) ? (WA + WB) : (WA + WB + 16);
-  static_assert(!KSPLIT || MT * NT * 256 <= KT * LD, "cross-wave reduction reuses the staging tile");
-  __shared__ __attribute__((aligned(16))) float s_t[KT * LD];
-  const int rows = toff[R] * 16;
-  const int WGRAD_CH = wgrad_chunk_rows(rows);
-  const int r0 = blockIdx.x * WGRAD_CH;
-  if (r0 >= rows) return;
-  const int r1 = min(r0 + WGRAD_CH, rows);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-  constexpr int MW = KSPLIT ? MT : (MT + 3) / 4;
-  f32x4 acc[MW][NT];
-#pragma unroll
-  for (int m = 0; m < MW; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
-  // Operands arrive in fragment order (lrf_common.h): A / B point at their first block of tile 0, a tile is 16 * ld
-  // floats further.  One float4 per thread and step: wave-instruction = one whole 1 KB block; inside it the lanes are
-  // dealt (s & 1, lane group, s >> 1) so that the eight lanes of an LDS write cycle land in eight different bank quads of
-  // the row-major staging tile (rows 2 apart share banks: LD = 16 mod 32).
-  constexpr int NBLK = MT + NT;                              // 16-column blocks per tile (A then B)
-  constexpr int NF4 = (KT / 16) * NBLK * 64;                 // float4 per K-step of 32 rows
-  constexpr int NQ = (NF4 + 255) / 256;                      // float4 per thread and tile
-  float4 pre0[NQ];
-  auto fetch = [&](float4 (&pre)[NQ], int rb) {                                  // global -> registers (next tile)
-#pragma unroll
-    for (int t = 0; t < NQ; ++t) {
-      const int q = threadIdx.x + 256 * t;
-      const int l = q & 63, bt = q >> 6, blk = bt % NBLK, th = bt / NBLK;
-      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      // no branch around the load (rows behind the chunk read row r0 again and are zeroed in stage()): the compiler
-      // counts unconditional loads, so stage() waits for ITS buffer only (vmcnt(n), not vmcnt(0))
-      const int row = rb + 16 * th + sr;
-      const size_t tile = (size_t)((q < NF4 && row < r1 ? row : r0) >> 4);
-      const float* src = blk < MT ? A + tile * (size_t)(16 * lda) + blk * 256 : B + tile * (size_t)(16 * ldb) + (blk - MT) * 256;
-      pre[t] = row_load4(src + ((gq * 16 + sr) << 2));
-    }
-  };
-  auto stage = [&](const float4 (&pre)[NQ], int rb) {         // registers -> LDS staging tile
-    __syncthreads();                                         // previous tile fully consumed
-#pragma unroll
-    for (int t = 0; t < NQ; ++t) {
-      const int q = threadIdx.x + 256 * t;
-      const int l = q & 63, bt = q >> 6, blk = bt % NBLK, th = bt / NBLK;
-      const int sr = (l & 1) | ((l >> 3) << 1), gq = (l >> 1) & 3;
-      const bool ok = rb + 16 * th + sr < r1;
-      if (q < NF4) *reinterpret_cast<float4*>(&s_t[(16 * th + sr) * LD + 16 * blk + 4 * gq]) = ok ? pre[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    __syncthreads();
-  };
-  auto compute = [&]() {
-    // (as in k_wgrad_w2: every LDS operand of the 32 rows first, behind a scheduling barrier, then the MFMAs)
-    constexpr int NKS = KSPLIT ? KT / 16 : KT / 4;
-    float a[NKS][MW], b[NKS][NT];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int kk = KSPLIT ? 4 * ks + wave : ks;
-      const float* rowp = &s_t[(4 * kk + g) * LD + i];
-#pragma unroll
-      for (int m = 0; m < MW; ++m) {
-        const int mt = KSPLIT ? m : wave + 4 * m;
-        a[ks][m] = (mt < MT) ? rowp[16 * mt] : 0.0f;
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b[ks][n] = rowp[WA + 16 * n];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[ks][m], b[ks][n], acc[m][n]);
-    };
-  // (Two prefetched steps in flight instead of one -- the loads are branch-free so that stage() waits with vmcnt(n) for
-  // its own buffer only -- were measured: the narrow products 126 -> 114, 101 -> 98 us, k_wgrad_w2 251 -> 274 us at
-  // 451 registers, forward+backward 1.99 vs 1.93-1.97 ms.  Not adopted; the branch-free loads stayed.)
-  fetch(pre0, r0);
-  for (int rb = r0; rb < r1; rb += KT) {
-    stage(pre0, rb);
-    fetch(pre0, rb + KT);
-    compute();
-  }
-  if (KSPLIT) {                                              // waves 1..3 hand their sums to wave 0, in order
-    for (int w = 1; w < 4; ++w) {
-      __syncthreads();
-      if (wave == w) {
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(&s_t[((m * NT + n) * 64 + lane) * 4]) = acc[m][n];
-      }
-      __syncthreads();
-      if (wave == 0) {
-#pragma unroll
-        for (int m = 0; m < MW; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(&s_t[((m * NT + n) * 64 + lane) * 4]);
-            acc[m][n] += o;
-          }
-      }
-    }
-    if (wave != 0) return;
-  }
-  float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + wp_off;
-#pragma unroll
-  for (int m = 0; m < MW; ++m) {
-    const int mt = KSPLIT ? m : wave + 4 * m;
-    if (mt < MT) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * (NT * 16) + 16 * n + i] = acc[m][n][r];
-    }
-  }
-}
-
 // dW2 (+ db2) = dz2^T [relu(h1) | 1] and dW3 (+ db3) = go^T [relu(h2) | dhat | 1] with NEITHER hidden activation stored
 // and without recomputing layer 2.  Round 3 read 576 B of h1 and 576 B of h2 per shaded sample here (and the forward
 // wrote them: 1.8 GB per step at BASELINE configs[1]).  With m2 = [h2 > 0] (the saved mask bits), B = [relu(h1) | 1]:
@@ -697,7 +560,7 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
 
 // dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in a fixed order) for
 // the seven weight / bias tensors in one launch: 16 lanes per output element.
-struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem, x_slots, nch; float* dst; };   // x_slots: source column of n is x_slot_col(n); nch: partial blocks (0: one per K-chunk of rows)
+struct WgradSeg { int off, ld, n_off, m_count, n_count, dst_ld, first_elem, x_slots, nch; float* dst; };   // x_slots: source column of channel n is 32 (n / 24) + n % 24 (WP_BAS); nch: partial blocks (0: one per K-chunk of rows)
 struct WgradSegs { WgradSeg s[7]; int total_elems; };
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ wpart, const int* __restrict__ toff, int R,
                                                       WgradSegs segs) {
@@ -712,7 +575,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   const int WGRAD_CH = wgrad_chunk_rows(toff[R] * 16);
   const int nch = sg.nch ? sg.nch : (toff[R] * 16 + WGRAD_CH - 1) / WGRAD_CH;
   float acc = 0.0f;
-  const int src = sg.off + m * sg.ld + sg.n_off + (sg.x_slots ? x_slot_col(n) : n);
+  const int src = sg.off + m * sg.ld + sg.n_off + (sg.x_slots ? 32 * (n / 24) + n % 24 : n);
   for (int c = sub; c < nch; c += 16) acc += wpart[(size_t)c * WP_FLOATS + src];
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);          // fixed tree: deterministic
@@ -1430,9 +1293,9 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
 
 // The row-saving colour kernel of the training forward is k_bwd_shade_fwd behind k_scan_tiles.  (Round 2 also built it
 // in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
-static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 without row stores / position gradient / products (timing only)
+static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 + k_train_app3 without row stores / position gradient and X / dz1 products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
-static int g_wgrad_split = 3;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n weight-gradient GEMMs on the caller's stream
+static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static int launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
                              const BwdWorkspace& b, hipStream_t st) {
   hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
@@ -1522,6 +1385,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_dgrad3<8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
       lds_attr_err[dev_id & 63] = e;
@@ -1535,10 +1400,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     if (launch_shade_save(d, rays, z, S, R, w, b, st)) return 1;
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
-  //   caller's stream: k_train_dgrad3 -> the weight-gradient kernels (g_wgrad_split of them) -> appearance bins + scatter   [-> join] -> ray partials
-  //   side stream:     k_bwd_ray -> density bins + scatter -> (dgrad done) k_wgrad (dW1, dbasis, dW3) -> (dW2 done) reduce
-  // (how many of the four GEMMs stay on the caller's stream is g_wgrad_split: 0..4 measured 2.53 / 2.45 / 2.53 / 2.57 / 2.59 ms in
-  // round 2; 2.00 / 1.90 / 1.86 / 1.92 / 2.01 ms with the round-3 kernels, 2.20 ms on one stream: two stay)
+  //   caller's stream: k_train_dgrad3 -> k_train_app3 [-> k_wgrad_w2w3] -> appearance bins + scatter   [-> join] -> ray partials
+  //   side stream:     k_bwd_ray -> density bins + scatter [-> (go / dfeat rows there) k_wgrad_w2w3] -> (partials there) reduce
+  // (which stream runs the weight-gradient kernel is g_wgrad_split; rounds 2 / 3 had four GEMMs to place: 2.53 / 2.45 / 2.53 /
+  // 2.57 / 2.59 ms and 2.00 / 1.90 / 1.86 / 1.92 / 2.01 ms for 0..4 of them on the caller's stream, 2.20 ms on one stream)
   // k_bwd_ray and the density scatter need nothing from the data-gradient kernel (the appearance lookups' position
   // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
   // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
@@ -1566,12 +1431,15 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int nblk = (int)((b.nmax + BIN_CHUNK - 1) / BIN_CHUNK);
   for (int q = 0; q < 3; ++q) if ((size_t)L.ll[q] * LRF_CA * 4 > 150 * 1024) return set_err("lrf_render_bwd: line too long for LDS accumulation");
 
-  // ---- caller's stream: data gradient of the colour network
-  const int n_dgrad_wg = min(cus, WGRAD_MAXCH);            // one dW1 partial block per workgroup (k_wgrad_reduce: fixed count)
-  hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16 + (size_t)S * 4, st, d,
-                     reinterpret_cast<const uint4*>(b.imt), rays, z, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
-                     b.grd, b.rowinfo, b.rpart, w.pmax, b.relu_bits, b.act, b.wpart, g_dgrad_dbg);
-  if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));
+  // ---- caller's stream: data gradient of the colour network, then its appearance half (dX, position gradient, dbasis)
+  const int n_dgrad_wg = min(cus, WGRAD_MAXCH);            // one dW1 / dbasis partial block per workgroup (k_wgrad_reduce: fixed count)
+  hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16, st, d,
+                     reinterpret_cast<const uint4*>(b.imt), rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
+                     b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
+  if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));         // go / dfeat rows: the weight-gradient kernel may start
+  hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8), st, d,
+                     reinterpret_cast<const uint4*>(b.imt), rays, z, S, w.toff, R, b.tileinfo, w.cidx,
+                     b.grd, b.rpart, w.pmax, b.wpart, g_dgrad_dbg & 3);
 
   // ---- side stream: per-ray backward, density scatter
   hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), sb,
@@ -1597,18 +1465,14 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   }
   if (sx) LRF_HIP(hipEventRecord(sx->bucket[0], sb));
 
-  // ---- side stream, once the data gradient is there: weight gradients (row reads, matrix pipe)
-  // weight gradients: the first g_wgrad_split of the four GEMMs (dW2, dW1, dbasis, dW3) stay on the caller's stream
-  // behind the data gradient, the rest run on the side stream behind the density scatter once the data gradient is done
+  // ---- dW2 / dW3 (row reads, matrix pipe): on the caller's stream behind the appearance kernel (g_wgrad_split > 0), or on the
+  // side stream behind the density scatter once the go / dfeat rows are there (g_wgrad_split == 0)
   const int nch_max = WGRAD_MAXCH;      // (blocks behind the last chunk of the actual row count return at once)
-  const int on_a = ss ? g_wgrad_split : 4;
-  if (ss && on_a < 4) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
-  auto wst = [&](int idx) { return idx < on_a ? st : sb; };
-  hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, wst(0), d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
+  const bool w23_on_st = !ss || g_wgrad_split > 0;
+  if (!w23_on_st) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
+  hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, w23_on_st ? st : sb, d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
                      b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
-  hipLaunchKernelGGL((k_wgrad<2, 5, true>), dim3(nch_max), dim3(256), 0, wst(1), b.grd + 16 * GRD_DFEAT, GRD_LD, b.act + 16 * ACT_X, ACT_LD,
-                     w.toff, R, b.wpart, WP_BAS);
-  if (ss && on_a > 0) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream GEMMs are done behind this
+  if (ss) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream partials (dW1, dbasis[, dW2, dW3]) are complete behind this
   {
     WgradSegs segs;
     int nseg = 0, elems = 0;
@@ -1620,11 +1484,11 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     seg(WP_W2, 144, 128, 128, 1, g->b2, 1);
     seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM, 0, n_dgrad_wg);     // accumulated by k_train_dgrad3: one block per workgroup
     seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1, 0, n_dgrad_wg);
-    seg(WP_BAS, 80, 0, LRF_APP_DIM, 72, g->basis, 72, 1);               // the X block is in slot order
+    seg(WP_BAS, 96, 0, LRF_APP_DIM, 72, g->basis, 72, 1, n_dgrad_wg);   // accumulated by k_train_app3: one block per workgroup
     seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
     seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
     segs.total_elems = elems;
-    if (ss && on_a > 0) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));      // partials of the caller's-stream GEMMs
+    if (ss) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));     // partials written on the caller's stream
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, sb, b.wpart, w.toff, R, segs);
   }
   if (sx) LRF_HIP(hipEventRecord(sx->bucket[1], sb));

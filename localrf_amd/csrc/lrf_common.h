@@ -102,22 +102,23 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
 
 // Device-side view of a field, passed by value to kernels.
 // ---- rows the training forward saves per shaded sample for the backward (floats; lrf_backward.inl) --------------
-//   ACT row: X[18 slots x 4 lane groups] (+8 pad) | feat[27], 1 (+pad)                        448 B
+//   ACT row: feat[27], 1 (+pad)                                                               128 B
 //   GRD row: go[3], 0, dhat[3], 1 (+pad) | dfeat | dX                                         512 B
 // The hidden activations are NOT rows (round 4): relu(h1) and relu(h2) are recomputed from `feat` by the one kernel that
 // needs them as GEMM operands (k_wgrad_w2w3: dW2 = dz2^T relu(h1), dW3 = go^T relu(h2)); the data-gradient kernel needs
 // only their signs (relu_bits, 32 B per sample).  That removed 1.15 KB written + 1.15 KB read per shaded sample.  dz1 is not
 // a row either: dW1 = dz1^T [feat | 1] is accumulated inside the data-gradient kernel (lrf_train32.inl), 0.5 + 0.5 KB more.
+// The plane x line products X are not a row either (they were 320 B, read once for dbasis = dfeat^T X): the appearance
+// kernel of the backward (k_train_app3) gathers the taps anyway for the position gradient, so it re-forms X and
+// accumulates dbasis in registers.
 // Layout in memory: MFMA-fragment order, not row-major.  The 16 rows of a tile are stored together; inside a tile every
 // 16-column block is the 1 KB a wave holds for it, [lane group g][sample s][4 columns]: column c of row s of tile t is at
 //   t * 16 * LD + (c / 16) * 256 + ((c / 4 % 4) * 16 + s) * 4 + c % 4            (frag_off below)
 // so that a producer's store instruction (lane (s, g) holds columns 16 b + 4 g .. + 3 of row s) writes 1 KB contiguous
-// instead of sixteen 64-byte pieces 1600 B apart, and the weight-gradient GEMMs stage whole blocks with contiguous
-// loads.  The X block is in the gather's slot order: slot q = 6 p + c (plane p, c < 6) of lane group g is column
-// 16 (q / 4) + 4 g + q % 4 and stands for appearance channel 24 p + 6 g + c (x_slot_col); slots 18, 19 are zero.
+// instead of sixteen 64-byte pieces apart, and the weight-gradient kernel stages whole blocks with contiguous loads.
 // Exception: the dX block of a GRD tile is row-major inside the tile (16 rows x 80 floats behind the 3 fragment
 // blocks, natural channel order): the binned scatter kernels read it one row at a time (grd_dx_row).
-constexpr int ACT_X = 0, ACT_FEAT = 80, ACT_LD = 112;
+constexpr int ACT_FEAT = 0, ACT_LD = 32;
 constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DX = 48, GRD_LD = 128;
 static_assert(ACT_FEAT % 16 == 0 && ACT_LD % 16 == 0, "fragment blocks are 16 columns");
 static_assert(GRD_DFEAT % 16 == 0 && GRD_DX % 16 == 0 && GRD_LD % 16 == 0 && GRD_LD - GRD_DX == 80, "fragment blocks are 16 columns");
@@ -127,25 +128,6 @@ __host__ __device__ inline size_t frag_off(size_t row, int col, int ld) {
 // where lane (s, g) of the wave that owns tile `tile` puts its float4 of block column COL (a multiple of 16): base + COL * 16
 __device__ __forceinline__ float* frag_lane_base(float* buf, size_t tile, int ld, int s, int g) {
   return buf + tile * (size_t)(16 * ld) + ((g * 16 + s) << 2);
-}
-__host__ __device__ inline int x_slot_col(int channel) {                    // appearance channel (0..71) -> column of the X block
-  const int p = channel / 24, c = channel % 24, g = c / 6, q = 6 * p + c % 6;
-  return 16 * (q >> 2) + 4 * g + (q & 3);
-}
-// X block of an ACT tile: the lane's six products of plane P go into its slots 6 P .. 6 P + 5 (five float4 per lane for
-// the three planes; xc carries slots 4, 5 from plane 0 to plane 1).  st(ptr, float4) is the caller's 16-byte store.
-template <int P, class ST>
-__device__ __forceinline__ void save_x_plane_with(float* afr, const float v[8], float xc[2], ST st) {
-  if (P == 0) {
-    st(afr + 16 * (ACT_X + 0), make_float4(v[0], v[1], v[2], v[3]));
-    xc[0] = v[4]; xc[1] = v[5];
-  } else if (P == 1) {
-    st(afr + 16 * (ACT_X + 16), make_float4(xc[0], xc[1], v[0], v[1]));
-    st(afr + 16 * (ACT_X + 32), make_float4(v[2], v[3], v[4], v[5]));
-  } else {
-    st(afr + 16 * (ACT_X + 48), make_float4(v[0], v[1], v[2], v[3]));
-    st(afr + 16 * (ACT_X + 64), make_float4(v[4], v[5], 0.0f, 0.0f));
-  }
 }
 __device__ __forceinline__ const float* grd_dx_row(const float* grd, size_t row) {
   return grd + (row >> 4) * (size_t)(16 * GRD_LD) + GRD_DX * 16 + (row & 15) * (GRD_LD - GRD_DX);

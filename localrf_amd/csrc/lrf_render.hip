@@ -1028,7 +1028,7 @@ void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (o
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
 // Where column `col` of saved row `row` lives, in floats from the start of the ACT (buffer 0) / GRD (buffer 1) region
 // of a training workspace (lrf_workspace_layout_bwd gives the regions): the fragment order of lrf_common.h, host side.
-// buffer 2: column of the ACT tile's X block that holds appearance channel `col` (x_slot_col).  -1 for bad arguments.
+// -1 for bad arguments.
 int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col) {
   using namespace lrf;
   if (buffer == 0) return (col < 0 || col >= ACT_LD) ? -1 : (int64_t)frag_off((size_t)row, col, ACT_LD);
@@ -1037,7 +1037,6 @@ int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col) {
     if (col >= GRD_DX) return (int64_t)((row >> 4) * (uint64_t)(16 * GRD_LD) + GRD_DX * 16 + (row & 15) * (GRD_LD - GRD_DX) + (col - GRD_DX));
     return (int64_t)frag_off((size_t)row, col, GRD_LD);
   }
-  if (buffer == 2) return (col < 0 || col >= 72) ? -1 : x_slot_col(col);
   return -1;
 }
 const char* lrf_last_error(void) { return lrf_error_slot(); }

@@ -88,8 +88,6 @@ __device__ __forceinline__ void gather_app6_plane32(const DField& f, const AxisT
   X[6] = 0.0f; X[7] = 0.0f;            // slots 6, 7 of a lane group are the texel's zero pads (app_pc): +0 x weights = +0
 }
 
-// plain 16-byte store for save_x_plane_with
-struct St16 { __device__ __forceinline__ void operator()(float* p, float4 q) const { *reinterpret_cast<float4*>(p) = q; } };
 template <bool COHERENT>
 __device__ __forceinline__ void finalize_ray(int ray, int nit, int pmax, uint32_t flags, const float* __restrict__ acc,
                                              const float* part, float* __restrict__ rgb, float* __restrict__ acc_out, int oray) {

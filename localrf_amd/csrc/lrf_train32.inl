@@ -1,28 +1,32 @@
-// lrf_train32.inl -- the data-gradient kernel of the training step on the k_shade3 skeleton (round 4): 32 samples per wave on
+// lrf_train32.inl -- the colour network's backward on the k_shade3 skeleton (round 4): 32 samples per wave on
 // v_mfma_f32_32x32x16_bf16, 512-thread workgroups, compiler-scheduled term-major chain.  Included by lrf_backward.inl.
 //
 // The round-3 kernel it replaces (16 samples per wave on v_mfma_f32_16x16x32_bf16, 1024-thread workgroups, 128 registers) issued ~1650
 // VALU + 143 MFMA + 179 LDS instructions per 16-sample tile and spent half its wave-cycles in issue stalls
 // (profiles/r11a: 320-330 us).  Here a wave takes two consecutive 16-row tiles of the saved rows (lane n = lane & 31 is
 // row 16 (n >> 4) + (n & 15) of the pair, h = lane >> 5 the K half), so every A fragment feeds 32 columns and the
-// D registers of a product are again the B operand of the next one:
-//   go -> dz2 (VALU: rank 3, gated by the saved layer-2 mask bits) -> dz1 = W2^T dz2 (4 x 8 x 3 MFMAs, gated by the layer-1
-//   bits) -> dfeat = W1^T dz1 (8 x 3) -> dX = basis^T dfeat (3 x 2 x 3), delivered per lane for exactly the channels its
-//   half gathers (12 h .. 12 h + 11 of each plane, the dense 24-channel texels of k_shade3), so the position gradient of
-//   the appearance lookups re-uses the forward's gather code.
+// D registers of a product are again the B operand of the next one.  Two kernels:
+//   k_train_dgrad3  go -> dz2 (VALU: rank 3, gated by the saved layer-2 mask bits) -> dz1 = W2^T dz2 (4 x 8 x 3 MFMAs, gated by
+//                   the layer-1 bits) -> dfeat = W1^T dz1 (8 x 3); writes the go block and dfeat; accumulates dW1.
+//   k_train_app3    dfeat -> dX = basis^T dfeat (3 x 2 x 3), delivered per lane for exactly the channels its half gathers
+//                   (12 h .. 12 h + 11 of each plane, the dense 24-channel texels of k_shade3); re-gathers the taps for the
+//                   position gradient of the appearance lookups, which also yields X = plane x line again -- so
+//                   dbasis = dfeat^T X is accumulated here and X is never a row (it was 320 B per shaded sample, written
+//                   by the forward and read once by a GEMM kernel).
 // The transposed network is packed per backward into the same fragment format as the forward image (k_pack_mlp_w32_t).
-// Rows are written in the 16-row fragment order the weight-gradient GEMMs and the scatter kernels read (lrf_common.h);
+// Rows are written in the 16-row fragment order the weight-gradient kernel and the scatter kernels read (lrf_common.h);
 // dX goes out as three 48-byte pieces per lane (round 3: nine 8-byte stores).
 //
-// dW1 (+ db1) = dz1^T [feat | 1] is accumulated HERE, so dz1 is never a row (512 B written + read per shaded sample: with
-// them the kernel ran 310-430 us against 160 us without any row store -- it was bound by its own stores).  The product
-// contracts over samples, which sit in the lane dimension of the chain's registers; both operands are therefore
+// dW1 (+ db1) = dz1^T [feat | 1] and dbasis = dfeat^T X are accumulated in registers, so dz1 and X are never rows (with the
+// dz1 rows the data-gradient kernel ran 310-430 us against 160 us without any row store -- it was bound by its own stores).
+// These products contract over samples, which sit in the lane dimension of the chain's registers; both operands are therefore
 // TRANSPOSED ON THE MATRIX PIPE, by multiplying with a 0/1 selector: with the sample-major fragment as A and a selector
 // as B, D[sample][unit] arrives with lane = unit and registers = samples -- exactly an A / B operand over K = samples
 // (the K order is again folded into w32_unit).  dz1's split halves exist anyway (B operand of the dfeat product): the
 // transpose costs 2 x 8 MFMAs, feat's 2 x 2, the product 4 x 2 x 3; selectors are exact in bf16, so the transposed value
-// is hi + lo of the original (what a split product sees anyway).  64 accumulator registers per wave, reduced over the
-// workgroup's waves once at the end -> one partial block per workgroup (WP_W1), summed by k_wgrad_reduce.
+// is hi + lo of the original (what a split product sees anyway).  64 (dW1) / 48 (dbasis) accumulator registers per wave,
+// reduced over the workgroup's waves once at the end -> one partial block per workgroup (WP_W1 / WP_BAS), summed by
+// k_wgrad_reduce.
 // (included inside namespace lrf)
 #pragma once
 
@@ -74,10 +78,11 @@ __global__ void k_pack_mlp_w32_t(LrfParams p, uint32_t* __restrict__ img) {
 }
 
 // position-gradient terms of plane p for lane half h: channels 12 h .. 12 h + 11 of the dense texels (gather_app12's taps),
-// dX[12] = d(loss)/d(X) of those channels.  Adds to gu[] the derivative with respect to the three normalised coordinates.
+// dX[12] = d(loss)/d(X) of those channels.  Adds to gu[] the derivative with respect to the three normalised coordinates
+// and returns the products X[12] = plane x line of those channels (tensoRF.py:153-195).
 template <int p>
 __device__ __forceinline__ void app12_position_grad(const DField& f, const int i0[3], const int i1[3], const float t[3],
-                                                    const float gm[3], int h, const float dX[12], float gu[3]) {
+                                                    const float gm[3], int h, const float dX[12], float gu[3], float X[12]) {
   const int x0 = i0[MAT0[p]], x1 = i1[MAT0[p]], y0 = i0[MAT1[p]], y1 = i1[MAT1[p]];
   const int l0 = i0[VEC[p]], l1 = i1[VEC[p]];
   const float tx = t[MAT0[p]], ty = t[MAT1[p]], tl = t[VEC[p]];
@@ -101,6 +106,7 @@ __device__ __forceinline__ void app12_position_grad(const DField& f, const int i
       const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
       const float Lv = e0 * (1.0f - tl) + e1 * tl;
       const float d = dX[4 * i + c];
+      X[4 * i + c] = P * Lv;
       const float dP = d * Lv, dL = d * P;
       gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
       giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
@@ -117,23 +123,21 @@ __device__ __forceinline__ void row_store_plain(float* p, float4 v) { *reinterpr
 // tileinfo[t] = (ray, first compact sample j0, samples in the tile, tile number inside the ray), written by k_bwd_shade_fwd
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
-    DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, int S,
     const int* __restrict__ toff, int R, const int4* __restrict__ tileinfo,
     const uint16_t* __restrict__ cidx, const float* __restrict__ cw, const float* __restrict__ crgb,
-    const float* __restrict__ g_rgb, float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ rpart, int pmax,
+    const float* __restrict__ g_rgb, float* __restrict__ grd, uint32_t* __restrict__ rowinfo,
     const uint32_t* __restrict__ relu_bits, const float* __restrict__ act /* saved feat rows */, float* __restrict__ wpart,
-    int dbg /* timing experiments: 1 no row stores, 2 no position gradient, 4 no products */) {
+    int dbg /* timing experiments: 1 no row stores, 4 no products */) {
   constexpr int NT = NW * 64;
   extern __shared__ uint4 s_dyn3[];
   uint4* img = s_dyn3;
   float* tail = reinterpret_cast<float*>(s_dyn3 + W32T_U4);
-  float* s_z = tail + W32T_T_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5, s = n & 15;
   {
     const int rot = (int)((blockIdx.x * 37u) % 93u) * 64;     // every workgroup starts its copy somewhere else (finding 18)
     for (int i = tid; i < W32T_ALL_U4; i += NT) { int j = i + rot; if (j >= W32T_ALL_U4) j -= W32T_ALL_U4; img[j] = imt[j]; }
   }
-  for (int i = tid; i < S; i += NT) s_z[i] = z[i];
   __syncthreads();
   const int T = toff[R];
   const int P = (T + 1) >> 1;                                 // pairs of 16-row tiles
@@ -175,7 +179,6 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
       m2a = rb[64 + 16 * (2 * h)]; m2b = rb[64 + 16 * (2 * h + 1)];   // layer 2: lane groups 2 h, 2 h + 1
     }
     const float* rp = rays + (size_t)ray * 6;
-    const float o[3] = {rp[0], rp[1], rp[2]};
     const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
     const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
     if (valid) {                                               // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k (tensorBase.py:632-633)
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
     f32x16 df;
 #pragma unroll
     for (int r = 0; r < 16; ++r) df[r] = 0.0f;
-    {                                                          // (one accumulator per product: the kernel lives at the 256-register limit)
+    {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         f32x16 dzt;                                            // dz1^T of M-tile m: lane = unit 32 m + n, registers = samples
@@ -293,71 +296,11 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
         }
       }
     }
-    if (have) {
+    if (have) {                                                // dfeat block: register r = feature 8 (r >> 2) + 4 h + (r & 3) of sample n
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         row_store_plain(grd + trow + (GRD_DFEAT / 16 + (q >> 1)) * 256 + (((2 * (q & 1) + h) * 16 + s) << 2),
                         make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]));
-    }
-    // ---- dX = basis^T dfeat: register r of tile mt = value 16 mt + r of this lane half = channel w32_chan(h, 16 mt + r)
-    f32x16 dx[3];
-#pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dx[mt][r] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = df[8 * q + j];
-      bf16x8 bh, bl;
-      split8c(v, bh, bl);
-      mma3_step<3>(img, W32T_BAS + q, 2, lane, bh, bl, dx);
-    }
-    float dX[36];
-#pragma unroll
-    for (int vv = 0; vv < 36; ++vv) dX[vv] = dx[vv >> 4][vv & 15];
-    if (have) {                                                // dX row, natural channel order: 48 contiguous bytes per plane and lane half
-      float* gdx = grd + trow + GRD_DX * 16 + s * (GRD_LD - GRD_DX) + 12 * h;
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-          row_store_plain(gdx + p * LRF_CA + 4 * i, make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]));
-    }
-    // ---- d/d(position) from the appearance lookups
-    const float zk = s_z[k];
-    float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
-    float xc[3] = {xr[0], xr[1], xr[2]};
-    contract3(xc[0], xc[1], xc[2]);
-    float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - f.lo[a]) * f.inv[a] - 1.0f;
-    if (valid && !(dbg & 2)) {
-      int i0[3], i1[3]; float t[3], gm[3];
-      tap1d_g(u[0], f.pw[0], i0[0], i1[0], t[0], gm[0]);       // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps)
-      tap1d_g(u[1], f.ph[0], i0[1], i1[1], t[1], gm[1]);
-      tap1d_g(u[2], f.ll[0], i0[2], i1[2], t[2], gm[2]);
-      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu);
-      __builtin_amdgcn_sched_barrier(0);                       // one plane's 18 gathers in flight at a time: the dW1 accumulators stay resident
-      app12_position_grad<1>(f, i0, i1, t, gm, h, dX + 12, gu);
-      __builtin_amdgcn_sched_barrier(0);
-      app12_position_grad<2>(f, i0, i1, t, gm, h, dX + 24, gu);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) gu[a] += __shfl_xor(gu[a], 32, 64);      // the two channel halves of a sample
-    float gx3[3] = {gu[0] * f.inv[0], gu[1] * f.inv[1], gu[2] * f.inv[2]};
-    contract3_bwd(xr, gx3);
-    float prt[6] = {gx3[0], gx3[1], gx3[2], gx3[0] * zk, gx3[1] * zk, gx3[2] * zk};
-    if (!valid) { prt[0] = prt[1] = prt[2] = prt[3] = prt[4] = prt[5] = 0.0f; }
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-      for (int dd = 1; dd < 16; dd <<= 1) prt[q] += __shfl_xor(prt[q], dd, 64);       // over the 16 samples of the lane's tile
-    if (have_t && s == 0 && h == 0) {
-      float* rpp = rpart + ((size_t)ray * pmax + ti.w) * 8;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) rpp[q] = prt[q];
     }
   }
   // ---- dW1 partial of the workgroup: the waves' accumulators meet in LDS (the image is no longer needed), upper half of the
@@ -391,6 +334,213 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[(32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * 32 + n] = w1acc[m][r];
   }
+}
+
+// ---- the appearance half of the colour network's backward: dfeat -> dX, d/d(position), dbasis.
+// Per pair of 16-row tiles (lane (n, h) as above): the dfeat block comes back exactly as k_train_dgrad3's lanes stored it
+// (D registers of the dfeat product), dX = basis^T dfeat lands per lane on the 36 channels its half gathers, the taps are
+// gathered once for both the position gradient and X = plane x line, and
+//   dbasis[f][channel] += sum over the 32 samples of dfeat[sample][f] X[sample][channel]
+// runs on the matrix pipe with both operands transposed by selector products: dfeat^T (2 K-steps x hi / lo = 4 MFMAs;
+// lane = feature, registers = samples) and, per plane, X^T of its 24 channels (column c < 24 of N-tile p = channel 24 p + c;
+// the lane's values 12 p .. 12 p + 11 sit in two of its five K-steps: 4 MFMAs), then 2 K-steps x 3 terms per plane.
+// 48 accumulator registers per wave, one [32][96] block per workgroup at WP_BAS (k_wgrad_reduce).
+constexpr int APP3_IMG_U4 = (W32T_NFRAG - W32T_BAS) * 128;       // the six basis^T fragments
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_train_app3(
+    DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
+    const int* __restrict__ toff, int R, const int4* __restrict__ tileinfo, const uint16_t* __restrict__ cidx,
+    float* __restrict__ grd /* in: dfeat blocks, out: dX blocks */, float* __restrict__ rpart, int pmax, float* __restrict__ wpart,
+    int dbg /* timing experiments: 1 no row stores, 2 no position gradient / X */) {
+  constexpr int NT = NW * 64;
+  extern __shared__ uint4 s_dyn4[];
+  uint4* img = s_dyn4;                                        // fragment q (0..5) = W32T_BAS + q of the transposed image
+  float* s_z = reinterpret_cast<float*>(s_dyn4 + APP3_IMG_U4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5, s = n & 15;
+  for (int i = tid; i < APP3_IMG_U4; i += NT) img[i] = imt[W32T_BAS * 128 + i];
+  for (int i = tid; i < S; i += NT) s_z[i] = z[i];
+  __syncthreads();
+  const int T = toff[R];
+  const int P = (T + 1) >> 1;                                 // pairs of 16-row tiles
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;   // XCD-aware order
+  const long long wid = (long long)lb * NW + wave, waves = (long long)nb * NW;
+  const int p_beg = (int)(wid * P / waves), p_end = (int)((wid + 1) * P / waves);
+  f32x16 bacc[3];                                              // dbasis partial: [f = 8 (r >> 2) + 4 h + (r & 3)][channel 24 p + n], n < 24
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bacc[p][r] = 0.0f;
+  auto selector = [&](auto key) {                              // slot j of lane (n, h) is 1 where key(j) == n (see k_train_dgrad3)
+    uint32_t wds[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2)
+      wds[q2] = (key(2 * q2) == n ? 0x3f80u : 0u) | (key(2 * q2 + 1) == n ? 0x3f800000u : 0u);
+    return __builtin_bit_cast(bf16x8, make_uint4(wds[0], wds[1], wds[2], wds[3]));
+  };
+  for (int pr = p_beg; pr < p_end; ++pr) {
+    asm volatile("" ::: "memory");                             // keep the LDS fragment reads inside the loop
+    const int tile = 2 * pr + (n >> 4);
+    const bool have_t = tile < T;
+    const bool have = have_t && !(dbg & 1);
+    const int4 ti = tileinfo[have_t ? tile : 2 * pr];
+    const int ray = ti.x, j0 = ti.y, cnt = ti.z;
+    const bool valid = have_t && s < cnt;
+    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
+    const int k = cidx[ci];
+    const size_t trow = (size_t)tile * (size_t)(16 * GRD_LD);
+    // ---- dfeat of this lane's sample: register r = feature 8 (r >> 2) + 4 h + (r & 3) (rows beyond the tile's count are zero: go = 0)
+    f32x16 df;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (have_t) v = *reinterpret_cast<const float4*>(grd + trow + (GRD_DFEAT / 16 + (q >> 1)) * 256 + (((2 * (q & 1) + h) * 16 + s) << 2));
+      df[4 * q] = v.x; df[4 * q + 1] = v.y; df[4 * q + 2] = v.z; df[4 * q + 3] = v.w;
+    }
+    const float* rp = rays + (size_t)ray * 6;
+    const float o[3] = {rp[0], rp[1], rp[2]};
+    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
+    __builtin_amdgcn_iglp_opt(0);
+    // ---- dX = basis^T dfeat: register r of tile mt = value 16 mt + r of this lane half = channel w32_chan(h, 16 mt + r);
+    //      dfeat^T through the selector (the same split halves as A)
+    bf16x8 Ah[2], Al[2];
+    float dX[36];
+    {
+      f32x16 dx[3], dft;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dx[0][r] = 0.0f; dx[1][r] = 0.0f; dx[2][r] = 0.0f; dft[r] = 0.0f; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = df[8 * q + j];
+        bf16x8 bh, bl;
+        split8c(v, bh, bl);
+        mma3_step<3>(img, q, 2, lane, bh, bl, dx);
+        const bf16x8 sel = selector([&](int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); });
+        dft = mfma32(bh, sel, dft);
+        dft = mfma32(bl, sel, dft);
+      }
+#pragma unroll
+      for (int vv = 0; vv < 36; ++vv) dX[vv] = dx[vv >> 4][vv & 15];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                            // A operand of the dbasis product: lane = feature, slots = samples
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dft[8 * q + j];
+        split8c(v, Ah[q], Al[q]);
+      }
+    }
+    if (have) {                                                // dX row, natural channel order: 48 contiguous bytes per plane and lane half
+      float* gdx = grd + trow + GRD_DX * 16 + s * (GRD_LD - GRD_DX) + 12 * h;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          row_store_plain(gdx + p * LRF_CA + 4 * i, make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]));
+    }
+    // ---- d/d(position) from the appearance lookups, and X again
+    const float zk = s_z[k];
+    float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
+    float xc[3] = {xr[0], xr[1], xr[2]};
+    contract3(xc[0], xc[1], xc[2]);
+    float u[3], gu[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = (xc[a] - f.lo[a]) * f.inv[a] - 1.0f;
+    float X[40];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) X[i] = 0.0f;
+    if (valid && !(dbg & 2)) {
+      int i0[3], i1[3]; float t[3], gm[3];
+      tap1d_g(u[0], f.pw[0], i0[0], i1[0], t[0], gm[0]);       // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps)
+      tap1d_g(u[1], f.ph[0], i0[1], i1[1], t[1], gm[1]);
+      tap1d_g(u[2], f.ll[0], i0[2], i1[2], t[2], gm[2]);
+      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu, X);
+      app12_position_grad<1>(f, i0, i1, t, gm, h, dX + 12, gu, X + 12);
+      app12_position_grad<2>(f, i0, i1, t, gm, h, dX + 24, gu, X + 24);
+    }
+    // ---- dbasis += dfeat^T X, plane by plane
+    {
+      bf16x8 xh[5], xl[5];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) split8c(X + 8 * ks, xh[ks], xl[ks]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        constexpr int KS0[3] = {0, 1, 3};                      // values 12 p .. 12 p + 11 of a lane half live in K-steps KS0[p], KS0[p] + 1
+        f32x16 xt;                                             // X^T of plane p: lane = channel n (< 24), registers = samples
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xt[r] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ks = KS0[p] + e;
+          const bf16x8 sel = selector([&](int j) { const int c = 8 * ks + j - 12 * p; return (c >= 0 && c < 12) ? 12 * h + c : -1; });
+          xt = mfma32(xh[ks], sel, xt);
+          xt = mfma32(xl[ks], sel, xt);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = xt[8 * q + j];
+          bf16x8 th, tl;
+          split8c(v, th, tl);
+          bacc[p] = mfma32(Al[q], th, bacc[p]);
+          bacc[p] = mfma32(Ah[q], tl, bacc[p]);
+          bacc[p] = mfma32(Ah[q], th, bacc[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gu[a] += __shfl_xor(gu[a], 32, 64);      // the two channel halves of a sample
+    float gx3[3] = {gu[0] * f.inv[0], gu[1] * f.inv[1], gu[2] * f.inv[2]};
+    contract3_bwd(xr, gx3);
+    float prt[6] = {gx3[0], gx3[1], gx3[2], gx3[0] * zk, gx3[1] * zk, gx3[2] * zk};
+    if (!valid) { prt[0] = prt[1] = prt[2] = prt[3] = prt[4] = prt[5] = 0.0f; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int dd = 1; dd < 16; dd <<= 1) prt[q] += __shfl_xor(prt[q], dd, 64);       // over the 16 samples of the lane's tile
+    if (have_t && s == 0 && h == 0) {
+      float* rpp = rpart + ((size_t)ray * pmax + ti.w) * 8;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rpp[q] = prt[q];
+    }
+  }
+  // ---- dbasis partial of the workgroup (as k_train_dgrad3's dW1 block)
+  f32x4* s_red = reinterpret_cast<f32x4*>(s_dyn4);           // [wave slot][12 float4 of the 48 accumulator registers][lane]
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (wave >= half && wave < 2 * half) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          s_red[((wave - half) * 12 + 4 * p + q) * 64 + lane] = f32x4{bacc[p][4 * q], bacc[p][4 * q + 1], bacc[p][4 * q + 2], bacc[p][4 * q + 3]};
+    }
+    __syncthreads();
+    if (wave < half) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o4 = s_red[(wave * 12 + 4 * p + q) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bacc[p][4 * q + r] += o4[r];
+        }
+    }
+  }
+  if (wave == 0) {
+    float* out = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_BAS;          // [32 features][3 planes x 32 columns (24 channels)]
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(8 * (r >> 2) + 4 * h + (r & 3)) * 96 + 32 * p + n] = bacc[p][r];
+  }
+}
+constexpr size_t app3_lds_bytes(int S, int NW) {
+  const size_t a = (size_t)APP3_IMG_U4 * 16 + (size_t)S * 4, b = (size_t)(NW / 2) * 12 * 64 * 16;
+  return a > b ? a : b;
 }
 
 // (Round 4 also built the ROW-SAVING FORWARD on this skeleton -- k_shade3's gather and chain on a pair of 16-row tiles per

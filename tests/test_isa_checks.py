@@ -9,8 +9,9 @@ __graft_entry__.build() compiles it and the device assembly is inspected.
    was the cause of the run-to-run differences of rounds 1-2 (DESIGN.md finding 17).
 2. k_shade3 (the default colour kernel): 135 v_mfma_f32_32x32x16_bf16 per tile (15 basis + 24 layer 1 + 96 layer 2),
    no scratch, at most 256 registers (two waves per SIMD).
-3. k_march and the row-saving forward of the training step (k_bwd_shade_fwd) use no scratch, the 32-sample data-gradient
-   kernel (k_train_dgrad3) at most two spilled addresses; the weight-gradient GEMMs keep their shape.
+3. k_march, the row-saving forward of the training step (k_bwd_shade_fwd) and the two 32-sample kernels of the colour
+   network's backward (k_train_dgrad3, k_train_app3) use no scratch and at most 256 registers; the weight-gradient kernel
+   keeps its shape.
 """
 import os
 import re
@@ -94,10 +95,8 @@ def test_shade3_shape(asm):
 
 
 def test_scratch_use_is_bounded(asm):
-    # (k_train_dgrad3 lives at the 256-register limit of two waves per SIMD with its 64 dW1 accumulators: two 8-byte address
-    # spills per pair of tiles are tolerated, nothing more)
     for pat, limit in ((r"k_marchILb1EE", 0), (r"k_marchILb0EE", 0), (r"k_bwd_shade_fwdE", 0),
-                       (r"k_train_dgrad3ILi8EE", 32)):
+                       (r"k_train_dgrad3ILi8EE", 0), (r"k_train_app3ILi8EE", 0)):
         for name, _ in _body(asm, pat):
             meta = asm[asm.index(".amdhsa_kernel " + name):]
             meta = meta[:meta.index(".end_amdhsa_kernel")]
@@ -105,7 +104,20 @@ def test_scratch_use_is_bounded(asm):
             assert priv and int(priv[1]) <= limit, (name, priv and priv[1])
 
 
-WGRAD = ("k_wgrad_w2w3E", "k_wgradILi2ELi5ELb1EE")
+def test_colour_backward_kernels_shape(asm):
+    """k_train_dgrad3: 96 (W2^T) + 24 (W1^T) MFMAs of the data chain, 4 + 16 selector transposes (feat^T, dz1^T), 24 for dW1.
+    k_train_app3: 18 (basis^T), 4 + 12 selector transposes (dfeat^T, X^T per plane), 18 for dbasis.  All on the 32x32x16
+    instruction, at most 256 registers (two waves per SIMD)."""
+    for pat, n in ((r"k_train_dgrad3ILi8EE", 96 + 24 + 4 + 16 + 24), (r"k_train_app3ILi8EE", 18 + 4 + 12 + 18)):
+        name, body = _body(asm, pat)[0]
+        assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) == n, (name, len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)))
+        meta = asm[asm.index(name + ":"):]
+        meta = meta[:meta.index(".end_amdhsa_kernel") + 4000]
+        vg = re.search(r"; NumVgprs: (\d+)", meta)
+        assert vg and int(vg[1]) <= 256, (name, vg and vg[1])
+
+
+WGRAD = ("k_wgrad_w2w3E",)
 
 
 def test_weight_gradient_gemms(asm):
