@@ -1386,7 +1386,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_dgrad3<8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
       lds_attr_err[dev_id & 63] = e;

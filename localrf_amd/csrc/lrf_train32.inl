@@ -80,40 +80,48 @@ __global__ void k_pack_mlp_w32_t(LrfParams p, uint32_t* __restrict__ img) {
 // position-gradient terms of plane p for lane half h: channels 12 h .. 12 h + 11 of the dense texels (gather_app12's taps),
 // dX[12] = d(loss)/d(X) of those channels.  Adds to gu[] the derivative with respect to the three normalised coordinates
 // and returns the products X[12] = plane x line of those channels (tensoRF.py:153-195).
+// Two channels per instruction: the float4 of a tap is two aligned register pairs, the arithmetic below is written on
+// float2 vectors with straight halves (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; finding 17 concerns crossed low selects
+// only, which this form cannot produce) -- 16 packed operations per pair of channels instead of ~50 scalar ones.
 template <int p>
 __device__ __forceinline__ void app12_position_grad(const DField& f, const int i0[3], const int i1[3], const float t[3],
                                                     const float gm[3], int h, const float dX[12], float gu[3], float X[12]) {
   const int x0 = i0[MAT0[p]], x1 = i1[MAT0[p]], y0 = i0[MAT1[p]], y1 = i1[MAT1[p]];
   const int l0 = i0[VEC[p]], l1 = i1[VEC[p]];
-  const float tx = t[MAT0[p]], ty = t[MAT1[p]], tl = t[VEC[p]];
+  const f32x2v tx = {t[MAT0[p]], t[MAT0[p]]}, ty = {t[MAT1[p]], t[MAT1[p]]}, tl = {t[VEC[p]], t[VEC[p]]};
   const unsigned hb = 48u * (unsigned)h;
   const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
   const unsigned o00 = (row0 + x0) * (LRF_CA * 4u) + hb, o10 = (row0 + x1) * (LRF_CA * 4u) + hb;
   const unsigned o01 = (row1 + x0) * (LRF_CA * 4u) + hb, o11 = (row1 + x1) * (LRF_CA * 4u) + hb;
   const unsigned q0 = (unsigned)l0 * (LRF_CA * 4u) + hb, q1 = (unsigned)l1 * (LRF_CA * 4u) + hb;
-  float gix = 0.0f, giy = 0.0f, gil = 0.0f;
+  f32x2v gix = {0.0f, 0.0f}, giy = {0.0f, 0.0f}, gil = {0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float4 a4 = ld4b(f.aplane2[p], o00 + 16 * i), b4 = ld4b(f.aplane2[p], o10 + 16 * i);
     const float4 c4 = ld4b(f.aplane2[p], o01 + 16 * i), d4 = ld4b(f.aplane2[p], o11 + 16 * i);
     const float4 e4 = ld4b(f.aline2[p], q0 + 16 * i), g4 = ld4b(f.aline2[p], q1 + 16 * i);
-    const float va[4] = {a4.x, a4.y, a4.z, a4.w}, vb[4] = {b4.x, b4.y, b4.z, b4.w};
-    const float vc[4] = {c4.x, c4.y, c4.z, c4.w}, vd[4] = {d4.x, d4.y, d4.z, d4.w};
-    const float ve[4] = {e4.x, e4.y, e4.z, e4.w}, vg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float v00 = va[c], v10 = vb[c], v01 = vc[c], v11 = vd[c], e0 = ve[c], e1 = vg[c];
-      const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
-      const float Lv = e0 * (1.0f - tl) + e1 * tl;
-      const float d = dX[4 * i + c];
-      X[4 * i + c] = P * Lv;
-      const float dP = d * Lv, dL = d * P;
-      gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
-      giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
-      gil += dL * (e1 - e0);
+    for (int c = 0; c < 2; ++c) {
+      const f32x2v v00 = c ? f32x2v{a4.z, a4.w} : f32x2v{a4.x, a4.y}, v10 = c ? f32x2v{b4.z, b4.w} : f32x2v{b4.x, b4.y};
+      const f32x2v v01 = c ? f32x2v{c4.z, c4.w} : f32x2v{c4.x, c4.y}, v11 = c ? f32x2v{d4.z, d4.w} : f32x2v{d4.x, d4.y};
+      const f32x2v e0 = c ? f32x2v{e4.z, e4.w} : f32x2v{e4.x, e4.y}, e1 = c ? f32x2v{g4.z, g4.w} : f32x2v{g4.x, g4.y};
+      const f32x2v d0 = v10 - v00, d1 = v11 - v01;             // d/dx along the two rows of the cell
+      const f32x2v r0 = tx * d0 + v00, r1 = tx * d1 + v01;     // the rows at tx
+      const f32x2v dy = r1 - r0;                               // d(plane)/d(ty)
+      const f32x2v P = ty * dy + r0;
+      const f32x2v dxp = ty * (d1 - d0) + d0;                  // d(plane)/d(tx)
+      const f32x2v de = e1 - e0;                               // d(line)/d(tl)
+      const f32x2v Lv = tl * de + e0;
+      const f32x2v d = {dX[4 * i + 2 * c], dX[4 * i + 2 * c + 1]};
+      const f32x2v x2 = P * Lv;
+      X[4 * i + 2 * c] = x2[0]; X[4 * i + 2 * c + 1] = x2[1];
+      const f32x2v dP = d * Lv, dL = d * P;
+      gix = dP * dxp + gix;
+      giy = dP * dy + giy;
+      gil = dL * de + gil;
     }
   }
-  gu[MAT0[p]] += gix * gm[MAT0[p]]; gu[MAT1[p]] += giy * gm[MAT1[p]]; gu[VEC[p]] += gil * gm[VEC[p]];
+  gu[MAT0[p]] += (gix[0] + gix[1]) * gm[MAT0[p]]; gu[MAT1[p]] += (giy[0] + giy[1]) * gm[MAT1[p]]; gu[VEC[p]] += (gil[0] + gil[1]) * gm[VEC[p]];
 }
 
 // plain (temporal) 16-byte row store: for this kernel's 512-byte segments the `nt` hint of the 16-sample kernels costs time
@@ -160,12 +168,15 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
       wds[q2] = (key(2 * q2) == n ? 0x3f80u : 0u) | (key(2 * q2 + 1) == n ? 0x3f800000u : 0u);
     return __builtin_bit_cast(bf16x8, make_uint4(wds[0], wds[1], wds[2], wds[3]));
   };
+  int4 ti_c = make_int4(0, 0, 0, 0);
+  if (p_beg < p_end) { const int t0 = 2 * p_beg + (n >> 4); ti_c = tileinfo[t0 < T ? t0 : 2 * p_beg]; }
   for (int pr = p_beg; pr < p_end; ++pr) {
     asm volatile("" ::: "memory");                             // keep the LDS fragment reads inside the loop
     const int tile = 2 * pr + (n >> 4);
     const bool have_t = tile < T;
     const bool have = have_t && !(dbg & 1);                    // (`have` guards the row stores)
-    const int4 ti = tileinfo[have_t ? tile : 2 * pr];
+    const int4 ti = ti_c;                                      // (fetched one pair ahead: the loads below depend on it)
+    if (pr + 1 < p_end) { const int tn = 2 * (pr + 1) + (n >> 4); ti_c = tileinfo[tn < T ? tn : 2 * (pr + 1)]; }
     const int ray = ti.x, j0 = ti.y, cnt = ti.z;
     const bool valid = have_t && s < cnt;
     const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
@@ -346,6 +357,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
 // the lane's values 12 p .. 12 p + 11 sit in two of its five K-steps: 4 MFMAs), then 2 K-steps x 3 terms per plane.
 // 48 accumulator registers per wave, one [32][96] block per workgroup at WP_BAS (k_wgrad_reduce).
 constexpr int APP3_IMG_U4 = (W32T_NFRAG - W32T_BAS) * 128;       // the six basis^T fragments
+constexpr int APP3_STG_FLOATS = 32 * (GRD_LD - GRD_DX);          // dX rows of a pair of tiles, per wave
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_train_app3(
     DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
@@ -355,10 +367,37 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
   constexpr int NT = NW * 64;
   extern __shared__ uint4 s_dyn4[];
   uint4* img = s_dyn4;                                        // fragment q (0..5) = W32T_BAS + q of the transposed image
-  float* s_z = reinterpret_cast<float*>(s_dyn4 + APP3_IMG_U4);
+  uint4* s_sel = s_dyn4 + APP3_IMG_U4;                        // the eight 0 / 1 selectors, [selector][lane]
+  float* s_stg = reinterpret_cast<float*>(s_sel + 8 * 64) + (size_t)(threadIdx.x >> 6) * APP3_STG_FLOATS;   // this wave's dX staging tile pair
+  float* s_z = reinterpret_cast<float*>(s_sel + 8 * 64) + (size_t)NW * APP3_STG_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5, s = n & 15;
   for (int i = tid; i < APP3_IMG_U4; i += NT) img[i] = imt[W32T_BAS * 128 + i];
   for (int i = tid; i < S; i += NT) s_z[i] = z[i];
+  // 0 / 1 selectors (B operands of the transposing products, see k_train_dgrad3): slot j of lane (n, h) is 1 where the K index
+  // of the slot is the lane's column.  0, 1: dfeat^T, K index = feature 16 q + 8 (j >> 2) + 4 h + (j & 3) (dfeat's D-register
+  // order); 2 + 2 p + e: X^T of plane p, K-step KS0[p] + e of the lane's 40 values: value 8 ks + j is channel 12 h + (8 ks + j - 12 p)
+  // of the plane when that is in 0..11.  Built once per workgroup, read back with one ds_read_b128 each per pair of tiles.
+  for (int i = tid; i < 8 * 64; i += NT) {
+    const int id = i >> 6, ln = i & 63, nn = ln & 31, hh = ln >> 5;
+    uint32_t wds[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      uint32_t wd = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * q2 + e;
+        int key;
+        if (id < 2) key = 16 * id + 8 * (j >> 2) + 4 * hh + (j & 3);
+        else {
+          const int pp = (id - 2) >> 1, ks = (pp == 0 ? 0 : pp == 1 ? 1 : 3) + ((id - 2) & 1), c = 8 * ks + j - 12 * pp;
+          key = (c >= 0 && c < 12) ? 12 * hh + c : -1;
+        }
+        if (key == nn) wd |= e ? 0x3f800000u : 0x3f80u;
+      }
+      wds[q2] = wd;
+    }
+    s_sel[i] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  }
   __syncthreads();
   const int T = toff[R];
   const int P = (T + 1) >> 1;                                 // pairs of 16-row tiles
@@ -371,23 +410,30 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) bacc[p][r] = 0.0f;
-  auto selector = [&](auto key) {                              // slot j of lane (n, h) is 1 where key(j) == n (see k_train_dgrad3)
-    uint32_t wds[4];
-#pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2)
-      wds[q2] = (key(2 * q2) == n ? 0x3f80u : 0u) | (key(2 * q2 + 1) == n ? 0x3f800000u : 0u);
-    return __builtin_bit_cast(bf16x8, make_uint4(wds[0], wds[1], wds[2], wds[3]));
+  auto selector = [&](int id) { return __builtin_bit_cast(bf16x8, s_sel[id * 64 + lane]); };
+  // The header of a pair (tile -> ray, first sample, count -> this lane's sample index) is a chain of dependent loads in
+  // front of the gathers: it is fetched one pair ahead (the tile record at the top of the previous pair, the index behind
+  // its matrix products), as k_shade3 does with its tile header.
+  auto tile_of = [&](int pr) { const int t = 2 * pr + (n >> 4); return t < T ? t : 2 * pr; };
+  auto index_of = [&](int pr, const int4& ti) {
+    const bool ok = 2 * pr + (n >> 4) < T && s < ti.z;
+    return cidx[(size_t)ti.x * S + ti.y + (ok ? s : 0)];
   };
+  int4 ti_c = make_int4(0, 0, 0, 0);
+  int k_c = 0;
+  if (p_beg < p_end) { ti_c = tileinfo[tile_of(p_beg)]; k_c = index_of(p_beg, ti_c); }
   for (int pr = p_beg; pr < p_end; ++pr) {
     asm volatile("" ::: "memory");                             // keep the LDS fragment reads inside the loop
     const int tile = 2 * pr + (n >> 4);
     const bool have_t = tile < T;
     const bool have = have_t && !(dbg & 1);
-    const int4 ti = tileinfo[have_t ? tile : 2 * pr];
-    const int ray = ti.x, j0 = ti.y, cnt = ti.z;
+    const int4 ti = ti_c;
+    const int ray = ti.x, cnt = ti.z;
     const bool valid = have_t && s < cnt;
-    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
-    const int k = cidx[ci];
+    const int k = k_c;
+    const bool more = pr + 1 < p_end;
+    int4 ti_n = ti;
+    if (more) ti_n = tileinfo[tile_of(pr + 1)];
     const size_t trow = (size_t)tile * (size_t)(16 * GRD_LD);
     // ---- dfeat of this lane's sample: register r = feature 8 (r >> 2) + 4 h + (r & 3) (rows beyond the tile's count are zero: go = 0)
     f32x16 df;
@@ -418,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
         bf16x8 bh, bl;
         split8c(v, bh, bl);
         mma3_step<3>(img, q, 2, lane, bh, bl, dx);
-        const bf16x8 sel = selector([&](int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); });
+        const bf16x8 sel = selector(q);
         dft = mfma32(bh, sel, dft);
         dft = mfma32(bl, sel, dft);
       }
@@ -432,13 +478,32 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
         split8c(v, Ah[q], Al[q]);
       }
     }
-    if (have) {                                                // dX row, natural channel order: 48 contiguous bytes per plane and lane half
-      float* gdx = grd + trow + GRD_DX * 16 + s * (GRD_LD - GRD_DX) + 12 * h;
+    int k_n = k;
+    if (more) k_n = index_of(pr + 1, ti_n);
+    if (!(dbg & 1)) {
+      // dX block of the two tiles (row-major inside a tile, natural channel order: the scatter kernels read it a row at a
+      // time).  A lane holds 3 x 48 B of its row: stored directly that is nine instructions of 64 scattered 16-byte pieces
+      // (65 of the kernel's 160 us); staged through this wave's LDS tile instead, every store instruction writes 1 KB contiguous.
+      float* sp = s_stg + n * (GRD_LD - GRD_DX) + 12 * h;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          row_store_plain(gdx + p * LRF_CA + 4 * i, make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]));
+          *reinterpret_cast<float4*>(sp + p * LRF_CA + 4 * i) = make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]);
+      *reinterpret_cast<float4*>(s_stg + n * (GRD_LD - GRD_DX) + 72 + 4 * h) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the rows' pad columns
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+        if (2 * pr + th < T) {
+          float* gdx = grd + (size_t)(2 * pr + th) * (size_t)(16 * GRD_LD) + GRD_DX * 16;
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            row_store_plain(gdx + (i * 64 + lane) * 4, *reinterpret_cast<const float4*>(s_stg + th * (16 * (GRD_LD - GRD_DX)) + (i * 64 + lane) * 4));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                         // (the next pair's staging writes stay behind these reads)
     }
     // ---- d/d(position) from the appearance lookups, and X again
     const float zk = s_z[k];
@@ -451,8 +516,8 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     float X[40];
 #pragma unroll
     for (int i = 0; i < 40; ++i) X[i] = 0.0f;
-    if (valid && !(dbg & 2)) {
-      int i0[3], i1[3]; float t[3], gm[3];
+    if (!(dbg & 2)) {                                          // every lane gathers (rows beyond the tile's count sit on the tile's first sample and carry dX = dfeat = 0):
+      int i0[3], i1[3]; float t[3], gm[3];                     // no branch between the matrix products and the gathers, the compiler interleaves them
       tap1d_g(u[0], f.pw[0], i0[0], i1[0], t[0], gm[0]);       // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps)
       tap1d_g(u[1], f.ph[0], i0[1], i1[1], t[1], gm[1]);
       tap1d_g(u[2], f.ll[0], i0[2], i1[2], t[2], gm[2]);
@@ -474,7 +539,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int ks = KS0[p] + e;
-          const bf16x8 sel = selector([&](int j) { const int c = 8 * ks + j - 12 * p; return (c >= 0 && c < 12) ? 12 * h + c : -1; });
+          const bf16x8 sel = selector(2 + 2 * p + e);
           xt = mfma32(xh[ks], sel, xt);
           xt = mfma32(xl[ks], sel, xt);
         }
@@ -506,6 +571,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
 #pragma unroll
       for (int q = 0; q < 6; ++q) rpp[q] = prt[q];
     }
+    ti_c = ti_n; k_c = k_n;
   }
   // ---- dbasis partial of the workgroup (as k_train_dgrad3's dW1 block)
   f32x4* s_red = reinterpret_cast<f32x4*>(s_dyn4);           // [wave slot][12 float4 of the 48 accumulator registers][lane]
@@ -539,7 +605,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
   }
 }
 constexpr size_t app3_lds_bytes(int S, int NW) {
-  const size_t a = (size_t)APP3_IMG_U4 * 16 + (size_t)S * 4, b = (size_t)(NW / 2) * 12 * 64 * 16;
+  const size_t a = (size_t)(APP3_IMG_U4 + 8 * 64) * 16 + (size_t)NW * APP3_STG_FLOATS * 4 + (size_t)S * 4, b = (size_t)(NW / 2) * 12 * 64 * 16;
   return a > b ? a : b;
 }
 
