@@ -178,150 +178,6 @@ __device__ __forceinline__ void load_dx6(const float* __restrict__ grd, size_t r
   for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
 }
 
-// ---------------------------------------------------------------- colour chain, saving rows
-// Same arithmetic as k_shade_bf16; additionally writes rgb per shaded sample and the ACT row.
-__global__ __launch_bounds__(1024) void k_bwd_shade_fwd(
-    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int* __restrict__ toff, int R,
-    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
-    float* __restrict__ crgb, float* __restrict__ act,
-    const float* __restrict__ cw /* with part: also emit the per-tile weighted colours of k_shade_bf16 */,
-    float* __restrict__ part, int pmax, uint32_t* __restrict__ relu_bits, int4* __restrict__ tileinfo) {
-  __shared__ uint4 img[IMGB_U4];
-  for (int i = threadIdx.x; i < IMGB_U4; i += blockDim.x) img[i] = f.mlpb[i];
-  __syncthreads();
-  const float* tail = reinterpret_cast<const float*>(img + IMGB_TAIL);
-  TileWalk tw = tile_walk_begin(toff, R);
-  for (; tw.t < tw.t_end; ++tw.t) {
-    asm volatile("" ::: "memory");
-    // the lane's coordinates are re-derived per tile (two instructions) instead of being kept -- and spilled -- across the
-    // 1800-instruction loop body
-    int lane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-    const int s = lane & 15, g = lane >> 4;
-    tile_walk_seek(tw, toff);
-    const int ray = __builtin_amdgcn_readfirstlane(tw.ray);
-    const int j0 = (tw.t - (tw.next_off - (ncomp[ray] + ITEM - 1) / ITEM)) * ITEM;
-    const int cnt = min(ITEM, ncomp[ray] - j0);
-    if (lane == 0) tileinfo[tw.t] = make_int4(ray, j0, cnt, j0 / ITEM);          // for k_train_dgrad3: no tile walk there
-    const float* rp = rays + (size_t)ray * 6;
-    const float o[3] = {rp[0], rp[1], rp[2]};
-    const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
-    const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
-    float vb[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3V + 4 * c]);
-      vb[c] = wv.w + wv.x * dh[0] + wv.y * dh[1] + wv.z * dh[2];
-    }
-    const bool valid = s < cnt;
-    const size_t ci = (size_t)ray * S + j0 + (valid ? s : 0);
-    const int k = cidx[ci];
-    float x[3], u[3];
-    sample_point(f, o, dh, z[k], x, u);
-
-    f32x4 fe[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]));
-    {
-      float v[8];
-      bf16x8 bh, bl;
-      int gx = f.pw[0], gy = f.ph[0], gz = f.ll[0];
-      asm volatile("" : "+s"(gx), "+s"(gy), "+s"(gz));               // (float)(size - 1) re-formed per tile: hoisted, the three values are spilled at 128 registers
-      const AxisTaps at = axis_taps(gx, gy, gz, u);                  // 32-bit gathers, taps once per axis
-      gather_app6_plane32<0>(f, at, g, v);
-      split8(v, bh, bl);
-      gemm_step<2>(img, IMGB_BAS / 128 + 0, 3, lane, bh, bl, fe);
-      gather_app6_plane32<1>(f, at, g, v);
-      split8(v, bh, bl);
-      gemm_step<2>(img, IMGB_BAS / 128 + 1, 3, lane, bh, bl, fe);
-      __builtin_amdgcn_sched_barrier(0);                 // the third plane's gathers stay behind the second's products: with all three
-      gather_app6_plane32<2>(f, at, g, v);               // in flight at once the kernel spilled 8 registers per tile (same speed)
-      split8(v, bh, bl);
-      gemm_step<2>(img, IMGB_BAS / 128 + 2, 3, lane, bh, bl, fe);
-      settle<2>(fe);
-    }
-    // feat (27) | 1 | 0 0 0 0
-    {
-      float4 a = make_float4(fe[0][0], fe[0][1], fe[0][2], fe[0][3]);
-      float4 b = make_float4(fe[1][0], fe[1][1], fe[1][2], fe[1][3]);
-      if (g == 2) b.w = 1.0f;                        // column 27 = bias column of the dW1 GEMM
-      if (g == 3) b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      float* afr = frag_lane_base(act, (size_t)tw.t, ACT_LD, s, g);      // + 16 * COL: this lane's float4 of block column COL
-      row_store_b<32>(afr + 16 * ACT_FEAT, a);
-      row_store_b<32>(afr + 16 * (ACT_FEAT + 16), b);
-    }
-    f32x4 h1[8];
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B1 + 16 * t1 + 4 * g]);
-    {
-      const float v[8] = {fe[0][0], fe[0][1], fe[0][2], fe[0][3], fe[1][0], fe[1][1], fe[1][2], fe[1][3]};
-      bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(img, IMGB_W1 / 128, 1, lane, bh, bl, h1);
-      settle<8>(h1);
-    }
-    // ReLU masks for the data-gradient kernel: bit 4 t1 + r of this lane's word = unit 16 t1 + 4 g + r of sample s is
-    // active.  One dword per lane and layer (512 B per tile) instead of re-reading the 16 KB of h1 / h2 rows there.
-    uint32_t m1 = 0, m2 = 0;
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        h1[t1][r] = fmaxf(h1[t1][r], 0.0f);
-        m1 |= min(__float_as_uint(h1[t1][r]), 1u) << (4 * t1 + r);        // relu output: +0 or positive
-      }
-    }
-    relu_bits[((size_t)tw.t * 2 + 0) * 64 + lane] = m1;
-    f32x4 h2[8];
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h2[t1] = *reinterpret_cast<const f32x4*>(&tail[TAIL_B2 + 16 * t1 + 4 * g]);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = h1[2 * ks + (j >> 2)][j & 3];
-      bf16x8 bh, bl;
-      split8(v, bh, bl);
-      gemm_step<8>(img, IMGB_W2 / 128 + ks, 4, lane, bh, bl, h2);
-    }
-    settle<8>(h2);
-    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
-#pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        h2[t1][r] = fmaxf(h2[t1][r], 0.0f);
-        m2 |= min(__float_as_uint(h2[t1][r]), 1u) << (4 * t1 + r);
-        const float4 wv = *reinterpret_cast<const float4*>(&tail[TAIL_W3H + g * TAIL_W3H_GS + (t1 * 4 + r) * 4]);
-        o0 += h2[t1][r] * wv.x; o1 += h2[t1][r] * wv.y; o2 += h2[t1][r] * wv.z;
-      }
-    }
-    relu_bits[((size_t)tw.t * 2 + 1) * 64 + lane] = m2;
-    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
-    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
-    if (valid && g == 0) {
-      float* cp = crgb + ((size_t)ray * S + j0 + s) * 3;
-      cp[0] = 1.0f / (1.0f + expf(-(o0 + vb[0])));
-      cp[1] = 1.0f / (1.0f + expf(-(o1 + vb[1])));
-      cp[2] = 1.0f / (1.0f + expf(-(o2 + vb[2])));
-    }
-    if (part) {                                   // lrf_render_fwd_train: this kernel IS the forward shade
-      const float w = valid ? cw[(size_t)ray * S + j0 + s] : 0.0f;
-      float cr = w / (1.0f + expf(-(o0 + vb[0])));
-      float cg = w / (1.0f + expf(-(o1 + vb[1])));
-      float cb = w / (1.0f + expf(-(o2 + vb[2])));
-#pragma unroll
-      for (int dd = 1; dd < 16; dd <<= 1) {
-        cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);
-      }
-      if (lane == 0) {
-        float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
-        pp[0] = cr; pp[1] = cg; pp[2] = cb;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------- helpers of the data-gradient / scatter kernels
 // aligned 16-byte load from a pointer known to be global memory
 __device__ __forceinline__ void ld4g(const float* p, float* out) {
@@ -746,7 +602,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   }
   // appearance partials of this ray's tiles (written by k_train_dgrad3); with rpart == null they are added
   // afterwards by k_rays_add_rpart, so that this kernel does not have to wait for the data-gradient kernel
-  const int nt = rpart ? (nsh + ITEM - 1) / ITEM : 0;
+  const int nt = rpart ? 2 * ((nsh + ITEM3 - 1) / ITEM3) : 0;          // 16-row tiles of the ray (k_shade3<SAVE>)
   for (int t = lane; t < nt; t += 64) {
     const float* rpp = rpart + ((size_t)ray * pmax + t) * 8;
 #pragma unroll
@@ -774,7 +630,7 @@ __global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict_
                                                         const int* __restrict__ perm) {
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
   if (ray >= R) return;
-  const int nt = (ncomp[ray] + ITEM - 1) / ITEM;
+  const int nt = 2 * ((ncomp[ray] + ITEM3 - 1) / ITEM3);    // 16-row tiles of the ray (k_shade3<SAVE>)
   float go3[3] = {0.0f, 0.0f, 0.0f}, gdh[3] = {0.0f, 0.0f, 0.0f};
   for (int t = 0; t < nt; ++t) {
     const float4* rpp = reinterpret_cast<const float4*>(rpart + ((size_t)ray * pmax + t) * 8);
@@ -1249,8 +1105,9 @@ struct BwdWorkspace {
   float* feat; float* crgb; float* imt; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
-  uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_bwd_shade_fwd -> k_train_dgrad3, k_wgrad_w2w3
-  int4* tileinfo;            // [tile] (ray, j0, count, tile in ray), k_bwd_shade_fwd -> k_train_dgrad3
+  uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_shade3<SAVE> -> k_train_dgrad3, k_wgrad_w2w3
+  int4* tileinfo;            // [tile] (ray, j0, count, tile in ray), k_shade3<SAVE> -> k_train_dgrad3, k_train_app3
+  int* toff32;               // [R + 1] k_shade3's own tile offsets when they do not fit in its LDS (fw.toff holds the 16-row tiles')
   uint16_t* tid2; int* hist2; int* offs2; int* cursor2; uint32_t* list2;   // bins of the appearance scatter (runs beside the density scatter)
   uint32_t nmax;
   size_t bytes;
@@ -1282,6 +1139,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.relu_bits = reinterpret_cast<uint32_t*>(take(rows / 16 * 128));
   b.tileinfo = reinterpret_cast<int4*>(take(rows / 16 * 4));
+  b.toff32 = reinterpret_cast<int*>(take((size_t)R + 1));
   b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
   b.hist2 = reinterpret_cast<int*>(take(BIN_MAX));
   b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
@@ -1291,16 +1149,17 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   return b;
 }
 
-// The row-saving colour kernel of the training forward is k_bwd_shade_fwd behind k_scan_tiles.  (Round 2 also built it
-// in the eval kernel's shape -- prefetched tile header, two launches: 0.83 vs 0.69 ms, it spilled; removed.)
+// The row-saving colour kernel of the training forward is the eval kernel itself: k_shade3<SAVE> (lrf_shade3.inl).
+// (Rounds 1-3 ran a separate 16-sample kernel, k_bwd_shade_fwd, behind k_scan_tiles: 166-179 us at BASELINE configs[1] with
+// the rows down to 160 B per sample; round 4 first tried the 32-sample chain on a static split of tile pairs: 318 us, see
+// lrf_train32.inl.)
 static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 + k_train_app3 without row stores / position gradient and X / dz1 products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
-static int launch_shade_save(const DField& d, const float* rays, const float* z, int S, int R, const Workspace& w,
-                             const BwdWorkspace& b, hipStream_t st) {
-  hipLaunchKernelGGL(k_bwd_shade_fwd, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx,
-                     b.crgb, b.act, w.cw, w.part, w.pmax, b.relu_bits, b.tileinfo);
-  return 0;
+static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
+                                    const BwdWorkspace& b, float* rgb, hipStream_t st) {
+  const SaveOut3 sv{b.crgb, b.act, b.relu_bits, b.tileinfo, w.toff};
+  return launch_shade3(d, rays, z, R, S, flags, w, b.toff32, rgb, nullptr, &sv, nullptr, st);
 }
 
 }  // namespace lrf
@@ -1336,11 +1195,9 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
   const Workspace& w = b.fw;
   rays = sort_rays_if_asked(d, rays, R, flags, w, st);
+  d.rdir = w.rdir;
   launch_march(d, rays, z, R, S, flags, 0.0f, depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-  if (launch_shade_save(d, rays, z, S, R, w, b, st)) return 1;
-  hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st,
-                     R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr, d.perm);
+  LRF_HIP(launch_shade_save(d, rays, z, S, R, flags, w, b, rgb, st));
   LRF_HIP(hipGetLastError());
   return 0;
 }
@@ -1395,9 +1252,9 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   }
   hipLaunchKernelGGL(k_pack_mlp_w32_t, dim3((W32T_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
+    d.rdir = w.rdir;
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-    if (launch_shade_save(d, rays, z, S, R, w, b, st)) return 1;
+    LRF_HIP(launch_shade_save(d, rays, z, S, R, flags, w, b, b.rgb, st));
   }
   // The backward runs as two branches that share no outputs (g_bwd_overlap, default on):
   //   caller's stream: k_train_dgrad3 -> k_train_app3 [-> k_wgrad_w2w3] -> appearance bins + scatter   [-> join] -> ray partials

@@ -905,7 +905,7 @@ static Workspace carve(void* ws, int R, int S) {
   Workspace w;
   char* p = reinterpret_cast<char*>(ws);
   size_t off = 0;
-  w.pmax = (S + ITEM - 1) / ITEM;                     // partial slots per ray: enough for 16- and 32-sample tiles
+  w.pmax = 2 * ((S + ITEM3 - 1) / ITEM3);             // partial slots per ray: enough for 16-sample tiles, 32-sample tiles and the training rows (two 16-row tiles per 32-sample tile)
   w.toff  = reinterpret_cast<int*>(p + off);       off += up256((size_t)(R + 1) * 4);
   w.ncomp = reinterpret_cast<int*>(p + off);       off += up256((size_t)R * 4);
   w.acc   = reinterpret_cast<float*>(p + off);     off += up256((size_t)R * 4);
@@ -1009,6 +1009,54 @@ static void launch_march(const DField& d, const float* rays, const float* z, int
   }
 }
 
+// k_march's output -> colours: k_shade3 behind an in-kernel scan of the tile offsets when they fit in LDS beside the image,
+// behind k_scan_tiles_n otherwise (toff32: R + 1 ints).  sv == nullptr: the eval forward; else the training forward, which
+// also leaves the rows of SaveOut3 (and sv->toff16 must not be toff32).  dump: lrf_debug_set_dump's buffer (eval only).
+static hipError_t launch_shade3(DField d, const float* rays, const float* z, int R, int S, uint32_t flags, const Workspace& w,
+                                int* toff32, float* rgb, float* acc_out, const SaveOut3* sv, float* dump, hipStream_t st) {
+  const size_t lds_base = (size_t)W32_ALL_U4 * sizeof(uint4) + (size_t)S * sizeof(float);
+  const size_t lds_toff = (size_t)(R + 1) * sizeof(int) + (size_t)R * sizeof(unsigned short) + 16;
+  const bool in_lds = lds_base + lds_toff + 64 <= 160 * 1024 - 256;
+  static std::once_flag attr3_once[64];                  // per device; the launch below must not overtake the opt-in on another host thread
+  static hipError_t attr3_err[64];
+  int dev = 0;
+  hipError_t e0 = hipGetDevice(&dev);
+  if (e0 != hipSuccess) return e0;
+  std::call_once(attr3_once[dev & 63], [dev] {
+    const int lim = 160 * 1024 - 256;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    attr3_err[dev & 63] = e;
+  });
+  if (attr3_err[dev & 63] != hipSuccess) return attr3_err[dev & 63];
+  const dim3 grid(device_cus()), block(512);
+  if (sv) {
+    if (in_lds) {
+      hipLaunchKernelGGL((k_shade3<8, true, false, true>), grid, block, lds_base + lds_toff, st,
+                         d, rays, z, S, toff32, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out, *sv);
+    } else {
+      hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, toff32);
+      hipLaunchKernelGGL((k_shade3<8, false, false, true>), grid, block, lds_base, st,
+                         d, rays, z, S, toff32, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out, *sv);
+    }
+  } else if (in_lds && dump) {                    // test hook: phase timing, s_memtime totals -> the dump buffer
+    d.dump = dump;
+    hipLaunchKernelGGL((k_shade3<8, true, true>), grid, block, lds_base + lds_toff, st,
+                       d, rays, z, S, toff32, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out, SaveOut3{});
+  } else if (in_lds) {
+    hipLaunchKernelGGL((k_shade3<8, true, false>), grid, block, lds_base + lds_toff, st,
+                       d, rays, z, S, toff32, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out, SaveOut3{});
+  } else {
+    hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, toff32);
+    hipLaunchKernelGGL((k_shade3<8, false, false>), grid, block, lds_base, st,
+                       d, rays, z, S, toff32, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out, SaveOut3{});
+  }
+  return hipSuccess;
+}
+
 }  // namespace lrf
 
 #include "lrf_backward.inl"
@@ -1091,32 +1139,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
     d.rdir = w.rdir;
     launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
     if (ev) LRF_HIP(hipEventRecord(ev[1], st));
-    const size_t lds_base = (size_t)W32_ALL_U4 * sizeof(uint4) + (size_t)S * sizeof(float);
-    const size_t lds_toff = (size_t)(R + 1) * sizeof(int) + (size_t)R * sizeof(unsigned short) + 16;
-    const bool in_lds = lds_base + lds_toff + 64 <= 160 * 1024 - 256;
-    static std::once_flag attr3_once[64];                  // per device; the launch below must not overtake the opt-in on another host thread
-    static hipError_t attr3_err[64];
-    int dev = 0;
-    LRF_HIP(hipGetDevice(&dev));
-    std::call_once(attr3_once[dev & 63], [dev] {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3<8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-      attr3_err[dev & 63] = e;
-    });
-    LRF_HIP(attr3_err[dev & 63]);
-    if (in_lds && g_dump) {                     // test hook: phase timing, s_memtime totals -> the dump buffer
-      d.dump = g_dump;
-      hipLaunchKernelGGL((k_shade3<8, true, true>), dim3(device_cus()), dim3(512), lds_base + lds_toff, st,
-                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
-    } else if (in_lds) {
-      hipLaunchKernelGGL((k_shade3<8, true, false>), dim3(device_cus()), dim3(512), lds_base + lds_toff, st,
-                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
-    } else {
-      hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
-      hipLaunchKernelGGL((k_shade3<8, false, false>), dim3(device_cus()), dim3(512), lds_base, st,
-                         d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out);
-    }
+    LRF_HIP(launch_shade3(d, rays, z, R, S, flags, w, w.toff, rgb, acc_out, nullptr, g_dump, st));
     if (ev) { LRF_HIP(hipEventRecord(ev[2], st)); LRF_HIP(hipEventRecord(ev[3], st)); }
     LRF_HIP(hipGetLastError());
     return 2;            // (internal) done, two launches: no finalize interval

@@ -142,8 +142,20 @@ __device__ __forceinline__ int toff_lower_bound_p(P toff, int n, int v) {
 // the top of the next tile, so the dependent chain tile -> ray -> sample index -> distance is off the critical path.
 struct Hdr3 {
   int ray, tile_in_ray, k;       // ray, tile number inside the ray, this lane's sample index into z
+  int cnt;                       // samples in the tile (SAVE)
   float wgt;                     // this lane's compositing weight (0 for lanes beyond the tile's count and for K half 1)
   float o[3], d[3];              // ray origin, unit direction
+};
+
+// What the training forward keeps for the backward (SAVE; lrf_backward.inl, lrf_common.h): a 32-sample tile t of this kernel
+// is the pair 2 t, 2 t + 1 of the backward's 16-row tiles (lane n -> row n & 15 of tile 2 t + (n >> 4)), so a ray owns
+// 2 ceil(n / 32) of them and the second of a pair may be empty.
+struct SaveOut3 {
+  float* crgb;            // [ray * S + j][3] sigmoid colour of compact sample j
+  float* act;             // feat rows, 16-row fragment order (ACT_LD)
+  uint32_t* relu_bits;    // [16-row tile][layer][lane s + 16 g]: bit 4 t1 + r = unit 16 t1 + 4 g + r is active
+  int4* tileinfo;         // [16-row tile] (ray, first compact sample, count, tile number inside the ray)
+  int* toff16;            // [R + 1] offsets of the rays' 16-row tiles (= 2 x this kernel's tile offsets)
 };
 
 // NW waves per workgroup (one workgroup per CU).  LDSTOFF: the tile offsets are scanned by every workgroup itself into
@@ -151,12 +163,14 @@ struct Hdr3 {
 // and toff_g holds them.
 // TIMED (debug, lrf_debug_set_dump): s_memtime totals per wave -> dump[block][wave][8] =
 // {rest of the prologue, header + position, gather + split, image copy, scan, chain, tiles, finalize}
-template <int NW, bool LDSTOFF, bool TIMED = false>
+// SAVE: the training forward -- the same tile loop additionally writes what SaveOut3 lists (128 B of feat + 32 B of mask bits
+// + 12 B of colour per shaded sample): the eval kernel IS the row-saving forward, its rgb is bit-identical to the eval's.
+template <int NW, bool LDSTOFF, bool TIMED = false, bool SAVE = false>
 __global__ __launch_bounds__(NW * 64) void k_shade3(
     DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff_g, int R, const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
     const float* __restrict__ cw, float* __restrict__ part, int pmax,
-    uint32_t flags, const float* __restrict__ acc, float* __restrict__ rgb_out, float* __restrict__ acc_out) {
+    uint32_t flags, const float* __restrict__ acc, float* __restrict__ rgb_out, float* __restrict__ acc_out, SaveOut3 sv) {
   constexpr int NT = NW * 64;
   extern __shared__ uint4 s_dyn[];                             // image, tail, z[S][, toff[R + 1]]
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -220,6 +234,9 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
   typedef typename std::conditional<LDSTOFF, const lds_int*, const int*>::type ToffP;
   ToffP toff;
   if constexpr (LDSTOFF) toff = s_toff; else toff = toff_g;
+  if constexpr (SAVE) {
+    if (blockIdx.x == 0) for (int r = tid; r <= R; r += NT) sv.toff16[r] = 2 * (int)toff[r];
+  }
 
   // this workgroup's rays [ra, rb) and tiles [T0, T1): the even split of the tile list, moved to ray boundaries
   const int nb = gridDim.x;
@@ -244,6 +261,7 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     hd.ray = w_ray; hd.tile_in_ray = t - w_tile0;
     const int j0 = hd.tile_in_ray * ITEM3;
     const int cnt = min(ITEM3, w_nc - j0);
+    hd.cnt = cnt;
     const size_t ci = (size_t)w_ray * S + j0 + (n < cnt ? n : 0);
     hd.k = cidx[ci];
     hd.wgt = (n < cnt && h == 0) ? cw[ci] : 0.0f;              // the two K halves of a sample hold the same colour: count it once
@@ -310,6 +328,21 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
       fc = mfma32(ah, xh[ks], fc);
     }
     const f32x16 fe = (fa + fb) + fc;
+    const size_t t16 = 2 * (size_t)t_cur + (size_t)(n >> 4);   // (SAVE) this lane's 16-row tile
+    if constexpr (SAVE) {                                      // feat row: register r = feature 8 (r >> 2) + 4 h + (r & 3); column 27 = 1 (bias column of dW1), 28.. = 0
+      float* ap = sv.act + t16 * (size_t)(16 * ACT_LD) + 16 * ACT_FEAT + ((n & 15) << 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v4 = make_float4(fe[4 * q], fe[4 * q + 1], fe[4 * q + 2], fe[4 * q + 3]);
+        if (q == 3) { if (h == 0) v4.w = 1.0f; else v4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+        *reinterpret_cast<float4*>(ap + (q >> 1) * 256 + (((2 * (q & 1) + h) * 16) << 2)) = v4;
+      }
+      if (lane == 0) {
+        const int j0 = cur.tile_in_ray * ITEM3;
+        sv.tileinfo[2 * (size_t)t_cur] = make_int4(cur.ray, j0, min(16, cur.cnt), 2 * cur.tile_in_ray);
+        sv.tileinfo[2 * (size_t)t_cur + 1] = make_int4(cur.ray, cur.cnt > 16 ? j0 + 16 : j0, max(0, cur.cnt - 16), 2 * cur.tile_in_ray + 1);
+      }
+    }
     f32x16 h1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -328,15 +361,26 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
       mma3_step<4>(img, W32_W1 + q, 2, lane, bh, bl, h1);
     }
     bf16x8 b2h[8], b2l[8];
+    // (SAVE) mask bits: register 4 q4 + r of M-tile m is unit 32 m + 8 q4 + 4 h + r = unit 16 t1 + 4 g + r of the 16-row
+    // layout with t1 = 2 m + (q4 >> 1), g = 2 (q4 & 1) + h: dword q4 & 1 of this lane, bit 4 t1 + r
+    uint32_t mk[2] = {0u, 0u};
 #pragma unroll
     for (int m0 = 0; m0 < 4; ++m0)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = relu_i(h1[m0][8 * q + j]);
+        for (int j = 0; j < 8; ++j) {
+          v[j] = relu_i(h1[m0][8 * q + j]);
+          if constexpr (SAVE) mk[j >> 2] |= min(__float_as_uint(v[j]), 1u) << (4 * (2 * m0 + q) + (j & 3));
+        }
         split8c(v, b2h[2 * m0 + q], b2l[2 * m0 + q]);
       }
+    if constexpr (SAVE) {
+      uint32_t* bp = sv.relu_bits + t16 * 128 + (n & 15) + 16 * h;
+      bp[0] = mk[0]; bp[32] = mk[1];
+      mk[0] = 0u; mk[1] = 0u;
+    }
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -359,6 +403,11 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
           const float4 w1 = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + W32_T_W3_LD + u]);
           const float4 w2 = *reinterpret_cast<const float4*>(&tail[W32_T_W3 + 2 * W32_T_W3_LD + u]);
           const float a0 = relu_i(h2[mm][4 * q]), a1 = relu_i(h2[mm][4 * q + 1]), a2 = relu_i(h2[mm][4 * q + 2]), a3 = relu_i(h2[mm][4 * q + 3]);
+          if constexpr (SAVE) {
+            const int b0 = 4 * (2 * (2 * half + mm) + (q >> 1));
+            mk[q & 1] |= (min(__float_as_uint(a0), 1u) << b0) | (min(__float_as_uint(a1), 1u) << (b0 + 1))
+                       | (min(__float_as_uint(a2), 1u) << (b0 + 2)) | (min(__float_as_uint(a3), 1u) << (b0 + 3));
+          }
           o0 += a0 * w0.x; o0 += a1 * w0.y; o0 += a2 * w0.z; o0 += a3 * w0.w;
           o1 += a0 * w1.x; o1 += a1 * w1.y; o1 += a2 * w1.z; o1 += a3 * w1.w;
           o2 += a0 * w2.x; o2 += a1 * w2.y; o2 += a2 * w2.z; o2 += a3 * w2.w;
@@ -367,9 +416,18 @@ __global__ __launch_bounds__(NW * 64) void k_shade3(
     __builtin_amdgcn_s_setprio(0);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
     // w * sigmoid(x) (:133, :632), hardware exp2 / reciprocal; partial colour of the tile = sum over its samples
-    float cr = cur.wgt * __frcp_rn(1.0f + __expf(-(o0 + vb[0])));
-    float cg = cur.wgt * __frcp_rn(1.0f + __expf(-(o1 + vb[1])));
-    float cb = cur.wgt * __frcp_rn(1.0f + __expf(-(o2 + vb[2])));
+    const float s0 = __frcp_rn(1.0f + __expf(-(o0 + vb[0]))), s1 = __frcp_rn(1.0f + __expf(-(o1 + vb[1]))), s2 = __frcp_rn(1.0f + __expf(-(o2 + vb[2])));
+    if constexpr (SAVE) {
+      uint32_t* bp = sv.relu_bits + t16 * 128 + 64 + (n & 15) + 16 * h;
+      bp[0] = mk[0]; bp[32] = mk[1];
+      if (h == 0 && n < cur.cnt) {
+        float* cp = sv.crgb + ((size_t)cur.ray * S + cur.tile_in_ray * ITEM3 + n) * 3;
+        cp[0] = s0; cp[1] = s1; cp[2] = s2;
+      }
+    }
+    float cr = cur.wgt * s0;
+    float cg = cur.wgt * s1;
+    float cb = cur.wgt * s2;
 #pragma unroll
     for (int dd = 1; dd < 32; dd <<= 1) {
       cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64);

@@ -7,9 +7,9 @@ __graft_entry__.build() compiles it and the device assembly is inspected.
    arithmetic; profiles/r08b_packed_fp32_beside_mfma.md).  hipcc's SLP vectoriser emits exactly that form for
    "broadcast weight x pair of texels"; the library is therefore built with -fno-slp-vectorize (csrc/lrf_tu.h).  This
    was the cause of the run-to-run differences of rounds 1-2 (DESIGN.md finding 17).
-2. k_shade3 (the default colour kernel): 135 v_mfma_f32_32x32x16_bf16 per tile (15 basis + 24 layer 1 + 96 layer 2),
-   no scratch, at most 256 registers (two waves per SIMD).
-3. k_march, the row-saving forward of the training step (k_bwd_shade_fwd) and the two 32-sample kernels of the colour
+2. k_shade3 (the default colour kernel, and with SAVE the row-saving forward of the training step): 135
+   v_mfma_f32_32x32x16_bf16 per tile (15 basis + 24 layer 1 + 96 layer 2), no scratch, at most 256 registers (two waves per SIMD).
+3. k_march and the two 32-sample kernels of the colour
    network's backward (k_train_dgrad3, k_train_app3) use no scratch and at most 256 registers; the weight-gradient kernel
    keeps its shape.
 """
@@ -82,7 +82,9 @@ def test_build_does_not_use_the_slp_vectoriser():
 
 
 def test_shade3_shape(asm):
-    for name, body in _body(asm, r"k_shade3ILi8ELb[01]ELb0E"):
+    hits = _body(asm, r"k_shade3ILi8ELb[01]ELb0ELb[01]E")                     # LDS / global tile offsets x eval / SAVE
+    assert len(hits) == 4, [k for k, _ in hits]
+    for name, body in hits:
         assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) == 135, name
         assert not re.search(r"v_mfma_f32_16x16x32_bf16", body), name
         meta = asm[asm.index(name + ":"):]
@@ -95,7 +97,7 @@ def test_shade3_shape(asm):
 
 
 def test_scratch_use_is_bounded(asm):
-    for pat, limit in ((r"k_marchILb1EE", 0), (r"k_marchILb0EE", 0), (r"k_bwd_shade_fwdE", 0),
+    for pat, limit in ((r"k_marchILb1EE", 0), (r"k_marchILb0EE", 0),
                        (r"k_train_dgrad3ILi8EE", 0), (r"k_train_app3ILi8EE", 0)):
         for name, _ in _body(asm, pat):
             meta = asm[asm.index(".amdhsa_kernel " + name):]

@@ -202,7 +202,7 @@ def kernel_relu_masks(f, rays, z, ws):
     toff = ws[toff_off:toff_off + 4 * (R + 1)].view(torch.int32)
     tiles = int(toff[R])
     rows = tiles * 16
-    # relu_bits[tile][layer][lane = s + 16 g]: bit 4 t1 + r = unit 16 t1 + 4 g + r of the tile's sample s (k_bwd_shade_fwd)
+    # relu_bits[tile][layer][lane = s + 16 g]: bit 4 t1 + r = unit 16 t1 + 4 g + r of the tile's sample s (k_shade3<SAVE>)
     bits = ws[bits_off:bits_off + tiles * 2 * 64 * 4].view(torch.int32).view(tiles, 2, 4, 16)        # [tile][layer][g][s]
     u = torch.arange(128, device=ws.device)
     t1, gq, r = u >> 4, (u >> 2) & 3, u & 3
