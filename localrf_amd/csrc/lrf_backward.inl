@@ -50,6 +50,29 @@ __host__ __device__ inline int wgrad_chunk_rows(int rows) {
   return max(512, (per + 255) / 256 * 256);
 }
 
+// ---- plane tiles of the binned scatter kernels (see there)
+constexpr int BTILE = 32, BCELL = BTILE + 1;
+constexpr int BIN_CHUNK = 4096;          // entries per block in the hist/fill passes
+constexpr int BIN_MAX = 2048;            // max tiles over the three planes (640^3 -> 1200)
+#ifndef LRF_LINE_WGS
+#define LRF_LINE_WGS 256
+#endif
+#ifndef LRF_DPLANE_MULT
+#define LRF_DPLANE_MULT 4
+#endif
+constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
+
+struct BinGeom { int tx[3], ty[3], base[3], total; };
+__host__ __device__ inline BinGeom make_bins(const Layout& L) {
+  BinGeom b; int off = 0;
+  for (int p = 0; p < 3; ++p) {
+    b.tx[p] = (L.pw[p] + BTILE - 1) / BTILE; b.ty[p] = (L.ph[p] + BTILE - 1) / BTILE;
+    b.base[p] = off; off += b.tx[p] * b.ty[p];
+  }
+  b.total = off;
+  return b;
+}
+
 // tap1d + d(ix)/d(u): (size-1)/2 inside, 0 where ATen's clip_coordinates_set_grad zeroes it
 __device__ __forceinline__ void tap1d_g(float u, int size, int& i0, int& i1, float& t, float& gmul) {
   const float raw = ((u + 1.0f) * 0.5f) * (float)(size - 1);
@@ -448,11 +471,20 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
     float* __restrict__ feat /* in: density feature; out: d(loss)/d(feature) */,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx,
     const float* __restrict__ crgb, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
-    const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays) {
+    const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays,
+    BinGeom bg, uint16_t* __restrict__ tid /* [3][nmax] plane-tile id of every density entry, 0xffff = none */,
+    int* __restrict__ hist /* += entries per tile */, uint32_t nmax) {
   extern __shared__ float s_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
-  if (ray >= R) return;
+  // first pass of the density scatter's counting sort (it was a kernel of its own that re-derived every sample's position):
+  // the workgroup's histogram over the plane tiles, behind the four per-ray arrays (one per wave was measured: four times the
+  // global atomics at the end, 80 -> 120 us)
+  int* s_h = reinterpret_cast<int*>(s_all + (size_t)16 * S);
+  for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
+  __syncthreads();
+  if (ray >= R) return;                                        // (a finished wave no longer counts at the barrier below)
+  const int nlive = min(4, R - (int)blockIdx.x * 4);
   float* s_alpha = s_all + (size_t)wave * 4 * S;
   float* s_w = s_alpha + S;
   float* s_gw = s_w + S;
@@ -548,10 +580,14 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       feat[(size_t)ray * S + k] = gf;      // consumed by the binned scatter kernels
     }
   }
-  // density scatter + position gradient
-  for (int k = lane; k < S - 1; k += 64) {
-    const float gf = s_alpha[k];
-    if (gf == 0.0f) continue;
+  // density scatter (tile ids for the binned scatter kernel) + position gradient
+  for (int k = lane; k < S; k += 64) {
+    const float gf = s_alpha[k];                               // (0 for the last sample)
+    const size_t ei = (size_t)ray * S + k;                     // entry index = sample id
+    if (gf == 0.0f) {
+      tid[ei] = 0xffff; tid[(size_t)nmax + ei] = 0xffff; tid[2 * (size_t)nmax + ei] = 0xffff;
+      continue;
+    }
     const float zk = z[k];
     float xr[3] = {o[0] + dh[0] * zk, o[1] + dh[1] * zk, o[2] + dh[2] * zk};
     float xc[3] = {xr[0], xr[1], xr[2]};
@@ -565,6 +601,11 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       tap1d_g(u[MAT0[p]], f.pw[p], x0, x1, tx, gx);
       tap1d_g(u[MAT1[p]], f.ph[p], y0, y1, ty, gy);
       tap1d_g(u[VEC[p]],  f.ll[p], l0, l1, tl, gl);
+      {
+        const int t = (y0 / BTILE) * bg.tx[p] + x0 / BTILE;
+        tid[(size_t)p * nmax + ei] = (uint16_t)t;
+        atomicAdd(&s_h[bg.base[p] + t], 1);
+      }
       // 32-bit byte offsets, two aligned float4 per tap (as density_feature32 in the forward)
       const unsigned row0 = (unsigned)y0 * (unsigned)f.pw[p], row1 = (unsigned)y1 * (unsigned)f.pw[p];
       const unsigned o00 = (row0 + x0) * (LRF_CD * 4u), o10 = (row0 + x1) * (LRF_CD * 4u);
@@ -621,6 +662,11 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       gp[3 + a] = (gdh[a] - dh[a] * dot) / dn - gd * depth / dn * dh[a];
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bg.total; i += 64 * nlive) {
+    const int v = s_h[i];
+    if (v) atomicAdd(&hist[i], v);
+  }
 }
 
 // d(loss)/d(rays) += the appearance lookups' position gradients (per-tile partials of k_train_dgrad3): the tail of
@@ -658,28 +704,6 @@ __global__ __launch_bounds__(256) void k_rays_add_rpart(const float* __restrict_
 // 32x32-texel plane tile (counting sort, LDS histograms), each tile's contributions are
 // accumulated in LDS (ds_add_f32) by the workgroups that own it and flushed once; lines are
 // accumulated per workgroup in LDS as well.  Global atomics remain only in the flushes.
-constexpr int BTILE = 32, BCELL = BTILE + 1;
-constexpr int BIN_CHUNK = 4096;          // entries per block in the hist/fill passes
-constexpr int BIN_MAX = 2048;            // max tiles over the three planes (640^3 -> 1200)
-#ifndef LRF_LINE_WGS
-#define LRF_LINE_WGS 256
-#endif
-#ifndef LRF_DPLANE_MULT
-#define LRF_DPLANE_MULT 4
-#endif
-constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
-
-struct BinGeom { int tx[3], ty[3], base[3], total; };
-__host__ __device__ inline BinGeom make_bins(const Layout& L) {
-  BinGeom b; int off = 0;
-  for (int p = 0; p < 3; ++p) {
-    b.tx[p] = (L.pw[p] + BTILE - 1) / BTILE; b.ty[p] = (L.ph[p] + BTILE - 1) / BTILE;
-    b.base[p] = off; off += b.tx[p] * b.ty[p];
-  }
-  b.total = off;
-  return b;
-}
-
 // entry i -> sample id (ray*S + k) or ~0u.  Density: every sample with a non-zero feature
 // gradient; appearance: the saved rows of the shaded samples.
 template <bool APP>
@@ -703,40 +727,8 @@ __device__ __forceinline__ void cid_point(const DField& f, const float* __restri
 }
 
 // pass 1: tile id of every entry in every plane + global histogram
-template <bool APP>
-__global__ __launch_bounds__(256) void k_bin_hist(DField f, BinGeom bg, const float* __restrict__ rays, const float* __restrict__ z,
-                                                  int R, int S, const int* __restrict__ toff, const float* __restrict__ gf,
-                                                  const uint32_t* __restrict__ rowinfo, uint32_t nmax,
-                                                  uint16_t* __restrict__ tid, int* __restrict__ hist) {
-  __shared__ int s_h[BIN_MAX];
-  const uint32_t n = entry_count<APP>(R, S, toff);
-  const uint32_t b0 = blockIdx.x * (uint32_t)BIN_CHUNK;
-  if (b0 >= n) return;
-  for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
-  __syncthreads();
-  for (uint32_t i = b0 + threadIdx.x; i < min(n, b0 + BIN_CHUNK); i += 256) {
-    const uint32_t cid = entry_cid<APP>(i, gf, rowinfo);
-    if (cid == 0xffffffffu) {
-      tid[i] = 0xffff; tid[(size_t)nmax + i] = 0xffff; tid[2 * (size_t)nmax + i] = 0xffff;
-      continue;
-    }
-    float u[3];
-    cid_point(f, rays, z, S, cid, u);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      int x0, x1, y0, y1; float tx, ty;
-      tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-      tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-      const int t = (y0 / BTILE) * bg.tx[p] + x0 / BTILE;
-      tid[(size_t)p * nmax + i] = (uint16_t)t;
-      atomicAdd(&s_h[bg.base[p] + t], 1);
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < bg.total; i += 256)
-    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-}
-
+// (The histogram pass of the counting sort is not a kernel: k_bwd_ray (density) and k_train_app3 (appearance) hold every
+// entry's taps anyway, write its three tile ids and count them in LDS histograms.)
 // exclusive scan of the histogram -> list offsets; cursors start at the offsets
 __global__ __launch_bounds__(1024) void k_bin_scan(const int* __restrict__ hist, int nb, int* __restrict__ offs, int* __restrict__ cursor) {
   __shared__ int s_wave[16];
@@ -1239,7 +1231,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4);
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4 + BIN_MAX * 4);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_dgrad3<8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8>),
@@ -1294,16 +1286,16 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                      reinterpret_cast<const uint4*>(b.imt), rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
                      b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));         // go / dfeat rows: the weight-gradient kernel may start
-  hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8), st, d,
+  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * bg.total, st));
+  hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
                      reinterpret_cast<const uint4*>(b.imt), rays, z, S, w.toff, R, b.tileinfo, w.cidx,
-                     b.grd, b.rpart, w.pmax, b.wpart, g_dgrad_dbg & 3);
+                     b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3);
 
   // ---- side stream: per-ray backward, density scatter
-  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float), sb,
-                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
-                     (const float*)nullptr, w.pmax, g_rays);
   LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * bg.total, sb));
-  hipLaunchKernelGGL((k_bin_hist<false>), dim3(nblk), dim3(256), 0, sb, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid, b.hist);
+  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
+                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
+                     (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, sb, b.hist, bg.total, b.offs, b.cursor);
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.cursor, b.list);
   const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
@@ -1352,8 +1344,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (ss) LRF_HIP(hipEventRecord(ss->join, sb));
 
   // ---- caller's stream: appearance scatter (its own bin buffers: the density scatter may still be running)
-  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * bg.total, st));
-  hipLaunchKernelGGL((k_bin_hist<true>), dim3(nblk), dim3(256), 0, st, d, bg, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.nmax, b.tid2, b.hist2);
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist2, bg.total, b.offs2, b.cursor2);
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.cursor2, b.list2);
   if (fuse_a) {

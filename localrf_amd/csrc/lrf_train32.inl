@@ -363,6 +363,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R, const int4* __restrict__ tileinfo, const uint16_t* __restrict__ cidx,
     float* __restrict__ grd /* in: dfeat blocks, out: dX blocks */, float* __restrict__ rpart, int pmax, float* __restrict__ wpart,
+    BinGeom bg, uint16_t* __restrict__ tile_id /* [3][nmax] plane-tile id of every row, 0xffff = none */, int* __restrict__ hist, uint32_t nmax,
     int dbg /* timing experiments: 1 no row stores, 2 no position gradient / X */) {
   constexpr int NT = NW * 64;
   extern __shared__ uint4 s_dyn4[];
@@ -370,6 +371,8 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
   uint4* s_sel = s_dyn4 + APP3_IMG_U4;                        // the eight 0 / 1 selectors, [selector][lane]
   float* s_stg = reinterpret_cast<float*>(s_sel + 8 * 64) + (size_t)(threadIdx.x >> 6) * APP3_STG_FLOATS;   // this wave's dX staging tile pair
   float* s_z = reinterpret_cast<float*>(s_sel + 8 * 64) + (size_t)NW * APP3_STG_FLOATS;
+  int* s_h = reinterpret_cast<int*>(s_z + S);                  // histogram of this workgroup's rows over the plane tiles (first pass of the appearance scatter's counting sort)
+  for (int i = threadIdx.x; i < bg.total; i += NT) s_h[i] = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5, s = n & 15;
   for (int i = tid; i < APP3_IMG_U4; i += NT) img[i] = imt[W32T_BAS * 128 + i];
   for (int i = tid; i < S; i += NT) s_z[i] = z[i];
@@ -516,12 +519,21 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     float X[40];
 #pragma unroll
     for (int i = 0; i < 40; ++i) X[i] = 0.0f;
+    int i0[3], i1[3]; float t[3], gm[3];
+    tap1d_g(u[0], f.pw[0], i0[0], i1[0], t[0], gm[0]);         // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps)
+    tap1d_g(u[1], f.ph[0], i0[1], i1[1], t[1], gm[1]);
+    tap1d_g(u[2], f.ll[0], i0[2], i1[2], t[2], gm[2]);
+    if (have_t && h == 0) {                                    // the row's tile in each plane, counted for the binned scatter
+      const uint32_t row = (uint32_t)tile * 16u + (uint32_t)s;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const int tt = ((unsigned)i0[MAT1[p]] / BTILE) * bg.tx[p] + (unsigned)i0[MAT0[p]] / BTILE;
+        tile_id[(uint32_t)p * nmax + row] = valid ? (uint16_t)tt : (uint16_t)0xffff;
+        if (valid) atomicAdd(&s_h[bg.base[p] + tt], 1);
+      }
+    }
     if (!(dbg & 2)) {                                          // every lane gathers (rows beyond the tile's count sit on the tile's first sample and carry dX = dfeat = 0):
-      int i0[3], i1[3]; float t[3], gm[3];                     // no branch between the matrix products and the gathers, the compiler interleaves them
-      tap1d_g(u[0], f.pw[0], i0[0], i1[0], t[0], gm[0]);       // grid[a] = pw[0], ph[0], ll[0] for a = 0, 1, 2 (axis_taps)
-      tap1d_g(u[1], f.ph[0], i0[1], i1[1], t[1], gm[1]);
-      tap1d_g(u[2], f.ll[0], i0[2], i1[2], t[2], gm[2]);
-      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu, X);
+      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu, X);  // no branch between the matrix products and the gathers, the compiler interleaves them
       app12_position_grad<1>(f, i0, i1, t, gm, h, dX + 12, gu, X + 12);
       app12_position_grad<2>(f, i0, i1, t, gm, h, dX + 24, gu, X + 24);
     }
@@ -573,6 +585,11 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     }
     ti_c = ti_n; k_c = k_n;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bg.total; i += NT) {
+    const int v = s_h[i];
+    if (v) atomicAdd(&hist[i], v);
+  }
   // ---- dbasis partial of the workgroup (as k_train_dgrad3's dW1 block)
   f32x4* s_red = reinterpret_cast<f32x4*>(s_dyn4);           // [wave slot][12 float4 of the 48 accumulator registers][lane]
   for (int half = NW / 2; half >= 1; half >>= 1) {
@@ -604,8 +621,8 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
       for (int r = 0; r < 16; ++r) out[(8 * (r >> 2) + 4 * h + (r & 3)) * 96 + 32 * p + n] = bacc[p][r];
   }
 }
-constexpr size_t app3_lds_bytes(int S, int NW) {
-  const size_t a = (size_t)(APP3_IMG_U4 + 8 * 64) * 16 + (size_t)NW * APP3_STG_FLOATS * 4 + (size_t)S * 4, b = (size_t)(NW / 2) * 12 * 64 * 16;
+constexpr size_t app3_lds_bytes(int S, int NW, int nbins) {
+  const size_t a = (size_t)(APP3_IMG_U4 + 8 * 64) * 16 + (size_t)NW * APP3_STG_FLOATS * 4 + (size_t)S * 4 + (size_t)nbins * 4, b = (size_t)(NW / 2) * 12 * 64 * 16;
   return a > b ? a : b;
 }
 
