@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 3      /* 3: lrf_render_bwd_wait, unknown flag bits rejected, training rows without h1 (round 4) */
+#define LRF_ABI_VERSION 4      /* 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32); 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -179,6 +179,11 @@ int lrf_app_feature(const LrfField* f, const float* u, int32_t P, float* app_fea
 int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size, float near_, float far_,
                         const float* jitter, int32_t R, int32_t N,
                         float* pts, float* t, uint8_t* inside, void* stream);
+
+/* The sample distances of TensorBase.sample_ray_contracted (tensorBase.py:419-437) for N_samples = 6 h: z [2 h] on the
+ * device, the first half linear in [0, 1), the second inverse-depth out to 1e3, + 0.1.  u1, u2 [h]: the two jitter draws
+ * of train mode (torch.rand_like, in the reference's order), both NULL in eval mode. */
+int lrf_z_schedule(int32_t h, const float* u1, const float* u2, float* z, void* stream);
 
 /* TensorBase.sample_ray_contracted (tensorBase.py:419-443): pts [R,S,3] = contract(o + d z) for a caller-supplied
  * schedule z [S] (the second return value of the reference's method; its third is all-true).  rays_o, rays_d [R,3]. */

@@ -95,6 +95,7 @@ SYMBOLS = {
     "lrf_sample_ray_aabb": (C.c_int, [_f, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, _f,
                                       C.c_int32, C.c_int32, _f, _f, C.c_void_p, C.c_void_p]),
     "lrf_sample_ray_contracted": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, _f, C.c_void_p]),
+    "lrf_z_schedule": (C.c_int, [C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_adam_step": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "lrf_density_l1_workspace": (C.c_size_t, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lrf_density_l1_fwd": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -146,7 +147,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if h.lrf_abi_version() != 3:
+        if h.lrf_abi_version() != 4:
             raise NativeError("localrf_amd: ABI version mismatch")
         _lib = h
     return _lib

@@ -3,34 +3,33 @@
 // lrf_render_fwd_train + lrf_render_bwd replace autograd through tensorBase.py:567-636 +
 // tensoRF.py:112-196 (paths relative to /root/reference/localTensoRF).
 //
-// forward with a graph (lrf_render_fwd_train; the same three kernels run at the head of
-// lrf_render_bwd when the caller has no saved workspace):
+// forward with a graph (lrf_render_fwd_train; the same two kernels run at the head of lrf_render_bwd when the caller has
+// no saved workspace):
 //   k_march (+feat)      density features of every sample, compaction lists (as in the forward)
-//   k_scan_tiles         tile offsets
-//   k_bwd_shade_fwd      the split-bf16 colour chain (16-sample tiles on v_mfma_f32_16x16x32_bf16), additionally
-//                        saving per shaded sample: rgb, the ReLU masks of both hidden layers as bits, and the
-//                        activation row ACT = [X | feat,1] in MFMA-fragment order (lrf_common.h: 1 KB per store
-//                        instruction).  The hidden activations themselves are not stored (round 4).
+//   k_shade3<SAVE>       (lrf_shade3.inl) the eval forward's colour kernel itself; additionally saves per shaded sample rgb,
+//                        the ReLU masks of both hidden layers as bits, and the activation row ACT = [feat, 1] in MFMA-
+//                        fragment order (lrf_common.h).  Hidden activations and plane x line products are not stored.
 // backward (two branches on two streams, lrf_render_bwd):
-//   k_train_dgrad3       (lrf_train32.inl) per pair of tiles: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat -> dX on TRANSPOSED
+//   k_train_dgrad3       (lrf_train32.inl) per pair of 16-row tiles: d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> dfeat on TRANSPOSED
 //                        weight fragments, split-bf16 on v_mfma_f32_32x32x16_bf16, 32 samples per wave (same register-
 //                        resident trick as k_shade3: D layout of one product = B operand of the next), ReLU masks
 //                        from the saved bits; dW1 / db1 accumulated in-kernel (transposes on the matrix pipe);
-//                        gradient row GRD = [go, dhat | dfeat | dX]; d/d(position) of the appearance lookups ->
-//                        per-tile ray partials
+//                        gradient row GRD = [go, dhat | dfeat | .]
+//   k_train_app3         (lrf_train32.inl) dfeat -> dX = basis^T dfeat (GRD's dX block, staged through LDS: 1 KB stores);
+//                        re-gathers the appearance taps: d/d(position) -> per-tile ray partials, X = plane x line ->
+//                        dbasis accumulated in-kernel; tile ids + histogram of the appearance scatter's counting sort
 //   k_wgrad_w2w3         dW2 = dz2^T [relu(h1) | 1] and dW3 = go^T [relu(h2) | dhat | 1] from three masked products over
 //                        relu(h1) recomputed from the saved feat rows; no h1 / h2 / dz2 rows
-//   k_wgrad<2,5,KSPLIT>  dbasis as a tall-skinny GEMM C = A^T B over the saved rows (K = shaded samples) on
-//                        v_mfma_f32_16x16x4_f32, per-chunk partials
-//   k_wgrad_reduce       ordered sum of the chunk partials into the reference's layouts (1 launch)
+//   k_wgrad_reduce       ordered sum of the per-chunk / per-workgroup partials into the reference's layouts (1 launch)
 //   k_bwd_ray            one wavefront per ray: weights, d(loss)/d(w), suffix sums ->
 //                        d/d(alpha) -> d/d(density feature); position gradients through
-//                        normalise / contraction to d(loss)/d(rays)
-//   k_bin_hist/scan/fill counting sort of the (sample, plane) entries by 32x32-texel tile
+//                        normalise / contraction to d(loss)/d(rays); tile ids + histogram of the density scatter's
+//                        counting sort
+//   k_bin_scan/fill      the rest of the counting sort of the (sample, plane) entries by 32x32-texel tile
 //   k_scatter_plane      plane AND line gradients of one pass over the binned entries, accumulated per workgroup in
-//                        LDS (CAS-loop fp32 adds; ds_add_f32 is 30x slower on this chip), runs of consecutive
-//                        same-cell entries merged in registers first, tiles added straight into the reference layout
-//                        (k_scatter_line: the fallback where tile + line accumulators exceed LDS)
+//                        LDS (CAS-loop fp32 adds, two channels per 64-bit CAS; ds_add_f32 is 30x slower on this chip),
+//                        runs of consecutive same-cell entries merged in registers first, tiles added straight into the
+//                        reference layout (k_scatter_line: the fallback where tile + line accumulators exceed LDS)
 #pragma once
 
 namespace lrf {
@@ -143,29 +142,13 @@ __device__ __forceinline__ void lds_add4_f32(float* p0, float v0, float* p1, flo
   if (r3 != o3) lds_add_retry(q3, r3, v3);
 }
 
-// Stores into / loads from the saved rows.  Rows are written once and read once by a later kernel: with the `nt` hint
-// they do not displace the field's texels in L2 under the gathers running beside them.  LRF_ROW_NT bits: 1 = 16-byte row
-// stores (h1, h2, dz1), 2 = the X block's stores, 4 = the weight-gradient GEMMs' row loads, 8 = the dX row's
-// stores, 16 = the scatter kernels' dX loads, 32 = the small blocks (feat, go, dfeat, bias columns).  Default 63.
-// Measured on one box each (scripts/ab_libs.sh), forward+backward: row-major rows 2.65 (bit 1 only) / 2.41 (13) /
-// 2.57 ms (15: 8-byte X stores); fragment-order rows (lrf_common.h) 1.93-2.00 (13) / 1.89-1.95 (15: the X block is
-// five coalesced float4 per lane now) / 1.87 (31) / 1.82 ms (47).
+// Loads from the saved rows.  Rows are written once (plain stores: with rows of 128 + 512 B the `nt` store hint of rounds
+// 2-3 no longer pays anywhere, profiles/r11 s3) and read by one or two later kernels with the `nt` hint, so that they do not
+// displace the field's texels in L2 under the gathers running beside them.  LRF_ROW_NT bits: 4 = the feat / go row loads of
+// k_train_dgrad3 and k_wgrad_w2w3, 16 = the scatter kernels' dX loads.  Default: both.
 #ifndef LRF_ROW_NT
 #define LRF_ROW_NT 63
 #endif
-__device__ __forceinline__ void row_store(float* p, f32x4 v) {
-#if LRF_ROW_NT & 1
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-#else
-  *reinterpret_cast<f32x4*>(p) = v;
-#endif
-}
-__device__ __forceinline__ void row_store(float* p, float4 v) { row_store(p, f32x4{v.x, v.y, v.z, v.w}); }
-template <int BIT>
-__device__ __forceinline__ void row_store_b(float* p, float4 v) {
-  if constexpr ((LRF_ROW_NT & BIT) != 0) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
-  else *reinterpret_cast<float4*>(p) = v;
-}
 template <int BIT>
 __device__ __forceinline__ float2 row_load2_b(const float2* p) {
   if constexpr ((LRF_ROW_NT & BIT) != 0) {
@@ -174,15 +157,6 @@ __device__ __forceinline__ float2 row_load2_b(const float2* p) {
     return make_float2(v[0], v[1]);
   } else {
     return *p;
-  }
-}
-template <int BIT = 2>
-__device__ __forceinline__ void row_store2(float* p, float a, float b) {
-  if constexpr ((LRF_ROW_NT & BIT) != 0) {
-    typedef float f32x2s __attribute__((ext_vector_type(2)));
-    __builtin_nontemporal_store(f32x2s{a, b}, reinterpret_cast<f32x2s*>(p));
-  } else {
-    *reinterpret_cast<float2*>(p) = make_float2(a, b);
   }
 }
 __device__ __forceinline__ float4 row_load4(const float* p) {
@@ -267,8 +241,8 @@ __device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
 //     T_c[u][v]  = sum_rows go[row][c] m2[row][u] B[row][v]                       (three 128 x 129 products, K = rows)
 //     dW2[u][v]  = sum_c W3[c][u] T_c[u][v],   db2[u] = sum_c W3[c][u] T_c[u][128]          (dz2 = m2 * W3^T go)
 //     dW3[c][u]  = sum_v W2[u][v] T_c[u][v] + b2[u] T_c[u][128]                   (relu(h2) = m2 * (W2 relu(h1) + b2))
-// so one GEMM family over the rows yields both gradients; relu(h1) is recomputed from the 108 B `feat` row with the
-// forward's own layer-1 fragments and order (bit-identical), and h2 never exists here.  The first version of this
+// so one GEMM family over the rows yields both gradients; relu(h1) is recomputed from the 108 B `feat` row with split-bf16
+// layer-1 fragments (the forward's products, summed in the 16-sample kernels' order), and h2 never exists here.  The first version of this
 // round recomputed layer 2 as well and contracted dW3 on the VALU at one wave per SIMD: 392 us, issue-bound (1450 VALU +
 // 230 MFMA + 305 LDS instructions per 64-row step and wave, profiles/r11a).  This one:
 //   * 512 threads, two waves per SIMD; a step is 128 rows = 8 tiles, one per wave for layer 1; relu(h1) goes to LDS
@@ -343,7 +317,7 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
   };
   auto stage = [&](const Pre& p, int rb) {
     __syncthreads();                                       // previous step's products have read LDS
-    // ---- layer 1 of the forward on this wave's 16 rows (k_bwd_shade_fwd: same fragments, same order)
+    // ---- layer 1 of the forward on this wave's 16 rows (the 16-sample fragments of the exact-order engines; k_shade3 sums the same products in another order: relu(h1) differs from the forward's in the last bit at most)
     f32x4 h1[8];
 #pragma unroll
     for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&s_b1[16 * t1 + 4 * g]);

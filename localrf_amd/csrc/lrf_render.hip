@@ -831,6 +831,21 @@ __global__ __launch_bounds__(256) void k_sample_contracted(const float* __restri
   pts[3 * i] = x; pts[3 * i + 1] = y; pts[3 * i + 2] = w;
 }
 
+// The ray-independent sample distances of sample_ray_contracted (tensorBase.py:419-437): z[i] = t_i (+ u1_i / h) + 0.1 and
+// z[h + i] = 1 / ((1 - s_i) + s_i / 1000) + 0.1 with s_i = t_i (+ u2_i / h), t_i = i / h -- the reference's sixteen
+// elementwise launches per training iteration as one; every operation rounded separately, in the reference's order.
+__global__ __launch_bounds__(256) void k_z_schedule(int h, const float* __restrict__ u1, const float* __restrict__ u2, float* __restrict__ z) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= h) return;
+  const float fh = (float)h;
+  const float t = __fdiv_rn((float)i, fh);
+  const float a = u1 ? __fadd_rn(t, __fdiv_rn(u1[i], fh)) : t;
+  const float s = u2 ? __fadd_rn(t, __fdiv_rn(u2[i], fh)) : t;
+  const float den = __fadd_rn(__fmul_rn(1.0f, __fsub_rn(1.0f, s)), __fmul_rn(1.0f / 1e3f, s));   // 1 / near * (1 - t) + 1 / far * t, near = 1
+  z[i] = __fadd_rn(a, 1e-1f);
+  z[h + i] = __fadd_rn(__fdiv_rn(1.0f, den), 1e-1f);
+}
+
 __global__ void k_sample_ray_aabb(const float* __restrict__ rays, float lo0, float lo1, float lo2,
                                   float hi0, float hi1, float hi2, float step, float near_, float far_,
                                   const float* __restrict__ jitter, int R, int N,
@@ -1260,6 +1275,14 @@ int lrf_sample_ray_aabb(const float* rays, const float aabb[6], float step_size,
   hipLaunchKernelGGL(k_sample_ray_aabb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      rays, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], step_size, near_, far_,
                      jitter, R, N, pts, t, inside);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+
+int lrf_z_schedule(int32_t h, const float* u1, const float* u2, float* z, void* stream) {
+  if (h <= 0 || !z) return set_err("lrf_z_schedule: need h > 0 and an output of 2 h floats");
+  if ((u1 == nullptr) != (u2 == nullptr)) return set_err("lrf_z_schedule: both jitters or none");
+  hipLaunchKernelGGL(k_z_schedule, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), h, u1, u2, z);
   LRF_HIP(hipGetLastError());
   return 0;
 }

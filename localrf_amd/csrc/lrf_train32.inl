@@ -128,7 +128,7 @@ __device__ __forceinline__ void app12_position_grad(const DField& f, const int i
 // (1 KB rows: 411 us with nt, 312 us without, profiles/r11c)
 __device__ __forceinline__ void row_store_plain(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// tileinfo[t] = (ray, first compact sample j0, samples in the tile, tile number inside the ray), written by k_bwd_shade_fwd
+// tileinfo[t] = (ray, first compact sample j0, samples in the tile, tile number inside the ray), written by k_shade3<SAVE>
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
     DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, int S,
@@ -626,8 +626,8 @@ constexpr size_t app3_lds_bytes(int S, int NW, int nbins) {
   return a > b ? a : b;
 }
 
-// (Round 4 also built the ROW-SAVING FORWARD on this skeleton -- k_shade3's gather and chain on a pair of 16-row tiles per
-// wave, X block / feat / mask dwords / rgb / partials written in the 16-row fragment order -- and measured it: correct on
-// all 103 GPU tests, 318-338 us against 175-179 us for k_bwd_shade_fwd.  Without k_shade3's tile queue and one-tile-ahead
-// header prefetch the dependent chain toff -> ncomp -> cidx -> z -> gathers is exposed at two waves per SIMD, and the
-// extra per-lane state pushed the chain into 95 spilled registers.  Not kept; profiles/r11 s7.)
+// (Round 4 first built the ROW-SAVING FORWARD on this skeleton -- k_shade3's gather and chain on a static split of tile pairs --
+// and measured it: 318-338 us against 175-179 us for the 16-sample kernel of rounds 1-3.  Without k_shade3's tile queue and
+// one-tile-ahead header prefetch the dependent chain toff -> ncomp -> cidx -> z -> gathers is exposed at two waves per SIMD,
+// and the extra per-lane state pushed the chain into 95 spilled registers; profiles/r11 s7.  What ships is the eval kernel
+// itself with a SAVE switch, k_shade3<SAVE>: 125 us.)

@@ -281,6 +281,30 @@ def test_early_termination_on_a_trained_like_scene(built_lib):
     assert skipped[0.0] == 0 and skipped[1e-9] > 0.2 * 512 * z.numel(), skipped
 
 
+@pytest.mark.gpu
+def test_z_schedule_kernel_vs_reference_expression(built_lib):
+    """lrf_z_schedule (one launch) against the reference's expression (tensorBase.py:419-437) evaluated with torch on the
+    host: eval mode bit-exact against the reference-recorded schedule, train mode bit-exact for the same two rand draws."""
+    g = load_golden("field_small_eval")
+    f = quiet(make_field, [int(v) for v in g["grid"]], "cpu").to(DEV)
+    z = f.z_schedule(False, int(g["N_samples"]), torch.device(DEV))
+    assert np.abs(_np(z) - g["z"]).max() == 0.0
+    for n in (96, 1536, 6 * 369):
+        h = n // 6
+        torch.manual_seed(5)
+        zt = f.z_schedule(True, n, torch.device(DEV)).cpu()
+        torch.manual_seed(5)                                                     # the same two draws, then the expression in numpy float32 (every operation IEEE-rounded)
+        u1, u2 = torch.rand(1, h, device=DEV).cpu().numpy()[0], torch.rand(1, h, device=DEV).cpu().numpy()[0]
+        f32 = np.float32
+        t = np.arange(h, dtype=f32) / f32(h)
+        a = t + u1 / f32(h)
+        sj = t + u2 / f32(h)
+        b = f32(1.0) / ((f32(1.0) - sj) + f32(1.0 / 1e3) * sj)
+        want = np.concatenate([a, b]) + f32(1e-1)
+        d = np.abs(zt.numpy() - want)
+        assert zt.shape[0] == 2 * h and d[:h].max() == 0.0 and (d[h:] <= 2.4e-7 * want[h:]).all(), (n, float(d.max()))   # the reciprocal of the inverse-depth half: within 2 ulp
+
+
 # ----------------------------------------------------------------- full-size properties
 @pytest.fixture(scope="module")
 def big(built_lib):
