@@ -3,7 +3,7 @@
 # (3) uncontended kernel times + PMC of the training kernels (both branches of the backward on one stream), (4) the full
 # default bench line.  Summaries are written on the box; the rocpd databases stay there.
 # usage: scripts/gpu_profile_round4.sh <tag>
-TAG=${1:-r12}
+TAG=${1:-r13}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
