@@ -833,6 +833,38 @@ def test_row_saving_forward_equals_recomputing_backward(built_lib):
         ((rgb * gr).sum() + (depth * gd).sum()).backward()
 
 
+def test_training_forward_is_the_eval_kernel_also_beyond_the_lds_scan(built_lib):
+    """The training forward is k_shade3 with its SAVE switch: rgb / depth of a forward that records a graph are BIT-identical
+    to the eval forward's, at a batch whose tile offsets fit in the colour kernel's LDS (300 rays) and at one where they do
+    not (12 000 rays: k_scan_tiles_n + offsets from global memory, 16-row tile offsets written to a second array).  The
+    gradients of the large batch equal the sum over its two halves (linearity; up to the order of the scatter adds)."""
+    f = quiet(make_field, [28, 30, 26], "cpu", seed=11).to(DEV)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(3.0)
+    for R in (300, 12000):
+        rays = make_rays(R, 7, pinhole=True).to(DEV)
+        _g = torch.Generator().manual_seed(R)
+        gr, gd = torch.randn(R, 3, generator=_g).to(DEV), torch.randn(R, generator=_g).to(DEV)
+        with torch.no_grad():
+            rgb_e, depth_e = f(rays, is_train=False, N_samples=48)
+
+        def grads(sel):
+            for p in f.parameters():
+                p.grad = None
+            r = rays[sel].clone().requires_grad_(True)
+            rgb, depth = f(r, is_train=False, N_samples=48)
+            ((rgb * gr[sel]).sum() + (depth * gd[sel]).sum()).backward()
+            return rgb.detach(), depth.detach(), [p.grad.clone() for p in f.parameters() if p.grad is not None], r.grad.clone()
+        rgb_t, depth_t, g_all, gr_all = grads(slice(0, R))
+        assert torch.equal(rgb_t, rgb_e) and torch.equal(depth_t, depth_e), R
+        _, _, g_a, gr_a = grads(slice(0, R // 2))
+        _, _, g_b, gr_b = grads(slice(R // 2, R))
+        for x, ya, yb in zip(g_all, g_a, g_b):
+            assert float((x - (ya + yb)).abs().max()) <= 2e-5 * max(float(x.abs().max()), 1e-12), R
+        assert float((gr_all - torch.cat([gr_a, gr_b])).abs().max()) <= 2e-5 * float(gr_all.abs().max()), R
+
+
 # ----------------------------------------------------------------- randomised sweep (was scripts/gpu_diag.py fuzz)
 @pytest.mark.parametrize("seed", [0, 1])
 def test_fuzz_forward_and_gradients_vs_aten_port(built_lib, seed):
