@@ -79,7 +79,7 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, field, rays, z, flags, floater, *params):
         # Default engine: the forward already leaves what the backward needs (density features,
         # shaded-sample lists, per-sample colours, activation rows) in a workspace owned by this
-        # graph node -- a 6.5 GB worst-case reservation at 4096 x 512, 288 GB of HBM -- instead of recomputing it.
+        # graph node -- a 1.5 GB worst-case reservation at 4096 x 512 (every sample shaded), 288 GB of HBM -- instead of recomputing it.
         if not flags & (N.LRF_FLAG_MLP_VALU | N.LRF_FLAG_MLP_F32):
             rgb, depth, ctx.ws, ctx.versions = field._native_forward_train(rays, z, flags)
         else:
