@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 4      /* 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32); 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 4      /* 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -44,7 +44,9 @@ extern "C" {
                                     rays that march through the same texels run on the same XCD at the same time.  Results are
                                     per-ray and do not depend on the order (bit-identical); ignored for R > 32768.  The same value
                                     must be passed to lrf_render_fwd_train and the lrf_render_bwd that follows it. */
-#define LRF_FLAG_ALL        63u  /* any other bit is an error (a caller built against another ABI version) */
+#define LRF_FLAG_PE_OFF     64u  /* fea_pe > 0 only: zeros in place of the feature encodings (MLPRender_Fea_late_view.forward with
+                                  * refine == False, tensorBase.py:118-126) */
+#define LRF_FLAG_ALL        127u /* any other bit is an error (a caller built against another ABI version) */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
  * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with
@@ -63,6 +65,11 @@ typedef struct LrfParams {
   const float* w3;         /* renderModule.mlp_view.0.weight [3,131] */
   const float* b3;         /* renderModule.mlp_view.0.bias   [3]     */
   int32_t grid[3];         /* gridSize (x,y,z) */
+  /* MLPRender_Fea_late_view configuration (tensorBase.py:97-113).  0 / 0 / 128 (opt.py:148-157, what train.py runs) takes the
+   * fast kernels and the shapes above; anything else the generic fp32 engine (csrc/lrf_generic.inl), with
+   * w1 [feature_c, 27 (1 + 2 fea_pe)], w2 [feature_c, feature_c], w3 [3, feature_c + 3 (1 + 2 view_pe)].
+   * fea_pe, view_pe <= 6, feature_c <= 256; feature_c == 0 is read as 128. */
+  int32_t fea_pe, view_pe, feature_c;
 } LrfParams;
 
 /* Derived, kernel-friendly image of a field ("layout cache").  Built by lrf_pack_field
@@ -83,9 +90,11 @@ typedef struct LrfField {
                             * samples count as empty (the forced last sample takes the rest).  No sample
                             * behind that point can pass weight_thres; sum(w z) moves by <= term_T * z_max.
                             * 0 = off (the reference evaluates every sample, tensorBase.py:600-610). */
-  /* natural-layout MLP weights, used only by the LRF_FLAG_MLP_VALU debug engine */
+  /* natural-layout MLP weights (the parameter tensors themselves): read by the generic engine -- any configuration other
+   * than fea_pe = view_pe = 0, feature_c = 128, and the LRF_FLAG_MLP_VALU debug engine of that one */
   const float* basis; const float* w1; const float* b1;
   const float* w2; const float* b2; const float* w3; const float* b3;
+  int32_t fea_pe, view_pe, feature_c;   /* as in LrfParams */
 } LrfField;
 
 /* Gradients wrt the reference's parameters, in the reference's (state-dict) layout.
@@ -130,14 +139,17 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
                            float* rgb, float* depth, void* workspace, void* stream,
                            float* ms_out, int32_t* n_shaded_out);
 
-/* Bytes of scratch lrf_render_bwd needs (worst case: every sample shaded). */
+/* Bytes of scratch lrf_render_bwd needs (worst case: every sample shaded).  _cfg: for a network configuration other than
+ * the default one (the generic engine keeps the weight-gradient operands as rows: ~ (4 feature_c + in1 + in_view) floats
+ * per shaded sample more); lrf_workspace_bytes_bwd = _cfg(..., 0, 0, 128). */
 size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]);
+size_t lrf_workspace_bytes_bwd_cfg(int32_t R, int32_t S, const int32_t grid[3], int32_t fea_pe, int32_t view_pe, int32_t feature_c);
 
 /* Training forward: same outputs as lrf_render_fwd (split-bf16 engine, floater_thresh 0), but the
  * per-sample state the backward needs (density features, shaded-sample lists, per-sample colours,
  * activation rows) is left in `workspace` (lrf_workspace_bytes_bwd bytes) instead of being
  * recomputed by lrf_render_bwd: pass the SAME workspace, field, rays and z to lrf_render_bwd with
- * LRF_FLAG_ROWS_SAVED set.  Memory for recompute: a 3.3 GB worst-case reservation at 4096 x 512 (1.2 GB touched when 35 % of the samples are shaded) against 288 GB of HBM. */
+ * LRF_FLAG_ROWS_SAVED set.  Memory: a 1.5 GB worst-case reservation at 4096 x 512 (0.6 GB touched when 35 % of the samples are shaded) against 288 GB of HBM. */
 int lrf_render_fwd_train(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                          uint32_t flags, float* rgb, float* depth, void* workspace, void* stream);
 

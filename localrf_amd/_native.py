@@ -14,6 +14,7 @@ LRF_FLAG_MLP_VALU = 4
 LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
 LRF_FLAG_SORT_RAYS = 32
+LRF_FLAG_PE_OFF = 64
 
 _f = C.c_void_p  # device float*
 
@@ -22,7 +23,7 @@ class LrfParams(C.Structure):
     _fields_ = [("density_plane", _f * 3), ("density_line", _f * 3),
                 ("app_plane", _f * 3), ("app_line", _f * 3),
                 ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f),
-                ("grid", C.c_int32 * 3)]
+                ("grid", C.c_int32 * 3), ("fea_pe", C.c_int32), ("view_pe", C.c_int32), ("feature_c", C.c_int32)]
 
 
 class LrfField(C.Structure):
@@ -30,7 +31,8 @@ class LrfField(C.Structure):
                 ("alpha_aabb", C.c_float * 6), ("aabb", C.c_float * 6), ("grid", C.c_int32 * 3),
                 ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float),
                 ("term_T", C.c_float),
-                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
+                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f),
+                ("fea_pe", C.c_int32), ("view_pe", C.c_int32), ("feature_c", C.c_int32)]
 
 
 class LrfSceneField(C.Structure):
@@ -87,6 +89,7 @@ SYMBOLS = {
     "lrf_render_fwd_train": (C.c_int, [C.POINTER(LrfField), _f, _f, C.c_int32, C.c_int32, C.c_uint32, _f, _f,
                                        C.c_void_p, C.c_void_p]),
     "lrf_workspace_bytes_bwd": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "lrf_workspace_bytes_bwd_cfg": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]),
     "lrf_render_bwd": (C.c_int, [C.POINTER(LrfField), C.POINTER(LrfParams), _f, _f, C.c_int32, C.c_int32,
                                  C.c_uint32, _f, _f, C.POINTER(LrfGrads), _f, C.c_void_p, C.c_void_p]),
     "lrf_render_bwd_wait": (C.c_int, [C.c_int32, C.c_void_p]),

@@ -501,8 +501,14 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   int* s_h = reinterpret_cast<int*>(s_all + (size_t)16 * S);
   for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
   __syncthreads();
-  if (ray >= R) return;                                        // (a finished wave no longer counts at the barrier below)
-  const int nlive = min(4, R - (int)blockIdx.x * 4);
+  auto flush_hist = [&]() {                                    // every wave of the workgroup, behind the one barrier at the end
+    __syncthreads();
+    for (int i = threadIdx.x; i < bg.total; i += 256) {
+      const int v = s_h[i];
+      if (v) atomicAdd(&hist[i], v);
+    }
+  };
+  if (ray >= R) { flush_hist(); return; }                      // (a wave without a ray still meets the others at that barrier)
   float* s_alpha = s_all + (size_t)wave * 4 * S;
   float* s_w = s_alpha + S;
   float* s_gw = s_w + S;
@@ -680,11 +686,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
       gp[3 + a] = (gdh[a] - dh[a] * dot) / dn - gd * depth / dn * dh[a];
     }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < bg.total; i += 64 * nlive) {
-    const int v = s_h[i];
-    if (v) atomicAdd(&hist[i], v);
-  }
+  flush_hist();
 }
 
 // d(loss)/d(rays) += the appearance lookups' position gradients (per-tile partials of k_train_dgrad3): the tail of
@@ -1141,12 +1143,13 @@ struct BwdWorkspace {
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
   uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_shade3<SAVE> -> k_train_dgrad3, k_wgrad_w2w3
   int4* tileinfo;            // [tile] (ray, j0, count, tile in ray), k_shade3<SAVE> -> k_train_dgrad3, k_train_app3
+  float* gen;                // generic engine (lrf_generic.inl): [row][gen_row_ld] operands of the weight gradients, or null
   int* toff32;               // [R + 1] k_shade3's own tile offsets when they do not fit in its LDS (fw.toff holds the 16-row tiles')
   uint16_t* tid2; int* hist2; int* offs2; int* cursor2; uint32_t* list2;   // bins of the appearance scatter (runs beside the density scatter)
   uint32_t nmax;
   size_t bytes;
 };
-static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
+static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int gen_ld = 0 /* generic engine: floats per row of weight-gradient operands */) {
   BwdWorkspace b;
   b.fw = carve(ws, R, S);
   char* p = reinterpret_cast<char*>(ws);
@@ -1179,6 +1182,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3]) {
   b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
   b.cursor2 = reinterpret_cast<int*>(take(BIN_MAX));
   b.list2 = reinterpret_cast<uint32_t*>(take(3 * rows));
+  b.gen = gen_ld ? take(rows * (size_t)gen_ld) : nullptr;
   b.bytes = off;
   return b;
 }
@@ -1192,6 +1196,15 @@ static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): 
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
                                     const BwdWorkspace& b, float* rgb, hipStream_t st) {
+  if (!gen_is_default(d.fea_pe, d.view_pe, d.fc)) {          // generic engine (lrf_generic.inl): same saved state, no mask bits
+    const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
+    hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, b.toff32);
+    hipLaunchKernelGGL(k_toff16, dim3((R + 256) / 256), dim3(256), 0, st, b.toff32, R, w.toff);
+    hipLaunchKernelGGL(k_shade_gen<true>, dim3(R * ((w.pmax + 3) / 4)), dim3(64), 0, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw,
+                       w.part, w.pmax, b.toff32, b.crgb, b.act, b.tileinfo);
+    hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr, d.perm);
+    return hipGetLastError();
+  }
   const SaveOut3 sv{b.crgb, b.act, b.relu_bits, b.tileinfo, w.toff};
   return launch_shade3(d, rays, z, R, S, flags, w, b.toff32, rgb, nullptr, &sv, nullptr, st);
 }
@@ -1200,8 +1213,17 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 
 extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_dgrad_dbg = (e >> 5) & 7; }
 
+namespace lrf {
+static int field_gen_ld(int fea_pe, int view_pe, int fc) {
+  fc = fc ? fc : LRF_FEATC;
+  return gen_is_default(fea_pe, view_pe, fc) ? 0 : gen_row_ld(gen_cfg(fea_pe, view_pe, fc, true));
+}
+}  // namespace lrf
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
+}
+extern "C" size_t lrf_workspace_bytes_bwd_cfg(int32_t R, int32_t S, const int32_t grid[3], int32_t fea_pe, int32_t view_pe, int32_t feature_c) {
+  return lrf::carve_bwd(nullptr, R, S, grid, lrf::field_gen_ld(fea_pe, view_pe, feature_c)).bytes;
 }
 
 // Byte offsets of the pieces of the training workspace a test may want to look at (debug / parity
@@ -1224,9 +1246,10 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   if (flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))
     return set_err("lrf_render_fwd_train: the row-saving forward runs the split-bf16 engine only");
   if (flags & ~LRF_FLAG_ALL) return set_err("lrf_render_fwd_train: unknown flag bits");
+  if (const char* bad = gen_check(f)) return set_err(bad);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DField d = make_dfield(f);
-  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
+  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid, field_gen_ld(f->fea_pe, f->view_pe, f->feature_c));
   const Workspace& w = b.fw;
   rays = sort_rays_if_asked(d, rays, R, flags, w, st);
   d.rdir = w.rdir;
@@ -1245,10 +1268,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (R <= 0 || S < 2 || S > LRF_MAX_S_TRAIN)
     return set_err("lrf_render_bwd: need R > 0 and 2 <= S <= LRF_MAX_S_TRAIN (2048: the per-ray backward keeps 16 B per sample in LDS)");
   if (flags & ~LRF_FLAG_ALL) return set_err("lrf_render_bwd: unknown flag bits");
+  if (const char* bad = gen_check(f)) return set_err(bad);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DField d = make_dfield(f);
   const Layout L = make_layout(f->grid);
-  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid);
+  const int gen_ld = field_gen_ld(f->fea_pe, f->view_pe, f->feature_c);
+  const bool generic = gen_ld != 0;
+  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid, gen_ld);
   const Workspace& w = b.fw;
   const int cus = device_cus();
   if (flags & LRF_FLAG_ROWS_SAVED) {                       // lrf_render_fwd_train sorted (or not) with the same flags: same workspace
@@ -1284,7 +1310,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     });
     LRF_HIP(lds_attr_err[dev_id & 63]);
   }
-  hipLaunchKernelGGL(k_pack_mlp_w32_t, dim3((W32T_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt));
+  hipLaunchKernelGGL(k_pack_mlp_w32_t, dim3((W32T_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt), generic ? 1 : 0);
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     d.rdir = w.rdir;
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
@@ -1324,9 +1350,15 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
 
   // ---- caller's stream: data gradient of the colour network, then its appearance half (dX, position gradient, dbasis)
   const int n_dgrad_wg = min(cus, WGRAD_MAXCH);            // one dW1 / dbasis partial block per workgroup (k_wgrad_reduce: fixed count)
-  hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16, st, d,
-                     reinterpret_cast<const uint4*>(b.imt), rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
-                     b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
+  const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
+  if (generic) {       // lrf_generic.inl: one lane per row; worst-case grid, rows behind the batch's last tile return at once
+    hipLaunchKernelGGL(k_gen_dgrad, dim3((unsigned)((b.nmax + 63) / 64)), dim3(64), 0, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx,
+                       w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
+  } else {
+    hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16, st, d,
+                       reinterpret_cast<const uint4*>(b.imt), rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
+                       b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
+  }
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));         // go / dfeat rows: the weight-gradient kernel may start
   LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * bg.total, st));
   hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
@@ -1361,23 +1393,40 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int nch_max = WGRAD_MAXCH;      // (blocks behind the last chunk of the actual row count return at once)
   const bool w23_on_st = !ss || g_wgrad_split > 0;
   if (!w23_on_st) LRF_HIP(hipStreamWaitEvent(sb, ss->app[0], 0));
-  hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, w23_on_st ? st : sb, d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
-                     b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
+  if (generic) {       // dW = A^T B over the operand rows k_gen_dgrad left (added straight into the reference-layout gradients)
+    const GenRowOff ro = gen_row_off(gc);
+    const int nchunk = (int)((b.nmax + GEN_GEMM_CHUNK - 1) / GEN_GEMM_CHUNK);
+    auto gemm = [&](int offA, int M, int offB, int N, float* dW, int ldw, float* db) {
+      hipLaunchKernelGGL(k_gen_gemm, dim3(((M + 63) / 64) * ((N + 63) / 64), nchunk), dim3(256), 0, w23_on_st ? st : sb,
+                         b.gen, gen_ld, offA, M, offB, N, w.toff, R, dW, ldw, db);
+    };
+    gemm(ro.dz1, gc.fc, ro.x1, gc.in1 + 1, g->w1, gc.in1, g->b1);
+    gemm(ro.dz2, gc.fc, ro.h1, gc.fc + 1, g->w2, gc.fc, g->b2);
+    gemm(ro.go, 3, ro.h2v, gc.fc + gc.inv + 1, g->w3, gc.fc + gc.inv, g->b3);
+  } else {
+    hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, w23_on_st ? st : sb, d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
+                       b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
+  }
   if (ss) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream partials (dW1, dbasis[, dW2, dW3]) are complete behind this
   {
     WgradSegs segs;
+    for (int q = 0; q < 7; ++q) segs.s[q] = WgradSeg{0, 1, 0, 0, 1, 1, 0x7fffffff, 0, 0, nullptr};    // unused slots: behind every element
     int nseg = 0, elems = 0;
     auto seg = [&](int off, int ld, int n_off, int m, int n, float* dst, int dst_ld, int x_slots = 0, int nch = 0) {
       segs.s[nseg++] = WgradSeg{off, ld, n_off, m, n, dst_ld, elems, x_slots, nch, dst};
       elems += m * n;
     };
-    seg(WP_W2, 144, 0, 128, 128, g->w2, 128);
-    seg(WP_W2, 144, 128, 128, 1, g->b2, 1);
-    seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM, 0, n_dgrad_wg);     // accumulated by k_train_dgrad3: one block per workgroup
-    seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1, 0, n_dgrad_wg);
+    if (!generic) {
+      seg(WP_W2, 144, 0, 128, 128, g->w2, 128);
+      seg(WP_W2, 144, 128, 128, 1, g->b2, 1);
+      seg(WP_W1, 32, 0, 128, LRF_APP_DIM, g->w1, LRF_APP_DIM, 0, n_dgrad_wg);     // accumulated by k_train_dgrad3: one block per workgroup
+      seg(WP_W1, 32, LRF_APP_DIM, 128, 1, g->b1, 1, 0, n_dgrad_wg);
+    }
     seg(WP_BAS, 96, 0, LRF_APP_DIM, 72, g->basis, 72, 1, n_dgrad_wg);   // accumulated by k_train_app3: one block per workgroup
-    seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
-    seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
+    if (!generic) {
+      seg(WP_W3, 144, 0, 3, LRF_FEATC + 3, g->w3, LRF_FEATC + 3);
+      seg(WP_W3, 144, LRF_FEATC + 3, 3, 1, g->b3, 1);
+    }
     segs.total_elems = elems;
     if (ss) LRF_HIP(hipStreamWaitEvent(sb, ss->app[1], 0));     // partials written on the caller's stream
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((elems * 16 + 255) / 256), dim3(256), 0, sb, b.wpart, w.toff, R, segs);

@@ -149,6 +149,7 @@ struct DField {
   float term_T;                // early termination: skip density gathers once transmittance < term_T (0 = off)
   const float* basis; const float* w1; const float* b1; const float* w2; const float* b2;
   const float* w3; const float* b3;
+  int fea_pe, view_pe, fc;     // MLPRender_Fea_late_view configuration (0 / 0 / 128: the fast kernels; else lrf_generic.inl)
   float* dump;                 // test hook: s_memtime totals of k_shade3<TIMED> (lrf_debug_set_dump), else null
   float* rdir;                 // k_march -> k_shade3: per ray (d / |d|, |d|), or null
   const int* perm;             // ray sorting (LRF_FLAG_SORT_RAYS): slot -> the caller's ray index for everything indexed by the

@@ -642,77 +642,8 @@ __device__ __forceinline__ void gemm_step(const uint4* img, int frag0, int strid
 #include "lrf_shade3.inl"
 namespace lrf {
 
-// Debug engine (LRF_FLAG_MLP_VALU): same work list, one lane per compact sample,
-// natural-layout weights from global memory, plain loops.  Slow by design; exists so a
-// parity failure can be bisected between the gather/compositing and the MFMA chain.
-__global__ __launch_bounds__(64) void k_shade_valu(
-    DField f, const float* __restrict__ rays, const float* __restrict__ z, int S,
-    const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
-    float* __restrict__ part, int pmax) {
-  const int ray = blockIdx.x / pmax, j0 = (blockIdx.x % pmax) * ITEM;
-  const int lane = threadIdx.x;
-  const int cnt = min(ITEM, ncomp[ray] - j0);
-  if (cnt <= 0) return;
-  const float* rp = rays + (size_t)ray * 6;
-  const float o[3] = {rp[0], rp[1], rp[2]};
-  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
-  const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
-  float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-  if (lane < cnt) {
-    const size_t ci = (size_t)ray * S + j0 + lane;
-    const int k = cidx[ci];
-    const float w = cw[ci];
-    float x[3], u[3];
-    sample_point(f, o, dh, z[k], x, u);
-    float X[72];
-    for (int p = 0; p < 3; ++p) {
-      int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-      tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-      tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-      tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-      const float* pl = f.aplane[p];
-      for (int c = 0; c < LRF_CA; ++c) {
-        const int pc = app_pc(c);
-        const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * (1.0f - ty))
-                      + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * (1.0f - ty))
-                      + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * ty)
-                      + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * ty);
-        const float l = f.aline[p][(size_t)l0 * LRF_CAS + pc] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CAS + pc] * tl;
-        X[p * LRF_CA + c] = v * l;
-      }
-    }
-    float fe[LRF_APP_DIM];
-    for (int i = 0; i < LRF_APP_DIM; ++i) {
-      float a = 0.0f;
-      for (int c = 0; c < 72; ++c) a += f.basis[i * 72 + c] * X[c];
-      fe[i] = a;
-    }
-    float h1[LRF_FEATC], h2[LRF_FEATC];
-    for (int i = 0; i < LRF_FEATC; ++i) {
-      float a = f.b1[i];
-      for (int c = 0; c < LRF_APP_DIM; ++c) a += f.w1[i * LRF_APP_DIM + c] * fe[c];
-      h1[i] = fmaxf(a, 0.0f);
-    }
-    for (int i = 0; i < LRF_FEATC; ++i) {
-      float a = f.b2[i];
-      for (int c = 0; c < LRF_FEATC; ++c) a += f.w2[i * LRF_FEATC + c] * h1[c];
-      h2[i] = fmaxf(a, 0.0f);
-    }
-    float oo[3];
-    for (int i = 0; i < 3; ++i) {
-      float a = f.b3[i];
-      for (int c = 0; c < LRF_FEATC; ++c) a += f.w3[i * (LRF_FEATC + 3) + c] * h2[c];
-      for (int c = 0; c < 3; ++c) a += f.w3[i * (LRF_FEATC + 3) + LRF_FEATC + c] * dh[c];
-      oo[i] = w / (1.0f + expf(-a));
-    }
-    cr = oo[0]; cg = oo[1]; cb = oo[2];
-  }
-  cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb);
-  if (lane == 0) {
-    float* pp = part + ((size_t)ray * pmax + j0 / ITEM) * 3;
-    pp[0] = cr; pp[1] = cg; pp[2] = cb;
-  }
-}
+// (the plain-loop engine of LRF_FLAG_MLP_VALU is k_shade_gen of lrf_generic.inl: the same kernel serves every non-default
+// network configuration)
 
 // rgb_map = sum_k w_k rgb_k (+ 1 - acc)                        (tensorBase.py:632-634)
 __global__ void k_finalize(int R, int pmax, uint32_t flags, const int* __restrict__ ncomp,
@@ -906,6 +837,7 @@ static DField make_dfield(const LrfField* f) {
   d.rdir = nullptr;
   d.perm = nullptr;
   d.basis = f->basis; d.w1 = f->w1; d.b1 = f->b1; d.w2 = f->w2; d.b2 = f->b2; d.w3 = f->w3; d.b3 = f->b3;
+  d.fea_pe = f->fea_pe; d.view_pe = f->view_pe; d.fc = f->feature_c ? f->feature_c : LRF_FEATC;
   return d;
 }
 
@@ -1074,6 +1006,18 @@ static hipError_t launch_shade3(DField d, const float* rays, const float* z, int
 
 }  // namespace lrf
 
+#include "lrf_generic.inl"
+namespace lrf {
+// network configuration of a field: null, or why it cannot be rendered
+static const char* gen_check(const LrfField* f) {
+  const int fc = f->feature_c ? f->feature_c : LRF_FEATC;
+  if (f->fea_pe < 0 || f->fea_pe > GEN_MAX_PE || f->view_pe < 0 || f->view_pe > GEN_MAX_PE || fc < 1 || fc > GEN_MAX_FC)
+    return "localrf: unsupported colour-network configuration (need 0 <= fea_pe, view_pe <= 6 and 1 <= featureC <= 256)";
+  if (!gen_is_default(f->fea_pe, f->view_pe, fc) && (!f->basis || !f->w1 || !f->b1 || !f->w2 || !f->b2 || !f->w3 || !f->b3))
+    return "localrf: a non-default colour-network configuration needs the natural-layout weights in LrfField (basis, w1 .. b3)";
+  return nullptr;
+}
+}  // namespace lrf
 #include "lrf_backward.inl"
 #include "lrf_scene.inl"
 #include "lrf_adam.inl"
@@ -1087,7 +1031,7 @@ extern "C" {
 
 int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
-void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): n GEMMs on the caller's stream
+void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): k_wgrad_w2w3 on the caller's stream (n > 0) or on the side stream (n = 0)
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
 // Where column `col` of saved row `row` lives, in floats from the start of the ACT (buffer 0) / GRD (buffer 1) region
 // of a training workspace (lrf_workspace_layout_bwd gives the regions): the fragment order of lrf_common.h, host side.
@@ -1125,6 +1069,10 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
     hmax = max(hmax, L.ph[q]);
   }
   hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 18), dim3(128), 0, st, tab);
+  if (!gen_is_default(p->fea_pe, p->view_pe, p->feature_c ? p->feature_c : LRF_FEATC)) {   // the generic engine reads the parameter tensors themselves
+    LRF_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
   hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_ALL * 4 + 255) / 256), dim3(256), 0, st, *p,
                      reinterpret_cast<uint32_t*>(base + L.mlpb));
@@ -1148,7 +1096,10 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));
   rays = sort_rays_if_asked(d, rays, R, flags, w, st);
-  if (!(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))) {
+  if (const char* bad = gen_check(f)) return set_err(bad);
+  const bool generic = !gen_is_default(d.fea_pe, d.view_pe, d.fc);
+  if (generic && (flags & LRF_FLAG_MLP_F32)) return set_err("lrf_render_fwd: the exact-fp32 MFMA engine is built for fea_pe = view_pe = 0, featureC = 128 only");
+  if (!generic && !(flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32))) {
     // Default engine: k_march -> k_shade3 (32 samples per wave on v_mfma_f32_32x32x16_bf16, lrf_shade3.inl); the tile
     // offsets are scanned inside the colour kernel when they fit in LDS beside the image, by k_scan_tiles_n otherwise.
     d.rdir = w.rdir;
@@ -1162,8 +1113,10 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   // exact-fp32 / plain-loop engines: 16-sample tiles, k_march -> [k_scan_tiles ->] colour kernel -> k_finalize
   launch_march(d, rays, z, R, S, flags, floater_thresh, depth, w.acc, weight_out, w.ncomp, w.cidx, w.cw, nullptr, st);
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
-  if (flags & LRF_FLAG_MLP_VALU) {
-    hipLaunchKernelGGL(k_shade_valu, dim3(R * w.pmax), dim3(64), 0, st, d, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
+  if (generic || (flags & LRF_FLAG_MLP_VALU)) {
+    const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
+    hipLaunchKernelGGL(k_shade_gen<false>, dim3(R * ((w.pmax + 3) / 4)), dim3(64), 0, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw,
+                       w.part, w.pmax, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (int4*)nullptr);
   } else {
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
     hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);

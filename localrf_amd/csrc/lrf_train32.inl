@@ -42,9 +42,10 @@ constexpr int W32T_U4 = W32T_NFRAG * 128;                        // 5888 uint4 =
 constexpr int W32T_T_W3 = 0, W32T_T_W3_LD = 132, W32T_T_FLOATS = 400;
 constexpr int W32T_ALL_U4 = W32T_U4 + W32T_T_FLOATS / 4;         // 5988 uint4 = 95,808 B
 
-__global__ void k_pack_mlp_w32_t(LrfParams p, uint32_t* __restrict__ img) {
+__global__ void k_pack_mlp_w32_t(LrfParams p, uint32_t* __restrict__ img, int basis_only /* generic engine: only k_train_app3's basis^T fragments exist in these shapes */) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= W32T_ALL_U4 * 4) return;
+  if (basis_only && (idx >= W32T_U4 * 4 || (idx >> 9) < W32T_BAS)) { img[idx] = 0u; return; }
   if (idx >= W32T_U4 * 4) {
     const int e = idx - W32T_U4 * 4, c = e / W32T_T_W3_LD, u = e % W32T_T_W3_LD;
     img[idx] = __float_as_uint(c < 3 && u < LRF_FEATC ? p.w3[c * (LRF_FEATC + 3) + u] : 0.0f);

@@ -248,10 +248,12 @@ class TensorVMSplit(torch.nn.Module):
                        "reference: tensorBase.py:627-629 passes 4 arguments)")
         if self.density_n_comp != [8, 8, 8] or self.app_n_comp != [24, 24, 24]:
             bad.append(f"n_comp {self.density_n_comp}/{self.app_n_comp} (built for [8,8,8]/[24,24,24])")
-        if self.app_dim != 27 or featureC != 128:
-            bad.append(f"app_dim={self.app_dim}, featureC={featureC} (built for 27/128)")
-        if view_pe != 0 or fea_pe != 0:
-            bad.append(f"view_pe={view_pe}, fea_pe={fea_pe} (built for 0/0, the opt.py defaults)")
+        if self.app_dim != 27:
+            bad.append(f"app_dim={self.app_dim} (built for 27)")
+        # view_pe / fea_pe / featureC other than opt.py's 0 / 0 / 128 render and train through the generic fp32 engine
+        # (csrc/lrf_generic.inl: plain loops, 10-30 x slower than the default kernels); its limits:
+        if not (0 <= view_pe <= 6 and 0 <= fea_pe <= 6 and 1 <= featureC <= 256):
+            bad.append(f"view_pe={view_pe}, fea_pe={fea_pe}, featureC={featureC} (0..6, 0..6, 1..256)")
         if self.fea2denseAct not in ("softplus", "relu"):
             bad.append(f"fea2denseAct={self.fea2denseAct!r}")
         if bad:
@@ -367,6 +369,7 @@ class TensorVMSplit(torch.nn.Module):
             cp.app_line[i] = ps[9 + i].data_ptr()
         (cp.basis, cp.w1, cp.b1, cp.w2, cp.b2, cp.w3, cp.b3) = [p.data_ptr() for p in ps[12:]]
         cp.grid[:] = self._grid_host
+        cp.fea_pe, cp.view_pe, cp.feature_c = int(self.fea_pe), int(self.view_pe), int(self.featureC)
         return cp, ps
 
     def _ensure_cache(self):
@@ -418,6 +421,7 @@ class TensorVMSplit(torch.nn.Module):
         f.term_T = float(self.early_term_T)
         ps = self._param_list()[12:]
         (f.basis, f.w1, f.b1, f.w2, f.b2, f.w3, f.b3) = [p.data_ptr() for p in ps]
+        f.fea_pe, f.view_pe, f.feature_c = int(self.fea_pe), int(self.view_pe), int(self.featureC)
         self._cfield, self._cfield_key = f, key
         return f
 
@@ -488,7 +492,8 @@ class TensorVMSplit(torch.nn.Module):
         if R == 0:
             return rgb, depth, None, None
         grid = (C.c_int32 * 3)(*self._grid_host)
-        ws = torch.empty(lib.lrf_workspace_bytes_bwd(R, S, grid), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.lrf_workspace_bytes_bwd_cfg(R, S, grid, int(self.fea_pe), int(self.view_pe), int(self.featureC)),
+                         dtype=torch.uint8, device=dev)
         f = self._c_field()
         st = torch.cuda.current_stream(dev).cuda_stream
         N.check(lib.lrf_render_fwd_train(C.byref(f), N.ptr(rays), N.ptr(z), R, S, flags, N.ptr(rgb), N.ptr(depth),
@@ -522,7 +527,7 @@ class TensorVMSplit(torch.nn.Module):
             cg.app_plane[i] = grads[6 + i].data_ptr()
             cg.app_line[i] = grads[9 + i].data_ptr()
         (cg.basis, cg.w1, cg.b1, cg.w2, cg.b2, cg.w3, cg.b3) = [g.data_ptr() for g in grads[12:]]
-        nbytes = lib.lrf_workspace_bytes_bwd(R, S, cp.grid)
+        nbytes = lib.lrf_workspace_bytes_bwd_cfg(R, S, cp.grid, int(self.fea_pe), int(self.view_pe), int(self.featureC))
         if saved_ws is not None:                 # filled by lrf_render_fwd_train for exactly this call
             ws = saved_ws
             flags = flags | N.LRF_FLAG_ROWS_SAVED
@@ -724,12 +729,14 @@ class TensorVMSplit(torch.nn.Module):
     def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, refine=True,
                 floater_thresh=0, out=None):
         """tensorBase.py:567-636.  rays_chunk [R,6] -> (rgb_map [R,3], depth_map [R]).
-        `refine` only matters when fea_pe > 0 (tensorBase.py:117-126); this build has fea_pe=0.
+        `refine` only matters when fea_pe > 0 (tensorBase.py:117-126): False feeds zeros in place of the feature encodings.
         `out=(rgb, depth)` (extension, no-grad calls only) renders into caller-owned tensors."""
         self._require_gpu(rays_chunk)
         z = self.z_schedule(is_train, N_samples, rays_chunk.device)
         use_white = bool(white_bg) or bool(is_train and torch.rand((1,)) < 0.5)   # :633
         flags = self._flags(use_white)
+        if self.fea_pe > 0 and not refine:
+            flags |= N.LRF_FLAG_PE_OFF
         needs_grad = torch.is_grad_enabled() and (
             rays_chunk.requires_grad or any(p.requires_grad for p in self._param_list()))
         if needs_grad:

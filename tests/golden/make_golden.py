@@ -150,6 +150,38 @@ def case_train_grad(TensorVMSplit, name, grid, R, N_samples, seed):
     save(name, **arrs)
 
 
+def case_pe(TensorVMSplit, name, grid, R, N_samples, seed, **over):
+    """A non-default MLPRender_Fea_late_view configuration (opt.py:148-157: view_pe / fea_pe / featureC; tensorBase.py:14-21,
+    97-135): eval forward with and without the feature encodings (refine), train-mode forward with recorded jitter +
+    autograd gradients."""
+    f = make_field(TensorVMSplit, grid, seed, scale_density=3.0, **over)
+    rays = make_rays(R, seed + 1, pinhole=True).requires_grad_(True)
+    with torch.no_grad():
+        rgb_e, depth_e = f(rays.detach().clone(), white_bg=True, is_train=False, N_samples=N_samples)
+        rgb_n, depth_n = f(rays.detach().clone(), white_bg=True, is_train=False, N_samples=N_samples, refine=False)
+    h = N_samples // 6
+    torch.manual_seed(seed + 2)
+    U = torch.rand(1, h)
+    U2 = torch.rand(1, h)
+    torch.manual_seed(seed + 2)              # same stream -> forward draws (U, U2)
+    rgb, depth = f(rays, white_bg=True, is_train=True, N_samples=N_samples)
+    g = torch.Generator().manual_seed(seed + 3)
+    g_rgb = torch.randn(R, 3, generator=g)
+    g_depth = torch.randn(R, generator=g)
+    loss = (rgb * g_rgb).sum() + (depth * g_depth).sum()
+    params = {k: v for k, v in f.named_parameters() if v.requires_grad}
+    grads = torch.autograd.grad(loss, list(params.values()) + [rays], allow_unused=True)
+    arrs = dict(rays=rays.detach().numpy(), U=U[0].numpy(), U2=U2[0].numpy(), N_samples=np.array(N_samples),
+                rgb=rgb.detach().numpy(), depth=depth.detach().numpy(), g_rgb=g_rgb.numpy(), g_depth=g_depth.numpy(),
+                rgb_eval=rgb_e.numpy(), depth_eval=depth_e.numpy(), rgb_eval_norefine=rgb_n.numpy(), depth_eval_norefine=depth_n.numpy(),
+                grid=np.array(grid), view_pe=np.array(over.get("view_pe", 0)), fea_pe=np.array(over.get("fea_pe", 0)),
+                featureC=np.array(over.get("featureC", 128)))
+    for (k, _), gr in zip(list(params.items()) + [("rays", None)], grads):
+        arrs[f"grad.{k}"] = (gr if gr is not None else torch.zeros(1)).numpy()
+    arrs.update(pack_field("f.", f))
+    save(name, **arrs)
+
+
 def case_local(LocalTensorfs, name, grid, seed):
     """LocalTensorfs.forward, 4 blended fields, exposure on."""
     torch.manual_seed(seed)
@@ -784,7 +816,10 @@ def main():
               "trajectory": lambda: case_trajectory(TensorVMSplit, LocalTensorfs, "trajectory_30it.npz"),
               "train500": lambda: case_train_grad_big(TensorVMSplit, "field_500_train_grad.npz", grid=(500, 500, 500), R=512, seed=41),
               "train640": lambda: case_train_grad_big(TensorVMSplit, "field_640_train_grad.npz", grid=(640, 640, 640), R=256, seed=43),
-              "ladder": lambda: case_ladder(TensorVMSplit, "ladder_64_to_640.npz")}
+              "ladder": lambda: case_ladder(TensorVMSplit, "ladder_64_to_640.npz"),
+              "pe": lambda: (case_pe(TensorVMSplit, "field_pe_2_3_64.npz", (20, 24, 28), 64, 96, 101, fea_pe=2, view_pe=3, featureC=64),
+                             case_pe(TensorVMSplit, "field_pe_0_2_128.npz", (24, 20, 22), 48, 96, 103, fea_pe=0, view_pe=2, featureC=128),
+                             case_pe(TensorVMSplit, "field_pe_6_6_200.npz", (16, 18, 20), 32, 60, 105, fea_pe=6, view_pe=6, featureC=200))}
         for k in only:
             r2[k]()
         return
@@ -820,6 +855,10 @@ def main():
     case_train_grad_big(TensorVMSplit, "field_500_train_grad.npz", grid=(500, 500, 500), R=512, seed=41)
     case_train_grad_big(TensorVMSplit, "field_640_train_grad.npz", grid=(640, 640, 640), R=256, seed=43)
     case_ladder(TensorVMSplit, "ladder_64_to_640.npz")
+    # round 4: non-default colour-network configurations (the generic engine, csrc/lrf_generic.inl)
+    case_pe(TensorVMSplit, "field_pe_2_3_64.npz", (20, 24, 28), 64, 96, 101, fea_pe=2, view_pe=3, featureC=64)
+    case_pe(TensorVMSplit, "field_pe_0_2_128.npz", (24, 20, 22), 48, 96, 103, fea_pe=0, view_pe=2, featureC=128)
+    case_pe(TensorVMSplit, "field_pe_6_6_200.npz", (16, 18, 20), 32, 60, 105, fea_pe=6, view_pe=6, featureC=200)
 
 
 if __name__ == "__main__":

@@ -82,7 +82,12 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(NotImplementedError):
         quiet(make_field, [16] * 3, shadingMode="MLP_PE")
     with pytest.raises(NotImplementedError):
-        quiet(make_field, [16] * 3, fea_pe=2)
+        quiet(make_field, [16] * 3, fea_pe=7)
+    with pytest.raises(NotImplementedError):
+        quiet(make_field, [16] * 3, featureC=512)
+    f = quiet(make_field, [16] * 3, fea_pe=2, view_pe=3, featureC=64)          # the generic engine's shapes (tensorBase.py:97-113)
+    assert tuple(f.renderModule.mlp[0].weight.shape) == (64, 27 * 5)
+    assert tuple(f.renderModule.mlp_view[0].weight.shape) == (3, 64 + 3 * 7)
     with pytest.raises(NotImplementedError):
         quiet(make_field, [16] * 3, density_n_comp=[16, 16, 16])
 

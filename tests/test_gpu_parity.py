@@ -865,6 +865,40 @@ def test_training_forward_is_the_eval_kernel_also_beyond_the_lds_scan(built_lib)
         assert float((gr_all - torch.cat([gr_a, gr_b])).abs().max()) <= 2e-5 * float(gr_all.abs().max()), R
 
 
+@pytest.mark.parametrize("name", ["field_pe_2_3_64", "field_pe_0_2_128", "field_pe_6_6_200"])
+def test_nondefault_colour_network_vs_reference_golden(built_lib, name):
+    """MLPRender_Fea_late_view with positional encodings of the features / the view direction and another hidden width
+    (opt.py:148-157; tensorBase.py:14-21, 97-135) -- the generic fp32 engine (csrc/lrf_generic.inl) -- against outputs and
+    autograd gradients recorded from the reference: eval forward with and without the feature encodings (refine), train-mode
+    forward with the recorded jitter, all parameter gradients and d/d(rays) at 1e-4 of each tensor's largest magnitude."""
+    g = load_golden(name)
+    cfg = dict(fea_pe=int(g["fea_pe"]), view_pe=int(g["view_pe"]), featureC=int(g["featureC"]))
+    fld = golden_field_dict(g)
+    f = quiet(make_field, [int(v) for v in g["grid"]], "cpu", **cfg)
+    f.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in fld.items()})
+    f = f.to(DEV)
+    rays = torch.from_numpy(g["rays"]).to(DEV)
+    with torch.no_grad():
+        rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=int(g["N_samples"]))
+        rgb_n, depth_n = f(rays, white_bg=True, is_train=False, N_samples=int(g["N_samples"]), refine=False)
+    _check_rays(_np(rgb), g["rgb_eval"]); _check_rays(_np(depth), g["depth_eval"])
+    _check_rays(_np(rgb_n), g["rgb_eval_norefine"]); _check_rays(_np(depth_n), g["depth_eval_norefine"])
+    if cfg["fea_pe"] > 0:
+        assert np.abs(g["rgb_eval"] - g["rgb_eval_norefine"]).max() > 1e-3           # the switch does something in this golden
+    f.z_override = torch.from_numpy(oracle.z_schedule(int(g["N_samples"]), np.float32, jitter=(g["U"], g["U2"])))
+    r = rays.clone().requires_grad_(True)
+    rgb_t, depth_t = f(r, white_bg=True, is_train=True, N_samples=int(g["N_samples"]))
+    _check_rays(_np(rgb_t.detach()), g["rgb"]); _check_rays(_np(depth_t.detach()), g["depth"])
+    gr, gd = torch.from_numpy(g["g_rgb"]).to(DEV), torch.from_numpy(g["g_depth"]).to(DEV)
+    ((rgb_t * gr).sum() + (depth_t * gd).sum()).backward()
+    mine = {k: p.grad for k, p in f.named_parameters() if p.grad is not None}
+    mine["rays"] = r.grad
+    ref = {k: torch.from_numpy(g["grad." + k]).to(DEV) for k in mine}
+    assert set(k for k in g if k.startswith("grad.") and g[k].size > 1) == set("grad." + k for k in mine)
+    worst = check_grads(mine, ref, 1e-4)
+    print(name, "worst", {k: "%.1e" % v for k, v in worst.items()})
+
+
 # ----------------------------------------------------------------- randomised sweep (was scripts/gpu_diag.py fuzz)
 @pytest.mark.parametrize("seed", [0, 1])
 def test_fuzz_forward_and_gradients_vs_aten_port(built_lib, seed):

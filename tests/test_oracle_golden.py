@@ -27,6 +27,23 @@ def test_field_forward_matches_reference(name, dt):
     assert rel_err(depth, g["depth"]) < 2e-6
 
 
+@pytest.mark.parametrize("name", ["field_pe_2_3_64", "field_pe_0_2_128", "field_pe_6_6_200"])
+def test_nondefault_colour_network_oracle_matches_reference(name):
+    """The oracle's positional encodings / late-view network for view_pe, fea_pe, featureC other than opt.py's defaults
+    (tensorBase.py:14-21, 97-135), with and without the feature encodings (refine)."""
+    g = load_golden(name)
+    fld = golden_field_dict(g)
+    fld["fea_pe"], fld["view_pe"] = int(g["fea_pe"]), int(g["view_pe"])
+    assert fld["renderModule.mlp.0.weight"].shape == (int(g["featureC"]), 27 * (1 + 2 * int(g["fea_pe"])))
+    z = oracle.z_schedule(int(g["N_samples"]), np.float64)
+    for refine, key in ((True, "eval"), (False, "eval_norefine")):
+        rgb, depth = oracle.render_field(fld, g["rays"].astype(np.float64), z, True, 0.0, refine=refine)
+        assert rel_err(rgb, g["rgb_" + key]) < 5e-6 and rel_err(depth, g["depth_" + key]) < 5e-6, (refine, rel_err(rgb, g["rgb_" + key]))
+    zt = oracle.z_schedule(int(g["N_samples"]), np.float64, jitter=(g["U"], g["U2"]))
+    rgb, depth = oracle.render_field(fld, g["rays"].astype(np.float64), zt, True, 0.0)
+    assert rel_err(rgb, g["rgb"]) < 5e-6 and rel_err(depth, g["depth"]) < 5e-6
+
+
 @pytest.mark.parametrize("name", FIELD_CASES)
 def test_feature_lookups_match_reference(name):
     g = load_golden(name)
