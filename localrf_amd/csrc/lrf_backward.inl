@@ -1200,8 +1200,8 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
     const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
     hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, b.toff32);
     hipLaunchKernelGGL(k_toff16, dim3((R + 256) / 256), dim3(256), 0, st, b.toff32, R, w.toff);
-    hipLaunchKernelGGL(k_shade_gen<true>, dim3(R * ((w.pmax + 3) / 4)), dim3(64), 0, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw,
-                       w.part, w.pmax, b.toff32, b.crgb, b.act, b.tileinfo);
+    hipError_t ge = launch_shade_gen(d, gc, rays, z, R, S, w, b.toff32, b.crgb, b.act, b.tileinfo, st);
+    if (ge != hipSuccess) return ge;
     hipLaunchKernelGGL(k_finalize, dim3((R + 255) / 256), dim3(256), 0, st, R, w.pmax, flags, w.ncomp, w.acc, w.part, rgb, (float*)nullptr, d.perm);
     return hipGetLastError();
   }
@@ -1352,8 +1352,12 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int n_dgrad_wg = min(cus, WGRAD_MAXCH);            // one dW1 / dbasis partial block per workgroup (k_wgrad_reduce: fixed count)
   const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
   if (generic) {       // lrf_generic.inl: one lane per row; worst-case grid, rows behind the batch's last tile return at once
-    hipLaunchKernelGGL(k_gen_dgrad, dim3((unsigned)((b.nmax + 63) / 64)), dim3(64), 0, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx,
-                       w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
+    LRF_HIP(gen_opt_in());
+    const int ls = gen_tile_samples(gc, true), nt = gen_block_threads(gc);
+    const size_t lds = (size_t)gen_lds(gc, ls, true).total * 4;
+    const dim3 grid((unsigned)((b.nmax + ls - 1) / ls));
+    if (ls == 32) hipLaunchKernelGGL(k_gen_dgrad<32>, grid, dim3(nt), lds, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
+    else          hipLaunchKernelGGL(k_gen_dgrad<16>, grid, dim3(nt), lds, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
   } else {
     hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16, st, d,
                        reinterpret_cast<const uint4*>(b.imt), rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,

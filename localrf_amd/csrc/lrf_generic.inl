@@ -2,13 +2,16 @@
 // encodings of the appearance features (fea_pe) and of the view direction (view_pe), any hidden width featureC <= 256.
 // The fast kernels (k_shade3, k_train_dgrad3, k_wgrad_w2w3) are specialised to opt.py's defaults (0 / 0 / 128), which is what
 // train.py runs; every other configuration takes this engine: plain fp32 loops on the vector ALU over the parameter
-// tensors in their natural layout, one lane per sample -- correct, differentiable, not tuned (expect 10-30 x the default
-// engine's time).  It is also the LRF_FLAG_MLP_VALU debug engine of the default configuration.
+// tensors in their natural layout.  A block owns 32 samples of one ray, keeps their activation vectors in LDS as
+// [element][sample] and gives every OUTPUT unit of a layer to a thread (weight read once, 32 broadcast multiply-adds): a plain
+// tile GEMM on the VALU.  (First version: one lane per sample with private arrays -- 3-7 KB of scratch per lane, gigabytes per
+// launch, every multiply-add waiting for HBM: 155 ms per 4096 x 512 batch.)  Correct and differentiable; not tuned further.
+// It is also the LRF_FLAG_MLP_VALU debug engine of the default configuration.
 //
-// Forward (k_shade_gen): a block renders two 32-sample tiles of one ray; with SAVE it leaves what the backward needs in the
+// Forward (k_shade_gen): a block renders 32 (16) consecutive samples of one ray; with SAVE it leaves what the backward needs in the
 // same places as k_shade3<SAVE> (colours, feat rows, tile records of the 16-row tiles) -- no mask bits: the backward
 // recomputes the network from the saved feat row with the same arithmetic, so its ReLU signs are the forward's.
-// Backward: k_gen_dgrad, one lane per saved row: recompute, d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> d(input) -> dfeat (through
+// Backward: k_gen_dgrad, a block per 32 (16) saved rows: recompute, d(loss)/d(pre-sigmoid) -> dz2 -> dz1 -> d(input) -> dfeat (through
 // the encodings), written as the gradient row's dfeat block -- from there k_train_app3 and the scatter kernels run unchanged --
 // and the operands of the weight gradients as rows [dz1 | dz2 | x, 1 | relu(h1), 1 | relu(h2), venc, 1 | go]; k_gen_gemm forms
 // dW = A^T B over those rows (three launches) and adds into the reference-layout gradients.
@@ -38,70 +41,114 @@ __host__ __device__ inline GenRowOff gen_row_off(const GenCfg& g) {
 }
 __host__ __device__ inline bool gen_is_default(int fea_pe, int view_pe, int fc) { return fea_pe == 0 && view_pe == 0 && fc == LRF_FEATC; }
 
-// positional_encoding (tensorBase.py:14-21): [sin(v_d 2^f)] then [cos(v_d 2^f)], index d * F + f inside each half
-__device__ __forceinline__ void gen_encode(const float* v, int D, int F, bool on, float* out /* [2 D F] */) {
-  for (int d = 0; d < D; ++d)
-    for (int q = 0; q < F; ++q) {
-      const float a = v[d] * (float)(1 << q);
-      out[d * F + q] = on ? sinf(a) : 0.0f;
-      out[D * F + d * F + q] = on ? cosf(a) : 0.0f;
-    }
-}
+// ---- block-cooperative pieces.  A block owns LS samples (32, or 16 where the LDS budget asks for it); every vector of a
+// sample lives in LDS as [element][sample], so a thread that owns an OUTPUT unit reads its weight once and multiplies it
+// with LS broadcast activations: 4 LS multiply-adds per (weight float4, four ds_read_b128 per sample quad).
 
-// the 27 appearance features of one sample (tensoRF.py:153-196) from the padded 32-channel texels
-__device__ __forceinline__ void gen_app_features(const DField& f, const float u[3], float fe[LRF_APP_DIM]) {
-  float X[72];
-  for (int p = 0; p < 3; ++p) {
-    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
-    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
-    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
-    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-    const float* pl = f.aplane[p];
-    for (int c = 0; c < LRF_CA; ++c) {
-      const int pc = app_pc(c);
-      const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * (1.0f - ty))
-                    + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * (1.0f - ty))
-                    + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * ty)
-                    + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * ty);
-      const float l = f.aline[p][(size_t)l0 * LRF_CAS + pc] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CAS + pc] * tl;
-      X[p * LRF_CA + c] = v * l;
+// out[i][s] = (relu) b[i] + sum_c W[i * nin + c] in[c][s]
+template <int LS>
+__device__ __forceinline__ void gen_tile_dense(const float* __restrict__ W, const float* __restrict__ b, int nout, int nin,
+                                               const float* in, float* out, bool relu) {
+  for (int i = threadIdx.x; i < nout; i += blockDim.x) {
+    float acc[LS];
+    const float bi = b ? b[i] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < LS; ++s) acc[s] = bi;
+    const float* wr = W + (size_t)i * nin;
+    int c = 0;
+    for (; c + 4 <= nin; c += 4) {
+      const float w0 = wr[c], w1 = wr[c + 1], w2 = wr[c + 2], w3 = wr[c + 3];
+#pragma unroll
+      for (int q = 0; q < LS / 4; ++q) {
+        const float4 v0 = *reinterpret_cast<const float4*>(in + (c + 0) * LS + 4 * q), v1 = *reinterpret_cast<const float4*>(in + (c + 1) * LS + 4 * q);
+        const float4 v2 = *reinterpret_cast<const float4*>(in + (c + 2) * LS + 4 * q), v3 = *reinterpret_cast<const float4*>(in + (c + 3) * LS + 4 * q);
+        acc[4 * q]     += w0 * v0.x; acc[4 * q + 1] += w0 * v0.y; acc[4 * q + 2] += w0 * v0.z; acc[4 * q + 3] += w0 * v0.w;
+        acc[4 * q]     += w1 * v1.x; acc[4 * q + 1] += w1 * v1.y; acc[4 * q + 2] += w1 * v1.z; acc[4 * q + 3] += w1 * v1.w;
+        acc[4 * q]     += w2 * v2.x; acc[4 * q + 1] += w2 * v2.y; acc[4 * q + 2] += w2 * v2.z; acc[4 * q + 3] += w2 * v2.w;
+        acc[4 * q]     += w3 * v3.x; acc[4 * q + 1] += w3 * v3.y; acc[4 * q + 2] += w3 * v3.z; acc[4 * q + 3] += w3 * v3.w;
+      }
+    }
+    for (; c < nin; ++c) {
+      const float w0 = wr[c];
+#pragma unroll
+      for (int q = 0; q < LS / 4; ++q) {
+        const float4 v0 = *reinterpret_cast<const float4*>(in + c * LS + 4 * q);
+        acc[4 * q] += w0 * v0.x; acc[4 * q + 1] += w0 * v0.y; acc[4 * q + 2] += w0 * v0.z; acc[4 * q + 3] += w0 * v0.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < LS / 4; ++q) {
+      float4 r = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      if (relu) { r.x = fmaxf(r.x, 0.0f); r.y = fmaxf(r.y, 0.0f); r.z = fmaxf(r.z, 0.0f); r.w = fmaxf(r.w, 0.0f); }
+      *reinterpret_cast<float4*>(out + i * LS + 4 * q) = r;
     }
   }
-  for (int i = 0; i < LRF_APP_DIM; ++i) {
-    float a = 0.0f;
-    for (int c = 0; c < 72; ++c) a += f.basis[i * 72 + c] * X[c];
-    fe[i] = a;
+}
+// out[c][s] = sum_r W[r * ld + c] in[r][s]  (the transposed products of the backward; consecutive threads read consecutive weights)
+template <int LS>
+__device__ __forceinline__ void gen_tile_dense_t(const float* __restrict__ W, int nrow, int ncol, int ld, const float* in, float* out) {
+  for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+    float acc[LS];
+#pragma unroll
+    for (int s = 0; s < LS; ++s) acc[s] = 0.0f;
+    for (int r = 0; r < nrow; ++r) {
+      const float w0 = W[(size_t)r * ld + c];
+#pragma unroll
+      for (int q = 0; q < LS / 4; ++q) {
+        const float4 v0 = *reinterpret_cast<const float4*>(in + r * LS + 4 * q);
+        acc[4 * q] += w0 * v0.x; acc[4 * q + 1] += w0 * v0.y; acc[4 * q + 2] += w0 * v0.z; acc[4 * q + 3] += w0 * v0.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < LS / 4; ++q)
+      *reinterpret_cast<float4*>(out + c * LS + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
 }
+// positional_encoding (tensorBase.py:14-21) of D rows v[d][s] -> out[2 D F][s]: [sin(v_d 2^f)] then [cos(v_d 2^f)], row d * F + f inside each half
+template <int LS>
+__device__ __forceinline__ void gen_tile_encode(const float* v, int D, int F, bool on, float* out) {
+  for (int e = threadIdx.x; e < D * F * LS; e += blockDim.x) {
+    const int s = e % LS, df = e / LS, d = df / F, q = df % F;
+    const float a = v[d * LS + s] * (float)(1 << q);
+    out[df * LS + s] = on ? sinf(a) : 0.0f;
+    out[(D * F + df) * LS + s] = on ? cosf(a) : 0.0f;
+  }
+}
+// LDS layout of a block (floats): x [in1][LS] | h1 [max(fc, 72)][LS] (first the 72 plane x line products) | h2v [fc + inv][LS]
+// | o [4][LS] | (backward) dz1 [fc][LS] | dx [in1][LS] | go [4][LS]
+struct GenLds { int x, h1, h2v, o, dz1, dx, go, total; };
+__host__ __device__ inline GenLds gen_lds(const GenCfg& g, int LS, bool bwd) {
+  GenLds l;
+  l.x = 0; l.h1 = l.x + g.in1 * LS; l.h2v = l.h1 + (g.fc > 72 ? g.fc : 72) * LS; l.o = l.h2v + (g.fc + g.inv) * LS;
+  l.dz1 = l.o + 4 * LS; l.dx = l.dz1 + (bwd ? g.fc * LS : 0); l.go = l.dx + (bwd ? g.in1 * LS : 0); l.total = l.go + (bwd ? 4 * LS : 0);
+  return l;
+}
+// samples per block: 32 unless the block's LDS image would pass 150 KB
+__host__ __device__ inline int gen_tile_samples(const GenCfg& g, bool bwd) { return gen_lds(g, 32, bwd).total * 4 <= 150 * 1024 ? 32 : 16; }
+__host__ __device__ inline int gen_block_threads(const GenCfg& g) { const int t = ((g.fc > 64 ? g.fc : 64) + 63) / 64 * 64; return t > 256 ? 256 : t; }
 
-// MLPRender_Fea_late_view.forward (tensorBase.py:115-135) for one sample: x = [feat, PE(feat)], h1 = relu(W1 x + b1),
-// h2 = relu(W2 h1 + b2), o = W3 [h2, d, PE(d)] + b3 (pre-sigmoid).  Arrays are the caller's (private memory).
-__device__ __forceinline__ void gen_network(const DField& f, const GenCfg& g, const float* feat, const float dh[3],
-                                            float* x, float* h1, float* h2, float* venc, float o[3]) {
-  for (int c = 0; c < LRF_APP_DIM; ++c) x[c] = feat[c];
-  if (g.fea_pe > 0) gen_encode(feat, LRF_APP_DIM, g.fea_pe, g.pe_on != 0, x + LRF_APP_DIM);
-  for (int i = 0; i < g.fc; ++i) {
-    float a = f.b1[i];
-    const float* wr = f.w1 + (size_t)i * g.in1;
-    for (int c = 0; c < g.in1; ++c) a += wr[c] * x[c];
-    h1[i] = fmaxf(a, 0.0f);
-  }
-  for (int i = 0; i < g.fc; ++i) {
-    float a = f.b2[i];
-    const float* wr = f.w2 + (size_t)i * g.fc;
-    for (int c = 0; c < g.fc; ++c) a += wr[c] * h1[c];
-    h2[i] = fmaxf(a, 0.0f);
-  }
-  venc[0] = dh[0]; venc[1] = dh[1]; venc[2] = dh[2];
-  if (g.view_pe > 0) gen_encode(dh, 3, g.view_pe, true, venc + 3);
-  const int ld3 = g.fc + g.inv;
-  for (int c = 0; c < 3; ++c) {
-    float a = f.b3[c];
+// the network on a block's LS samples: x rows 0..26 hold feat, dirs[s] the unit view direction of sample s (all the same ray).
+// Leaves x (with encodings), h1 = relu(..), h2v = [relu(h2) | venc], o = pre-sigmoid colours.  MLPRender_Fea_late_view.forward
+// (tensorBase.py:115-135).
+template <int LS>
+__device__ __forceinline__ void gen_tile_network(const DField& f, const GenCfg& g, const float dh[3], float* sm, const GenLds& l) {
+  float* x = sm + l.x; float* h1 = sm + l.h1; float* h2v = sm + l.h2v; float* o = sm + l.o;
+  if (g.fea_pe > 0) gen_tile_encode<LS>(x, LRF_APP_DIM, g.fea_pe, g.pe_on != 0, x + LRF_APP_DIM * LS);
+  for (int e = threadIdx.x; e < 3 * LS; e += blockDim.x) h2v[(g.fc + e / LS) * LS + e % LS] = dh[e / LS];
+  __syncthreads();
+  gen_tile_dense<LS>(f.w1, f.b1, g.fc, g.in1, x, h1, true);
+  if (g.view_pe > 0) gen_tile_encode<LS>(h2v + g.fc * LS, 3, g.view_pe, true, h2v + (g.fc + 3) * LS);
+  __syncthreads();
+  gen_tile_dense<LS>(f.w2, f.b2, g.fc, g.fc, h1, h2v, true);
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * LS; e += blockDim.x) {     // the three colours: one thread per (colour, sample)
+    const int c = e / LS, s = e % LS, ld3 = g.fc + g.inv;
     const float* wr = f.w3 + (size_t)c * ld3;
-    for (int u = 0; u < g.fc; ++u) a += wr[u] * h2[u];
-    for (int j = 0; j < g.inv; ++j) a += wr[g.fc + j] * venc[j];
-    o[c] = a;
+    float a = f.b3[c];
+    for (int u = 0; u < ld3; ++u) a += wr[u] * h2v[u * LS + s];
+    o[c * LS + s] = a;
   }
+  __syncthreads();
 }
 
 // toff16[r] = 2 toff32[r]: a ray owns two 16-row tiles per 32-sample tile (as k_shade3<SAVE>)
@@ -110,129 +157,191 @@ __global__ void k_toff16(const int* __restrict__ toff32, int R, int* __restrict_
   if (r <= R) toff16[r] = 2 * toff32[r];
 }
 
-// block = (ray, pair q of 32-sample tiles): lanes 0..31 tile 2 q, lanes 32..63 tile 2 q + 1; lane & 31 = sample of the tile.
-// Partial colours per 16 samples -> part[ray][2 t32 + half] (k_finalize sums ceil(n / 16) of them).
-template <bool SAVE>
-__global__ __launch_bounds__(64) void k_shade_gen(
+// block = (ray, chunk q of LS consecutive compact samples).  Partial colours per 16 samples -> part[ray][16-sample slot]
+// (k_finalize sums ceil(n / 16) of them).
+template <int LS, bool SAVE>
+__global__ __launch_bounds__(256) void k_shade_gen(
     DField f, GenCfg g, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ ncomp, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     float* __restrict__ part, int pmax, const int* __restrict__ toff32, float* __restrict__ crgb, float* __restrict__ act,
     int4* __restrict__ tileinfo) {
-  const int npair = (pmax + 3) / 4;                          // pairs of 32-sample tiles per ray (pmax 16-sample slots)
-  const int ray = blockIdx.x / npair, q = blockIdx.x % npair;
-  const int lane = threadIdx.x, n = lane & 31, tir = 2 * q + (lane >> 5);
+  extern __shared__ __attribute__((aligned(16))) float s_gen[];
+  __shared__ float s_u[3][LS];                               // normalised sample positions
+  const GenLds l = gen_lds(g, LS, false);
+  const int nq = (pmax * 16 + LS - 1) / LS;                  // chunks per ray
+  const int ray = blockIdx.x / nq, q = blockIdx.x % nq;
   const int nc = ncomp[ray];
-  const int j0 = tir * 32, cnt = min(32, nc - j0);
-  if (nc - 2 * q * 32 <= 0) return;                          // both tiles of the block are behind the ray's samples
-  const bool valid = cnt > 0 && n < cnt;
+  if (q * LS >= nc) return;                                   // the chunk is behind the ray's samples
+  const int tid = threadIdx.x, j0 = q * LS, cnt = min(LS, nc - j0);
   const float* rp = rays + (size_t)ray * 6;
   const float o3[3] = {rp[0], rp[1], rp[2]};
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
   const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
-  float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-  if (valid) {
-    const size_t ci = (size_t)ray * S + j0 + n;
-    const int k = cidx[ci];
-    const float w = cw[ci];
+  float* x = s_gen + l.x; float* X = s_gen + l.h1; float* o = s_gen + l.o;
+  if (tid < LS) {                                             // samples beyond the ray's count sit on its last one (results unused)
+    const size_t ci = (size_t)ray * S + j0 + min(tid, cnt - 1);
     float xp[3], u[3];
-    sample_point(f, o3, dh, z[k], xp, u);
-    float fe[LRF_APP_DIM];
-    gen_app_features(f, u, fe);
-    float x[GEN_MAX_IN1], h1[GEN_MAX_FC], h2[GEN_MAX_FC], venc[GEN_MAX_INV], o[3];
-    gen_network(f, g, fe, dh, x, h1, h2, venc, o);
-    const float s0 = 1.0f / (1.0f + expf(-o[0])), s1 = 1.0f / (1.0f + expf(-o[1])), s2 = 1.0f / (1.0f + expf(-o[2]));
-    cr = w * s0; cg = w * s1; cb = w * s2;
-    if (SAVE) {
-      float* cp = crgb + ci * 3;
-      cp[0] = s0; cp[1] = s1; cp[2] = s2;
-      const size_t row = ((size_t)2 * (toff32[ray] + tir) + (n >> 4)) * 16 + (n & 15);
-      for (int c = 0; c < LRF_APP_DIM; ++c) act[frag_off(row, ACT_FEAT + c, ACT_LD)] = fe[c];
-      act[frag_off(row, ACT_FEAT + LRF_APP_DIM, ACT_LD)] = 1.0f;
+    sample_point(f, o3, dh, z[cidx[ci]], xp, u);
+    s_u[0][tid] = u[0]; s_u[1][tid] = u[1]; s_u[2][tid] = u[2];
+  }
+  __syncthreads();
+  for (int e = tid; e < 72 * LS; e += blockDim.x) {           // the 72 plane x line products of every sample (tensoRF.py:153-195)
+    const int s = e % LS, pcn = e / LS, p = pcn / LRF_CA, c = pcn % LRF_CA;
+    const float u[3] = {s_u[0][s], s_u[1][s], s_u[2][s]};
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+    tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
+    tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
+    tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
+    const float* pl = f.aplane[p];
+    const int pc = app_pc(c);
+    const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * (1.0f - ty))
+                  + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * (1.0f - ty))
+                  + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * ty)
+                  + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * ty);
+    const float ln = f.aline[p][(size_t)l0 * LRF_CAS + pc] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CAS + pc] * tl;
+    X[pcn * LS + s] = v * ln;
+  }
+  __syncthreads();
+  gen_tile_dense<LS>(f.basis, nullptr, LRF_APP_DIM, 72, X, x, false);     // feat = basis_mat(X) (tensoRF.py:196)
+  __syncthreads();
+  gen_tile_network<LS>(f, g, dh, s_gen, l);
+  if (tid < LS) {
+    const int j = j0 + tid;
+    const bool valid = tid < cnt;
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    if (valid) {
+      const size_t ci = (size_t)ray * S + j;
+      const float w = cw[ci];
+      const float s0 = 1.0f / (1.0f + expf(-o[tid])), s1 = 1.0f / (1.0f + expf(-o[LS + tid])), s2 = 1.0f / (1.0f + expf(-o[2 * LS + tid]));
+      cr = w * s0; cg = w * s1; cb = w * s2;
+      if (SAVE) {
+        float* cp = crgb + ci * 3;
+        cp[0] = s0; cp[1] = s1; cp[2] = s2;
+        const size_t row = ((size_t)2 * (toff32[ray] + (j >> 5)) + ((j >> 4) & 1)) * 16 + (j & 15);
+        for (int c = 0; c < LRF_APP_DIM; ++c) act[frag_off(row, ACT_FEAT + c, ACT_LD)] = x[c * LS + tid];
+        act[frag_off(row, ACT_FEAT + LRF_APP_DIM, ACT_LD)] = 1.0f;
+        if ((j & 31) == 0) {                                  // the first sample of a 32-sample tile writes its two 16-row tile records
+          const int tir = j >> 5, c32 = min(32, nc - j);
+          const size_t t16 = (size_t)2 * (toff32[ray] + tir);
+          tileinfo[t16] = make_int4(ray, j, min(16, c32), 2 * tir);
+          tileinfo[t16 + 1] = make_int4(ray, c32 > 16 ? j + 16 : j, max(0, c32 - 16), 2 * tir + 1);
+        }
+      }
     }
-  }
-  if (SAVE && cnt > 0 && n == 0) {
-    const size_t t16 = (size_t)2 * (toff32[ray] + tir);
-    tileinfo[t16] = make_int4(ray, j0, min(16, cnt), 2 * tir);
-    tileinfo[t16 + 1] = make_int4(ray, cnt > 16 ? j0 + 16 : j0, max(0, cnt - 16), 2 * tir + 1);
-  }
 #pragma unroll
-  for (int dd = 1; dd < 16; dd <<= 1) { cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64); }
-  if ((n & 15) == 0 && cnt > 16 * ((n >> 4))) {                // this 16-sample slot holds samples
-    float* pp = part + ((size_t)ray * pmax + 2 * tir + (n >> 4)) * 3;
-    pp[0] = cr; pp[1] = cg; pp[2] = cb;
+    for (int dd = 1; dd < 16; dd <<= 1) { cr += __shfl_xor(cr, dd, 64); cg += __shfl_xor(cg, dd, 64); cb += __shfl_xor(cb, dd, 64); }
+    if ((j & 15) == 0 && valid) {                              // this 16-sample slot holds samples
+      float* pp = part + ((size_t)ray * pmax + (j >> 4)) * 3;
+      pp[0] = cr; pp[1] = cg; pp[2] = cb;
+    }
   }
 }
 
-// One lane per saved row (16-row tiles of tileinfo).  See the file header.
-__global__ __launch_bounds__(64) void k_gen_dgrad(
+// A block per LS saved rows (LS / 16 of the 16-row tiles of tileinfo; LS = 32: the two tiles of one 32-sample tile, one ray).
+// See the file header.
+template <int LS>
+__global__ __launch_bounds__(256) void k_gen_dgrad(
     DField f, GenCfg g, const float* __restrict__ rays, int S, const int* __restrict__ toff16, int R,
     const int4* __restrict__ tileinfo, const uint16_t* __restrict__ cidx, const float* __restrict__ cw,
     const float* __restrict__ crgb, const float* __restrict__ g_rgb, const float* __restrict__ act,
     float* __restrict__ grd, uint32_t* __restrict__ rowinfo, float* __restrict__ gen, int ld) {
-  const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float s_gen[];
+  const GenLds l = gen_lds(g, LS, true);
+  const int tid = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * LS;
   const int T = toff16[R];
-  if (row >= (size_t)T * 16) return;
-  const int tile = (int)(row >> 4), s = (int)(row & 15);
-  const int4 ti = tileinfo[tile];
-  const int ray = ti.x;
-  const bool valid = s < ti.z;
-  const GenRowOff ro = gen_row_off(g);
-  float* gr = gen + row * (size_t)ld;
-  for (int c = 0; c < LRF_APP_DIM + 5; ++c) grd[frag_off(row, GRD_DFEAT + c, GRD_LD)] = 0.0f;   // dfeat block (32 columns)
-  if (!valid) {
-    rowinfo[row] = 0xffffffffu;
-    for (int c = 0; c < ld; ++c) gr[c] = 0.0f;
-    return;
-  }
-  const size_t ci = (size_t)ray * S + ti.y + s;
-  rowinfo[row] = (uint32_t)((size_t)ray * S + cidx[ci]);
+  if (row0 >= (size_t)T * 16) return;
+  const int4 ti0 = tileinfo[row0 >> 4];
+  const int ray = ti0.x;                                       // (LS = 32: both tiles belong to this ray; the second may be missing when T is odd -- it is not: T is even)
+  float* x = s_gen + l.x; float* h1 = s_gen + l.h1; float* h2v = s_gen + l.h2v; float* o = s_gen + l.o;
+  float* dz1 = s_gen + l.dz1; float* dx = s_gen + l.dx; float* go = s_gen + l.go;
   const float* rp = rays + (size_t)ray * 6;
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
   const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
-  float fe[LRF_APP_DIM];
-  for (int c = 0; c < LRF_APP_DIM; ++c) fe[c] = act[frag_off(row, ACT_FEAT + c, ACT_LD)];
-  float x[GEN_MAX_IN1], h1[GEN_MAX_FC], h2[GEN_MAX_FC], venc[GEN_MAX_INV], o[3];
-  gen_network(f, g, fe, dh, x, h1, h2, venc, o);
-  // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k (tensorBase.py:632-633), the saved sigmoid values
-  const float w = cw[ci];
-  const int oray = f.perm ? f.perm[ray] : ray;
-  float go[3];
-  for (int c = 0; c < 3; ++c) {
-    const float r = crgb[ci * 3 + c];
-    go[c] = g_rgb[(size_t)oray * 3 + c] * w * r * (1.0f - r);
+  const GenRowOff ro = gen_row_off(g);
+  // feat rows; rows beyond a tile's count read the tile's first row (finite values, gradients forced to zero below)
+  for (int e = tid; e < LRF_APP_DIM * LS; e += blockDim.x) {
+    const int s = e % LS, c = e / LS;
+    const int4 ti = tileinfo[(row0 + s) >> 4];
+    const size_t row = row0 + (((s & 15) < ti.z) ? s : (s & ~15));
+    x[c * LS + s] = act[frag_off(row, ACT_FEAT + c, ACT_LD)];
   }
-  const int ld3 = g.fc + g.inv;
-  float dz2[GEN_MAX_FC], dz1[GEN_MAX_FC], dx[GEN_MAX_IN1];
-  for (int u = 0; u < g.fc; ++u) {
-    const float v = f.w3[u] * go[0] + f.w3[ld3 + u] * go[1] + f.w3[2 * ld3 + u] * go[2];
-    dz2[u] = h2[u] > 0.0f ? v : 0.0f;
+  __syncthreads();
+  gen_tile_network<LS>(f, g, dh, s_gen, l);
+  if (tid < LS) {                                              // d(loss)/d(pre-sigmoid colour): rgb_map = sum_k w_k rgb_k (tensorBase.py:632-633)
+    const size_t row = row0 + tid;
+    const int4 ti = tileinfo[row >> 4];
+    const int s16 = tid & 15;
+    const bool valid = s16 < ti.z;
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    if (valid) {
+      const size_t ci = (size_t)ray * S + ti.y + s16;
+      rowinfo[row] = (uint32_t)((size_t)ray * S + cidx[ci]);
+      const float w = cw[ci];
+      const int oray = f.perm ? f.perm[ray] : ray;
+      const float r0 = crgb[ci * 3], r1 = crgb[ci * 3 + 1], r2 = crgb[ci * 3 + 2];
+      g0 = g_rgb[(size_t)oray * 3] * w * r0 * (1.0f - r0);
+      g1 = g_rgb[(size_t)oray * 3 + 1] * w * r1 * (1.0f - r1);
+      g2 = g_rgb[(size_t)oray * 3 + 2] * w * r2 * (1.0f - r2);
+    } else {
+      rowinfo[row] = 0xffffffffu;
+    }
+    go[tid] = g0; go[LS + tid] = g1; go[2 * LS + tid] = g2; go[3 * LS + tid] = 0.0f;
   }
-  for (int v = 0; v < g.fc; ++v) {
-    float a = 0.0f;
-    for (int u = 0; u < g.fc; ++u) a += f.w2[(size_t)u * g.fc + v] * dz2[u];
-    dz1[v] = h1[v] > 0.0f ? a : 0.0f;
-  }
-  for (int c = 0; c < g.in1; ++c) {
-    float a = 0.0f;
-    for (int v = 0; v < g.fc; ++v) a += f.w1[(size_t)v * g.in1 + c] * dz1[v];
-    dx[c] = a;
-  }
-  const int F = g.fea_pe, DF = LRF_APP_DIM * F;
-  for (int d = 0; d < LRF_APP_DIM; ++d) {
-    float a = dx[d];
-    if (F > 0 && g.pe_on)
-      for (int qf = 0; qf < F; ++qf) {                         // d sin(v 2^q) = 2^q cos(..), d cos(v 2^q) = -2^q sin(..): the encodings are in x
-        const float sc = (float)(1 << qf);
-        a += sc * (x[LRF_APP_DIM + DF + d * F + qf] * dx[LRF_APP_DIM + d * F + qf] - x[LRF_APP_DIM + d * F + qf] * dx[LRF_APP_DIM + DF + d * F + qf]);
+  __syncthreads();
+  // operand rows of the weight gradients, part 1 (before the activations are overwritten): [x, 1], [relu(h1), 1], [relu(h2), venc, 1], go
+  for (int s = 0; s < LS; ++s) {
+    float* gr = gen + (row0 + s) * (size_t)ld;
+    const bool live = go[s] != 0.0f || go[LS + s] != 0.0f || go[2 * LS + s] != 0.0f;     // rows without gradient contribute nothing: zero rows
+    for (int e = tid; e < ld; e += blockDim.x) {
+      float v = 0.0f;
+      if (live) {
+        if (e >= ro.go) v = e - ro.go < 3 ? go[(e - ro.go) * LS + s] : 0.0f;
+        else if (e >= ro.h2v) v = e - ro.h2v < g.fc + g.inv ? h2v[(e - ro.h2v) * LS + s] : 1.0f;
+        else if (e >= ro.h1) v = e - ro.h1 < g.fc ? h1[(e - ro.h1) * LS + s] : 1.0f;
+        else if (e >= ro.x1) v = e - ro.x1 < g.in1 ? x[(e - ro.x1) * LS + s] : 1.0f;
       }
-    grd[frag_off(row, GRD_DFEAT + d, GRD_LD)] = a;
+      if (e >= ro.x1) gr[e] = v;                               // (dz1, dz2 columns follow below)
+    }
   }
-  for (int v = 0; v < g.fc; ++v) { gr[ro.dz1 + v] = dz1[v]; gr[ro.dz2 + v] = dz2[v]; gr[ro.h1 + v] = h1[v]; gr[ro.h2v + v] = h2[v]; }
-  for (int c = 0; c < g.in1; ++c) gr[ro.x1 + c] = x[c];
-  gr[ro.x1 + g.in1] = 1.0f; gr[ro.h1 + g.fc] = 1.0f;
-  for (int j = 0; j < g.inv; ++j) gr[ro.h2v + g.fc + j] = venc[j];
-  gr[ro.h2v + g.fc + g.inv] = 1.0f;
-  gr[ro.go] = go[0]; gr[ro.go + 1] = go[1]; gr[ro.go + 2] = go[2]; gr[ro.go + 3] = 0.0f;
+  __syncthreads();
+  const int ld3 = g.fc + g.inv;
+  for (int u = tid; u < g.fc; u += blockDim.x) {               // dz2 = (W3[:, :fc]^T go) * [h2 > 0], in place of relu(h2)
+    const float w0 = f.w3[u], w1 = f.w3[ld3 + u], w2 = f.w3[2 * ld3 + u];
+    for (int s = 0; s < LS; ++s) {
+      const float v = w0 * go[s] + w1 * go[LS + s] + w2 * go[2 * LS + s];
+      const float d2 = h2v[u * LS + s] > 0.0f ? v : 0.0f;
+      h2v[u * LS + s] = d2;
+      gen[(row0 + s) * (size_t)ld + ro.dz2 + u] = d2;
+    }
+  }
+  __syncthreads();
+  gen_tile_dense_t<LS>(f.w2, g.fc, g.fc, g.fc, h2v, dz1);
+  __syncthreads();
+  for (int v = tid; v < g.fc; v += blockDim.x)
+    for (int s = 0; s < LS; ++s) {
+      const float d1 = h1[v * LS + s] > 0.0f ? dz1[v * LS + s] : 0.0f;
+      dz1[v * LS + s] = d1;
+      gen[(row0 + s) * (size_t)ld + ro.dz1 + v] = d1;
+    }
+  __syncthreads();
+  gen_tile_dense_t<LS>(f.w1, g.fc, g.in1, g.in1, dz1, dx);
+  __syncthreads();
+  const int F = g.fea_pe, DF = LRF_APP_DIM * F;
+  for (int e = tid; e < 32 * LS; e += blockDim.x) {            // dfeat block of the gradient row (32 columns; 27.. are zero)
+    const int s = e % LS, d = e / LS;
+    float a = 0.0f;
+    if (d < LRF_APP_DIM) {
+      a = dx[d * LS + s];
+      if (F > 0 && g.pe_on)
+        for (int qf = 0; qf < F; ++qf) {                       // d sin(v 2^q) = 2^q cos(..), d cos(v 2^q) = -2^q sin(..): the encodings are in x
+          const float sc = (float)(1 << qf);
+          a += sc * (x[(LRF_APP_DIM + DF + d * F + qf) * LS + s] * dx[(LRF_APP_DIM + d * F + qf) * LS + s]
+                     - x[(LRF_APP_DIM + d * F + qf) * LS + s] * dx[(LRF_APP_DIM + DF + d * F + qf) * LS + s]);
+        }
+    }
+    grd[frag_off(row0 + s, GRD_DFEAT + d, GRD_LD)] = a;
+  }
 }
 
 // C[m][n] += sum over the K-chunk's rows of A[row][m] B[row][n], A = gen + offA (M columns), B = gen + offB (N columns; the

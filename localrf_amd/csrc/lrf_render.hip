@@ -1017,6 +1017,40 @@ static const char* gen_check(const LrfField* f) {
     return "localrf: a non-default colour-network configuration needs the natural-layout weights in LrfField (basis, w1 .. b3)";
   return nullptr;
 }
+// dynamic LDS above 64 KB has to be opted into once per device
+static hipError_t gen_opt_in() {
+  static std::once_flag once[64];
+  static hipError_t err[64];
+  int dev = 0;
+  hipError_t e0 = hipGetDevice(&dev);
+  if (e0 != hipSuccess) return e0;
+  std::call_once(once[dev & 63], [dev] {
+    const void* ks[6] = {reinterpret_cast<const void*>(&k_shade_gen<32, false>), reinterpret_cast<const void*>(&k_shade_gen<32, true>),
+                         reinterpret_cast<const void*>(&k_shade_gen<16, false>), reinterpret_cast<const void*>(&k_shade_gen<16, true>),
+                         reinterpret_cast<const void*>(&k_gen_dgrad<32>), reinterpret_cast<const void*>(&k_gen_dgrad<16>)};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    err[dev & 63] = e;
+  });
+  return err[dev & 63];
+}
+// the generic colour kernel behind k_march; toff32 != null: the training forward (also leaves colours, feat rows, tile records)
+static hipError_t launch_shade_gen(const DField& d, const GenCfg& gc, const float* rays, const float* z, int R, int S, const Workspace& w,
+                                   const int* toff32, float* crgb, float* act, int4* tileinfo, hipStream_t st) {
+  hipError_t e = gen_opt_in();
+  if (e != hipSuccess) return e;
+  const int ls = gen_tile_samples(gc, false), nt = gen_block_threads(gc);
+  const size_t lds = (size_t)gen_lds(gc, ls, false).total * 4;
+  const dim3 grid(R * ((w.pmax * 16 + ls - 1) / ls));
+  if (toff32) {
+    if (ls == 32) hipLaunchKernelGGL((k_shade_gen<32, true>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
+    else          hipLaunchKernelGGL((k_shade_gen<16, true>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
+  } else {
+    if (ls == 32) hipLaunchKernelGGL((k_shade_gen<32, false>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
+    else          hipLaunchKernelGGL((k_shade_gen<16, false>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
+  }
+  return hipGetLastError();
+}
 }  // namespace lrf
 #include "lrf_backward.inl"
 #include "lrf_scene.inl"
@@ -1115,8 +1149,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   if (ev) LRF_HIP(hipEventRecord(ev[1], st));
   if (generic || (flags & LRF_FLAG_MLP_VALU)) {
     const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
-    hipLaunchKernelGGL(k_shade_gen<false>, dim3(R * ((w.pmax + 3) / 4)), dim3(64), 0, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw,
-                       w.part, w.pmax, (const int*)nullptr, (float*)nullptr, (float*)nullptr, (int4*)nullptr);
+    LRF_HIP(launch_shade_gen(d, gc, rays, z, R, S, w, nullptr, nullptr, nullptr, nullptr, st));
   } else {
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.ncomp, R, w.toff);
     hipLaunchKernelGGL(k_shade, dim3(device_cus()), dim3(1024), 0, st, d, rays, z, S, w.toff, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax);
