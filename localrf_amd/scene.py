@@ -149,7 +149,7 @@ class LocalTensorfs(SceneLifecycle):
             return scene_forward(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole,
                                  [self.tensorfs[rf] for rf in active], white_bg, floater_thresh,
                                  max(per_field, self.min_chunk), bw,
-                                 self._exposure_for(view_ids, test_id))
+                                 self._exposure_for(view_ids, test_id), refine=self.is_refining)
         # with a tape the caller's chunk is honoured as is: the row-saving workspace is ~0.37 MB per ray at S = 512
         chunk = per_field
         rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole)

@@ -172,7 +172,7 @@ def scene_blend(rgb_f, dep_f, blend_w, exposure, per_view):
 
 
 def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360, fields, white_bg, floater_thresh,
-                  chunk, blend_w, exposure):
+                  chunk, blend_w, exposure, refine=True):
     """LocalTensorfs.forward without a tape as ONE native call (lrf_scene_fwd): rays of every active field, the per-field
     renders in the reference's chunk / field order (local_tensorfs.py:440-474), blend, exposure, clamp.
     `fields`: the active TensorVMSplit objects; world2rf [n_rf,3].  -> (rgbs [R,3], depth [R], directions [R,3], ij [R,2])."""
@@ -203,7 +203,7 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
         arr[k].field = C.pointer(cf)
         arr[k].z = z.data_ptr()
         arr[k].S = int(z.shape[0])
-        arr[k].flags = f._flags(bool(white_bg))
+        arr[k].flags = f._flags(bool(white_bg)) | (N.LRF_FLAG_PE_OFF if (f.fea_pe > 0 and not refine) else 0)   # local_tensorfs.py:446 passes refine=self.is_refining
         arr[k].workspace = ws.data_ptr()
     rays = torch.empty(n_rf, R, 6, dtype=torch.float32, device=dev)
     rgb_f = torch.empty(n_rf, R, 3, dtype=torch.float32, device=dev)

@@ -963,6 +963,47 @@ def test_scene_forward_single_native_call_equals_the_per_field_path(chunk, min_c
         assert np.abs(native[0].cpu().numpy() - g["rgbs_testid"]).max() < 1e-4
 
 
+def test_scene_with_a_nondefault_colour_network_trains_and_renders():
+    """LocalTensorfs over fields with positional encodings and another hidden width (the generic engine, csrc/lrf_generic.inl):
+    the no-grad scene forward (one native call) equals the taped path's outputs bit for bit, a backward fills every field
+    and pose gradient with finite values, an optimiser step moves the loss, and the state dict keeps the reference's shapes."""
+    from localrf_amd import LocalTensorfs
+    W, H = 32, 24
+    torch.manual_seed(7)
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).to(DEV)
+    kw = dict(FIELD_KW, fea_pe=1, view_pe=2, featureC=48)
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=5, n_overlap=3, WH=(W, H),
+               n_iters_per_frame=600, n_iters_reg=100, lr_R_init=5e-3, lr_t_init=5e-4,
+               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[],
+               camera_prior=None, device=DEV, lr_upsample_reset=True, aabb=aabb, gridSize=[20, 24, 28], **kw).to(DEV)
+    sd = lt.state_dict()
+    assert tuple(sd["tensorfs.0.renderModule.mlp.0.weight"].shape) == (48, 27 * 3)
+    assert tuple(sd["tensorfs.0.renderModule.mlp_view.0.weight"].shape) == (3, 48 + 15)
+    g = torch.Generator().manual_seed(3)
+    view_ids = torch.tensor([0, 2, 4])
+    ray_ids = torch.randint(0, W * H, (3 * 64,), generator=g)
+    target = torch.rand(3 * 64, 3, generator=g).to(DEV)
+    with torch.no_grad():
+        e_off = lt(ray_ids, view_ids.tolist(), W, H, is_train=False, white_bg=True)
+        lt.is_refining = True                                       # local_tensorfs.py:446: refine = self.is_refining switches the feature encodings on
+        e = lt(ray_ids, view_ids.tolist(), W, H, is_train=False, white_bg=True)
+    assert float((e[0] - e_off[0]).abs().max()) > 1e-4
+    lt.tensorfs[-1].z_override = lt.tensorfs[-1].z_schedule(False, -1, torch.device(DEV)).clone()      # the same samples in both paths
+    losses = []
+    for it in range(3):
+        rgb, depth, _, _ = lt(ray_ids, view_ids.tolist(), W, H, is_train=True, white_bg=True)
+        if it == 0:
+            with torch.no_grad():
+                e2 = lt(ray_ids, view_ids.tolist(), W, H, is_train=False, white_bg=True)
+            assert torch.equal(e[0], e2[0])
+            assert float((rgb.detach() - e2[0]).abs().max()) < 1e-6 and float((depth.detach() - e2[1]).abs().max()) < 1e-5
+        loss = ((rgb - target) ** 2).mean()
+        losses.append(float(loss.detach()))
+        lt.optimizer_step(loss, True)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 def test_gradient_buckets_become_final_in_order_and_can_be_awaited_separately(built_lib):
     """lrf_render_bwd_wait (the hand-off localrf_amd.dist uses to start the density all-reduce while the rest of the
     backward runs): after a backward, a side stream that waits for bucket k only must see that bucket's gradients final --
