@@ -693,6 +693,28 @@ def main():
                 del wf
             except Exception as e:                           # noqa: BLE001
                 work["trained_like"] = {"error": repr(e)}
+            try:                                             # a non-default colour network (opt.py:148-157): the generic fp32 engine
+                torch.manual_seed(0)
+                gf = TensorVMSplit(torch.device("cpu"), 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), [GRID] * 3,
+                                   **{**FIELD_KW, "view_pe": 2, "fea_pe": 2}).to(dev)
+                with torch.no_grad():
+                    gfw = lambda: gf(rays, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)   # noqa: E731
+                    dg = timed(gfw, 5, 2, sync)
+                ggr, ggd = torch.randn(R_PER_GPU, 3, device=dev), torch.randn(R_PER_GPU, device=dev)
+
+                def gfb():
+                    for p_ in gf.parameters():
+                        p_.grad = None
+                    a_, b_ = gf(rays, white_bg=True, is_train=True, N_samples=N_SAMPLES_ARG)
+                    ((a_ * ggr).sum() + (b_ * ggd).sum()).backward()
+                dgb = timed(gfb, 3, 1, sync)
+                work["nondefault_network"] = {
+                    "what": "same grid and batch, view_pe = fea_pe = 2 (MLPRender_Fea_late_view with positional encodings): "
+                            "csrc/lrf_generic.inl, fp32 tile GEMMs on the vector ALU -- supported, not tuned",
+                    "rays_per_s": R_PER_GPU * 5 / dg, "ms_per_step": dg / 5 * 1e3, "forward_backward_ms": dgb / 3 * 1e3}
+                del gf
+            except Exception as e:                           # noqa: BLE001
+                work["nondefault_network"] = {"error": repr(e)}
             try:                                             # the same field on a 16 x larger batch (an eval image is rendered this way)
                 big = make_rays(16 * R_PER_GPU, 7).to(dev)
                 with torch.no_grad():
