@@ -259,12 +259,11 @@ __global__ __launch_bounds__(256) void k_gen_dgrad(
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
   const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
   const GenRowOff ro = gen_row_off(g);
-  // feat rows; rows beyond a tile's count read the tile's first row (finite values, gradients forced to zero below)
+  // feat rows; rows beyond a tile's count were never written by the forward: zeros (finite activations; their gradients are zero)
   for (int e = tid; e < LRF_APP_DIM * LS; e += blockDim.x) {
     const int s = e % LS, c = e / LS;
     const int4 ti = tileinfo[(row0 + s) >> 4];
-    const size_t row = row0 + (((s & 15) < ti.z) ? s : (s & ~15));
-    x[c * LS + s] = act[frag_off(row, ACT_FEAT + c, ACT_LD)];
+    x[c * LS + s] = (s & 15) < ti.z ? act[frag_off(row0 + s, ACT_FEAT + c, ACT_LD)] : 0.0f;
   }
   __syncthreads();
   gen_tile_network<LS>(f, g, dh, s_gen, l);

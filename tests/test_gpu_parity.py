@@ -899,6 +899,43 @@ def test_nondefault_colour_network_vs_reference_golden(built_lib, name):
     print(name, "worst", {k: "%.1e" % v for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("cfg", [dict(), dict(fea_pe=2, view_pe=1, featureC=96)])
+def test_training_results_do_not_depend_on_what_the_workspace_held(built_lib, cfg):
+    """The training workspace is uninitialised memory (torch.empty): rows the forward never writes (beyond a tile's count, the
+    empty second half of a pair of 16-row tiles) must not reach any result.  The same forward + backward twice, the second
+    time with the allocator handing back blocks that were just filled with NaN patterns: outputs identical, gradients equal up
+    to the order of the scatter adds."""
+    import ctypes as C
+    from localrf_amd import _native as N
+    f = quiet(make_field, [28, 30, 26], "cpu", seed=13, **cfg).to(DEV)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(3.0)
+    R = 700
+    rays = make_rays(R, 9, pinhole=True).to(DEV)
+    _g = torch.Generator().manual_seed(5)
+    gr, gd = torch.randn(R, 3, generator=_g).to(DEV), torch.randn(R, generator=_g).to(DEV)
+    f.z_override = f.z_schedule(False, 60, torch.device(DEV)).clone()
+    nbytes = N.lib().lrf_workspace_bytes_bwd_cfg(R, f.z_override.numel(), (C.c_int32 * 3)(*f._grid_host), int(f.fea_pe), int(f.view_pe), int(f.featureC))
+
+    def run(poison):
+        for p in f.parameters():
+            p.grad = None
+        if poison:                                               # blocks of the workspace's size (and of the gradient buffer's), full of NaN bit patterns, back to the allocator
+            junk = [torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=DEV) for _ in range(2)]
+            del junk
+        r = rays.clone().requires_grad_(True)
+        rgb, depth = f(r, white_bg=True, is_train=True, N_samples=60)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+        return rgb.detach().clone(), depth.detach().clone(), [p.grad.clone() for p in f.parameters() if p.grad is not None] + [r.grad.clone()]
+    a = run(False)
+    b = run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert torch.isfinite(y).all()
+        assert float((x - y).abs().max()) <= 2e-5 * max(float(x.abs().max()), 1e-12)
+
+
 # ----------------------------------------------------------------- randomised sweep (was scripts/gpu_diag.py fuzz)
 @pytest.mark.parametrize("seed", [0, 1])
 def test_fuzz_forward_and_gradients_vs_aten_port(built_lib, seed):
