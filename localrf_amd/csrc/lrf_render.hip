@@ -1025,11 +1025,10 @@ static hipError_t gen_opt_in() {
   hipError_t e0 = hipGetDevice(&dev);
   if (e0 != hipSuccess) return e0;
   std::call_once(once[dev & 63], [dev] {
-    const void* ks[6] = {reinterpret_cast<const void*>(&k_shade_gen<32, false>), reinterpret_cast<const void*>(&k_shade_gen<32, true>),
-                         reinterpret_cast<const void*>(&k_shade_gen<16, false>), reinterpret_cast<const void*>(&k_shade_gen<16, true>),
+    const void* ks[4] = {reinterpret_cast<const void*>(&k_shade_gen<32, false>), reinterpret_cast<const void*>(&k_shade_gen<32, true>),
                          reinterpret_cast<const void*>(&k_gen_dgrad<32>), reinterpret_cast<const void*>(&k_gen_dgrad<16>)};
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     err[dev & 63] = e;
   });
   return err[dev & 63];
@@ -1039,16 +1038,12 @@ static hipError_t launch_shade_gen(const DField& d, const GenCfg& gc, const floa
                                    const int* toff32, float* crgb, float* act, int4* tileinfo, hipStream_t st) {
   hipError_t e = gen_opt_in();
   if (e != hipSuccess) return e;
-  const int ls = gen_tile_samples(gc, false), nt = gen_block_threads(gc);
+  constexpr int ls = 32;                                      // (the forward's LDS image stays below 102 KB for every allowed configuration)
+  const int nt = gen_block_threads(gc);
   const size_t lds = (size_t)gen_lds(gc, ls, false).total * 4;
   const dim3 grid(R * ((w.pmax * 16 + ls - 1) / ls));
-  if (toff32) {
-    if (ls == 32) hipLaunchKernelGGL((k_shade_gen<32, true>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
-    else          hipLaunchKernelGGL((k_shade_gen<16, true>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
-  } else {
-    if (ls == 32) hipLaunchKernelGGL((k_shade_gen<32, false>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
-    else          hipLaunchKernelGGL((k_shade_gen<16, false>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
-  }
+  if (toff32) hipLaunchKernelGGL((k_shade_gen<32, true>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
+  else        hipLaunchKernelGGL((k_shade_gen<32, false>), grid, dim3(nt), lds, st, d, gc, rays, z, S, w.ncomp, w.cidx, w.cw, w.part, w.pmax, toff32, crgb, act, tileinfo);
   return hipGetLastError();
 }
 }  // namespace lrf
