@@ -113,3 +113,23 @@ def test_members_of_the_reference_class_exist_on_the_native_one(hybrid):
                  lambda: mine.filtering_rays(torch.zeros(4, 6), torch.zeros(4, 3))):
         with pytest.raises(NotImplementedError):
             call()
+
+
+@pytest.mark.parametrize("cfg", [dict(view_pe=2, fea_pe=2, featureC=64), dict(view_pe=6, fea_pe=0, featureC=128), dict(view_pe=0, fea_pe=6, featureC=256)])
+def test_nondefault_colour_network_has_the_reference_state_dict(hybrid, cfg):
+    """opt.py:148-157 off their defaults: the native class builds the same parameter tensors (names, shapes, values under
+    the same seed) as the reference's, so checkpoints interchange; the generic engine (csrc/lrf_generic.inl) renders them."""
+    ref_lt, ref_field, quiet = hybrid
+    import localrf_amd
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    kw = dict(FIELD_KW, **cfg)
+    torch.manual_seed(9)
+    theirs = quiet(ref_field, "cpu", aabb, [10, 12, 8], **kw)
+    torch.manual_seed(9)
+    mine = quiet(localrf_amd.TensorVMSplit, "cpu", aabb, [10, 12, 8], **kw)
+    sd_t, sd_m = theirs.state_dict(), mine.state_dict()
+    assert list(sd_t) == list(sd_m)
+    for k in sd_t:
+        assert sd_t[k].shape == sd_m[k].shape and torch.equal(sd_t[k], sd_m[k]), k
+    mine.load_state_dict(sd_t)
+    assert mine.get_kwargs()["view_pe"] == cfg["view_pe"] and mine.get_kwargs()["fea_pe"] == cfg["fea_pe"] and mine.get_kwargs()["featureC"] == cfg["featureC"]
