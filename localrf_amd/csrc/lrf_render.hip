@@ -11,7 +11,8 @@
 //                appearance gather, basis -> 128 -> 128 as a register-resident split-bf16 MFMA chain, VALU head,
 //                per-ray ordered sum of the tile partials + white background.
 // Other colour engines behind the same ABI: k_shade (exact fp32 on v_mfma_f32_16x16x4_f32, LRF_FLAG_MLP_F32) and
-// k_shade_valu (plain loops, LRF_FLAG_MLP_VALU), both 16 samples per tile behind k_scan_tiles / k_finalize.
+// k_shade_gen (lrf_generic.inl: fp32 tile GEMMs on the vector ALU -- LRF_FLAG_MLP_VALU, and every colour-network configuration
+// other than opt.py's defaults), both behind k_finalize.
 // The split-bf16 helpers of the 16-sample chain (gemm_step ...) serve the training kernels of lrf_backward.inl.
 //
 // Reference lines (relative to /root/reference/localTensoRF) are cited at each step.

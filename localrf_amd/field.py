@@ -225,7 +225,8 @@ class TensorVMSplit(torch.nn.Module):
         self._cache_key = None
         self._ws = None
         # colour-MLP engine: "bf16x3" split-bf16 (hi + lo, 3-term) MFMA chain, 32 samples per wave, k_shade3 (default) |
-        # "f32" exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu" plain-loop debug engine (LRF_FLAG_MLP_VALU)
+        # "f32" exact fp32 MFMA chain (LRF_FLAG_MLP_F32) | "valu" the generic fp32 engine on the vector ALU (LRF_FLAG_MLP_VALU); a non-default
+        # view_pe / fea_pe / featureC always runs the generic engine, whatever this says
         self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
         # early termination of the march (LrfField.term_T in include/lrf.h).  Default 0 = every sample is evaluated, the
