@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, ScatterDst dst, c
 
 struct BwdWorkspace {
   Workspace fw;
-  float* feat; float* crgb; float* imt; float* act; float* grd; float* rpart; float* wpart;
+  float* feat; float* crgb; float* act; float* grd; float* rpart; float* wpart;
   float* depth; float* rgb;
   uint32_t* rowinfo; uint16_t* tid; int* hist; int* offs; int* cursor; uint32_t* list;
   uint32_t* relu_bits;       // [tile][layer 1, 2][lane]: ReLU masks, k_shade3<SAVE> -> k_train_dgrad3, k_wgrad_w2w3
@@ -1160,7 +1160,6 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   auto take = [&](size_t nfloat) { float* q = reinterpret_cast<float*>(p + off); off += up256(nfloat * 4); return q; };
   b.feat = take((size_t)R * S);
   b.crgb = take((size_t)R * S * 3);
-  b.imt = take(W32T_ALL_U4 * 4);
   b.act = take(rows * ACT_LD);
   b.grd = take(rows * GRD_LD);
   b.rpart = take((size_t)R * b.fw.pmax * 8);
@@ -1310,7 +1309,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     });
     LRF_HIP(lds_attr_err[dev_id & 63]);
   }
-  hipLaunchKernelGGL(k_pack_mlp_w32_t, dim3((W32T_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p, reinterpret_cast<uint32_t*>(b.imt), generic ? 1 : 0);
   if (!(flags & LRF_FLAG_ROWS_SAVED)) {            // otherwise lrf_render_fwd_train left all of this in place
     d.rdir = w.rdir;
     launch_march(d, rays, z, R, S, flags, 0.0f, b.depth, w.acc, nullptr, w.ncomp, w.cidx, w.cw, b.feat, st);
@@ -1360,13 +1358,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     else          hipLaunchKernelGGL(k_gen_dgrad<16>, grid, dim3(nt), lds, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
   } else {
     hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16, st, d,
-                       reinterpret_cast<const uint4*>(b.imt), rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
+                       d.mlpwt, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
                        b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
   }
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));         // go / dfeat rows: the weight-gradient kernel may start
   LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * bg.total, st));
   hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
-                     reinterpret_cast<const uint4*>(b.imt), rays, z, S, w.toff, R, b.tileinfo, w.cidx,
+                     d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
                      b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3);
 
   // ---- side stream: per-ray backward, density scatter

@@ -73,9 +73,16 @@ __host__ __device__ constexpr int w32_unit(int m0, int q, int h, int j) { return
 // dense 24-channel texel), -1 for the four pad slots of the fifth K-step
 __host__ __device__ constexpr int w32_chan(int h, int v) { return v >= 36 ? -1 : 24 * (v / 12) + 12 * h + v % 12; }
 
+// transposed w32 image of the backward (fragment order: lrf_train32.inl)
+constexpr int W32T_W2 = 0, W32T_W1 = 32, W32T_BAS = 40, W32T_NFRAG = 46;
+constexpr int W32T_U4 = W32T_NFRAG * 128;                        // 5888 uint4 = 94,208 B
+constexpr int W32T_T_W3 = 0, W32T_T_W3_LD = 132, W32T_T_FLOATS = 400;
+constexpr int W32T_ALL_U4 = W32T_U4 + W32T_T_FLOATS / 4;         // 5988 uint4 = 95,808 B
+
 struct Layout {
   size_t dplane[3], dline[3], aplane[3], aline[3], mlp, mlpb, total;   // float offsets
   size_t aplane2[3], aline2[3], mlpw;     // dense 24-channel appearance planes / lines and the w32 image (k_shade3)
+  size_t mlpwt;                           // transposed w32 image (k_train_dgrad3, k_train_app3)
   int pw[3], ph[3], ll[3];
 };
 
@@ -96,6 +103,7 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
   for (int p = 0; p < 3; ++p) { L.aplane2[p] = off; off = align64(off + (size_t)L.pw[p] * L.ph[p] * LRF_CA); }
   for (int p = 0; p < 3; ++p) { L.aline2[p]  = off; off = align64(off + (size_t)L.ll[p] * LRF_CA); }
   L.mlpw = off; off = align64(off + (size_t)W32_ALL_U4 * 4);
+  L.mlpwt = off; off = align64(off + (size_t)W32T_ALL_U4 * 4);
   L.total = off;
   return L;
 }
@@ -140,6 +148,7 @@ struct DField {
   const uint4* mlpb;
   const float* aplane2[3]; const float* aline2[3];     // dense [H][W][24] / [L][24] (k_shade3)
   const uint4* mlpw;                                   // w32 image
+  const uint4* mlpwt;                                  // transposed w32 image (backward)
   int pw[3], ph[3], ll[3];
   const float* alpha_vol; int ax, ay, az;
   float m_lo[3], m_inv[3];     // alpha-mask aabb: lo and 2/size   (tensorBase.py:57-58)

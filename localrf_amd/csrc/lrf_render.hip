@@ -41,8 +41,27 @@ static int set_err(const char* msg, hipError_t e = hipSuccess) {
 // [C,H,W] -> [H,W,CS] channel-last; app=1: padded appearance layout (slot app_pc(c), zero pads)
 struct PackSeg { const float* src; float* dst; int C, H, W, CS, app; };
 struct PackTab { PackSeg s[18]; };
-// all plane / line tensors of a field (the appearance ones twice: padded and dense) in one launch (blockIdx.z selects; a line [C,L,1] is a plane with H = 1)
-__global__ __launch_bounds__(128) void k_pack_planes(PackTab tab) {
+struct PackMlp { float* mlp; uint32_t* mlpb; uint32_t* mlpw; uint32_t* mlpwt; int mode; };   // mode 0: all four network images; 1: generic engine (only the basis^T fragments of mlpwt)
+__device__ void pack_mlp_elem(const LrfParams& p, float* __restrict__ img, int idx);
+__device__ void pack_mlp_bf16_elem(const LrfParams& p, uint32_t* __restrict__ img, int idx);
+__device__ void pack_mlp_w32_elem(const LrfParams& p, uint32_t* __restrict__ img, int idx);
+__device__ void pack_mlp_w32_t_elem(const LrfParams& p, uint32_t* __restrict__ img, int idx, int basis_only);
+// The whole layout cache in ONE launch: all plane / line tensors of a field (the appearance ones twice: padded and dense;
+// blockIdx.z < 18 selects; a line [C,L,1] is a plane with H = 1) and, in slice 18, the four fragment-ordered images of the
+// colour network (they were four launches of ~5 us each, three of them in front of every training forward).
+__global__ __launch_bounds__(128) void k_pack_planes(PackTab tab, LrfParams p, PackMlp pm) {
+  if (blockIdx.z == 18) {
+    const int nthr = gridDim.x * gridDim.y * 128;
+    for (int idx = (blockIdx.y * gridDim.x + blockIdx.x) * 128 + threadIdx.x; idx < 26880; idx += nthr) {   // >= the largest image (IMGB_ALL * 4 = 26624)
+      if (pm.mode == 0) {
+        pack_mlp_elem(p, pm.mlp, idx);
+        pack_mlp_bf16_elem(p, pm.mlpb, idx);
+        pack_mlp_w32_elem(p, pm.mlpw, idx);
+      }
+      pack_mlp_w32_t_elem(p, pm.mlpwt, idx, pm.mode);
+    }
+    return;
+  }
   const PackSeg sg = tab.s[blockIdx.z];
   const float* __restrict__ src = sg.src;
   float* __restrict__ dst = sg.dst;
@@ -68,8 +87,7 @@ __global__ __launch_bounds__(128) void k_pack_planes(PackTab tab) {
 }
 // colour network -> MFMA-fragment-ordered image (see lrf_common.h IMG_*).
 // Fragment lane l = (i = l & 15, g = l >> 4): A operand row 16t'+i, K-slot g.
-__global__ void k_pack_mlp(LrfParams p, float* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void pack_mlp_elem(const LrfParams& p, float* __restrict__ img, int idx) {
   if (idx >= IMG_FLOATS) return;
   float v = 0.0f;
   if (idx < IMG_W1) {                       // basis_mat.weight [27,72]   (tensoRF.py:25-27,196)
@@ -116,8 +134,7 @@ __device__ __forceinline__ float bf16_val(unsigned short b) {
 
 // colour network -> split-bf16 fragment image (lrf_common.h IMGB_*).  One thread per
 // 32-bit word (two bf16) of the fragment area, then the fp32 tail.
-__global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void pack_mlp_bf16_elem(const LrfParams& p, uint32_t* __restrict__ img, int idx) {
   if (idx >= IMGB_ALL * 4) return;
   if (idx >= IMGB_W3F * 4) {                                   // head fragments (k_mlp): frag = ks
     const int e = idx - IMGB_W3F * 4;
@@ -181,8 +198,7 @@ __global__ void k_pack_mlp_bf16(LrfParams p, uint32_t* __restrict__ img) {
 }
 
 // colour network -> w32 fragment image (lrf_common.h W32_*), for k_shade3.  One thread per 32-bit word.
-__global__ void k_pack_mlp_w32(LrfParams p, uint32_t* __restrict__ img) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void pack_mlp_w32_elem(const LrfParams& p, uint32_t* __restrict__ img, int idx) {
   if (idx >= W32_ALL_U4 * 4) return;
   if (idx >= W32_U4 * 4) {                                     // fp32 tail
     const int e = idx - W32_U4 * 4;
@@ -823,6 +839,7 @@ static DField make_dfield(const LrfField* f) {
   d.mlpb = reinterpret_cast<const uint4*>(base + L.mlpb);
   for (int p = 0; p < 3; ++p) { d.aplane2[p] = base + L.aplane2[p]; d.aline2[p] = base + L.aline2[p]; }
   d.mlpw = reinterpret_cast<const uint4*>(base + L.mlpw);
+  d.mlpwt = reinterpret_cast<const uint4*>(base + L.mlpwt);
   d.alpha_vol = f->alpha_vol;
   d.ax = f->alpha_dim[0]; d.ay = f->alpha_dim[1]; d.az = f->alpha_dim[2];
   for (int a = 0; a < 3; ++a) {
@@ -1098,16 +1115,12 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
     wmax = max(wmax, max(L.pw[q], L.ll[q]));
     hmax = max(hmax, L.ph[q]);
   }
-  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 18), dim3(128), 0, st, tab);
-  if (!gen_is_default(p->fea_pe, p->view_pe, p->feature_c ? p->feature_c : LRF_FEATC)) {   // the generic engine reads the parameter tensors themselves
-    LRF_HIP(hipGetLastError());
-    return 0;
-  }
-  hipLaunchKernelGGL(k_pack_mlp, dim3((IMG_FLOATS + 255) / 256), dim3(256), 0, st, *p, base + L.mlp);
-  hipLaunchKernelGGL(k_pack_mlp_bf16, dim3((IMGB_ALL * 4 + 255) / 256), dim3(256), 0, st, *p,
-                     reinterpret_cast<uint32_t*>(base + L.mlpb));
-  hipLaunchKernelGGL(k_pack_mlp_w32, dim3((W32_ALL_U4 * 4 + 255) / 256), dim3(256), 0, st, *p,
-                     reinterpret_cast<uint32_t*>(base + L.mlpw));
+  static_assert(IMG_FLOATS <= 26880 && IMGB_ALL * 4 <= 26880 && W32_ALL_U4 * 4 <= 26880 && W32T_ALL_U4 * 4 <= 26880, "slice 18 of k_pack_planes covers every network image");
+  PackMlp pm;
+  pm.mlp = base + L.mlp; pm.mlpb = reinterpret_cast<uint32_t*>(base + L.mlpb); pm.mlpw = reinterpret_cast<uint32_t*>(base + L.mlpw);
+  pm.mlpwt = reinterpret_cast<uint32_t*>(base + L.mlpwt);
+  pm.mode = gen_is_default(p->fea_pe, p->view_pe, p->feature_c ? p->feature_c : LRF_FEATC) ? 0 : 1;   // the generic engine reads the parameter tensors themselves
+  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 19), dim3(128), 0, st, tab, *p, pm);
   LRF_HIP(hipGetLastError());
   return 0;
 }

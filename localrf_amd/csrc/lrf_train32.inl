@@ -13,7 +13,8 @@
 //                   position gradient of the appearance lookups, which also yields X = plane x line again -- so
 //                   dbasis = dfeat^T X is accumulated here and X is never a row (it was 320 B per shaded sample, written
 //                   by the forward and read once by a GEMM kernel).
-// The transposed network is packed per backward into the same fragment format as the forward image (k_pack_mlp_w32_t).
+// The transposed network is packed with the layout cache (slice 18 of k_pack_planes) into the same fragment format as the
+// forward image (pack_mlp_w32_t_elem).
 // Rows are written in the 16-row fragment order the weight-gradient kernel and the scatter kernels read (lrf_common.h);
 // dX goes out as three 48-byte pieces per lane (round 3: nine 8-byte stores).
 //
@@ -37,13 +38,9 @@
 //                                          row n <-> (half hr = (n >> 2) & 1, value vv = 16 mt + 4 (n >> 3) + (n & 3)):
 //                                          channel w32_chan(hr, vv), zero rows for vv >= 36
 // then an fp32 tail: mlp_view.0.weight[c][0..127] padded to 132 per colour.
-constexpr int W32T_W2 = 0, W32T_W1 = 32, W32T_BAS = 40, W32T_NFRAG = 46;
-constexpr int W32T_U4 = W32T_NFRAG * 128;                        // 5888 uint4 = 94,208 B
-constexpr int W32T_T_W3 = 0, W32T_T_W3_LD = 132, W32T_T_FLOATS = 400;
-constexpr int W32T_ALL_U4 = W32T_U4 + W32T_T_FLOATS / 4;         // 5988 uint4 = 95,808 B
+// (W32T_* constants: lrf_common.h)
 
-__global__ void k_pack_mlp_w32_t(LrfParams p, uint32_t* __restrict__ img, int basis_only /* generic engine: only k_train_app3's basis^T fragments exist in these shapes */) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void pack_mlp_w32_t_elem(const LrfParams& p, uint32_t* __restrict__ img, int idx, int basis_only /* generic engine: only k_train_app3's basis^T fragments exist in these shapes */) {
   if (idx >= W32T_ALL_U4 * 4) return;
   if (basis_only && (idx >= W32T_U4 * 4 || (idx >> 9) < W32T_BAS)) { img[idx] = 0u; return; }
   if (idx >= W32T_U4 * 4) {
