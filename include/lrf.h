@@ -141,9 +141,10 @@ int lrf_render_fwd_profile(const LrfField* f, const float* rays, const float* z,
 
 /* Bytes of scratch lrf_render_bwd needs (worst case: every sample shaded).  _cfg: for a network configuration other than
  * the default one (the generic engine keeps the weight-gradient operands as rows: ~ (4 feature_c + in1 + in_view) floats
- * per shaded sample more); lrf_workspace_bytes_bwd = _cfg(..., 0, 0, 128). */
+ * per shaded sample more -- also for the default configuration when `flags` carries LRF_FLAG_MLP_VALU: the backward then runs the
+ * generic fp32 engine too, an exact-fp32 training path); lrf_workspace_bytes_bwd = _cfg(..., 0, 0, 128, 0). */
 size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]);
-size_t lrf_workspace_bytes_bwd_cfg(int32_t R, int32_t S, const int32_t grid[3], int32_t fea_pe, int32_t view_pe, int32_t feature_c);
+size_t lrf_workspace_bytes_bwd_cfg(int32_t R, int32_t S, const int32_t grid[3], int32_t fea_pe, int32_t view_pe, int32_t feature_c, uint32_t flags);
 
 /* Training forward: same outputs as lrf_render_fwd (split-bf16 engine, floater_thresh 0), but the
  * per-sample state the backward needs (density features, shaded-sample lists, per-sample colours,

@@ -89,7 +89,7 @@ SYMBOLS = {
     "lrf_render_fwd_train": (C.c_int, [C.POINTER(LrfField), _f, _f, C.c_int32, C.c_int32, C.c_uint32, _f, _f,
                                        C.c_void_p, C.c_void_p]),
     "lrf_workspace_bytes_bwd": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
-    "lrf_workspace_bytes_bwd_cfg": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32]),
+    "lrf_workspace_bytes_bwd_cfg": (C.c_size_t, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_uint32]),
     "lrf_render_bwd": (C.c_int, [C.POINTER(LrfField), C.POINTER(LrfParams), _f, _f, C.c_int32, C.c_int32,
                                  C.c_uint32, _f, _f, C.POINTER(LrfGrads), _f, C.c_void_p, C.c_void_p]),
     "lrf_render_bwd_wait": (C.c_int, [C.c_int32, C.c_void_p]),

@@ -1195,7 +1195,7 @@ static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): 
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
                                     const BwdWorkspace& b, float* rgb, hipStream_t st) {
-  if (!gen_is_default(d.fea_pe, d.view_pe, d.fc)) {          // generic engine (lrf_generic.inl): same saved state, no mask bits
+  if (!gen_is_default(d.fea_pe, d.view_pe, d.fc) || (flags & LRF_FLAG_MLP_VALU)) {          // generic engine (lrf_generic.inl): same saved state, no mask bits
     const GenCfg gc = gen_cfg(d.fea_pe, d.view_pe, d.fc, !(flags & LRF_FLAG_PE_OFF));
     hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, R, b.toff32);
     hipLaunchKernelGGL(k_toff16, dim3((R + 256) / 256), dim3(256), 0, st, b.toff32, R, w.toff);
@@ -1213,16 +1213,18 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_dgrad_dbg = (e >> 5) & 7; }
 
 namespace lrf {
-static int field_gen_ld(int fea_pe, int view_pe, int fc) {
+// floats per row of weight-gradient operands when the backward runs the generic engine (any non-default network, or
+// LRF_FLAG_MLP_VALU on the default one: the exact-fp32 training path), else 0
+static int field_gen_ld(int fea_pe, int view_pe, int fc, uint32_t flags) {
   fc = fc ? fc : LRF_FEATC;
-  return gen_is_default(fea_pe, view_pe, fc) ? 0 : gen_row_ld(gen_cfg(fea_pe, view_pe, fc, true));
+  return (gen_is_default(fea_pe, view_pe, fc) && !(flags & LRF_FLAG_MLP_VALU)) ? 0 : gen_row_ld(gen_cfg(fea_pe, view_pe, fc, true));
 }
 }  // namespace lrf
 extern "C" size_t lrf_workspace_bytes_bwd(int32_t R, int32_t S, const int32_t grid[3]) {
   return lrf::carve_bwd(nullptr, R, S, grid).bytes;
 }
-extern "C" size_t lrf_workspace_bytes_bwd_cfg(int32_t R, int32_t S, const int32_t grid[3], int32_t fea_pe, int32_t view_pe, int32_t feature_c) {
-  return lrf::carve_bwd(nullptr, R, S, grid, lrf::field_gen_ld(fea_pe, view_pe, feature_c)).bytes;
+extern "C" size_t lrf_workspace_bytes_bwd_cfg(int32_t R, int32_t S, const int32_t grid[3], int32_t fea_pe, int32_t view_pe, int32_t feature_c, uint32_t flags) {
+  return lrf::carve_bwd(nullptr, R, S, grid, lrf::field_gen_ld(fea_pe, view_pe, feature_c, flags)).bytes;
 }
 
 // Byte offsets of the pieces of the training workspace a test may want to look at (debug / parity
@@ -1248,7 +1250,7 @@ extern "C" int lrf_render_fwd_train(const LrfField* f, const float* rays, const 
   if (const char* bad = gen_check(f)) return set_err(bad);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DField d = make_dfield(f);
-  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid, field_gen_ld(f->fea_pe, f->view_pe, f->feature_c));
+  const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid, field_gen_ld(f->fea_pe, f->view_pe, f->feature_c, flags));
   const Workspace& w = b.fw;
   rays = sort_rays_if_asked(d, rays, R, flags, w, st);
   d.rdir = w.rdir;
@@ -1271,7 +1273,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   DField d = make_dfield(f);
   const Layout L = make_layout(f->grid);
-  const int gen_ld = field_gen_ld(f->fea_pe, f->view_pe, f->feature_c);
+  const int gen_ld = field_gen_ld(f->fea_pe, f->view_pe, f->feature_c, flags);
   const bool generic = gen_ld != 0;
   const BwdWorkspace b = carve_bwd(workspace, R, S, f->grid, gen_ld);
   const Workspace& w = b.fw;

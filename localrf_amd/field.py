@@ -493,7 +493,7 @@ class TensorVMSplit(torch.nn.Module):
         if R == 0:
             return rgb, depth, None, None
         grid = (C.c_int32 * 3)(*self._grid_host)
-        ws = torch.empty(lib.lrf_workspace_bytes_bwd_cfg(R, S, grid, int(self.fea_pe), int(self.view_pe), int(self.featureC)),
+        ws = torch.empty(lib.lrf_workspace_bytes_bwd_cfg(R, S, grid, int(self.fea_pe), int(self.view_pe), int(self.featureC), flags),
                          dtype=torch.uint8, device=dev)
         f = self._c_field()
         st = torch.cuda.current_stream(dev).cuda_stream
@@ -528,7 +528,7 @@ class TensorVMSplit(torch.nn.Module):
             cg.app_plane[i] = grads[6 + i].data_ptr()
             cg.app_line[i] = grads[9 + i].data_ptr()
         (cg.basis, cg.w1, cg.b1, cg.w2, cg.b2, cg.w3, cg.b3) = [g.data_ptr() for g in grads[12:]]
-        nbytes = lib.lrf_workspace_bytes_bwd_cfg(R, S, cp.grid, int(self.fea_pe), int(self.view_pe), int(self.featureC))
+        nbytes = lib.lrf_workspace_bytes_bwd_cfg(R, S, cp.grid, int(self.fea_pe), int(self.view_pe), int(self.featureC), flags)
         if saved_ws is not None:                 # filled by lrf_render_fwd_train for exactly this call
             ws = saved_ws
             flags = flags | N.LRF_FLAG_ROWS_SAVED
