@@ -1359,7 +1359,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     if (ls == 32) hipLaunchKernelGGL(k_gen_dgrad<32>, grid, dim3(nt), lds, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
     else          hipLaunchKernelGGL(k_gen_dgrad<16>, grid, dim3(nt), lds, st, d, gc, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb, b.act, b.grd, b.rowinfo, b.gen, gen_ld);
   } else {
-    hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16, st, d,
+    hipLaunchKernelGGL((k_train_dgrad3<8>), dim3(n_dgrad_wg), dim3(512), (size_t)W32T_ALL_U4 * 16 + 4 * 64 * 16, st, d,
                        d.mlpwt, rays, S, w.toff, R, b.tileinfo, w.cidx, w.cw, b.crgb, g_rgb,
                        b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
   }

@@ -139,7 +139,27 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
   extern __shared__ uint4 s_dyn3[];
   uint4* img = s_dyn3;
   float* tail = reinterpret_cast<float*>(s_dyn3 + W32T_U4);
+  uint4* s_sel = s_dyn3 + W32T_ALL_U4;                          // the four 0 / 1 selectors, [selector][lane] (built once per workgroup)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5, s = n & 15;
+  for (int i = tid; i < 4 * 64; i += NT) {
+    // selectors (B operands of the transposing products): slot j of lane (n, h) is 1 where the K index of the slot equals the
+    // lane's column.  0, 1: K index = feature 16 ks + 8 h + j (the order the feat row is loaded in); 2, 3: K index = unit
+    // 16 q + 8 (j >> 2) + 4 h + (j & 3) of a 32-unit M-tile (dz1's D-register order)
+    const int id = i >> 6, ln = i & 63, nn = ln & 31, hh = ln >> 5;
+    uint32_t wds[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      uint32_t wd = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * q2 + e;
+        const int key = id < 2 ? 16 * id + 8 * hh + j : 16 * (id - 2) + 8 * (j >> 2) + 4 * hh + (j & 3);
+        if (key == nn) wd |= e ? 0x3f800000u : 0x3f80u;
+      }
+      wds[q2] = wd;
+    }
+    s_sel[i] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  }
   {
     const int rot = (int)((blockIdx.x * 37u) % 93u) * 64;     // every workgroup starts its copy somewhere else (finding 18)
     for (int i = tid; i < W32T_ALL_U4; i += NT) { int j = i + rot; if (j >= W32T_ALL_U4) j -= W32T_ALL_U4; img[j] = imt[j]; }
@@ -156,16 +176,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) w1acc[m][r] = 0.0f;
-  // 0 / 1 selectors (B operands of the transposing products): slot j of lane (n, h) is 1 where the K index of the slot
-  // equals the lane's column.  sel_u[q]: K index = unit 16 q + 8 (j >> 2) + 4 h + (j & 3) of a 32-unit M-tile (dz1's
-  // D-register order); sel_f[ks]: K index = feature 16 ks + 8 h + j (the order the feat row is loaded in).
-  auto selector = [&](auto key) {
-    uint32_t wds[4];
-#pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2)
-      wds[q2] = (key(2 * q2) == n ? 0x3f80u : 0u) | (key(2 * q2 + 1) == n ? 0x3f800000u : 0u);
-    return __builtin_bit_cast(bf16x8, make_uint4(wds[0], wds[1], wds[2], wds[3]));
-  };
+  auto selector = [&](int id) { return __builtin_bit_cast(bf16x8, s_sel[id * 64 + lane]); };
   int4 ti_c = make_int4(0, 0, 0, 0);
   if (p_beg < p_end) { const int t0 = 2 * p_beg + (n >> 4); ti_c = tileinfo[t0 < T ? t0 : 2 * p_beg]; }
   for (int pr = p_beg; pr < p_end; ++pr) {
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         bf16x8 fh, fl;
         split8c(v, fh, fl);
-        const bf16x8 sel = selector([&](int j) { return 16 * ks + 8 * h + j; });
+        const bf16x8 sel = selector(ks);
         ft = mfma32(fh, sel, ft);
         ft = mfma32(fl, sel, ft);
       }
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
           bf16x8 bh, bl;
           split8c(v, bh, bl);
           const bf16x8 ah = w32_frag(img, W32T_W1 + 2 * m + q, 0, lane), al = w32_frag(img, W32T_W1 + 2 * m + q, 1, lane);
-          const bf16x8 sel = selector([&](int j) { return 16 * q + 8 * (j >> 2) + 4 * h + (j & 3); });
+          const bf16x8 sel = selector(2 + q);
           df = mfma32(al, bh, df);
           dzt = mfma32(bh, sel, dzt);                          // the same split halves as A: transposed by the selector
           df = mfma32(ah, bl, df);
