@@ -63,6 +63,9 @@ constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
 #ifndef LRF_SCATTER_CAS64
 #define LRF_SCATTER_CAS64 1
 #endif
+#ifndef LRF_APP_NT
+#define LRF_APP_NT 1024                  // threads of the appearance scatter's workgroup (one per CU: its tile + line accumulators fill the LDS)
+#endif
 #ifndef LRF_DENS_LPE
 #define LRF_DENS_LPE 4                   // lanes per entry of the density scatter (8 channels): 4 lanes x one pair each (64-bit CAS), 259 -> 224 us against 8 lanes x one channel
 #endif
@@ -1289,9 +1292,9 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     int dev_id = 0;
     LRF_HIP(hipGetDevice(&dev_id));
     std::call_once(lds_attr_once[dev_id & 63], [dev_id] {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024, false>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, LRF_APP_NT, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, 1024, true>),
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_plane<LRF_CD, false, 512, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1442,10 +1445,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist2, bg.total, b.offs2, b.cursor2);
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.cursor2, b.list2);
   if (fuse_a) {
-    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024, true>), dim3(cus), dim3(1024), lds_ap + lds_al, st,
+    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,
                        d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
   } else {
-    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, 1024, false>), dim3(cus), dim3(1024), lds_ap, st,
+    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, false>), dim3(cus), dim3(LRF_APP_NT), lds_ap, st,
                        d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
     hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_al, st,
                        d, dst_a, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd);
