@@ -25,7 +25,7 @@
 //                        d/d(alpha) -> d/d(density feature); position gradients through
 //                        normalise / contraction to d(loss)/d(rays); tile ids + histogram of the density scatter's
 //                        counting sort
-//   k_bin_scan/fill      the rest of the counting sort of the (sample, plane) entries by 32x32-texel tile
+//   k_bin_fill           the rest of the counting sort of the (sample, plane) entries by 32x32-texel tile (scans the histogram itself)
 //   k_scatter_plane      plane AND line gradients of one pass over the binned entries, accumulated per workgroup in
 //                        LDS (CAS-loop fp32 adds, two channels per 64-bit CAS; ds_add_f32 is 30x slower on this chip),
 //                        runs of consecutive same-cell entries merged in registers first, tiles added straight into the
@@ -752,42 +752,39 @@ __device__ __forceinline__ void cid_point(const DField& f, const float* __restri
 // pass 1: tile id of every entry in every plane + global histogram
 // (The histogram pass of the counting sort is not a kernel: k_bwd_ray (density) and k_train_app3 (appearance) hold every
 // entry's taps anyway, write its three tile ids and count them in LDS histograms.)
-// exclusive scan of the histogram -> list offsets; cursors start at the offsets
-__global__ __launch_bounds__(1024) void k_bin_scan(const int* __restrict__ hist, int nb, int* __restrict__ offs, int* __restrict__ cursor) {
-  __shared__ int s_wave[16];
-  __shared__ int s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    const int r = base + tid;
-    const int v = r < nb ? hist[r] : 0;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < wave; ++q) woff += s_wave[q];
-    const int carry = s_carry;
-    if (r < nb) { offs[r] = carry + woff + incl - v; cursor[r] = carry + woff + incl - v; }
-    __syncthreads();
-    if (tid == 1023) s_carry = carry + woff + incl;
-    __syncthreads();
-  }
-  if (tid == 0) offs[nb] = s_carry;
-}
-
-// pass 2: entry ids into per-tile lists (block-level reservation, LDS ranks)
+// Second pass of the counting sort.  Every block scans the (<= 2048-entry) histogram itself -- there is no scan kernel --
+// and reserves its entries' places with one atomic per tile on `cursor` (zero when the pass starts: cleared with the
+// histogram); block 0 leaves the tile offsets in `offs` for the scatter kernel.
 __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int R, int S, const int* __restrict__ toff, int app,
-                                                  const uint16_t* __restrict__ tid, int* __restrict__ cursor,
-                                                  uint32_t* __restrict__ list) {
+                                                  const uint16_t* __restrict__ tid, const int* __restrict__ hist, int* __restrict__ cursor,
+                                                  int* __restrict__ offs, uint32_t* __restrict__ list) {
   __shared__ int s_h[BIN_MAX];
+  __shared__ int s_off[BIN_MAX];
+  __shared__ int s_wsum[4];
   const uint32_t n = app ? (uint32_t)toff[R] * 16u : (uint32_t)R * (uint32_t)S;
   const uint32_t b0 = blockIdx.x * (uint32_t)BIN_CHUNK;
+  if (b0 >= n && blockIdx.x != 0) return;                      // (block 0 always writes the offsets)
+  {                                                            // exclusive scan of hist[0 .. total): 8 consecutive tiles per thread
+    constexpr int PT = BIN_MAX / 256;
+    const int t0 = threadIdx.x * PT, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int v[PT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { v[i] = t0 + i < bg.total ? hist[t0 + i] : 0; sum += v[i]; }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int q = 0; q < wave; ++q) base += s_wsum[q];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { if (t0 + i < BIN_MAX) s_off[t0 + i] = base; base += v[i]; }
+    if (blockIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < PT; ++i) if (t0 + i < bg.total) offs[t0 + i] = s_off[t0 + i];
+      if (threadIdx.x == 255) offs[bg.total] = base;           // = the number of entries
+    }
+  }
   if (b0 >= n) return;
   for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
   __syncthreads();
@@ -807,7 +804,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
   }
   __syncthreads();
   for (int i = threadIdx.x; i < bg.total; i += 256)
-    if (s_h[i]) s_h[i] = atomicAdd(&cursor[i], s_h[i]);
+    if (s_h[i]) s_h[i] = s_off[i] + atomicAdd(&cursor[i], s_h[i]);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
@@ -1172,17 +1169,17 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.nmax = (uint32_t)rows;                                     // rows >= R*S
   b.rowinfo = reinterpret_cast<uint32_t*>(take(rows));
   b.tid = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
-  b.hist = reinterpret_cast<int*>(take(BIN_MAX));
+  b.hist = reinterpret_cast<int*>(take(2 * BIN_MAX));           // histogram, then the fill pass's cursors: cleared by one memset
+  b.cursor = b.hist + BIN_MAX;
   b.offs = reinterpret_cast<int*>(take(BIN_MAX + 1));
-  b.cursor = reinterpret_cast<int*>(take(BIN_MAX));
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.relu_bits = reinterpret_cast<uint32_t*>(take(rows / 16 * 128));
   b.tileinfo = reinterpret_cast<int4*>(take(rows / 16 * 4));
   b.toff32 = reinterpret_cast<int*>(take((size_t)R + 1));
   b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
-  b.hist2 = reinterpret_cast<int*>(take(BIN_MAX));
+  b.hist2 = reinterpret_cast<int*>(take(2 * BIN_MAX));
+  b.cursor2 = b.hist2 + BIN_MAX;
   b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
-  b.cursor2 = reinterpret_cast<int*>(take(BIN_MAX));
   b.list2 = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.gen = gen_ld ? take(rows * (size_t)gen_ld) : nullptr;
   b.bytes = off;
@@ -1367,18 +1364,17 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                        b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
   }
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));         // go / dfeat rows: the weight-gradient kernel may start
-  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * bg.total, st));
+  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * 2 * BIN_MAX, st));
   hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
                      d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
                      b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3);
 
   // ---- side stream: per-ray backward, density scatter
-  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * bg.total, sb));
+  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * 2 * BIN_MAX, sb));
   hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
                      d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
                      (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, sb, b.hist, bg.total, b.offs, b.cursor);
-  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.cursor, b.list);
+  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
   const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
   // line gradients ride on the plane pass when tile + line accumulators fit in LDS (g_scatter_fused; appearance at 640^3 does not)
   const size_t lds_dp = sizeof(float) * BCELL * BCELL * LRF_CD, lds_dl = sizeof(float) * LRF_CD * ll_max;
@@ -1442,8 +1438,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   if (ss) LRF_HIP(hipEventRecord(ss->join, sb));
 
   // ---- caller's stream: appearance scatter (its own bin buffers: the density scatter may still be running)
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b.hist2, bg.total, b.offs2, b.cursor2);
-  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.cursor2, b.list2);
+  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.hist2, b.cursor2, b.offs2, b.list2);
   if (fuse_a) {
     hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,
                        d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
