@@ -1004,6 +1004,60 @@ def test_scene_with_a_nondefault_colour_network_trains_and_renders():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
+def test_render_calls_can_be_captured_in_a_hip_graph():
+    """The C calls enqueue kernels, memsets and event waits only (no allocation, no synchronisation, no host read-back after
+    their first use on a device), so a caller can capture them in a HIP graph (torch.cuda.CUDAGraph) and replay it: the eval
+    forward bit-identically, forward + backward of a training step -- with the library's side stream and events forked
+    from and joined back into the capturing stream -- with the eager gradients up to the order of the scatter adds."""
+    from util import make_field, make_rays
+    f = quiet(make_field, [48, 40, 44], "cpu", seed=5).to(DEV)
+    with torch.no_grad():
+        for p in f.density_plane:
+            p.mul_(3.0)
+    R = 600
+    rays = make_rays(R, 3, pinhole=True).to(DEV)
+    f.z_override = f.z_schedule(False, 96, torch.device(DEV)).clone()
+    with torch.no_grad():
+        rgb0, d0 = f(rays, white_bg=True, is_train=False, N_samples=96)
+        out = (torch.empty_like(rgb0), torch.empty_like(d0))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            f(rays, white_bg=True, is_train=False, N_samples=96, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            f(rays, white_bg=True, is_train=False, N_samples=96, out=out)
+        out[0].zero_(); out[1].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], rgb0) and torch.equal(out[1], d0)
+    gen = torch.Generator().manual_seed(3)
+    gr, gd = torch.randn(R, 3, generator=gen).to(DEV), torch.randn(R, generator=gen).to(DEV)
+    r = rays.clone().requires_grad_(True)
+
+    def fb():
+        for p in f.parameters():
+            p.grad = None
+        r.grad = None
+        rgb, depth = f(r, white_bg=True, is_train=False, N_samples=96)
+        ((rgb * gr).sum() + (depth * gd).sum()).backward()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fb()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref = [p.grad.clone() for p in f.parameters() if p.grad is not None] + [r.grad.clone()]
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        fb()
+    for _ in range(2):
+        g2.replay()
+    torch.cuda.synchronize()
+    got = [p.grad for p in f.parameters() if p.grad is not None] + [r.grad]
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-12)
+
+
 def test_gradient_buckets_become_final_in_order_and_can_be_awaited_separately(built_lib):
     """lrf_render_bwd_wait (the hand-off localrf_amd.dist uses to start the density all-reduce while the rest of the
     backward runs): after a backward, a side stream that waits for bucket k only must see that bucket's gradients final --
