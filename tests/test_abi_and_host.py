@@ -209,6 +209,14 @@ def test_c_abi_argument_validation_without_a_gpu():
     grid = (C.c_int32 * 3)(300, 300, 300)
     assert lib.lrf_workspace_bytes_bwd(4096, 512, grid) > lib.lrf_workspace_bytes(4096, 512) > 0
     assert lib.lrf_cache_bytes(grid) >= 34_800_000
+    # the generic engine's operand rows: only for a non-default colour network, or the exact-fp32 training path (LRF_FLAG_MLP_VALU = 4)
+    base = lib.lrf_workspace_bytes_bwd(4096, 512, grid)
+    assert lib.lrf_workspace_bytes_bwd_cfg(4096, 512, grid, 0, 0, 128, 0) == base == lib.lrf_workspace_bytes_bwd_cfg(4096, 512, grid, 0, 0, 0, 1)
+    pe = lib.lrf_workspace_bytes_bwd_cfg(4096, 512, grid, 2, 2, 128, 0)
+    assert pe > base and lib.lrf_workspace_bytes_bwd_cfg(4096, 512, grid, 0, 0, 128, 4) > base
+    rows = 4096 * 512
+    ld = 2 * 128 + (27 * 5 + 1) + 129 + (128 + 15 + 1) + 4
+    assert 0 <= pe - base - rows * ld * 4 < 4096
 
 
 def test_saved_row_layout_is_a_bijection_and_matches_the_test_reader(built_lib):
