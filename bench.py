@@ -501,6 +501,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)        # what the driver runs
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-baselines", action="store_true", help="skip the CPU / torch-ROCm baselines and extra workloads")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged, ranks may share a GPU (launch test)")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
     ap.add_argument("--child", nargs="?", const="fwd", default=None, choices=("fwd", "train"),
                     help="(internal) the timed loop only: what the PMC passes profile (fwd: eval forward; train: training step)")
@@ -512,31 +514,58 @@ def main():
         raise SystemExit("--grid / --n-samples are for the PMC child runs; the headline workload is BASELINE configs[1]")
     grid, ns_arg = args.grid, args.n_samples
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher the driver would have used -- one rank per GPU under
+        # torch.distributed.run, same arguments (rank 0 prints the JSON line)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     import torch.distributed as dist
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.device_count() == 0)")
+    if local >= n_dev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but {n_dev} GPU(s) visible -- RCCL needs one GPU per rank "
+                         "(--backend gloo shares GPUs between ranks: a launch test, not a measurement)")
+    dev_index = local % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so the
     # RCCL code path below is the same for every N
     ddp = (world > 1 or "RANK" in os.environ) and not args.child
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")                  # host-staged: several ranks may share a GPU
+        if world == 1:
+            os.environ.setdefault("LRF_DIST_FORCE", "1")     # one rank: still issue every collective of the N-rank step
+
+    def barrier():
+        if args.backend == "nccl":
+            dist.barrier(device_ids=[dev_index])
+        else:
+            dist.barrier()
 
     import __graft_entry__ as ge
     if ddp and local != 0:                                    # one rank compiles, the rest wait for it
-        dist.barrier(device_ids=[local])
+        barrier()
     ge.build()
     if ddp and local == 0:
-        dist.barrier(device_ids=[local])
+        barrier()
     from localrf_amd import FusedAdam, TensorVMSplit
     from localrf_amd.dist import allreduce_grads
 
@@ -549,7 +578,7 @@ def main():
     def sync():
         torch.cuda.synchronize(dev)
         if ddp:
-            dist.barrier(device_ids=[local])
+            barrier()
             torch.cuda.synchronize(dev)
 
     def fwd():
@@ -566,10 +595,13 @@ def main():
         dt = timed(fwd, args.steps, args.warmup, sync) if args.child != "train" else 1.0
     if args.child == "fwd":
         return
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if ddp:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def max_over_ranks(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        if ddp:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    dt = max_over_ranks([dt])[0]
     ms_per_step = dt / args.steps * 1e3
     value = world * R_PER_GPU * args.steps / dt
 
@@ -581,17 +613,18 @@ def main():
     reduced = [0]
 
     comm = [True]
+    comm_stats = {}
 
     def train_step():
         opt.zero_grad()
         rgb, depth = field(rays, white_bg=True, is_train=True, N_samples=ns_arg)
         ((rgb * gr).sum() + (depth * gd).sum()).backward()
         if ddp and comm[0]:
-            reduced[0] = allreduce_grads(field)
+            reduced[0] = allreduce_grads(field, stats=comm_stats)
         opt.step()
     t_steps = max(5, min(args.steps, 20))
     dtt_nocomm = None
-    if ddp and world > 1:                                    # the same step without the collective: what the all-reduce costs on this N
+    if ddp:                                                  # the same step without the collectives: what the exchange costs on this N
         comm[0] = False
         dtt_nocomm = timed(train_step, t_steps, 3, sync)
         comm[0] = True
@@ -600,12 +633,10 @@ def main():
         return
     field.load_state_dict(sd_init)
     del sd_init
-    tmax = torch.tensor([dtt, dtt_nocomm if dtt_nocomm is not None else 0.0], device=dev, dtype=torch.float64)
-    if ddp:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dtt = float(tmax[0].item())
+    tm = max_over_ranks([dtt, dtt_nocomm if dtt_nocomm is not None else 0.0])
+    dtt = tm[0]
     if dtt_nocomm is not None:
-        dtt_nocomm = float(tmax[1].item())
+        dtt_nocomm = tm[1]
 
     if rank == 0:
         z = field.z_schedule(False, N_SAMPLES_ARG, dev).contiguous()
@@ -633,6 +664,11 @@ def main():
         train_bytes = rows * ((128 + 512 + 32 + 16) + (224 + 172 + 128 + 304)) + R_PER_GPU * S * 4 * 3 + n_par * 4 * (3 + 7)
         train = {"ms_per_step": dtt / t_steps * 1e3, "rays_per_s": world * R_PER_GPU * t_steps / dtt, "steps": t_steps,
                  "ms_per_step_without_allreduce": (dtt_nocomm / t_steps * 1e3 if dtt_nocomm is not None else None),
+                 "allreduce": ({"backend": args.backend, "n_ranks_seen": dist.get_world_size(), "collectives_per_step": comm_stats.get("collectives"),
+                                "bytes_per_piece": comm_stats.get("chunks"), "field_bytes": comm_stats.get("field_bytes"),
+                                "order": "density planes+lines | colour network | appearance plane 0 | plane 1 | plane 2 + lines: each handed to the "
+                                         "collective behind the event lrf_render_bwd records when that piece is final (side stream), in place in the flat gradient buffer",
+                                "forced_at_one_rank": world == 1} if ddp else None),
                  "what": "lrf_render_fwd_train + lrf_render_bwd + "
                          + (f"allreduce_grads over RCCL ({reduced[0] / 1e6:.1f} MB in place) + " if ddp else "")
                          + "FusedAdam, 4096 rays x 512 samples per GPU, jittered samples",
@@ -657,7 +693,7 @@ def main():
                 train["roofline"]["traffic"] = None
                 train["roofline"]["traffic_source"] = tr_src
         out = {"metric": "rays/sec (4096-ray batch, 512 samples, 300^3 grid)", "value": value,
-               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "rays/s", "n_gpus": world, "n_ranks_seen": (dist.get_world_size() if ddp else 1), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32 (colour network: split-bf16 3-term products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, <= 3e-5 vs the exact-fp32 engine; gathers and compositing fp32)",
                "data": "synthetic",
@@ -775,7 +811,7 @@ def main():
             out["speedup_vs_torch_rocm"] = value / world / out["torch_rocm_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if ddp:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

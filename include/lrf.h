@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 4      /* 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 5      /* 5: LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -46,7 +46,10 @@ extern "C" {
                                     must be passed to lrf_render_fwd_train and the lrf_render_bwd that follows it. */
 #define LRF_FLAG_PE_OFF     64u  /* fea_pe > 0 only: zeros in place of the feature encodings (MLPRender_Fea_late_view.forward with
                                   * refine == False, tensorBase.py:118-126) */
-#define LRF_FLAG_ALL        127u /* any other bit is an error (a caller built against another ABI version) */
+#define LRF_FLAG_PLANE_EVENTS 128u /* lrf_render_bwd only (data parallel): the appearance scatter runs as one pass per plane and records an
+                                  * event behind planes 0 and 1 (lrf_render_bwd_wait buckets 3 / 4), so that the all-reduce of a plane's
+                                  * gradient overlaps the scatter of the next one.  Same gradients. */
+#define LRF_FLAG_ALL        255u /* any other bit is an error (a caller built against another ABI version) */
 
 /* Parameters of one TensorVMSplit field as the reference stores them (state-dict layout,
  * models/tensoRF.py:18-50, models/tensorBase.py:97-113).  Plane p is [1,C,H_p,W_p] with
@@ -167,8 +170,9 @@ int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float* rays, con
 /* Data-parallel hand-off (no reference counterpart): makes `stream` wait until one bucket of the gradients
  * of the most recent lrf_render_bwd enqueued on the current device is final, so that a collective over that bucket can
  * start while the rest of the backward still runs.  bucket 0: density planes + lines (the per-ray branch finishes
- * early), 1: colour network (basis, mlp, mlp_view), 2: appearance planes + lines (= everything).  Error if no
- * lrf_render_bwd ran on this device. */
+ * early), 1: colour network (basis, mlp, mlp_view), 2: appearance planes + lines (= everything), 3 / 4: appearance plane 0 / 1
+ * alone (behind their own scatter pass when the backward ran with LRF_FLAG_PLANE_EVENTS; otherwise the same point as 2).
+ * Error if no lrf_render_bwd ran on this device. */
 int lrf_render_bwd_wait(int32_t bucket, void* stream);
 
 /* Debug / parity diagnostics: byte offsets inside the training workspace of {activation rows, gradient rows,

@@ -15,6 +15,7 @@ LRF_FLAG_MLP_F32 = 8
 LRF_FLAG_ROWS_SAVED = 16
 LRF_FLAG_SORT_RAYS = 32
 LRF_FLAG_PE_OFF = 64
+LRF_FLAG_PLANE_EVENTS = 128
 
 _f = C.c_void_p  # device float*
 
@@ -150,7 +151,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if h.lrf_abi_version() != 4:
+        if h.lrf_abi_version() != 5:
             raise NativeError("localrf_amd: ABI version mismatch")
         _lib = h
     return _lib

@@ -832,14 +832,17 @@ template <int C, bool APP, int NT, bool LINES>
 __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, ScatterDst dst, const float* __restrict__ rays,
                                                        const float* __restrict__ z, int S, const int* __restrict__ offs,
                                                        const uint32_t* __restrict__ list, const float* __restrict__ gf,
-                                                       const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd) {
+                                                       const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
+                                                       int bin_lo, int bin_hi) {
   extern __shared__ float s_acc[];                     // [BCELL*BCELL][C], then (LINES) [L_p][C]
   float* s_lacc = s_acc + BCELL * BCELL * C;
-  const long long E = offs[bg.total];
-  int a = (int)(E * blockIdx.x / gridDim.x);
-  const int b = (int)(E * (blockIdx.x + 1) / gridDim.x);
+  // this launch's share of the list: the entries of bins [bin_lo, bin_hi) -- all of them (0, bg.total), or one plane's
+  // when lrf_render_bwd runs the pass per plane (LRF_FLAG_PLANE_EVENTS: plane p's gradient is final behind its launch)
+  const long long E0 = offs[bin_lo], E = (long long)offs[bin_hi] - E0;
+  int a = (int)(E0 + E * blockIdx.x / gridDim.x);
+  const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
   if (a >= b) return;
-  int lo = 0, hi = bg.total;                           // largest bin with offs[bin] <= a
+  int lo = bin_lo, hi = bin_hi;                        // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
   int bin = lo;
   int lplane = -1;                                     // plane whose line gradient s_lacc currently holds (LINES)
@@ -1382,10 +1385,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024, fuse_a = g_scatter_fused && lds_ap + lds_al <= 158 * 1024;
   if (fuse_d) {
     hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512, true>), dim3(cus * LRF_DPLANE_MULT), dim3(512), lds_dp + lds_dl, sb,
-                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd);
+                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, 0, bg.total);
   } else {
     hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512, false>), dim3(cus * LRF_DPLANE_MULT), dim3(512), lds_dp, sb,
-                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd);
+                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, 0, bg.total);
     hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_dl, sb,
                        d, dst_d, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd);
   }
@@ -1439,27 +1442,39 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
 
   // ---- caller's stream: appearance scatter (its own bin buffers: the density scatter may still be running)
   hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, st, bg, b.nmax, R, S, w.toff, 1, b.tid2, b.hist2, b.cursor2, b.offs2, b.list2);
-  if (fuse_a) {
-    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,
-                       d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
-  } else {
-    hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, false>), dim3(cus), dim3(LRF_APP_NT), lds_ap, st,
-                       d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd);
+  // LRF_FLAG_PLANE_EVENTS (data parallel): one pass per plane, an event behind planes 0 and 1 -- a collective over plane p's
+  // gradient (8.6 MB each at 300^3) starts while the later planes are still being scattered; otherwise one pass over all bins
+  const int npass = (flags & LRF_FLAG_PLANE_EVENTS) ? 3 : 1;
+  for (int q = 0; q < npass; ++q) {
+    const int blo = npass == 1 ? 0 : bg.base[q], bhi = (npass == 1 || q == 2) ? bg.total : bg.base[q + 1];
+    if (fuse_a) {
+      hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,
+                         d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, blo, bhi);
+    } else {
+      hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, false>), dim3(cus), dim3(LRF_APP_NT), lds_ap, st,
+                         d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, blo, bhi);
+    }
+    if (npass == 3 && q < 2 && sx) LRF_HIP(hipEventRecord(sx->bucket[3 + q], st));    // app_plane[q] is final (its line only if fused: bucket 2)
+  }
+  if (!fuse_a)
     hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_al, st,
                        d, dst_a, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd);
-  }
 
   // ---- join: both branches done
   if (ss) LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   hipLaunchKernelGGL(k_rays_add_rpart, dim3((R + 255) / 256), dim3(256), 0, st, rays, R, w.ncomp, b.rpart, w.pmax, g_rays, d.perm);
-  if (sx) { LRF_HIP(hipEventRecord(sx->bucket[2], st)); sx->bucket_set = true; }
+  if (sx) {
+    LRF_HIP(hipEventRecord(sx->bucket[2], st));
+    if (npass == 1) { LRF_HIP(hipEventRecord(sx->bucket[3], st)); LRF_HIP(hipEventRecord(sx->bucket[4], st)); }   // no per-plane passes: the planes are final with everything else
+    sx->bucket_set = true;
+  }
   LRF_HIP(hipGetLastError());
   return 0;
 }
 
 extern "C" int lrf_render_bwd_wait(int32_t bucket, void* stream) {
   using namespace lrf;
-  if (bucket < 0 || bucket > 2) return set_err("lrf_render_bwd_wait: bucket must be 0 (density), 1 (colour network) or 2 (appearance = all)");
+  if (bucket < 0 || bucket > 4) return set_err("lrf_render_bwd_wait: bucket must be 0 (density), 1 (colour network), 2 (appearance = all), 3 or 4 (appearance plane 0 / 1)");
   SideStream* sx = side_stream();
   if (!sx) return set_err("lrf_render_bwd_wait: no event resources on this device");
   std::lock_guard<std::mutex> lk(sx->mu);

@@ -781,7 +781,10 @@ __global__ __launch_bounds__(256) void k_sample_contracted(const float* __restri
 
 // The ray-independent sample distances of sample_ray_contracted (tensorBase.py:419-437): z[i] = t_i (+ u1_i / h) + 0.1 and
 // z[h + i] = 1 / ((1 - s_i) + s_i / 1000) + 0.1 with s_i = t_i (+ u2_i / h), t_i = i / h -- the reference's sixteen
-// elementwise launches per training iteration as one; every operation rounded separately, in the reference's order.
+// elementwise launches per training iteration as one; every operation rounded separately, in the reference's order, with
+// IEEE divisions: bit-identical to the reference evaluated on the CPU (what the goldens record).  A reference run on a GPU
+// evaluates tensor / python_scalar as tensor * (1 / scalar) (ATen's scalar fast path): z then differs by <= 1 ulp for h
+// that is not a power of two -- below every tolerance of the path, but not bit-identical.
 __global__ __launch_bounds__(256) void k_z_schedule(int h, const float* __restrict__ u1, const float* __restrict__ u2, float* __restrict__ z) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= h) return;
@@ -902,7 +905,7 @@ static int device_cus() {                 // of the current device (one process 
 }
 
 static int g_bwd_overlap = 1;      // lrf_debug_set_bwd_overlap: weight-gradient GEMMs on a side stream, beside the scatter kernels
-struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2], bucket[3]; bool ok, bucket_set; std::mutex mu; };   // bucket[]: lrf_render_bwd_wait
+struct SideStream { hipStream_t s; hipEvent_t fork, join, app[2], bucket[5]; bool ok, bucket_set; std::mutex mu; };   // bucket[]: lrf_render_bwd_wait
 static SideStream* side_stream() {
   static SideStream tab[64];
   static std::mutex init_mu;
@@ -916,7 +919,7 @@ static SideStream* side_stream() {
         hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x.app[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&x.app[1], hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < 5; ++q)
       if (hipEventCreateWithFlags(&x.bucket[q], hipEventDisableTiming) != hipSuccess) return nullptr;
     x.bucket_set = false;
     x.ok = true;
@@ -1056,7 +1059,7 @@ static hipError_t launch_shade_gen(const DField& d, const GenCfg& gc, const floa
                                    const int* toff32, float* crgb, float* act, int4* tileinfo, hipStream_t st) {
   hipError_t e = gen_opt_in();
   if (e != hipSuccess) return e;
-  constexpr int ls = 32;                                      // (the forward's LDS image stays below 102 KB for every allowed configuration)
+  constexpr int ls = 32;                                      // (the forward's LDS image is at most ~116 KB (fea_pe = view_pe = 6, feature_c = 256), under the 159 KB opt-in)
   const int nt = gen_block_threads(gc);
   const size_t lds = (size_t)gen_lds(gc, ls, false).total * 4;
   const dim3 grid(R * ((w.pmax * 16 + ls - 1) / ls));
@@ -1134,7 +1137,7 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
                            float* weight_out, float* acc_out, void* workspace, hipStream_t st, hipEvent_t* ev) {
   if (!f || !f->cache || !rays || !z || !rgb || !depth || !workspace) return set_err("lrf_render_fwd: null argument");
   if (R <= 0 || S < 2 || S > 4096) return set_err("lrf_render_fwd: need R > 0 and 2 <= S <= 4096");
-  if (flags & ~(LRF_FLAG_ALL & ~LRF_FLAG_ROWS_SAVED)) return set_err("lrf_render_fwd: unknown flag bits (caller built against another ABI version?)");
+  if (flags & ~(LRF_FLAG_ALL & ~(LRF_FLAG_ROWS_SAVED | LRF_FLAG_PLANE_EVENTS))) return set_err("lrf_render_fwd: unknown flag bits (caller built against another ABI version?)");
   DField d = make_dfield(f);
   const Workspace w = carve(workspace, R, S);
   if (ev) LRF_HIP(hipEventRecord(ev[0], st));

@@ -441,7 +441,8 @@ class TensorVMSplit(torch.nn.Module):
         if self.mlp_engine == "valu":
             fl |= N.LRF_FLAG_MLP_VALU
         elif self.mlp_engine == "f32":
-            fl |= N.LRF_FLAG_MLP_F32
+            if self.fea_pe == 0 and self.view_pe == 0 and self.featureC == 128:    # a non-default network has one engine (generic fp32): the flag would be rejected
+                fl |= N.LRF_FLAG_MLP_F32
         elif self.mlp_engine != "bf16x3":
             raise ValueError(f"unknown mlp_engine {self.mlp_engine!r}")
         if self.sort_rays:
@@ -501,6 +502,25 @@ class TensorVMSplit(torch.nn.Module):
                                          ws.data_ptr(), st), "lrf_render_fwd_train")
         return rgb, depth, ws, self._param_versions()
 
+    def _new_grad_bucket(self, keep, R, dev, plane_events=False, events=False):
+        """One zero-filled buffer, one launch: the 19 gradients (and d/d rays [R,6] behind them) are views into it, 256-byte
+        aligned.  grad_bucket() / grad_chunks(): the data-parallel all-reduce runs in place on it, without copies.
+        `events`: the bucket events of lrf_render_bwd_wait belong to the backward that fills this buffer -- not for an empty
+        batch, and not inside a stream capture (a captured event cannot be waited for from outside the graph)."""
+        sizes = [p.numel() for p in keep] + [R * 6]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 63) // 64 * 64)
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
+        g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
+        self._grad_flat = {"flat": flat, "params": keep, "views": grads, "n_param": offs[-2],
+                           "dens": (offs[0], offs[6]), "app": (offs[6], offs[12]), "net": (offs[12], offs[-2]),
+                           "app_planes": (offs[6], offs[7], offs[8]),
+                           "events": bool(events), "plane_events": bool(plane_events)}
+        self._grad_fresh = True                    # written by THIS backward (localrf_amd.dist reduces fresh buckets only)
+        return grads, g_rays
+
     def _native_backward(self, rays, z, flags, g_rgb, g_depth, saved_ws=None):
         lib = N.lib()
         self._ensure_cache()
@@ -509,16 +529,10 @@ class TensorVMSplit(torch.nn.Module):
         R, S = rays.shape[0], z.shape[0]
         dev = rays.device
         cp, keep = self._c_params()
-        # one zero-filled buffer, one launch: the 19 gradients (and d/d rays) are views into it
-        sizes = [p.numel() for p in keep] + [R * 6]
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + (n + 63) // 64 * 64)         # 256-byte aligned views
-        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
-        grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
-        g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
-        self._grad_flat = (flat, keep, offs[-2], (offs[0], offs[6], offs[12], offs[-2]))   # see grad_bucket(): data-parallel all-reduce without copies
-        self._grad_fresh = True                    # written by THIS backward (localrf_amd.dist reduces fresh buckets only)
+        from . import dist as _dist
+        plane_events = _dist.active()              # ranks exchange gradients: per-plane passes + events in the appearance scatter
+        grads, g_rays = self._new_grad_bucket(keep, R, dev, plane_events,
+                                              events=R > 0 and not torch.cuda.is_current_stream_capturing())
         if R == 0:
             return g_rays, grads
         cg = N.LrfGrads()
@@ -532,6 +546,8 @@ class TensorVMSplit(torch.nn.Module):
         if saved_ws is not None:                 # filled by lrf_render_fwd_train for exactly this call
             ws = saved_ws
             flags = flags | N.LRF_FLAG_ROWS_SAVED
+        if plane_events:
+            flags = flags | N.LRF_FLAG_PLANE_EVENTS
         else:
             if getattr(self, "_ws_bwd", None) is None or self._ws_bwd.numel() < nbytes or self._ws_bwd.device != dev:
                 self._ws_bwd = None
@@ -551,30 +567,81 @@ class TensorVMSplit(torch.nn.Module):
         after a backward, if .grad of every parameter is still a view of it (autograd adopts the views
         when .grad was None, i.e. after zero_grad(set_to_none=True) -- what the optimisers here do).
         localrf_amd.dist.allreduce_grads reduces it in place: one collective, no copies.  None when the
-        gradients were accumulated elsewhere."""
+        gradients were accumulated elsewhere (rebucket_grads() brings them back)."""
         gf = getattr(self, "_grad_flat", None)
         if gf is None:
             return None
-        flat, _, n_param = gf[:3]
+        flat = gf["flat"]
         base = flat.untyped_storage().data_ptr()
         ps = [p for p in self._param_list() if p.requires_grad]
         for p in ps:
             if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
                 return None
-        return flat[:n_param], ps                    # the parameter part: the d/d rays tail behind it is rank-local
+        return flat[:gf["n_param"]], ps              # the parameter part: the d/d rays tail behind it is rank-local
+
+    def rebucket_grads(self):
+        """Bring the gradients back into the flat buffer of the last backward when autograd put (some of) them elsewhere: it
+        sums the contributions to a parameter BEFORE it writes .grad, so with a regulariser in the loss (density_L1 / TV,
+        local_tensorfs.py:316-330: their node runs first) .grad of the density tensors is the regulariser's tensor with the
+        render gradient added to it, not the view lrf_render_bwd wrote.  One multi-tensor copy (device to device, the size of
+        the strays) and .grad re-pointed to the views -- instead of a concatenation of the whole field and a host read-back
+        on the data-parallel path.  Returns grad_bucket()."""
+        gf = getattr(self, "_grad_flat", None)
+        if gf is None:
+            return None
+        base = gf["flat"].untyped_storage().data_ptr()
+        src, dst, who = [], [], []
+        for p, v in zip(gf["params"], gf["views"]):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:                       # (no gradient reached it: nothing to bring back, nothing is invented)
+                return None
+            if p.grad.untyped_storage().data_ptr() != base:
+                if p.grad.shape != v.shape or p.grad.dtype != v.dtype or p.grad.device != v.device:
+                    return None
+                src.append(p.grad)
+                dst.append(v)
+                who.append(p)
+        if src:
+            torch._foreach_copy_(dst, src)
+            for p, v in zip(who, dst):
+                p.grad = v
+            gf["events"] = False                     # the bucket events of lrf_render_bwd are behind these copies
+        return self.grad_bucket()
 
     def grad_segments(self):
         """[(start, end)] float offsets into grad_bucket()'s flat buffer of the three branches of lrf_render_bwd, in the order
         lrf_render_bwd_wait numbers them: density planes + lines, colour network (basis, three layers), appearance planes +
-        lines.  localrf_amd.dist reduces them as three collectives."""
+        lines.  (grad_chunks() is what localrf_amd.dist reduces.)"""
         gf = getattr(self, "_grad_flat", None)
         if gf is None:
             return None
-        d0, a0, n0, end = gf[3]
-        return [(d0, a0), (n0, end), (a0, n0)]
+        return [gf["dens"], gf["net"], gf["app"]]
+
+    def grad_chunks(self):
+        """[(bucket, start, end)] in the order the backward finishes them: the pieces localrf_amd.dist all-reduces one by one,
+        each behind lrf_render_bwd_wait(bucket).  Density planes + lines (bucket 0: the per-ray branch ends early), colour
+        network (1), then the appearance tensors -- as ONE piece (2), or, when the backward ran its appearance scatter per
+        plane (LRF_FLAG_PLANE_EVENTS: a process group with more than one rank exists), plane 0 (3), plane 1 (4) and plane 2
+        with the three lines (2), so that only the last ~ third of the 26 MB (300^3) is exposed behind the backward."""
+        gf = getattr(self, "_grad_flat", None)
+        if gf is None:
+            return None
+        out = [(0,) + gf["dens"], (1,) + gf["net"]]
+        a0, a1, a2 = gf["app_planes"]
+        if gf["plane_events"]:
+            out += [(3, a0, a1), (4, a1, a2), (2, a2, gf["app"][1])]
+        else:
+            out.append((2,) + gf["app"])
+        return out
+
+    def grad_events_valid(self):
+        """True when the bucket events of lrf_render_bwd_wait belong to the backward that filled grad_bucket()."""
+        gf = getattr(self, "_grad_flat", None)
+        return bool(gf is not None and gf["events"])
 
     def _wait_bwd_bucket(self, which, stream):
-        """Make `stream` wait until bucket `which` (grad_segments order) of the last lrf_render_bwd on this device is final."""
+        """Make `stream` wait until bucket `which` (grad_chunks numbering) of the last lrf_render_bwd on this device is final."""
         N.check(N.lib().lrf_render_bwd_wait(int(which), stream.cuda_stream), "lrf_render_bwd_wait")
 
     # ------------------------------------------------------------------ sampling
@@ -685,7 +752,11 @@ class TensorVMSplit(torch.nn.Module):
         """tensorBase.py:289-315.  Only the mode train.py runs exists in this build (see _check_supported)."""
         self._check_supported(shadingMode, pos_pe, view_pe, fea_pe, featureC)
         self.renderModule = MLPRender_Fea_late_view(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        # the kernels, the workspace size and get_kwargs() read the configuration from these attributes (ADVICE round 4:
+        # stale values made the kernels index the new weights with the old shapes)
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
         self._cache_key = None
+        self._cfield_key = None
 
     def get_arange(self, idx):
         """tensoRF.py:14-16 (unused by the reference): the lattice coordinates along axis idx, pulled 1e-6 inside the box."""

@@ -270,3 +270,154 @@ def test_shard_views_keeps_rays_per_view_integral():
     import pytest
     with pytest.raises(ValueError):
         shard_views(ray_ids, view_ids[:15], rank=0, world=8)
+
+
+class _StrayField(_BucketField):
+    """A fresh field whose gradients autograd accumulated outside the flat buffer and that cannot bring them back (no
+    rebucket_grads): grad_bucket() is None, every tensor of it must travel in the small bucket."""
+
+    def fill(self, seed):
+        super().fill(seed)
+        for p in (self.dens, self.app, self.net):
+            p.grad = p.grad.clone() + 1.0
+
+    def grad_bucket(self):
+        return None
+
+
+class _StrayScene(torch.nn.Module):
+    def __init__(self, rank):
+        super().__init__()
+        self.live = _StrayField(7 + rank)
+        g = torch.Generator().manual_seed(50 + rank)
+        self.poses = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(3, generator=g)) for _ in range(3)])
+        for i in ((0, 1) if rank == 0 else (1,)):            # view 2 is sampled by nobody
+            self.poses[i].grad = torch.randn(3, generator=g)
+
+
+class _RealFieldScene(torch.nn.Module):
+    """A real TensorVMSplit with the gradient bucket of its backward (field._new_grad_bucket: the product's layout), whose
+    density tensors carry a regulariser: autograd summed that contribution first, so .grad of those six tensors is NOT a
+    view of the flat buffer (what density_L1 does on every iteration of its phase)."""
+
+    def __init__(self, rank):
+        super().__init__()
+        self.field = quiet(make_field, [10, 12, 14], "cpu", seed=3)
+        keep = self.field._param_list()
+        grads, _ = self.field._new_grad_bucket(keep, 5, torch.device("cpu"), plane_events=True)
+        g = torch.Generator().manual_seed(100 + rank)
+        self.full = []
+        for i, (p, v) in enumerate(zip(keep, grads)):
+            v.copy_(torch.randn(v.shape, generator=g))
+            p.grad = v if i >= 6 else v.clone() + 1.0
+            self.full.append(p.grad.clone())
+        self.pose = torch.nn.Parameter(torch.zeros(3))
+        self.pose.grad = torch.full((3,), float(rank + 1))
+
+
+def _worker_strays(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from localrf_amd.dist import allreduce_grads
+    res = {}
+    for mode in ("flags", "hint"):
+        m = _StrayScene(rank)
+        hint = None if mode == "flags" else [m.poses[0], m.poses[1]]
+        nbytes = allreduce_grads(m, has_grad=hint)
+        res[mode] = {"dens": m.live.dens.grad.clone(), "app": m.live.app.grad.clone(), "net": m.live.net.grad.clone(),
+                     "poses": [None if p.grad is None else p.grad.clone() for p in m.poses], "bytes": nbytes}
+        r = _RealFieldScene(rank)
+        st = {}
+        nb = allreduce_grads(r, has_grad=None if mode == "flags" else [r.pose], stats=st)
+        bucket = r.field.grad_bucket()
+        base = r.field._grad_flat["flat"].untyped_storage().data_ptr()
+        res["real_" + mode] = {"grads": [p.grad.clone() for p in r.field._param_list()], "pose": r.pose.grad.clone(), "bytes": nb,
+                               "stats": st, "bucket": bucket is not None,
+                               "views": all(p.grad.untyped_storage().data_ptr() == base for p in r.field._param_list())}
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fresh_field_with_gradients_outside_its_bucket_is_still_reduced(tmp_path):
+    """with a regulariser in the loss autograd sums the contributions to a density tensor before it writes
+    .grad, so .grad is not the view lrf_render_bwd wrote.  (a) A real TensorVMSplit brings the strays back into its flat
+    buffer (rebucket_grads: one multi-tensor copy) and is reduced in place, piece by piece -- five pieces with the per-plane
+    appearance split, 19 views of the buffer afterwards; (b) a field that cannot do that travels in the small bucket and
+    the has_grad hint (which names poses only) must not drop it: ranks would silently diverge."""
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_worker_strays, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    a, b = _StrayScene(0), _StrayScene(1)
+    ra, rb = _RealFieldScene(0), _RealFieldScene(1)
+    n_field = sum(p.numel() for p in ra.field._param_list())
+    for mode in ("flags", "hint"):
+        r = got[mode]
+        for name in ("dens", "app", "net"):
+            want = getattr(a.live, name).grad + getattr(b.live, name).grad
+            assert torch.equal(r[name], want), (mode, name)
+        assert torch.equal(r["poses"][0], a.poses[0].grad) and torch.allclose(r["poses"][1], a.poses[1].grad + b.poses[1].grad)
+        assert r["poses"][2] is None
+        assert r["bytes"] == 4 * (37 + 101 + 13 + 6)
+        q = got["real_" + mode]
+        assert q["bucket"] and q["views"], mode
+        for i, (ga, gb_) in enumerate(zip(ra.full, rb.full)):
+            assert torch.equal(q["grads"][i], ga + gb_), (mode, i)
+        assert torch.equal(q["pose"], torch.full((3,), 3.0))
+        assert q["bytes"] == 4 * (n_field + 3) and q["stats"]["field_bytes"] == 4 * n_field
+        assert q["stats"]["collectives"] == 5 + 1 and len(q["stats"]["chunks"]) == 5      # density, network, plane 0, plane 1, plane 2 + lines; small bucket
+        assert sum(q["stats"]["chunks"]) >= 4 * n_field
+
+
+def _weighted_loss(model, ray_ids, view_ids, target, weights, norm):
+    """train.py:369-371 with a sum in place of the mean (shards add up): 0.25 |rgb - target| w / mean(w)."""
+    rgb, _ = model(ray_ids, view_ids)
+    return (0.25 * (rgb - target).abs() * weights[:, None] / norm).sum()
+
+
+def _worker_weighted(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from localrf_amd.dist import allreduce_grads, global_mean, shard_views
+    model = OracleScene()
+    ray_ids, view_ids, target = _batch()
+    weights = 0.2 + 3.0 * torch.rand(ray_ids.shape[0], generator=torch.Generator().manual_seed(9)) * (torch.arange(ray_ids.shape[0]) / 96.0)
+    r_ids, v_ids = shard_views(ray_ids, view_ids)
+    per = ray_ids.shape[0] // view_ids.shape[0]
+    lo, hi = rank * 4 * per, (rank + 1) * 4 * per
+    w = weights[lo:hi]
+    res = {}
+    for name, norm in (("global", global_mean(w)), ("local", w.mean())):
+        model.zero_grad(set_to_none=True)
+        _weighted_loss(model, r_ids, v_ids, target[lo:hi], w, norm).backward()
+        allreduce_grads(model)
+        res[name] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    res["norm"] = float(global_mean(w))
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_global_loss_normalisation_is_rank_count_invariant(tmp_path):
+    """train.py:369 divides the photometric loss by loss_weights.mean() over the WHOLE batch -- the one batch-global
+    statistic of the loop (the quantile clips of train.py:406,419 are per view, and shard_views keeps views whole).
+    With dist.global_mean the 2-rank gradients equal the 1-rank gradients for non-uniform weights; with the per-shard
+    mean they do not (the test makes sure it would notice)."""
+    out = str(tmp_path / "w.pt")
+    mp.spawn(_worker_weighted, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = OracleScene()
+    ray_ids, view_ids, target = _batch()
+    weights = 0.2 + 3.0 * torch.rand(ray_ids.shape[0], generator=torch.Generator().manual_seed(9)) * (torch.arange(ray_ids.shape[0]) / 96.0)
+    assert abs(got["norm"] - float(weights.mean())) < 1e-6
+    _weighted_loss(model, ray_ids, view_ids, target, weights, weights.mean()).backward()
+    worst_local = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        den = max(float(p.grad.abs().max()), 1e-9)
+        assert float((got["global"][n] - p.grad).abs().max()) <= 2e-5 * den, n
+        worst_local = max(worst_local, float((got["local"][n] - p.grad).abs().max()) / den)
+    assert worst_local > 1e-2, worst_local                   # the per-shard mean is a different loss

@@ -652,6 +652,133 @@ def test_two_rank_data_parallel_step_on_one_gpu(tmp_path):
     assert got[0]["bytes"] >= 4 * sum(p.numel() for p in lt.tensorfs[-1].parameters() if p.requires_grad)
 
 
+def _rccl_one_rank_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LRF_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))      # RCCL
+    from localrf_amd import dist as ldist
+    assert ldist.active()
+    lt = _scene()
+    field = lt.tensorfs[-1]
+    ray_ids, view_ids, gr, gd = _dp_batch()
+    res = {}
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in lt.named_parameters() if p.grad is not None}
+
+    # (a) the in-place path: five pieces, each behind its lrf_render_bwd_wait event on the side stream
+    _dp_loss_backward(lt, ray_ids, view_ids, gr, gd)
+    res["a_bucket"] = field.grad_bucket() is not None
+    res["a_events"] = field.grad_events_valid()
+    res["a_chunks"] = [c[0] for c in field.grad_chunks()]
+    before = snapshot()
+    st = {}
+    res["a_bytes"] = ldist.allreduce_grads(lt, has_grad=ldist.scene_has_grad(lt, view_ids), stats=st, average=True)
+    after = snapshot()
+    res["a_stats"] = st
+    res["a_same"] = sorted(before) == sorted(after) and all(torch.equal(before[k], after[k]) for k in before)
+    res["a_views"] = field.grad_bucket() is not None
+    # the same backward without a process group's collectives in between, as the reference run: per-plane passes give the
+    # gradients of the single pass (LDS / global adds in another order: not bit-identical, within fp32 accumulation noise)
+    os.environ["LRF_DIST_FORCE"] = "0"
+    _dp_loss_backward(lt, ray_ids, view_ids, gr, gd)
+    res["single_pass_chunks"] = [c[0] for c in field.grad_chunks()]
+    one = snapshot()
+    os.environ["LRF_DIST_FORCE"] = "1"
+    res["plane_vs_single"] = max(float((one[k] - before[k]).abs().max()) / max(float(one[k].abs().max()), 1e-12) for k in one)
+    # (b) density_L1 in the loss (local_tensorfs.py:361-375): autograd sums the regulariser's gradient first, .grad of the
+    # density tensors is no view of the bucket -> rebucket_grads, then the same in-place pieces in plain stream order
+    field.z_override = field.z_schedule(False, -1, torch.device(DEV)).clone()
+    for p in lt.parameters():
+        p.grad = None
+    rgb, depth, _, _ = lt(ray_ids.to(DEV), view_ids.to(DEV), lt.W, lt.H, is_train=True, white_bg=True)
+    _, l1 = lt.get_reg_loss(None, 0, 0, 1e-4)
+    ((rgb * gr.to(DEV)).sum() + (depth * gd.to(DEV)).sum() + 50.0 * l1).backward()
+    res["b_bucket_before"] = field.grad_bucket() is not None
+    before = snapshot()
+    st = {}
+    res["b_bytes"] = ldist.allreduce_grads(lt, stats=st)                 # flag path: one host read-back of a few flags
+    after = snapshot()
+    res["b_stats"] = st
+    res["b_same"] = sorted(before) == sorted(after) and all(torch.equal(before[k], after[k]) for k in before)
+    res["b_bucket_after"] = field.grad_bucket() is not None
+    res["b_events"] = field.grad_events_valid()
+    # (c) an empty shard on this rank: no lrf_render_bwd ran, the events are not this backward's -> plain stream order, no hang
+    for p in lt.parameters():
+        p.grad = None
+    rays0 = torch.zeros(0, 6, device=DEV)
+    rgb0, depth0 = field(rays0, white_bg=True, is_train=True, N_samples=-1)
+    (rgb0.sum() + depth0.sum()).backward()
+    res["c_events"] = field.grad_events_valid()
+    st = {}
+    res["c_bytes"] = ldist.allreduce_grads(field, stats=st)
+    torch.cuda.synchronize()
+    res["c_stats"] = st
+    res["c_zero"] = all(float(p.grad.abs().max()) == 0.0 for p in field.parameters() if p.grad is not None)
+    # an optimiser step behind the reduced gradients
+    lt.rf_optimizer.step()
+    torch.cuda.synchronize()
+    res["finite"] = all(bool(torch.isfinite(p).all()) for p in field.parameters())
+    torch.save(res, out)
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_on_rccl_with_one_rank_runs_every_collective(tmp_path):
+    """the data-parallel exchange had only ever run on gloo.  Here it runs on the nccl (= RCCL)
+    backend on this GPU with LRF_DIST_FORCE=1 -- a one-rank group that still issues every collective of the N-rank step:
+    the backward with its per-plane appearance passes and five bucket events, each piece handed to RCCL from the side stream
+    behind lrf_render_bwd_wait, async works waited for on the caller's stream, in-place average; with a regulariser
+    (gradients brought back by rebucket_grads) and with an empty shard (no events: plain stream order).  One rank's sum
+    is the identity: gradients must come back bit-identical, nothing may hang."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_one_rank_worker, args=(1, port, out), nprocs=1, join=True)
+    r = torch.load(out)
+    n_field = 4 * sum(p.numel() for p in _scene().tensorfs[-1].parameters() if p.requires_grad)
+    assert r["a_bucket"] and r["a_events"] and r["a_chunks"] == [0, 1, 3, 4, 2], r
+    assert r["a_same"] and r["a_views"]
+    assert r["a_stats"]["collectives"] == 6 and r["a_stats"]["field_bytes"] == n_field and len(r["a_stats"]["chunks"]) == 5
+    assert r["a_bytes"] > n_field                              # + poses / exposure of the four sampled views
+    assert r["single_pass_chunks"] == [0, 1, 2] and r["plane_vs_single"] < 1e-5, r["plane_vs_single"]
+    assert not r["b_bucket_before"], "density_L1 no longer strays: the rebucket path is not exercised"
+    assert r["b_same"] and r["b_bucket_after"] and not r["b_events"]
+    assert r["b_stats"]["collectives"] == 6 and r["b_stats"]["field_bytes"] == n_field
+    assert not r["c_events"] and r["c_stats"]["collectives"] == 5 and r["c_zero"]
+    assert r["finite"]
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher must become the launcher (it used to exit
+    with a usage message).  Two ranks on this one GPU need --backend gloo (RCCL refuses two ranks per device); everything
+    else is the driver's N = 2 run: process group, barriers, max-over-ranks timing, per-rank ray shard, the train step with
+    its piecewise gradient exchange, one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--no-baselines", "--no-pmc"], capture_output=True, text=True, timeout=420, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    ar = d["train_step"]["allreduce"]
+    assert ar["n_ranks_seen"] == 2 and ar["collectives_per_step"] == 5 and len(ar["bytes_per_piece"]) == 5
+    assert d["train_step"]["ms_per_step_without_allreduce"] is not None
+
+
 def test_bench_under_torch_distributed_run_one_rank(tmp_path):
     """The driver launches the multi-GPU bench as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.
     The same plumbing with N = 1: RCCL process group on this GPU, barrier + max-over-ranks timing, the train step with its
@@ -677,6 +804,9 @@ def test_bench_under_torch_distributed_run_one_rank(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["value"] > 1e6 and abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     assert "RCCL" in d["train_step"]["what"] or "allreduce" in d["train_step"]["what"], d["train_step"]["what"]
+    ar = d["train_step"]["allreduce"]                       # one rank, yet every collective of the N-rank step was issued (LRF_DIST_FORCE)
+    assert ar["backend"] == "nccl" and ar["forced_at_one_rank"] and ar["collectives_per_step"] == 5 and d["n_ranks_seen"] == 1
+    assert sum(ar["bytes_per_piece"]) >= ar["field_bytes"] > 30e6
     assert d["roofline"]["kernel"] in ("k_shade3", "k_march") and d["roofline"]["bound"] in ("hbm", "mfma")
 
 
