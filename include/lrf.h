@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 5      /* 5: LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 5      /* 5: LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -271,6 +271,12 @@ typedef struct LrfAdamTensor {
 } LrfAdamTensor;
 int lrf_adam_step(const LrfAdamTensor* tensors /* host array */, int32_t count, float beta1, float beta2,
                   float eps, void* stream);
+/* The same launch with step_size / bc2_sqrt read from DEVICE memory when the kernel runs (dev_scalars [count][2]; the two
+ * fields of the host structs are ignored): the launch can be captured in a hipGraph and replayed with the learning rates and
+ * bias corrections the host wrote before each replay.  bc2_sqrt <= 0 skips a tensor (torch.optim.Adam skips a parameter
+ * whose .grad is None: local_tensorfs.py:229-243 steps the poses of sampled views only). */
+int lrf_adam_step_dev(const LrfAdamTensor* tensors /* host array */, int32_t count, const float* dev_scalars, float beta1, float beta2,
+                      float eps, void* stream);
 
 /* density_L1 regulariser (tensoRF.py:83-92), on by default while
  * rf_iter < n_iters_reg (opt.py:111, local_tensorfs.py:361-375):

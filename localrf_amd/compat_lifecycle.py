@@ -167,7 +167,21 @@ class SceneLifecycle(torch.nn.Module):
 
     def optimizer_step(self, loss, optimize_poses):
         """One optimisation step of the current field, its linked poses/exposures and the
-        intrinsics, plus the scheduled upsample / alpha-mask rebuild (local_tensorfs.py:193-290)."""
+        intrinsics, plus the scheduled upsample / alpha-mask rebuild (local_tensorfs.py:193-290).  In three parts so that
+        a captured iteration (localrf_amd/graph_step.py) can run the device work of the middle as one graph replay."""
+        pose_ids, tune_intrinsics = self.step_begin(optimize_poses)
+        loss.backward()
+        if self.grad_sync is not None:          # data parallel: localrf_amd.dist.allreduce_grads(self)
+            self.grad_sync(self)
+        self.rf_optimizer.step()
+        self.step_schedule()
+        small = self.small_optimizers(pose_ids, optimize_poses, tune_intrinsics)
+        if small:
+            FusedAdam.step_many(small)          # :229-249, one launch for all of them
+        return self.step_finish()
+
+    def step_begin(self, optimize_poses, zero_grad=True):
+        """The schedule bookkeeping and learning-rate decays ahead of the backward (local_tensorfs.py:193-228)."""
         it = self.rf_iter[-1]
         if it == 0:
             self.lr_factor = 1
@@ -190,25 +204,28 @@ class SceneLifecycle(torch.nn.Module):
         for i in pose_ids:
             if optimize_poses:
                 decay(self.r_optimizers[i]); decay(self.t_optimizers[i])
-                self.r_optimizers[i].zero_grad(); self.t_optimizers[i].zero_grad()
+                if zero_grad:
+                    self.r_optimizers[i].zero_grad(); self.t_optimizers[i].zero_grad()
             if self.lr_exposure_init > 0:
                 decay(self.exp_optimizers[i])
-                self.exp_optimizers[i].zero_grad()
+                if zero_grad:
+                    self.exp_optimizers[i].zero_grad()
         tune_intrinsics = (self.lr_i_init > 0 and self.blending_weights.shape[1] == 1
                            and self.is_refining)
         if tune_intrinsics:
             decay(self.intrinsic_optimizer)
-            self.intrinsic_optimizer.zero_grad()
-        self.rf_optimizer.zero_grad()
+            if zero_grad:
+                self.intrinsic_optimizer.zero_grad()
+        if zero_grad:
+            self.rf_optimizer.zero_grad()
+        return pose_ids, tune_intrinsics
 
-        loss.backward()
-        if self.grad_sync is not None:          # data parallel: localrf_amd.dist.allreduce_grads(self)
-            self.grad_sync(self)
-
-        self.rf_optimizer.step()
+    def step_schedule(self):
+        """Behind the field's Adam step: its decay while refining, the scheduled upsample and alpha-mask rebuild
+        (local_tensorfs.py:245-266)."""
         if self.is_refining:
-            decay(self.rf_optimizer)
-
+            for grp in self.rf_optimizer.param_groups:
+                grp["lr"] *= self.lr_factor
         if self.rf_iter[-1] in self.N_voxel_list:               # :251-261
             reso = N_to_reso(self.N_voxel_list[self.rf_iter[-1]], self.tensorfs[-1].aabb)
             self.tensorfs[-1].upsample_volume_grid(reso)
@@ -219,7 +236,8 @@ class SceneLifecycle(torch.nn.Module):
         if self.rf_iter[-1] in self.update_AlphaMask_list:      # :264-266
             self.tensorfs[-1].updateAlphaMask(tuple((self.tensorfs[-1].gridSize / 2).int().tolist()))
 
-        small = []                                              # :229-249, one launch for all of them
+    def small_optimizers(self, pose_ids, optimize_poses, tune_intrinsics):
+        small = []
         for i in pose_ids:
             if optimize_poses:
                 small += [self.r_optimizers[i], self.t_optimizers[i]]
@@ -227,12 +245,12 @@ class SceneLifecycle(torch.nn.Module):
                 small.append(self.exp_optimizers[i])
         if tune_intrinsics:
             small.append(self.intrinsic_optimizer)
-        if small:
-            FusedAdam.step_many(small)
+        return small
+
+    def step_finish(self):
         if self.is_refining:
             self.rf_iter[-1] += 1
         return self.rf_iter[-1] >= self.n_iters - 1             # can_add_rf
-
 
     def get_kwargs(self):
         """local_tensorfs.py:301-324."""

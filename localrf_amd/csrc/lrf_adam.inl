@@ -26,10 +26,18 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
   p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1, float b2, float eps) {
+// dev_scalars (lrf_adam_step_dev): [count][2] = {step_size, bc2_sqrt} per tensor in DEVICE memory, read at execution time -- the
+// launch can sit in a captured hipGraph whose replays step with the learning rates / bias corrections (and skip the tensors,
+// bc2_sqrt <= 0) the host wrote before each replay.
+__global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
   int ti = 0;
   while (ti + 1 < tab.count && (int)blockIdx.x >= tab.first_block[ti + 1]) ++ti;   // <= 64 uniform steps
-  const LrfAdamTensor T = tab.t[ti];
+  LrfAdamTensor T = tab.t[ti];
+  if (dev_scalars) {
+    T.step_size = dev_scalars[2 * ti];
+    T.bc2_sqrt = dev_scalars[2 * ti + 1];
+    if (!(T.bc2_sqrt > 0.0f)) return;                // not stepped this iteration (a view nobody sampled: torch skips .grad None)
+  }
   const long long base = (long long)((int)blockIdx.x - tab.first_block[ti]) * ADAM_CHUNK;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(T.p) | reinterpret_cast<uintptr_t>(T.g) |
                         reinterpret_cast<uintptr_t>(T.m) | reinterpret_cast<uintptr_t>(T.v)) & 15) == 0;
@@ -59,8 +67,8 @@ __global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1
 
 }  // namespace lrf
 
-extern "C" int lrf_adam_step(const LrfAdamTensor* tensors, int32_t count, float beta1, float beta2, float eps,
-                             void* stream) {
+static int adam_step_impl(const LrfAdamTensor* tensors, int32_t count, const float* dev_scalars, float beta1, float beta2, float eps,
+                          void* stream) {
   using namespace lrf;
   if (count < 0 || count > LRF_ADAM_MAX) return set_err("lrf_adam_step: count must be in [0, LRF_ADAM_MAX]");
   if (!count) return 0;
@@ -79,7 +87,17 @@ extern "C" int lrf_adam_step(const LrfAdamTensor* tensors, int32_t count, float 
   tab.first_block[count] = blocks;
   if (!blocks) return 0;
   hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(ADAM_TPB), 0, reinterpret_cast<hipStream_t>(stream), tab,
-                     beta1, beta2, eps);
+                     beta1, beta2, eps, dev_scalars);
   LRF_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int lrf_adam_step(const LrfAdamTensor* tensors, int32_t count, float beta1, float beta2, float eps, void* stream) {
+  return adam_step_impl(tensors, count, nullptr, beta1, beta2, eps, stream);
+}
+
+extern "C" int lrf_adam_step_dev(const LrfAdamTensor* tensors, int32_t count, const float* dev_scalars, float beta1, float beta2,
+                                 float eps, void* stream) {
+  if (!dev_scalars) return lrf::set_err("lrf_adam_step_dev: null scalar table");
+  return adam_step_impl(tensors, count, dev_scalars, beta1, beta2, eps, stream);
 }

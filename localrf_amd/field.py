@@ -229,6 +229,7 @@ class TensorVMSplit(torch.nn.Module):
         # view_pe / fea_pe / featureC always runs the generic engine, whatever this says
         self.mlp_engine = "bf16x3"
         self.z_override = None          # tests: inject a recorded z schedule
+        self.jitter_override = None     # (u1, u2): the two jitter draws of a training forward, supplied by the caller
         # early termination of the march (LrfField.term_T in include/lrf.h).  Default 0 = every sample is evaluated, the
         # reference's arithmetic (tensorBase.py:600-610).  Opt-in: EARLY_TERM_T_FAST (1e-9) skips the density gathers of a
         # ray once no later sample can pass rayMarch_weight_thres -- colours / acc identical, depth within 1e-6 absolute
@@ -660,7 +661,11 @@ class TensorVMSplit(torch.nn.Module):
         if torch.device(device).type == "cuda":   # one launch (lrf_z_schedule) instead of sixteen elementwise ones per training iteration
             dev = torch.device(device)
             z = torch.empty(2 * h, dtype=torch.float32, device=dev)
-            if is_train:                        # the reference's two rand_like draws, in its order
+            if is_train and self.jitter_override is not None:   # (u1, u2) device buffers of >= h floats the caller fills (a captured
+                u1, u2 = self.jitter_override                   # iteration draws them outside its graph: localrf_amd/graph_step.py)
+                if u1.numel() < h or u2.numel() < h:
+                    raise ValueError("jitter_override buffers are smaller than the sample schedule")
+            elif is_train:                      # the reference's two rand_like draws, in its order
                 u1 = torch.rand(1, h, dtype=torch.float32, device=dev)
                 u2 = torch.rand(1, h, dtype=torch.float32, device=dev)
             N.check(N.lib().lrf_z_schedule(h, N.ptr(u1) if is_train else None, N.ptr(u2) if is_train else None, N.ptr(z),

@@ -1,0 +1,242 @@
+"""A training iteration of a LocalTensorfs scene as ONE replayed hipGraph (BASELINE.json configs[4]: the progressive loop).
+
+The loop of train.py:349-474 is a few hundred microseconds of GPU work at the early grid sizes and ~2 ms of host work
+(~ 80 launches through autograd, a dozen tiny optimisers, the lifecycle bookkeeping): driven from Python it is bound by the
+host at every resolution (profiles/r13_train_synth_500.json: 1.9-2.2 ms per iteration from 97^3 to 500^3).
+Nothing in an iteration depends on values the host reads back, so the whole of it -- pose assembly, ray generation, the
+field's forward, the losses, autograd's backward through all of them, the Adam launches of the field and of every
+per-frame pose / exposure optimiser, the layout refresh -- is captured once per lifecycle state and replayed:
+
+    host, per iteration:  sample ids -> one pinned staging block -> ONE async copy -> two jitter draws -> graph launch
+
+What changes from iteration to iteration travels through a static device block the captured kernels read at execution
+time: pixel ids, view ids, their index into the assembled poses, the scalars of the loss (schedule weights), and one
+(step_size, bc2_sqrt) row per optimised tensor (lrf_adam_step_dev; a zero row skips the tensor, as torch.optim.Adam skips a
+parameter without gradient -- the poses of views nobody sampled, local_tensorfs.py:229-243).  What changes the SET of
+tensors or shapes -- append_frame, append_rf, a grid upsample, an alpha-mask rebuild, the end of the regularised phase -- is a
+lifecycle event: the next iteration runs eagerly (the same Python function, not captured) and the one after is captured
+again.  The two jitter draws of the sample schedule stay outside the graph (torch.rand into static buffers, in the
+reference's order) so that the random stream is the eager loop's.
+
+Data parallel (scene.grad_sync set): two graphs per iteration -- forward + backward, then the Adam launches -- with the
+gradient exchange (localrf_amd.dist.allreduce_grads, RCCL) between them on the same stream.
+
+No reference counterpart (train.py drives the same work from Python); results equal the eager loop's
+(tests/test_gpu_training.py::test_captured_iteration_matches_the_eager_loop)."""
+import numpy as np
+import torch
+
+from .optim import StaticAdamPlan
+
+_NP = {torch.int64: np.int64, torch.int32: np.int32, torch.float32: np.float32}
+
+
+class StaticInputs:
+    """Named device tensors inside ONE device block, fed from a ring of pinned host blocks with one asynchronous copy per
+    iteration.  `dev[name]`: the static device view captured kernels read; stage() -> (slot, {name: numpy view}) to fill;
+    push(slot): enqueue the copy on the current stream.  A pinned block is reused only after its copy has run."""
+
+    def __init__(self, device, fields, ring=4):
+        self.device = torch.device(device)
+        offs, off = {}, 0
+        for name, (shape, dtype) in fields.items():
+            nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+            offs[name] = (off, nbytes, tuple(shape), dtype)
+            off += (nbytes + 255) // 256 * 256
+        self.nbytes = max(off, 256)
+        self.blob = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.dev = {n: self.blob[o:o + b].view(dt).view(sh) for n, (o, b, sh, dt) in offs.items()}
+        self._host = [torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(ring)]
+        self._np = [{n: h.numpy()[o:o + b].view(_NP[dt]).reshape(sh) for n, (o, b, sh, dt) in offs.items()} for h in self._host]
+        self._ev = [None] * ring
+        self._next = 0
+
+    def stage(self):
+        k = self._next
+        self._next = (k + 1) % len(self._host)
+        if self._ev[k] is not None:
+            self._ev[k].synchronize()                             # (a copy issued `ring` iterations ago: long done)
+        return k, self._np[k]
+
+    def push(self, k):
+        self.blob.copy_(self._host[k], non_blocking=True)
+        ev = self._ev[k]
+        if ev is None:
+            ev = self._ev[k] = torch.cuda.Event()
+        ev.record()
+
+
+class StepInputs:
+    """What the loss function of a captured iteration sees besides the render's outputs (all static device tensors)."""
+
+    def __init__(self, ray_ids, view_ids, frame, scalars, cam2world_all, start, n_views):
+        self.ray_ids, self.view_ids, self.frame = ray_ids, view_ids, frame    # int64 [B], int64 [V], int64 [V] = view - start
+        self.scalars = scalars                                    # {name: 0-dim float32 tensor}
+        self.cam2world_all, self.start, self.n_views = cam2world_all, start, n_views   # get_cam2world(starting_id=start)
+
+
+class CapturedIteration:
+    """scene: localrf_amd.LocalTensorfs.  loss_fn(rgb, depth, directions, ij, inputs: StepInputs) -> (total loss, {name:
+    tensor to keep readable after the step}).  step(...) runs one iteration: forward, loss, backward, [grad_sync,] every Adam
+    launch -- eagerly right after a lifecycle event, as a graph replay otherwise.  The caller keeps driving the lifecycle
+    (scene.step_begin / step_schedule / step_finish around step(), see scripts/train_synth.py)."""
+
+    def __init__(self, scene, W, H, batch, n_views, loss_fn, scalar_names=(), optimize_poses=True, enabled=True):
+        self.scene, self.W, self.H, self.batch, self.n_views = scene, int(W), int(H), int(batch), int(n_views)
+        self.loss_fn, self.scalar_names, self.optimize_poses = loss_fn, tuple(scalar_names), bool(optimize_poses)
+        self.enabled = bool(enabled)
+        self._sig = None
+        self._graphs = None
+        self._eager_done = False
+        self.kept = {}
+        self.stats = {"eager": 0, "captures": 0, "replays": 0}
+        self.extra_signature = lambda: ()
+
+    # ------------------------------------------------------------------ lifecycle state
+    def _signature(self, start, pose_ids, tune_intrinsics):
+        lt = self.scene
+        f = lt.tensorfs[-1]
+        return (len(lt.tensorfs), len(lt.r_c2w), tuple(int(g) for g in f.gridSize.tolist()), int(f.nSamples), id(f.alphaMask),
+                None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr(), id(lt.rf_optimizer), bool(lt.is_refining),
+                int(start), tuple(pose_ids), bool(tune_intrinsics), lt.grad_sync is not None,
+                tuple(p.data_ptr() for p in f._param_list())) + tuple(self.extra_signature())
+
+    def _build(self, start, pose_ids, tune_intrinsics):
+        """Static buffers and the Adam plan for the current lifecycle state."""
+        lt = self.scene
+        dev = lt.blending_weights.device
+        field = lt.tensorfs[-1]
+        pairs = [(lt.rf_optimizer, p) for g in lt.rf_optimizer.param_groups for p in g["params"]]
+        self._pose_params = {}
+        for i in pose_ids:
+            if self.optimize_poses:
+                pairs += [(lt.r_optimizers[i], lt.r_c2w[i]), (lt.t_optimizers[i], lt.t_c2w[i])]
+                self._pose_params[i] = (id(lt.r_c2w[i]), id(lt.t_c2w[i]))
+            if lt.lr_exposure_init > 0:
+                pairs.append((lt.exp_optimizers[i], lt.exposure[i]))
+        if tune_intrinsics:
+            pairs += [(lt.intrinsic_optimizer, p) for g in lt.intrinsic_optimizer.param_groups for p in g["params"]]
+        self.plan = StaticAdamPlan(pairs)
+        self._always = {id(p) for _, p in pairs} - {q for pr in self._pose_params.values() for q in pr}
+        h = int(field.nSamples) // 6
+        fields = {"ray_ids": ((self.batch,), torch.int64), "view_ids": ((self.n_views,), torch.int64),
+                  "frame": ((self.n_views,), torch.int64), "adam": ((len(self.plan), 2), torch.float32),
+                  "scalars": ((max(1, len(self.scalar_names)),), torch.float32)}
+        self.inputs = StaticInputs(dev, fields)
+        self.u1 = torch.empty(1, h, dtype=torch.float32, device=dev)
+        self.u2 = torch.empty(1, h, dtype=torch.float32, device=dev)
+        self.start = int(start)
+        self._graphs = None
+        self._eager_done = False
+
+    # ------------------------------------------------------------------ the iteration (eager or under capture)
+    def _forward_backward(self):
+        lt, d = self.scene, self.inputs.dev
+        field = lt.tensorfs[-1]
+        c2w_all = lt.get_cam2world(starting_id=self.start)        # one assembly: the render's poses and the flow loss's
+        c2w_r = c2w_all
+        if lt.reference_cross and len(lt.r_c2w) - self.start == 3:
+            # the reference's dim-less torch.cross (utils/utils.py:386) fires for exactly three assembled frames: that is the
+            # flow loss's assembly (train.py:388), never the render's (16 sampled views) -- assemble those without it
+            lt.reference_cross = False
+            try:
+                c2w_r = lt.get_cam2world(starting_id=self.start)
+            finally:
+                lt.reference_cross = True
+        c2w = c2w_r.index_select(0, d["frame"])
+        field.jitter_override = (self.u1, self.u2)
+        try:
+            rgb, depth, directions, ij = lt(d["ray_ids"], d["view_ids"], self.W, self.H, is_train=True, cam2world=c2w, test_id=False)
+        finally:
+            field.jitter_override = None
+        sc = {n: d["scalars"][i] for i, n in enumerate(self.scalar_names)}
+        total, kept = self.loss_fn(rgb, depth, directions, ij,
+                                   StepInputs(d["ray_ids"], d["view_ids"], d["frame"], sc, c2w_all, self.start, self.n_views))
+        total.backward()
+        self.kept = {k: v.detach() for k, v in kept.items()}
+
+    def _adam(self):
+        self.plan.launch(self.inputs.dev["adam"])
+
+    def _zero_grads(self):
+        for _, p in self.plan.pairs:
+            p.grad = None
+        lt = self.scene
+        for p in list(lt.r_c2w[self.start:]) + list(lt.t_c2w[self.start:]) + list(lt.exposure):
+            p.grad = None                                         # (frames outside the plan are differentiated too; their .grad is never read)
+        for p in (lt.focal_offset, lt.center_rel):
+            if isinstance(p, torch.Tensor):
+                p.grad = None
+
+    def _capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            g.capture_begin()
+            try:
+                fn()
+            finally:
+                g.capture_end()
+        cur.wait_stream(side)
+        return g
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self, view_list, ray_ids, scalars=None, all_poses_active=False, pose_ids=(), tune_intrinsics=False, start=0):
+        """view_list: the batch's view ids (host ints, n_views of them); ray_ids: host int64 [batch] pixel ids, view-major;
+        scalars: {name: float}; all_poses_active: every pose of `pose_ids` receives a gradient this iteration (the flow loss
+        differentiates through all assembled frames) -- otherwise only the sampled views' poses are stepped; pose_ids /
+        tune_intrinsics: what scene.step_begin returned; start: first frame of the pose assembly (the flow loss's
+        starting_frame_id; every sampled view must be >= start)."""
+        lt = self.scene
+        sig = self._signature(start, pose_ids, tune_intrinsics)
+        if sig != self._sig:
+            self._build(start, pose_ids, tune_intrinsics)
+            self._sig = sig
+        k, host = self.inputs.stage()
+        host["ray_ids"][:] = np.asarray(ray_ids, dtype=np.int64).reshape(-1)
+        views = np.asarray(view_list, dtype=np.int64).reshape(-1)
+        host["view_ids"][:] = views
+        host["frame"][:] = views - self.start
+        if views.min() < self.start:
+            raise IndexError("a sampled view lies before the first assembled frame")
+        for i, n in enumerate(self.scalar_names):
+            host["scalars"][i] = float(scalars[n])
+        if all_poses_active:
+            active = None
+        else:
+            active = set(self._always)
+            for v in set(int(x) for x in views.tolist()):
+                active.update(self._pose_params.get(v, ()))
+        self.plan.host_scalars(host["adam"], active)
+        self.inputs.push(k)
+        torch.rand(self.u1.shape, out=self.u1)                    # the reference's two rand_like draws, in its order
+        torch.rand(self.u2.shape, out=self.u2)
+        sync = lt.grad_sync
+        field = lt.tensorfs[-1]
+        if not self.enabled or not self._eager_done:              # first iteration of this lifecycle state: plain launches
+            self._zero_grads()
+            self._forward_backward()
+            if sync is not None:
+                sync(lt)
+            self._adam()
+            self._eager_done = True
+            self.stats["eager"] += 1
+        else:
+            if self._graphs is None:
+                self._zero_grads()                                # gradients are created inside the capture: static addresses in its pool
+                field._cache_key = None                           # the layout refresh (lrf_pack_field) is the graph's first node
+                if sync is None:
+                    self._graphs = (self._capture(lambda: (self._forward_backward(), self._adam())),)
+                else:
+                    self._graphs = (self._capture(self._forward_backward), self._capture(self._adam))
+                self.stats["captures"] += 1
+            self._graphs[0].replay()
+            if sync is not None:
+                field._grad_fresh = True                          # (set by the backward's Python, which a replay does not run)
+                sync(lt)
+                self._graphs[1].replay()
+            self.stats["replays"] += 1
+        self.plan.bump_versions()                                 # the parameters changed behind autograd's back
+        return self.kept

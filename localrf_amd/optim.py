@@ -107,3 +107,78 @@ class FusedAdam(torch.optim.Optimizer):
                 raise TypeError("step_many takes FusedAdam optimisers")
             entries.extend(opt._entries())
         FusedAdam._launch(entries)
+
+
+class StaticAdamPlan:
+    """The Adam launches of one training iteration in capturable form: a fixed list of (optimiser, parameter) pairs whose
+    per-tensor step_size / bc2_sqrt are read by the kernel from a DEVICE table at execution time (lrf_adam_step_dev), so
+    that the launches can be captured once in a hipGraph and replayed with the learning rates, bias corrections and
+    "this view was not sampled: skip" flags the host writes before each replay.  Same arithmetic and per-parameter
+    state (`step`, `exp_avg`, `exp_avg_sq`) as FusedAdam.step / torch.optim.Adam; state dicts stay interchangeable."""
+
+    def __init__(self, pairs):
+        self.pairs = list(pairs)                                  # [(FusedAdam, parameter)], launch order
+        for opt, p in self.pairs:
+            if not isinstance(opt, FusedAdam):
+                raise TypeError("StaticAdamPlan takes FusedAdam optimisers")
+            st = opt.state[p]
+            if len(st) == 0:                                      # as FusedAdam._entries / torch.optim.Adam._init_group
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        self._group = {}
+        for opt, _ in self.pairs:
+            for grp in opt.param_groups:
+                for q in grp["params"]:
+                    self._group[(id(opt), id(q))] = grp
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def launch(self, scalars_dev):
+        """Enqueue (or capture) the launches.  scalars_dev: float32 [len(self), 2] on the device.  Every parameter must
+        hold its gradient (.grad) at this point: the pointers are baked into the launch."""
+        lib = N.lib()
+        classes = {}
+        for i, (opt, p) in enumerate(self.pairs):
+            grp = self._group[(id(opt), id(p))]
+            if p.grad is None:
+                raise RuntimeError("StaticAdamPlan.launch: a parameter of the plan has no gradient")
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.is_contiguous() or p.dtype != torch.float32:
+                raise N.NativeError("localrf_amd: StaticAdamPlan needs contiguous fp32 parameters and gradients")
+            classes.setdefault((tuple(grp["betas"]), grp["eps"], p.device), []).append(i)
+        order = [i for idx in classes.values() for i in idx]
+        if order != list(range(len(self.pairs))):
+            raise ValueError("StaticAdamPlan: pairs must be grouped by (betas, eps, device)")
+        for ((b1, b2), eps, dev), idx in classes.items():
+            st = torch.cuda.current_stream(dev).cuda_stream
+            for lo in range(0, len(idx), N.LRF_ADAM_MAX):
+                part = idx[lo:lo + N.LRF_ADAM_MAX]
+                tab = (N.LrfAdamTensor * len(part))()
+                for t, i in zip(tab, part):
+                    opt, p = self.pairs[i]
+                    s = opt.state[p]
+                    t.p, t.g, t.m, t.v = p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()
+                    t.n, t.step_size, t.bc2_sqrt = p.numel(), 0.0, 0.0
+                N.check(lib.lrf_adam_step_dev(tab, len(part), scalars_dev[part[0]:].data_ptr(), b1, b2, eps, st), "lrf_adam_step_dev")
+
+    def host_scalars(self, out, active=None):
+        """Advance the step counters of the parameters stepped this iteration and write their (step_size, bc2_sqrt) rows into
+        `out` (a float32 [len(self), 2] numpy view of pinned memory); rows of parameters outside `active` (ids; None = all)
+        are zero: the kernel leaves those tensors alone, as torch.optim.Adam leaves a parameter whose .grad is None."""
+        for i, (opt, p) in enumerate(self.pairs):
+            if active is not None and id(p) not in active:
+                out[i, 0] = 0.0
+                out[i, 1] = 0.0
+                continue
+            grp = self._group[(id(opt), id(p))]
+            b1, b2 = grp["betas"]
+            st = opt.state[p]
+            step = int(st["step"]) + 1
+            st["step"] = step
+            out[i, 0] = grp["lr"] / (1.0 - b1 ** step)
+            out[i, 1] = math.sqrt(1.0 - b2 ** step)
+
+    def bump_versions(self):
+        """The replayed kernels rewrote the parameters behind autograd's back (see FusedAdam._launch)."""
+        increment_version([p for _, p in self.pairs])

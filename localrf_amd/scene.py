@@ -83,14 +83,19 @@ class LocalTensorfs(SceneLifecycle):
         # Any pageable host->device copy blocks the host until the stream drains (measured,
         # scripts/ubench/h2d_sync.py), so a caller that keeps ids on the host overlaps its next
         # iteration's host work with this one's kernels.
-        if torch.is_tensor(view_ids) and view_ids.is_cuda:
+        if torch.is_tensor(view_ids) and view_ids.is_cuda and cam2world is not None and is_train:
+            view_list = None                                    # poses supplied, one field trains: nothing on the host needs the ids
+            n_views = int(view_ids.shape[0])                    # (no read-back: this call can sit in a captured graph)
+        elif torch.is_tensor(view_ids) and view_ids.is_cuda:
             view_list = view_ids.tolist()
         else:
             view_list = [int(v) for v in (view_ids.tolist() if hasattr(view_ids, "tolist") else view_ids)]
             view_ids = _upload_ids(view_list, dev)
         if not (torch.is_tensor(ray_ids) and ray_ids.is_cuda):
             ray_ids = _upload_ids(ray_ids, dev)
-        n_rays, n_views = ray_ids.shape[0], len(view_list)
+        n_rays = ray_ids.shape[0]
+        if view_list is not None:
+            n_views = len(view_list)
         if cam2world is None:
             cam2world = self.get_cam2world(view_list)
         if world2rf is None:

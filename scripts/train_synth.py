@@ -141,8 +141,43 @@ def geo_by_field(curve):
     return out
 
 
+class LateScalar:
+    """A device scalar the host reads one iteration late: request() enqueues a copy into pinned memory behind the work issued so
+    far, value() waits for THAT copy only -- the host stays one iteration ahead of the GPU instead of draining the stream on
+    every iteration (train.py:441 reads get_dist_to_last_rf().cpu().item() synchronously)."""
+
+    def __init__(self, initial=0.0):
+        self.pin = torch.zeros(1, pin_memory=True)
+        self.pin[0] = initial
+        self.ev = None
+
+    def request(self, t):
+        self.pin.copy_(t.detach().reshape(1), non_blocking=True)
+        if self.ev is None:
+            self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def value(self):
+        if self.ev is not None:
+            self.ev.synchronize()
+        return float(self.pin[0])
+
+
+def geometric_terms(lt, data, depth_map, directions, ij, cam2world_all, view_ids, start, vsel, psel, W, H):
+    """train.py:385-423: the optical-flow and monocular-depth losses of one batch (localrf_amd.losses kernels).  view_ids:
+    host or device ids; vsel [V] / psel [V, n]: device indices of the batch's views / pixels into the dataset tensors."""
+    from localrf_amd import losses as geo_losses
+    last = data.num_images - 1
+    fl = geo_losses.flow_loss(depth_map, directions, ij, cam2world_all, view_ids, start,
+                              data.fwd_flow[vsel[:, None], psel], (vsel < last).float()[:, None].expand(psel.shape),
+                              data.bwd_flow[vsel[:, None], psel], (vsel > 0).float()[:, None].expand(psel.shape),
+                              lt.focal(W), lt.center(W, H))
+    dl = geo_losses.depth_loss(depth_map, data.invdepths[vsel[:, None], psel], int(vsel.shape[0]))
+    return fl, dl
+
+
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False):
     from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -171,7 +206,34 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     # frame and short runs do not recover that motion, so the frame-count criterion (n_max_frames) is what starts a
     # refinement / a new field here
     L1_weight, add_frames_every, n_overlap = 1e-2, max(1, round(100 * sc)), 3
+    # graph=True: the iteration as one replayed hipGraph (localrf_amd/graph_step.py) -- the same loss written against static
+    # device inputs; what this iteration's loss contains (decided by the PREVIOUS optimizer_step, as in the eager branch below)
+    # is part of the captured state
+    phase = {"reg": False}
+
+    def graph_loss(rgb_map, depth_map, directions, ij, inp):
+        V = inp.n_views
+        psel = inp.ray_ids.reshape(V, -1)
+        target = data.images[inp.view_ids[:, None], psel].reshape(-1, 3)
+        loss = (0.25 * torch.abs(rgb_map - target)).mean()
+        total, kept = loss, {"photo": loss}
+        if phase["reg"] and geo:
+            fl, dl = geometric_terms(lt, data, depth_map, directions, ij, inp.cam2world_all, inp.view_ids, inp.start, inp.view_ids, psel, W, H)
+            total = total + fl * (inp.scalars["reg_w"] / ((W + H) / 2)) + dl * (0.1 * inp.scalars["reg_w"])
+            kept.update(flow=fl, depth=dl)
+        if phase["reg"]:
+            tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)
+            total = total + tv + l1
+        return total, kept
+
+    gs = None
+    if graph:
+        from localrf_amd.graph_step import CapturedIteration
+        gs = CapturedIteration(lt, W, H, batch // world, 16 // world, graph_loss, scalar_names=("reg_w",), optimize_poses=True)
+        gs.extra_signature = lambda: (phase["reg"],)
     n_added, last_add, it = 0, 0, 0
+    drift, drift_prev = LateScalar(), 0.0
+    all_losses = []
     losses, per_res, events, geo_vals, geo_curve = [], {}, [], [], []
     torch.cuda.reset_peak_memory_stats(dev)
     mem_marks = []
@@ -180,76 +242,89 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     res = int(lt.tensorfs[-1].gridSize[0])
     while training and (max_iters is None or it < max_iters):
         view_ids, ray_idx, (vv, pp) = data.sample(batch)
-        # indices go up through pinned memory: indexing a device tensor with host indices (or any pageable
-        # host->device copy, as train.py:352-358 does) blocks the host until the stream has drained
-        vv_d = vv.pin_memory().to(dev, non_blocking=True)
-        pp_d = pp.pin_memory().to(dev, non_blocking=True)
-        target = data.images[vv_d, pp_d].reshape(-1, 3)
-        if ddp:                                                        # this rank's views of the common batch
-            per = ray_idx.shape[0] // view_ids.shape[0]
-            ray_idx, v_sh = shard_views(ray_idx, view_ids, rank, world)
-            v0 = rank * v_sh.shape[0]
-            target = target[v0 * per:(v0 + v_sh.shape[0]) * per]
-            view_ids = v_sh
-        rgb_map, depth_map, directions, ij = lt(ray_idx, view_ids.tolist(), W, H, is_train=True, test_id=False)
-        loss = (0.25 * torch.abs(rgb_map - target)).mean()             # train.py:369-371, unit loss weights
-        total = loss
-        if lt.regularize and geo:                                      # train.py:357,385-423; opt.py: weights 1 and 0.1
+        if gs is not None:                                             # the captured iteration: the same schedule calls around one replay
+            if ddp:
+                ray_idx, view_ids = shard_views(ray_idx, view_ids, rank, world)
+            phase["reg"] = bool(lt.regularize)
             reg_w = lt.lr_factor ** lt.rf_iter[-1]
             start = max(data.active_frames_bounds[0] - 1, 0)
-            if ddp:
-                vsel = view_ids.pin_memory().to(dev, non_blocking=True)
-                psel = ray_idx.reshape(view_ids.shape[0], -1).pin_memory().to(dev, non_blocking=True)
-            else:
-                vsel, psel = vv_d[:, 0], pp_d
-            last = data.num_images - 1
-            fl = geo_losses.flow_loss(depth_map, directions, ij, lt.get_cam2world(starting_id=start), view_ids, start,
-                                      data.fwd_flow[vsel[:, None], psel], (vsel < last).float()[:, None].expand(psel.shape),
-                                      data.bwd_flow[vsel[:, None], psel], (vsel > 0).float()[:, None].expand(psel.shape),
-                                      lt.focal(W), lt.center(W, H))
-            dl = geo_losses.depth_loss(depth_map, data.invdepths[vsel[:, None], psel], view_ids.shape[0])
-            total = total + fl * 1.0 * reg_w / ((W + H) / 2) + dl * 0.1 * reg_w
-            geo_vals.append((float(fl.detach()), float(dl.detach())) if it % geo_every == 0 else None)
-            if it % geo_every == 0:                                    # the curve, phase by phase (profiles/r09*_geo_curve)
-                lo, hi = data.active_frames_bounds
-                with torch.no_grad():
-                    t_est = torch.stack([lt.t_c2w[f].detach() for f in range(lo, hi)]).cpu()
-                    step_est = (t_est[1:] - t_est[:-1]).norm(dim=-1).mean() if hi - lo > 1 else torch.zeros(())
-                    rel = (t_est - t_est[:1]) - (data.cam_t[lo:hi] - data.cam_t[lo:lo + 1])
-                    # diagnostics in plain torch (train.py:388-404 restated; not the loss that is optimised)
-                    c2w = lt.get_cam2world(starting_id=start).detach()
-                    fr = (vsel - start).long()
-                    nxt = (fr + 1).clamp(max=c2w.shape[0] - 1)
-                    Rn, tn = c2w[nxt, :3, :3], c2w[nxt, :3, 3]
-                    Rc, tc = c2w[fr, :3, :3], c2w[fr, :3, 3]
-                    dm = depth_map.detach().reshape(fr.shape[0], -1)
-                    pts = directions.detach().reshape(fr.shape[0], -1, 3) * dm[..., None]
-                    p_w = torch.einsum("vij,vnj->vni", Rc, pts) + tc[:, None]
-                    q = torch.einsum("vji,vnj->vni", Rn, p_w - tn[:, None])
-                    f_, c_ = lt.focal(W).detach(), lt.center(W, H).detach()
-                    # pts2px (utils/utils.py:15-21): x / z * f + cx - 0.5 with the camera looking down -z, y up
-                    px = torch.stack([q[..., 0] / -q[..., 2] * f_ + c_[0] - 0.5, -q[..., 1] / -q[..., 2] * f_ + c_[1] - 0.5], -1)
-                    pred = px - ij.detach().reshape(fr.shape[0], -1, 2).float()
-                    tgt = data.fwd_flow[vsel[:, None], psel]
-                    ok = (fr < c2w.shape[0] - 1)
-                    cosang = ((torch.einsum("vii->v", torch.einsum("vji,vjk->vik", Rc, Rn)) - 1) / 2).clamp(-1, 1)
-                    diag = {"pred_flow_mag": float(pred[ok].norm(dim=-1).mean()) if ok.any() else 0.0,
-                            "target_flow_mag": float(tgt[ok].norm(dim=-1).mean()) if ok.any() else 0.0,
-                            "fwd_err": float((pred - tgt)[ok].abs().sum(-1).mean()) if ok.any() else 0.0,
-                            "depth_median": float(dm.median()), "teacher_depth_median": float((1.0 / data.invdepths[vsel[:, None], psel]).median()),
-                            "rot_step_deg": float(torch.rad2deg(torch.acos(cosang))[ok].mean()) if ok.any() else 0.0}
-                geo_curve.append({**diag, "it": it, "field": len(lt.tensorfs) - 1, "rf_iter": int(lt.rf_iter[-1]), "refining": bool(lt.is_refining),
-                                  "reg_w": float(reg_w), "flow": geo_vals[-1][0], "depth": geo_vals[-1][1], "photo": float(loss.detach()),
-                                  "frames": [lo, hi], "res": int(lt.tensorfs[-1].gridSize[0]),
-                                  "pose_err": float(rel.norm(dim=-1).mean()), "est_step": float(step_est), "true_step": 0.04})
-        if lt.regularize:
-            tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)         # train.py:425-429, opt.py:111-113
-            total = total + tv + l1
-        can_add_rf = lt.optimizer_step(total, True)
+            pose_ids, tune = lt.step_begin(True, zero_grad=False)
+            kept = gs.step(view_ids.tolist(), ray_idx.numpy(), {"reg_w": reg_w}, all_poses_active=phase["reg"] and geo,
+                           pose_ids=pose_ids, tune_intrinsics=tune, start=start)
+            lt.step_schedule()
+            can_add_rf = lt.step_finish()
+            loss = kept["photo"]
+            if phase["reg"] and geo:
+                geo_vals.append((float(kept["flow"]), float(kept["depth"])) if it % geo_every == 0 else None)
+        else:
+            # indices go up through pinned memory: indexing a device tensor with host indices (or any pageable
+            # host->device copy, as train.py:352-358 does) blocks the host until the stream has drained
+            vv_d = vv.pin_memory().to(dev, non_blocking=True)
+            pp_d = pp.pin_memory().to(dev, non_blocking=True)
+            target = data.images[vv_d, pp_d].reshape(-1, 3)
+            if ddp:                                                        # this rank's views of the common batch
+                per = ray_idx.shape[0] // view_ids.shape[0]
+                ray_idx, v_sh = shard_views(ray_idx, view_ids, rank, world)
+                v0 = rank * v_sh.shape[0]
+                target = target[v0 * per:(v0 + v_sh.shape[0]) * per]
+                view_ids = v_sh
+            rgb_map, depth_map, directions, ij = lt(ray_idx, view_ids.tolist(), W, H, is_train=True, test_id=False)
+            loss = (0.25 * torch.abs(rgb_map - target)).mean()             # train.py:369-371, unit loss weights
+            total = loss
+            if lt.regularize and geo:                                      # train.py:357,385-423; opt.py: weights 1 and 0.1
+                reg_w = lt.lr_factor ** lt.rf_iter[-1]
+                start = max(data.active_frames_bounds[0] - 1, 0)
+                if ddp:
+                    vsel = view_ids.pin_memory().to(dev, non_blocking=True)
+                    psel = ray_idx.reshape(view_ids.shape[0], -1).pin_memory().to(dev, non_blocking=True)
+                else:
+                    vsel, psel = vv_d[:, 0], pp_d
+                fl, dl = geometric_terms(lt, data, depth_map, directions, ij, lt.get_cam2world(starting_id=start), view_ids, start, vsel, psel, W, H)
+                total = total + fl * 1.0 * reg_w / ((W + H) / 2) + dl * 0.1 * reg_w
+                geo_vals.append((float(fl.detach()), float(dl.detach())) if it % geo_every == 0 else None)
+                if it % geo_every == 0:                                    # the curve, phase by phase (profiles/r09*_geo_curve)
+                    lo, hi = data.active_frames_bounds
+                    with torch.no_grad():
+                        t_est = torch.stack([lt.t_c2w[f].detach() for f in range(lo, hi)]).cpu()
+                        step_est = (t_est[1:] - t_est[:-1]).norm(dim=-1).mean() if hi - lo > 1 else torch.zeros(())
+                        rel = (t_est - t_est[:1]) - (data.cam_t[lo:hi] - data.cam_t[lo:lo + 1])
+                        # diagnostics in plain torch (train.py:388-404 restated; not the loss that is optimised)
+                        c2w = lt.get_cam2world(starting_id=start).detach()
+                        fr = (vsel - start).long()
+                        nxt = (fr + 1).clamp(max=c2w.shape[0] - 1)
+                        Rn, tn = c2w[nxt, :3, :3], c2w[nxt, :3, 3]
+                        Rc, tc = c2w[fr, :3, :3], c2w[fr, :3, 3]
+                        dm = depth_map.detach().reshape(fr.shape[0], -1)
+                        pts = directions.detach().reshape(fr.shape[0], -1, 3) * dm[..., None]
+                        p_w = torch.einsum("vij,vnj->vni", Rc, pts) + tc[:, None]
+                        q = torch.einsum("vji,vnj->vni", Rn, p_w - tn[:, None])
+                        f_, c_ = lt.focal(W).detach(), lt.center(W, H).detach()
+                        # pts2px (utils/utils.py:15-21): x / z * f + cx - 0.5 with the camera looking down -z, y up
+                        px = torch.stack([q[..., 0] / -q[..., 2] * f_ + c_[0] - 0.5, -q[..., 1] / -q[..., 2] * f_ + c_[1] - 0.5], -1)
+                        pred = px - ij.detach().reshape(fr.shape[0], -1, 2).float()
+                        tgt = data.fwd_flow[vsel[:, None], psel]
+                        ok = (fr < c2w.shape[0] - 1)
+                        cosang = ((torch.einsum("vii->v", torch.einsum("vji,vjk->vik", Rc, Rn)) - 1) / 2).clamp(-1, 1)
+                        diag = {"pred_flow_mag": float(pred[ok].norm(dim=-1).mean()) if ok.any() else 0.0,
+                                "target_flow_mag": float(tgt[ok].norm(dim=-1).mean()) if ok.any() else 0.0,
+                                "fwd_err": float((pred - tgt)[ok].abs().sum(-1).mean()) if ok.any() else 0.0,
+                                "depth_median": float(dm.median()), "teacher_depth_median": float((1.0 / data.invdepths[vsel[:, None], psel]).median()),
+                                "rot_step_deg": float(torch.rad2deg(torch.acos(cosang))[ok].mean()) if ok.any() else 0.0}
+                    geo_curve.append({**diag, "it": it, "field": len(lt.tensorfs) - 1, "rf_iter": int(lt.rf_iter[-1]), "refining": bool(lt.is_refining),
+                                      "reg_w": float(reg_w), "flow": geo_vals[-1][0], "depth": geo_vals[-1][1], "photo": float(loss.detach()),
+                                      "frames": [lo, hi], "res": int(lt.tensorfs[-1].gridSize[0]),
+                                      "pose_err": float(rel.norm(dim=-1).mean()), "est_step": float(step_est), "true_step": 0.04})
+            if lt.regularize:
+                tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)         # train.py:425-429, opt.py:111-113
+                total = total + tv + l1
+            can_add_rf = lt.optimizer_step(total, True)
         training |= data.active_frames_bounds[1] != data.num_images
         if not lt.is_refining:                                         # train.py:438-460
+            if n_added > n_overlap:                                    # the drift as of the previous iteration (LateScalar)
+                drift_prev = drift.value()
+                drift.request(lt.get_dist_to_last_rf())
             should_refine = (not data.has_left_frames()) or (n_added > n_overlap and (
-                float(lt.get_dist_to_last_rf()) > max_drift
+                drift_prev > max_drift
                 or data.active_frames_bounds[1] - data.active_frames_bounds[0] >= n_max_frames))
             if should_refine and (it - last_add) >= add_frames_every:
                 lt.is_refining = True
@@ -271,6 +346,8 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                 events.append((it, "append_rf"))
             else:
                 training = False
+        if record_all:                                                 # (tests: every iteration's photometric loss; synchronises)
+            all_losses.append(float(loss.detach()))
         it += 1
         new_res = int(lt.tensorfs[-1].gridSize[0])
         if new_res != res or not training or (max_iters is not None and it == max_iters):
@@ -307,6 +384,8 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             "geometric_losses": {"iterations_with_them": len(geo_vals), "flow_first_last": [v[0] for v in geo_vals if v][:1] + [v[0] for v in geo_vals if v][-1:],
                                  "depth_first_last": [v[1] for v in geo_vals if v][:1] + [v[1] for v in geo_vals if v][-1:]},
             "geo_curve": geo_curve, "geo_by_field": geo_by_field(geo_curve),
+            "graph": (dict(gs.stats) if gs is not None else None), "all_losses": all_losses,
+            "param_checksum": float(sum(p.detach().double().abs().sum() for p in lt.parameters())),
             "checkpoint_roundtrip": bool(same), "checkpoint_keys_follow_reference": bool(keys_ok), "world": world,
             "final_resolution": res}
 
@@ -319,6 +398,7 @@ def main():
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--n-max-frames", type=int, default=12, help="frames per field before refinement (the reference: 100)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--graph", action="store_true", help="the iteration as one replayed hipGraph (localrf_amd/graph_step.py)")
     ap.add_argument("--no-geo", action="store_true", help="without the optical-flow / monocular-depth losses")
     ap.add_argument("--backend", default="nccl", help="under torchrun: nccl (= RCCL, one rank per GPU) or gloo (ranks may share a GPU)")
     args = ap.parse_args()
@@ -342,7 +422,7 @@ def main():
     if ddp and first:
         bar()
     out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
-              dev=f"cuda:{local}", ddp=ddp, geo=not args.no_geo, log=lambda m: print(m, file=sys.stderr, flush=True))
+              dev=f"cuda:{local}", ddp=ddp, geo=not args.no_geo, graph=args.graph, log=lambda m: print(m, file=sys.stderr, flush=True))
     if not ddp or int(os.environ["RANK"]) == 0:
         print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)))
         if args.json:

@@ -1223,3 +1223,30 @@ def test_gradient_buckets_become_final_in_order_and_can_be_awaited_separately(bu
         assert float(snap.abs().max()) > 0
     assert N.lib().lrf_render_bwd_wait(3, C.c_void_p(side.cuda_stream)) != 0
     assert b"bucket" in N.lib().lrf_last_error()
+
+
+def test_captured_iteration_matches_the_eager_loop():
+    """the training iteration without the host in it.  scripts/train_synth.py with graph=True runs
+    every iteration as one replayed hipGraph (localrf_amd/graph_step.py: pose assembly, rays, field forward, losses, backward,
+    all Adam launches, layout refresh), re-captured at every lifecycle event; the same seeds through the eager loop must
+    give the same trajectory -- the photometric loss of every iteration (the scatter kernels' atomics make even two eager
+    runs differ in the last bits, and a training trajectory amplifies that: early iterations tight, the end loose), the same
+    lifecycle events, and nearly all iterations must have been replays."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import train_synth
+    kw = dict(frames=9, final=80, iters_per_frame=30, n_max_frames=5, dev=DEV, geo_every=5, record_all=True)
+    eager = train_synth.run(graph=False, **kw)
+    graph = train_synth.run(graph=True, **kw)
+    assert graph["iterations"] == eager["iterations"] and graph["events"] == eager["events"], (graph["events"], eager["events"])
+    assert graph["fields"] == eager["fields"] and graph["frames"] == eager["frames"] and graph["final_resolution"] == eager["final_resolution"]
+    a, b = np.array(eager["all_losses"]), np.array(graph["all_losses"])
+    assert a.shape == b.shape and np.isfinite(b).all()
+    assert np.abs(a[:10] - b[:10]).max() <= 2e-5 * np.abs(a[:10]).max(), (a[:10], b[:10])
+    assert np.abs(a[:60] - b[:60]).max() <= 5e-3 * np.abs(a[:60]).max(), np.abs(a[:60] - b[:60]).max()
+    assert abs(a[-20:].mean() - b[-20:].mean()) <= 0.15 * a[-20:].mean(), (a[-20:].mean(), b[-20:].mean())
+    st = graph["graph"]
+    assert st["replays"] + st["eager"] == graph["iterations"] and st["captures"] >= 3, st
+    assert st["replays"] >= 0.6 * graph["iterations"], st
+    assert graph["checkpoint_roundtrip"] and graph["geometric_losses"]["iterations_with_them"] > 0
