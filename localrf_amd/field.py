@@ -412,7 +412,11 @@ class TensorVMSplit(torch.nn.Module):
             vol = mask.alpha_volume.detach()
             f.alpha_vol = vol.data_ptr()
             f.alpha_dim[:] = [vol.shape[-1], vol.shape[-2], vol.shape[-3]]
-            f.alpha_aabb[:] = [float(v) for v in mask.aabb.detach().reshape(-1).tolist()]
+            mk = (mask.aabb.data_ptr(), mask.aabb._version)
+            if getattr(mask, "_aabb_host_key", None) != mk:       # read back once per mask (a rebuild makes a new mask): _c_field can
+                mask._aabb_host = [float(v) for v in mask.aabb.detach().reshape(-1).tolist()]   # then run inside a stream capture
+                mask._aabb_host_key = mk
+            f.alpha_aabb[:] = mask._aabb_host
         else:
             f.alpha_vol = None
             f.alpha_dim[:] = [0, 0, 0]
@@ -515,7 +519,9 @@ class TensorVMSplit(torch.nn.Module):
         flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
         grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
         g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
-        self._grad_flat = {"flat": flat, "params": keep, "views": grads, "n_param": offs[-2],
+        # (the view tensors themselves are NOT kept: autograd adopts an incoming gradient as .grad without a copy only while
+        # nobody else holds a reference to it)
+        self._grad_flat = {"flat": flat, "params": keep, "offs": offs[:len(keep)], "n_param": offs[-2],
                            "dens": (offs[0], offs[6]), "app": (offs[6], offs[12]), "net": (offs[12], offs[-2]),
                            "app_planes": (offs[6], offs[7], offs[8]),
                            "events": bool(events), "plane_events": bool(plane_events)}
@@ -547,13 +553,13 @@ class TensorVMSplit(torch.nn.Module):
         if saved_ws is not None:                 # filled by lrf_render_fwd_train for exactly this call
             ws = saved_ws
             flags = flags | N.LRF_FLAG_ROWS_SAVED
-        if plane_events:
-            flags = flags | N.LRF_FLAG_PLANE_EVENTS
         else:
             if getattr(self, "_ws_bwd", None) is None or self._ws_bwd.numel() < nbytes or self._ws_bwd.device != dev:
                 self._ws_bwd = None
                 self._ws_bwd = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             ws = self._ws_bwd
+        if plane_events:
+            flags = flags | N.LRF_FLAG_PLANE_EVENTS
         f = self._c_field()
         st = torch.cuda.current_stream(dev).cuda_stream
         g_rgb_c = g_rgb.contiguous().float()         # named: must outlive the launch below
@@ -592,7 +598,9 @@ class TensorVMSplit(torch.nn.Module):
             return None
         base = gf["flat"].untyped_storage().data_ptr()
         src, dst, who = [], [], []
-        for p, v in zip(gf["params"], gf["views"]):
+        flat = gf["flat"]
+        for p, o in zip(gf["params"], gf["offs"]):
+            v = flat[o:o + p.numel()].view(p.shape)
             if not p.requires_grad:
                 continue
             if p.grad is None:                       # (no gradient reached it: nothing to bring back, nothing is invented)

@@ -96,7 +96,7 @@ class CapturedIteration:
     def _signature(self, start, pose_ids, tune_intrinsics):
         lt = self.scene
         f = lt.tensorfs[-1]
-        return (len(lt.tensorfs), len(lt.r_c2w), tuple(int(g) for g in f.gridSize.tolist()), int(f.nSamples), id(f.alphaMask),
+        return (len(lt.tensorfs), len(lt.r_c2w), tuple(int(g) for g in f._grid_host), int(f.nSamples), id(f.alphaMask),
                 None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr(), id(lt.rf_optimizer), bool(lt.is_refining),
                 int(start), tuple(pose_ids), bool(tune_intrinsics), lt.grad_sync is not None,
                 tuple(p.data_ptr() for p in f._param_list())) + tuple(self.extra_signature())

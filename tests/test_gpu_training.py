@@ -1221,7 +1221,10 @@ def test_gradient_buckets_become_final_in_order_and_can_be_awaited_separately(bu
     for (a, b), snap in zip(segs, snaps):
         assert torch.equal(snap, flat[a:b])
         assert float(snap.abs().max()) > 0
-    assert N.lib().lrf_render_bwd_wait(3, C.c_void_p(side.cuda_stream)) != 0
+    for which in (3, 4):                                     # appearance planes 0 / 1 alone: without per-plane passes the same point as 2
+        f._wait_bwd_bucket(which, side)
+    assert [c[0] for c in f.grad_chunks()] == [0, 1, 2] and f.grad_events_valid()
+    assert N.lib().lrf_render_bwd_wait(5, C.c_void_p(side.cuda_stream)) != 0
     assert b"bucket" in N.lib().lrf_last_error()
 
 
