@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 5      /* 5: LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 5      /* 5: LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -366,6 +366,19 @@ int lrf_depth_loss_fwd(const float* depth, const float* gt, int32_t V, int32_t n
                        float* stats, float* view_sum, void* stream);
 int lrf_depth_loss_bwd(const float* depth, const float* gt, int32_t V, int32_t n, const float* arr_out, const float* stats,
                        const float* g_loss /* device [1] */, float scale, float* g_depth, void* stream);
+
+/* Photometric loss of train.py:369-371: loss = mean over [R,3] of 0.25 |rgb - target| w_i / mean(w), one launch each way.
+ * w [R] or NULL (unit weights); w_mean: device [1] or NULL (= the mean of w over this batch; under ray sharding the batch-global
+ * mean).  loss, aux: device [1] each; aux carries 0.25 / (mean(w) 3 R) to the backward.  g_rgb [R,3] = g_loss[0] d loss / d rgb. */
+int lrf_photo_loss_fwd(const float* rgb, const float* target, const float* w, const float* w_mean, int32_t R, float* loss, float* aux, void* stream);
+int lrf_photo_loss_bwd(const float* rgb, const float* target, const float* w, const float* aux, const float* g_loss /* device [1] */,
+                       int32_t R, float* g_rgb, void* stream);
+
+/* Row gather out[v,:] = src[idx[v],:] (src [F,K], idx int64 [V], negative ids count from the end) and its backward
+ * g_src[f,:] = sum_{v: idx[v]=f} g_out[v,:] in v order (no atomics): the per-view poses / exposures a batch picks out of the per-frame
+ * tables (local_tensorfs.py:292-299 stacks the sampled frames' parameters; :496 indexes the stacked exposures). */
+int lrf_rows_gather(const float* src, const int64_t* idx, int32_t V, int32_t K, int32_t F, float* out, void* stream);
+int lrf_rows_gather_bwd(const float* g_out, const int64_t* idx, int32_t V, int32_t K, int32_t F, float* g_src, void* stream);
 
 #ifdef __cplusplus
 }

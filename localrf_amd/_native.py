@@ -101,6 +101,10 @@ SYMBOLS = {
     "lrf_sample_ray_contracted": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_z_schedule": (C.c_int, [C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_adam_step": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "lrf_photo_loss_fwd": (C.c_int, [_f, _f, _f, _f, C.c_int32, _f, _f, C.c_void_p]),
+    "lrf_photo_loss_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, _f, C.c_void_p]),
+    "lrf_rows_gather": (C.c_int, [_f, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f, C.c_void_p]),
+    "lrf_rows_gather_bwd": (C.c_int, [_f, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_adam_step_dev": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, _f, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "lrf_density_l1_workspace": (C.c_size_t, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lrf_density_l1_fwd": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -59,6 +59,10 @@ class SceneLifecycle(torch.nn.Module):
         # data-parallel hook (localrf_amd/dist.py): called between backward and the optimiser steps of
         # optimizer_step with this module; None = single process, as the reference
         self.grad_sync = None
+        # extension: True = focal() / center() are computed without a tape (the intrinsics' .grad is left alone).  The
+        # reference always differentiates through them and reads the result only while it tunes the intrinsics
+        # (local_tensorfs.py:218-222); a captured iteration sets this when they are not tuned
+        self.freeze_intrinsics = False
         # lower bound of the rays per field call in forward (see there); 1 = chunk exactly as the reference
         self.min_chunk = 65536
 

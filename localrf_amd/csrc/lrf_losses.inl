@@ -439,3 +439,102 @@ extern "C" int lrf_depth_loss_bwd(const float* depth, const float* gt, int32_t V
   LRF_HIP(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------- photometric loss, row gather
+// The photometric loss of train.py:369-371, loss = mean_{i,c}(0.25 |rgb - target| w_i / mean(w)), as ONE launch each way
+// (the reference -- and autograd through it -- is a dozen elementwise / reduction launches of 5 us each on a [4096, 3] batch:
+// at the early grid sizes of the progressive schedule that is a tenth of the iteration).  w [R] or NULL (ones); w_mean
+// device [1] or NULL (the mean of w over THIS batch; under ray sharding the caller passes the batch-global mean,
+// localrf_amd.dist.global_mean).  One workgroup, fixed summation order: the value does not depend on anything but the inputs.
+// aux[0] = 0.25 / (mean(w) 3 R) is what the backward multiplies sign(rgb - target) w_i with.
+namespace lrf {
+__global__ __launch_bounds__(1024) void k_photo_loss_fwd(const float* __restrict__ rgb, const float* __restrict__ target, const float* __restrict__ w,
+                                                         const float* __restrict__ w_mean, int R, float* __restrict__ loss, float* __restrict__ aux) {
+  __shared__ float s_red[1024];
+  __shared__ float s_wm;
+  const int t = threadIdx.x;
+  if (w && !w_mean) {
+    float a = 0.0f;
+    for (int i = t; i < R; i += 1024) a += w[i];
+    s_red[t] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (t < s) s_red[t] += s_red[t + s]; __syncthreads(); }
+    if (t == 0) s_wm = s_red[0] / (float)R;
+    __syncthreads();
+  } else if (t == 0) {
+    s_wm = w_mean ? w_mean[0] : 1.0f;
+  }
+  __syncthreads();
+  float a = 0.0f;
+  for (int i = t; i < 3 * R; i += 1024) a += fabsf(rgb[i] - target[i]) * (w ? w[i / 3] : 1.0f);
+  __syncthreads();
+  s_red[t] = a;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) { if (t < s) s_red[t] += s_red[t + s]; __syncthreads(); }
+  if (t == 0) {
+    const float sc = 0.25f / (s_wm * (float)(3 * R));
+    aux[0] = sc;
+    loss[0] = s_red[0] * sc;
+  }
+}
+__global__ void k_photo_loss_bwd(const float* __restrict__ rgb, const float* __restrict__ target, const float* __restrict__ w,
+                                 const float* __restrict__ aux, const float* __restrict__ g_loss, int R, float* __restrict__ g_rgb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * R) return;
+  const float d = rgb[i] - target[i];
+  const float sg = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);       // torch's abs backward: sign(x), 0 at 0
+  g_rgb[i] = g_loss[0] * aux[0] * (w ? w[i / 3] : 1.0f) * sg;
+}
+// out[v, :] = src[idx[v], :] (K floats per row) and its backward g_src[f, :] = sum over the v with idx[v] == f of g_out[v, :],
+// summed in v order by one thread per output element: no atomics, no zero fill, the same bits every time.  For the per-view rows a
+// training batch picks out of per-frame tables (poses [F,12], exposures [N,9]): torch's index_select / index backward are an
+// index_add / a sort-based index_put of 8 launches and 35 us for sixteen rows.
+__global__ void k_rows_gather(const float* __restrict__ src, const long long* __restrict__ idx, int V, int K, int F, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * K) return;
+  long long f = idx[i / K];
+  if (f < 0) f += F;
+  out[i] = (f >= 0 && f < F) ? src[f * K + i % K] : 0.0f;
+}
+__global__ void k_rows_gather_bwd(const float* __restrict__ g_out, const long long* __restrict__ idx, int V, int K, int F, float* __restrict__ g_src) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * K) return;
+  const int f = i / K, k = i % K;
+  float a = 0.0f;
+  for (int v = 0; v < V; ++v) {
+    long long q = idx[v];
+    if (q < 0) q += F;
+    if (q == f) a += g_out[v * K + k];
+  }
+  g_src[i] = a;
+}
+}  // namespace lrf
+
+extern "C" int lrf_photo_loss_fwd(const float* rgb, const float* target, const float* w, const float* w_mean, int32_t R, float* loss, float* aux, void* stream) {
+  using namespace lrf;
+  if (!rgb || !target || !loss || !aux || R <= 0) return set_err("lrf_photo_loss_fwd: bad argument");
+  hipLaunchKernelGGL(k_photo_loss_fwd, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), rgb, target, w, w_mean, R, loss, aux);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int lrf_photo_loss_bwd(const float* rgb, const float* target, const float* w, const float* aux, const float* g_loss, int32_t R, float* g_rgb, void* stream) {
+  using namespace lrf;
+  if (!rgb || !target || !aux || !g_loss || !g_rgb || R <= 0) return set_err("lrf_photo_loss_bwd: bad argument");
+  hipLaunchKernelGGL(k_photo_loss_bwd, dim3((3 * R + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rgb, target, w, aux, g_loss, R, g_rgb);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int lrf_rows_gather(const float* src, const int64_t* idx, int32_t V, int32_t K, int32_t F, float* out, void* stream) {
+  using namespace lrf;
+  if (!src || !idx || !out || V <= 0 || K <= 0 || F <= 0) return set_err("lrf_rows_gather: bad argument");
+  hipLaunchKernelGGL(k_rows_gather, dim3((V * K + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, reinterpret_cast<const long long*>(idx), V, K, F, out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int lrf_rows_gather_bwd(const float* g_out, const int64_t* idx, int32_t V, int32_t K, int32_t F, float* g_src, void* stream) {
+  using namespace lrf;
+  if (!g_out || !idx || !g_src || V <= 0 || K <= 0 || F <= 0) return set_err("lrf_rows_gather_bwd: bad argument");
+  hipLaunchKernelGGL(k_rows_gather_bwd, dim3((F * K + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g_out, reinterpret_cast<const long long*>(idx), V, K, F, g_src);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}

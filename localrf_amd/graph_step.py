@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from .optim import StaticAdamPlan
+from .scene_ops import rows_gather
 
 _NP = {torch.int64: np.int64, torch.int32: np.int32, torch.float32: np.float32}
 
@@ -126,6 +127,7 @@ class CapturedIteration:
         self.u1 = torch.empty(1, h, dtype=torch.float32, device=dev)
         self.u2 = torch.empty(1, h, dtype=torch.float32, device=dev)
         self.start = int(start)
+        self._tune_intrinsics = bool(tune_intrinsics)
         self._graphs = None
         self._eager_done = False
 
@@ -143,15 +145,20 @@ class CapturedIteration:
                 c2w_r = lt.get_cam2world(starting_id=self.start)
             finally:
                 lt.reference_cross = True
-        c2w = c2w_r.index_select(0, d["frame"])
+        c2w = rows_gather(c2w_r, d["frame"])
         field.jitter_override = (self.u1, self.u2)
+        frozen = lt.freeze_intrinsics
+        lt.freeze_intrinsics = frozen or not self._tune_intrinsics   # nobody reads d/d(focal, centre) unless they are tuned
         try:
-            rgb, depth, directions, ij = lt(d["ray_ids"], d["view_ids"], self.W, self.H, is_train=True, cam2world=c2w, test_id=False)
+            # world2rf is a constant of the scene (never in an optimiser): no gradient is formed for it here
+            rgb, depth, directions, ij = lt(d["ray_ids"], d["view_ids"], self.W, self.H, is_train=True, cam2world=c2w, test_id=False,
+                                            world2rf=[w.detach() for w in lt.world2rf])
+            sc = {n: d["scalars"][i] for i, n in enumerate(self.scalar_names)}
+            total, kept = self.loss_fn(rgb, depth, directions, ij,
+                                       StepInputs(d["ray_ids"], d["view_ids"], d["frame"], sc, c2w_all, self.start, self.n_views))
         finally:
             field.jitter_override = None
-        sc = {n: d["scalars"][i] for i, n in enumerate(self.scalar_names)}
-        total, kept = self.loss_fn(rgb, depth, directions, ij,
-                                   StepInputs(d["ray_ids"], d["view_ids"], d["frame"], sc, c2w_all, self.start, self.n_views))
+            lt.freeze_intrinsics = frozen
         total.backward()
         self.kept = {k: v.detach() for k, v in kept.items()}
 

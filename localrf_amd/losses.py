@@ -67,6 +67,8 @@ class _FlowLossFn(torch.autograd.Function):
         g = _f32c(g_loss).reshape(1)
         N.check(N.lib().lrf_flow_loss_bwd(C.byref(a), N.ptr(arr), N.ptr(g), 1.0 / float(V * n), N.ptr(g_depth), N.ptr(g_dirs),
                                           N.ptr(g_c2w), N.ptr(g_intr), N.ptr(ws), _stream(dev)), "lrf_flow_loss_bwd")
+        if not (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):   # intrinsics without a tape (LocalTensorfs.freeze_intrinsics)
+            return g_depth, g_dirs, g_c2w, None, None, None, None, None, None, None, None, None, None
         s = g_intr.sum(0)
         return g_depth, g_dirs, g_c2w, s[0:1].reshape(ctx.focal_shape), s[1:3], None, None, None, None, None, None, None, None
 
@@ -144,3 +146,40 @@ def depth_loss(depth_map, invdepths, n_views, quantile=0.8, return_arr=False):
         raise ValueError(f"at most {N.LRF_LOSS_MAX_PER_VIEW} rays per view")
     loss, arr = _DepthLossFn.apply(depth, invdepths.reshape(depth.shape), quantile)
     return (loss, arr) if return_arr else loss
+
+
+class _PhotoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, target, weights, w_mean):
+        r, t = _f32c(rgb), _f32c(target)
+        w = None if weights is None else _f32c(weights).reshape(-1)
+        wm = None if w_mean is None else _f32c(w_mean).reshape(-1)
+        dev = r.device
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        N.check(N.lib().lrf_photo_loss_fwd(N.ptr(r), N.ptr(t), N.ptr(w), N.ptr(wm), r.shape[0], N.ptr(out[0:1]), N.ptr(out[1:2]), _stream(dev)),
+                "lrf_photo_loss_fwd")
+        ctx.keep = (r.detach(), t.detach(), w, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        r, t, w, out = ctx.keep
+        g = _f32c(g_loss).reshape(1)
+        g_rgb = torch.empty_like(r)
+        N.check(N.lib().lrf_photo_loss_bwd(N.ptr(r), N.ptr(t), N.ptr(w), N.ptr(out[1:2]), N.ptr(g), r.shape[0], N.ptr(g_rgb), _stream(r.device)),
+                "lrf_photo_loss_bwd")
+        return g_rgb, None, None, None
+
+
+def photometric_loss(rgb_map, rgb_train, loss_weights=None, weights_mean=None):
+    """train.py:369-371: `(0.25 * |rgb_map - rgb_train| * loss_weights / loss_weights.mean()).mean()` as one launch each way
+    (differentiable in rgb_map).  rgb_map, rgb_train [R,3]; loss_weights [R] / [R,1] or None (ones); weights_mean: a device
+    scalar to divide by instead of this batch's own mean -- under ray sharding the batch-global mean
+    (localrf_amd.dist.global_mean), so that an N-rank step equals the 1-rank step."""
+    if rgb_map.device.type != "cuda":
+        raise N.NativeError("localrf_amd.losses: tensors must be on the GPU (there is no CPU fallback)")
+    if rgb_map.dim() != 2 or rgb_map.shape[1] != 3 or rgb_train.shape != rgb_map.shape:
+        raise ValueError("rgb_map and rgb_train must both be [R,3]")
+    if loss_weights is not None and loss_weights.numel() != rgb_map.shape[0]:
+        raise ValueError("loss_weights must hold one weight per ray")
+    return _PhotoLossFn.apply(rgb_map, rgb_train, loss_weights, weights_mean)

@@ -20,7 +20,7 @@ import torch
 from ._native import NativeError
 from .compat_lifecycle import SceneLifecycle
 from .rays import sixD_to_mtx
-from .scene_ops import pose_assemble, scene_blend, scene_forward, scene_rays
+from .scene_ops import pose_assemble, rows_gather, scene_blend, scene_forward, scene_rays
 
 
 def _upload_ids(ids, dev):
@@ -58,9 +58,18 @@ class LocalTensorfs(SceneLifecycle):
         return torch.cat([sixD_to_mtx(torch.stack(r, 0), self.reference_cross), torch.stack(t, 0)[..., None]], dim=-1)
 
     def focal(self, W):
+        if self.freeze_intrinsics:                              # no optimiser reads their gradients this iteration: no backward chain
+            with torch.no_grad():
+                return self.init_focal * self.focal_offset * W / self.W
         return self.init_focal * self.focal_offset * W / self.W
 
     def center(self, W, H):
+        if self.freeze_intrinsics:
+            with torch.no_grad():
+                return self._center(W, H)
+        return self._center(W, H)
+
+    def _center(self, W, H):
         key = (W, H, self.center_rel.device)
         wh = getattr(self, "_wh_cache", {}).get(key)
         if wh is None:                          # the reference uploads [W, H] on every call (:380)
@@ -183,7 +192,10 @@ class LocalTensorfs(SceneLifecycle):
             nxt[prev == view_ids] = len(self.exposure) - 2
             stacked = torch.stack(list(self.exposure), dim=0).clone().detach()
             return (stacked[prev] + stacked[nxt]) / 2
-        return torch.stack(list(self.exposure), dim=0)[view_ids]
+        stacked = torch.stack(list(self.exposure), dim=0)
+        if stacked.is_cuda and view_ids.is_cuda and view_ids.dtype == torch.int64:
+            return rows_gather(stacked, view_ids)               # [view_ids] and its index_put backward in one launch each way
+        return stacked[view_ids]
 
     def _ones(self, n, dev):
         key = (n, str(dev))

@@ -62,10 +62,10 @@ class _SceneRaysFn(torch.autograd.Function):
                                            W, H, fov360, N.ptr(g_rays), N.ptr(g_dirs), N.ptr(g_c2w),
                                            N.ptr(g_intr), N.ptr(g_w2rf), _stream(dev)), "lrf_scene_rays_bwd")
         g_focal = g_center = None
-        if not fov360:
+        if not fov360 and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
             s = g_intr.sum(0)
             g_focal, g_center = s[0:1], s[1:3]
-        return None, g_c2w, g_w2rf.sum(0), g_focal, g_center, None, None, None, None
+        return None, g_c2w, (g_w2rf.sum(0) if ctx.needs_input_grad[2] else None), g_focal, g_center, None, None, None, None
 
 
 class _SceneBlendFn(torch.autograd.Function):
@@ -218,3 +218,37 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
                                       N.ptr(bw), N.ptr(ex), N.ptr(rays), N.ptr(rgb_f), N.ptr(dep_f), N.ptr(dirs), ij.data_ptr(),
                                       N.ptr(rgbs), N.ptr(depth), _stream(dev)), "lrf_scene_fwd")
     return rgbs, depth, dirs, ij
+
+
+class _RowsGatherFn(torch.autograd.Function):
+    """out[v] = src[idx[v]] through lrf_rows_gather / _bwd (one launch each way, deterministic sums for repeated ids)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        s = _f32c(src)
+        F, K = s.shape
+        V = idx.shape[0]
+        out = torch.empty(V, K, dtype=torch.float32, device=s.device)
+        N.check(N.lib().lrf_rows_gather(N.ptr(s), idx.data_ptr(), V, K, F, N.ptr(out), _stream(s.device)), "lrf_rows_gather")
+        ctx.save_for_backward(idx)
+        ctx.shape = (F, K)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (idx,) = ctx.saved_tensors
+        F, K = ctx.shape
+        g = _f32c(g_out)
+        g_src = torch.empty(F, K, dtype=torch.float32, device=g.device)
+        N.check(N.lib().lrf_rows_gather_bwd(N.ptr(g), idx.data_ptr(), idx.shape[0], K, F, N.ptr(g_src), _stream(g.device)), "lrf_rows_gather_bwd")
+        return g_src, None
+
+
+def rows_gather(src, idx):
+    """src [F, ...] indexed by a DEVICE int64 vector idx [V] along dim 0 -> [V, ...]; differentiable in src.  What
+    torch.stack(params)[view_ids] (local_tensorfs.py:292-299,496) costs autograd eight launches for."""
+    if not (src.is_cuda and idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 1):
+        raise N.NativeError("localrf_amd: rows_gather takes a device tensor and a device int64 index vector")
+    F = src.shape[0]
+    out = _RowsGatherFn.apply(src.reshape(F, -1), idx.contiguous())
+    return out.reshape((idx.shape[0],) + tuple(src.shape[1:]))

@@ -177,7 +177,7 @@ def geometric_terms(lt, data, depth_map, directions, ij, cam2world_all, view_ids
 
 
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, keep=None):
     from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -215,7 +215,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
         V = inp.n_views
         psel = inp.ray_ids.reshape(V, -1)
         target = data.images[inp.view_ids[:, None], psel].reshape(-1, 3)
-        loss = (0.25 * torch.abs(rgb_map - target)).mean()
+        loss = geo_losses.photometric_loss(rgb_map, target)
         total, kept = loss, {"photo": loss}
         if phase["reg"] and geo:
             fl, dl = geometric_terms(lt, data, depth_map, directions, ij, inp.cam2world_all, inp.view_ids, inp.start, inp.view_ids, psel, W, H)
@@ -269,7 +269,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                 target = target[v0 * per:(v0 + v_sh.shape[0]) * per]
                 view_ids = v_sh
             rgb_map, depth_map, directions, ij = lt(ray_idx, view_ids.tolist(), W, H, is_train=True, test_id=False)
-            loss = (0.25 * torch.abs(rgb_map - target)).mean()             # train.py:369-371, unit loss weights
+            loss = geo_losses.photometric_loss(rgb_map, target)            # train.py:369-371, unit loss weights (one launch each way)
             total = loss
             if lt.regularize and geo:                                      # train.py:357,385-423; opt.py: weights 1 and 0.1
                 reg_w = lt.lr_factor ** lt.rf_iter[-1]
@@ -364,6 +364,8 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             if log and rank == 0:
                 log(f"it {it} loss {losses[-1]:.4f} res {res} fields {len(lt.tensorfs)} frames {len(lt.r_c2w)}")
     torch.cuda.synchronize(dev)
+    if keep is not None:                                               # (probes: the live objects of the run)
+        keep.update(scene=lt, captured=gs, data=data)
     # checkpoint round trip into the reference's key set (local_tensorfs.py:326-356)
     sd = {k: v.detach().clone() for k, v in lt.state_dict().items()}
     lt2 = quiet(LocalTensorfs, **{**lt.get_kwargs(), "device": dev})

@@ -1253,3 +1253,38 @@ def test_captured_iteration_matches_the_eager_loop():
     assert st["replays"] + st["eager"] == graph["iterations"] and st["captures"] >= 3, st
     assert st["replays"] >= 0.6 * graph["iterations"], st
     assert graph["checkpoint_roundtrip"] and graph["geometric_losses"]["iterations_with_them"] > 0
+
+
+def test_photometric_loss_and_row_gather_vs_torch_expressions():
+    """lrf_photo_loss_* against train.py:369-371 written in torch (value and d/d rgb, with and without weights, with a
+    supplied batch-global mean); lrf_rows_gather* against torch.stack(params)[view_ids] with repeated and negative ids
+    (local_tensorfs.py:292-299,496) -- values bit-identical, gradients to fp32 summation order."""
+    from localrf_amd.losses import photometric_loss
+    from localrf_amd.scene_ops import rows_gather
+    g = torch.Generator().manual_seed(5)
+    R = 4096
+    rgb = torch.rand(R, 3, generator=g).to(DEV).requires_grad_(True)
+    tgt = torch.rand(R, 3, generator=g).to(DEV)
+    with torch.no_grad():
+        tgt[:7] = rgb[:7]                                           # exact zeros of |.|: sign(0) = 0 in torch's backward
+    w = (0.1 + 3 * torch.rand(R, 1, generator=g)).to(DEV)
+    wm = torch.tensor(1.7, device=DEV)
+    for weights, mean in ((None, None), (w, None), (w, wm)):
+        ref_w = torch.ones(R, 1, device=DEV) if weights is None else weights
+        ref = (0.25 * torch.abs(rgb - tgt) * ref_w / (ref_w.mean() if mean is None else mean)).mean()
+        (g_ref,) = torch.autograd.grad(ref * 3.0, rgb)
+        out = photometric_loss(rgb, tgt, weights, mean)
+        (g_out,) = torch.autograd.grad(out * 3.0, rgb)
+        assert abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref)), (float(out), float(ref))
+        assert float((g_out - g_ref).abs().max()) <= 2e-6 * float(g_ref.abs().max())
+        assert float(g_out[:7].abs().max()) == 0.0
+    src = torch.randn(23, 3, 4, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.tensor([0, 5, 5, 22, -1, 7, 5, 0], device=DEV)
+    up = torch.randn(8, 3, 4, generator=g).to(DEV)
+    a = rows_gather(src, idx)
+    b = src[idx]
+    assert torch.equal(a, b)
+    (ga,) = torch.autograd.grad((a * up).sum(), src)
+    (gb,) = torch.autograd.grad((b * up).sum(), src)
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
+    assert torch.equal(ga[1], torch.zeros(3, 4, device=DEV))
