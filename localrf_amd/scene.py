@@ -58,16 +58,37 @@ class LocalTensorfs(SceneLifecycle):
         return torch.cat([sixD_to_mtx(torch.stack(r, 0), self.reference_cross), torch.stack(t, 0)[..., None]], dim=-1)
 
     def focal(self, W):
-        if self.freeze_intrinsics:                              # no optimiser reads their gradients this iteration: no backward chain
-            with torch.no_grad():
-                return self.init_focal * self.focal_offset * W / self.W
+        if self.freeze_intrinsics:                              # no optimiser reads their gradients this iteration: no backward chain,
+            return self._frozen("focal", (W,), (self.init_focal, self.focal_offset),   # and the value is kept until they change
+                                lambda: self.init_focal * self.focal_offset * W / self.W)
         return self.init_focal * self.focal_offset * W / self.W
 
     def center(self, W, H):
         if self.freeze_intrinsics:
-            with torch.no_grad():
-                return self._center(W, H)
+            return self._frozen("center", (W, H), (self.center_rel,), lambda: self._center(W, H))
         return self._center(W, H)
+
+    def _frozen(self, name, args, params, fn):
+        key = (args,) + tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.setdefault("_frozen_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = cache[name] = (key, fn())
+        return hit[1]
+
+    def _shifts(self, world2rf, active):
+        """[n_active, 3] world -> field translations (local_tensorfs.py:427-431), stacked once per set of tensors: they are
+        constants of the scene between lifecycle events, and a tape through them only when one of them wants a gradient."""
+        ws = [world2rf[rf] for rf in active]
+        if any(w.requires_grad for w in ws) and torch.is_grad_enabled():
+            return torch.stack(ws, dim=0)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        hit = self.__dict__.get("_shift_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, torch.stack([w.detach() for w in ws], dim=0))
+            self.__dict__["_shift_cache"] = hit
+        return hit[1]
 
     def _center(self, W, H):
         key = (W, H, self.center_rel.device)
@@ -146,7 +167,7 @@ class LocalTensorfs(SceneLifecycle):
             raise ValueError("ray_ids must hold the same number of rays for every view")
         per_view = n_rays // n_views
 
-        shifts = torch.stack([world2rf[rf] for rf in active], dim=0)
+        shifts = self._shifts(world2rf, active)
         for rf in active:
             if self.tensorfs[rf].device != dev:
                 self.tensorfs[rf].to(dev)                       # stays there (no shuttle back)
@@ -166,10 +187,11 @@ class LocalTensorfs(SceneLifecycle):
                                  self._exposure_for(view_ids, test_id), refine=self.is_refining)
         # with a tape the caller's chunk is honoured as is: the row-saving workspace is ~0.37 MB per ray at S = 512
         chunk = per_field
-        rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole)
+        single = len(active) == 1 and chunk >= n_rays          # one field, one call: its rays without indexing the [1,R,6] result
+        rays, directions, ij = scene_rays(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole, squeeze=single)
         cols_rgb, cols_dep = [], []
         for k, rf in enumerate(active):
-            parts = [self.tensorfs[rf](rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
+            parts = [self.tensorfs[rf](rays if single else rays[k, lo:lo + chunk], is_train=is_train, white_bg=white_bg,
                                        N_samples=-1, refine=self.is_refining, floater_thresh=floater_thresh)
                      for lo in range(0, n_rays, chunk)]
             cols_rgb.append(parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], 0))

@@ -28,7 +28,7 @@ def _f32c(t):
 
 class _SceneRaysFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360):
+    def forward(ctx, ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360, squeeze=False):
         dev = ray_ids.device
         R, n_rf = ray_ids.shape[0], world2rf.shape[0]
         ids = ray_ids.detach().contiguous().long()
@@ -44,6 +44,8 @@ class _SceneRaysFn(torch.autograd.Function):
         ctx.save_for_backward(ids, c2w, fo, ce)
         ctx.meta = (R, per_view, n_rf, W, H, int(fov360))
         ctx.mark_non_differentiable(ij)
+        if squeeze:                                              # one field: its rays [R,6] as the output itself (indexing the [1,R,6]
+            rays = rays.view(R, 6)                               # result costs autograd a zero fill and a copy on the way back)
         return rays, dirs, ij
 
     @staticmethod
@@ -65,7 +67,7 @@ class _SceneRaysFn(torch.autograd.Function):
         if not fov360 and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
             s = g_intr.sum(0)
             g_focal, g_center = s[0:1], s[1:3]
-        return None, g_c2w, (g_w2rf.sum(0) if ctx.needs_input_grad[2] else None), g_focal, g_center, None, None, None, None
+        return None, g_c2w, (g_w2rf.sum(0) if ctx.needs_input_grad[2] else None), g_focal, g_center, None, None, None, None, None
 
 
 class _SceneBlendFn(torch.autograd.Function):
@@ -155,14 +157,18 @@ def _require_gpu(t):
                             f"{t.device} tensor. There is no CPU fallback.")
 
 
-def scene_rays(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360=False):
+def scene_rays(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, fov360=False, squeeze=False):
     """-> rays [n_rf,R,6] (origin | unnormalised direction, per field), directions [R,3], ij [R,2].
-    cam2world [V,3,4] (or [V,4,4]); world2rf [n_rf,3]; focal [1] / center [2] tensors (None for 360)."""
+    cam2world [V,3,4] (or [V,4,4]); world2rf [n_rf,3]; focal [1] / center [2] tensors (None for 360).
+    squeeze (one field only): rays come back as [R,6]."""
     _require_gpu(ray_ids)
     if ray_ids.shape[0] % per_view:
         raise ValueError("number of rays must be a multiple of the number of views")
-    return _SceneRaysFn.apply(ray_ids, cam2world[:, :3, :], world2rf, focal, center, int(per_view),
-                              int(W), int(H), bool(fov360))
+    if squeeze and world2rf.shape[0] != 1:
+        raise ValueError("squeeze needs exactly one field")
+    c2w = cam2world if cam2world.shape[1] == 3 else cam2world[:, :3, :]
+    return _SceneRaysFn.apply(ray_ids, c2w, world2rf, focal, center, int(per_view),
+                              int(W), int(H), bool(fov360), bool(squeeze))
 
 
 def scene_blend(rgb_f, dep_f, blend_w, exposure, per_view):

@@ -16,7 +16,7 @@ a = ap.parse_args()
 keep = {}
 pr = cProfile.Profile() if a.profile else None
 if pr: pr.enable()
-out = train_synth.run(frames=14, final=a.final, iters_per_frame=300, n_max_frames=8, max_iters=a.max_iters, dev="cuda:0", graph=True, keep=keep)
+out = train_synth.run(frames=14, final=a.final, iters_per_frame=300, n_max_frames=8, max_iters=a.max_iters, dev="cuda:0", graph=True, live=keep)
 if pr: pr.disable()
 gs = keep["captured"]
 print("ms/iter by res", out["ms_per_iteration_by_resolution"], out["graph"], "res", out["final_resolution"])

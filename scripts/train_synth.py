@@ -177,7 +177,7 @@ def geometric_terms(lt, data, depth_map, directions, ij, cam2world_all, view_ids
 
 
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, keep=None):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, live=None):
     from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -364,8 +364,8 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             if log and rank == 0:
                 log(f"it {it} loss {losses[-1]:.4f} res {res} fields {len(lt.tensorfs)} frames {len(lt.r_c2w)}")
     torch.cuda.synchronize(dev)
-    if keep is not None:                                               # (probes: the live objects of the run)
-        keep.update(scene=lt, captured=gs, data=data)
+    if live is not None:                                               # (probes: the live objects of the run)
+        live.update(scene=lt, captured=gs, data=data)
     # checkpoint round trip into the reference's key set (local_tensorfs.py:326-356)
     sd = {k: v.detach().clone() for k, v in lt.state_dict().items()}
     lt2 = quiet(LocalTensorfs, **{**lt.get_kwargs(), "device": dev})
