@@ -534,7 +534,37 @@ def _grads_vs_port_with_forced_masks(f, rays_np, z, g_rgb, g_depth, white=True, 
     assert info.get("n_forced", 0) >= 0.98 * masks[3], (info, masks[3])      # the port shades (all but threshold cases of) the same samples
     assert info.get("max_pre", 0.0) < 2e-5, info                             # flipped units sit on the kink
     worst = check_grads(mine, ref, tol, tol_for=tol_for)
+    info["port_forced"] = ref
     return rgb, depth, mine, info, worst
+
+
+# (sample, unit) pairs whose ReLU the split-bf16 engine may switch differently from fp32: pre-activations within 2e-5 of
+# zero (asserted above).  Today's counts: 0 at 20x24x28, 4-5 at 128^3, 2 at 500^3, 0 at 640^3; a regression that
+# flipped many more would not be "rounding at the kink" any more
+MAX_FLIPS = {"field_small_train_grad": 0, "field_128_train_grad": 16, "field_500_train_grad": 16, "field_640_train_grad": 16}
+
+
+def _reference_bar_on_all_tensors(name, f, g, z, gr, gd, grads, info, subset=None, gmax=None, skip=()):
+    """The default (split-bf16) engine against the gradients the REFERENCE's autograd recorded, all 19 tensors at 1e-4,
+    unconditionally.  The number of flipped ReLU units is asserted, not printed.  When there are
+    flips, the two sides differentiate functions that differ in exactly those units: their contribution is
+    (port with its own signs) - (port with the kernel's masks) -- the port with its own signs IS the reference's function
+    (pinned to the same goldens: test_train_grad_500_port_vs_reference_golden) -- and is added to the kernel's gradients
+    before they face the reference's numbers.  (One flipped unit moves a sparse 500^3 appearance plane -- a handful of samples per
+    texel -- by up to ~1 % of its largest entry: the correction is bounded at 5 %, the count of flips by MAX_FLIPS.)"""
+    assert info["n_flips"] <= MAX_FLIPS[name], (name, info["n_flips"], info["max_pre"])
+    names = [n for n in grads if n not in skip]
+    ref = {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in names}
+    mine = {n: grads[n] for n in names}
+    if info["n_flips"]:
+        free, _ = port_gradients(f, torch.as_tensor(g["rays"]).to(DEV), z.to(DEV), gr, gd, True, None, names)
+        for n in names:
+            delta = free[n] - info["port_forced"][n]
+            assert float(delta.abs().max()) <= 5e-2 * max(float(free[n].abs().max()), 1e-12), (n, float(delta.abs().max()))
+            mine[n] = mine[n] + delta
+        print(name, "flip correction, largest share of a tensor's maximum:",
+              max(float((free[n] - info["port_forced"][n]).abs().max()) / max(float(free[n].abs().max()), 1e-12) for n in names))
+    return check_grads(mine, ref, 1e-4, subset=subset, gmax=gmax)
 
 
 def test_backward_vs_reference_autograd_golden(built_lib):
@@ -550,9 +580,7 @@ def test_backward_vs_reference_autograd_golden(built_lib):
     _check_rays(_np(rgb), g["rgb"])
     assert info["n_forced"] > 1000, info
     print("flips", info["n_flips"], "max |pre|", info["max_pre"], "worst", {k: "%.1e" % v for k, v in worst.items()})
-    if info["n_flips"] == 0:
-        ref = {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in grads}
-        check_grads(grads, ref, 1e-4)
+    _reference_bar_on_all_tensors("field_small_train_grad", f, g, z, gr, gd, grads, info)
 
 
 def test_backward_128cube_vs_reference_autograd_golden(built_lib):
@@ -571,8 +599,7 @@ def test_backward_128cube_vs_reference_autograd_golden(built_lib):
     gmax = {n: float(g["gmax." + n]) for n in grads}
     dens = {n: v for n, v in grads.items() if n.startswith("density_")}
     check_grads(dens, ref, 1e-4, subset=subset, gmax=gmax)
-    if info["n_flips"] == 0:
-        check_grads(grads, ref, 1e-4, subset=subset, gmax=gmax)
+    _reference_bar_on_all_tensors("field_128_train_grad", f, g, z, gr, gd, grads, info, subset=subset, gmax=gmax)
     for n in grads:                                   # the whole tensor, through its L2 norm
         assert abs(float(grads[n].double().norm()) - float(g["gl2." + n])) <= 2e-3 * float(g["gl2." + n]), n
     print("flips", info["n_flips"], "max |pre|", info["max_pre"], "worst", {k: "%.1e" % v for k, v in worst.items()})
@@ -603,8 +630,7 @@ def test_backward_at_training_sizes_vs_reference_autograd_golden(built_lib, name
     gmax = {n: float(g["gmax." + n]) for n in grads}
     dens = {n: v for n, v in grads.items() if n.startswith("density_")}
     check_grads(dens, ref, 1e-4, subset=subset, gmax=gmax)
-    if info["n_flips"] == 0:
-        check_grads({n: v for n, v in grads.items() if n != "rays"}, ref, 1e-4, subset=subset, gmax=gmax)
+    _reference_bar_on_all_tensors(name, f, g, z, gr, gd, grads, info, subset=subset, gmax=gmax, skip=("rays",))
     for n in grads:
         if n != "rays":
             assert abs(float(grads[n].double().norm()) - float(g["gl2." + n])) <= 2e-3 * float(g["gl2." + n]), n
