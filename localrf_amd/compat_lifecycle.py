@@ -65,6 +65,7 @@ class SceneLifecycle(torch.nn.Module):
         self.freeze_intrinsics = False
         # lower bound of the rays per field call in forward (see there); 1 = chunk exactly as the reference
         self.min_chunk = 65536
+        self.max_untaped_workspace = 1 << 30                    # ... unless that call's workspace would exceed this many bytes (scene.py)
 
         # schedule state until optimizer_step rescales it by the number of training frames (local_tensorfs.py:77-82)
         self.lr_factor, self.regularize = 1, True

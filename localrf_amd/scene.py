@@ -183,7 +183,7 @@ class LocalTensorfs(SceneLifecycle):
         if not taped and not is_train:                          # one native call for the whole scene forward (lrf_scene_fwd)
             return scene_forward(ray_ids, cam2world, shifts, focal, center, per_view, W, H, not pinhole,
                                  [self.tensorfs[rf] for rf in active], white_bg, floater_thresh,
-                                 max(per_field, self.min_chunk), bw,
+                                 self._untaped_chunk(per_field, [self.tensorfs[rf] for rf in active]), bw,
                                  self._exposure_for(view_ids, test_id), refine=self.is_refining)
         # with a tape the caller's chunk is honoured as is: the row-saving workspace is ~0.37 MB per ray at S = 512
         chunk = per_field
@@ -202,6 +202,19 @@ class LocalTensorfs(SceneLifecycle):
         exposure = self._exposure_for(view_ids, test_id)
         rgbs, depth_maps = scene_blend(rgb_f, dep_f, bw, exposure, per_view)
         return rgbs, depth_maps, directions, ij
+
+    def _untaped_chunk(self, per_field, fields):
+        """Rays per field call of a forward without a tape: the caller's chunk // n_active, raised to self.min_chunk (an
+        eval image rendered 4096 rays at a time, renderer.py:75, is launch-bound on this GPU) -- but only while the
+        per-call workspace of the largest active field stays below self.max_untaped_workspace bytes (default 1 GiB: 65536
+        rays are 0.31 GiB at 640^3's 738 samples); beyond that the caller's bound is what it asked for and is honoured."""
+        want = max(per_field, self.min_chunk)
+        if want > per_field:
+            from . import _native as N
+            S = max(2 * (int(f.nSamples) // 6) for f in fields)
+            while want > per_field and N.lib().lrf_workspace_bytes(want, S) > self.max_untaped_workspace:
+                want = max(per_field, want // 2)
+        return want
 
     def _exposure_for(self, view_ids, test_id):
         """Per-view 3x3 colour transform (local_tensorfs.py:481-496); None when exposure is not optimised."""

@@ -299,3 +299,24 @@ class _FakeCuda:
     @property
     def shape(self):
         return self._t.shape
+
+
+def test_untaped_chunk_honours_the_caller_beyond_the_workspace_bound(built_lib):
+    """LocalTensorfs renders up to min_chunk rays per field call when no gradient is recorded, whatever the caller's chunk --
+    but only while that call's workspace stays under max_untaped_workspace; a caller that bounds memory with `chunk` gets its
+    bound back once the raised chunk would exceed it."""
+    from localrf_amd.scene import LocalTensorfs
+
+    class F:                                                  # what _untaped_chunk reads of a field
+        def __init__(self, n):
+            self.nSamples = n
+    s = LocalTensorfs.__new__(LocalTensorfs)
+    s.min_chunk, s.max_untaped_workspace = 65536, 1 << 30
+    assert s._untaped_chunk(4096, [F(2214)]) == 65536          # 640^3: 0.31 GiB per call, under the bound
+    s.max_untaped_workspace = 100 << 20
+    got = s._untaped_chunk(4096, [F(2214)])
+    assert 4096 <= got < 65536 and built_lib.lrf_workspace_bytes(got, 738) <= 100 << 20
+    s.max_untaped_workspace = 1 << 20
+    assert s._untaped_chunk(4096, [F(2214)]) == 4096            # the caller's chunk, exactly
+    s.min_chunk = 1
+    assert s._untaped_chunk(4096, [F(2214)]) == 4096
