@@ -255,6 +255,22 @@ def size_workloads(dev, sync, use_pmc):
     return out
 
 
+def progressive_loop_workload(dev):
+    """BASELINE configs[4]: the progressive loop of train.py:349-474 (scripts/train_synth.py: synthetic frames, append_frame /
+    append_rf, the upsample ladder, alpha-mask rebuilds, photometric + flow + depth + density_L1 losses, every Adam) on the
+    reference's schedule (600 iterations per frame, a frame every 100), bounded to ~3 s per mode: ms per iteration at each
+    grid size, the iteration captured as one replayed hipGraph (localrf_amd/graph_step.py) beside the eager loop."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import train_synth
+    out = {"what": "scripts/train_synth.py, 8 frames 64x48, 4096 rays per iteration, 64^3 -> 200^3, iters_per_frame 600 (the reference's), "
+                   "first 2400 iterations; full runs to 500^3: profiles/r14_train_synth_500_*.json"}
+    for mode in ("graph", "eager"):
+        r = train_synth.run(frames=8, final=200, iters_per_frame=600, n_max_frames=6, max_iters=2400, dev=str(dev), graph=(mode == "graph"))
+        out[mode] = {"ms_per_iteration_by_resolution": r["ms_per_iteration_by_resolution"], "iterations_by_resolution": r["iterations_by_resolution"],
+                     "loss_first": r["loss_first"], "loss_last": r["loss_last"], "capture_stats": r["graph"]}
+    return out
+
+
 def geometric_losses_workload(dev, V=16, n=256, Fr=20, W=640, H=480, iters=100):
     """the flow + depth losses of train.py:385-423 on a 4096-ray batch (16 views), forward + backward:
     localrf_amd.losses (HIP) and, beside it, the ATen op chain (oracle/vm_render_torch.py: baseline leg only)."""
@@ -799,6 +815,10 @@ def main():
                 work["geometric_losses"] = geometric_losses_workload(dev)
             except Exception as e:                           # noqa: BLE001
                 work["geometric_losses"] = {"error": repr(e)}
+            try:
+                work["progressive_loop"] = progressive_loop_workload(dev)
+            except Exception as e:                           # noqa: BLE001
+                work["progressive_loop"] = {"error": repr(e)}
             out["workloads"] = work
             sd = field.state_dict()
             out["torch_rocm_baseline"] = torch_rocm_baseline(sd, rays)
