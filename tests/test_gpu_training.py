@@ -1288,3 +1288,33 @@ def test_photometric_loss_and_row_gather_vs_torch_expressions():
     (gb,) = torch.autograd.grad((b * up).sum(), src)
     assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max())
     assert torch.equal(ga[1], torch.zeros(3, 4, device=DEV))
+
+
+def test_two_rank_progressive_loop_with_captured_iterations(tmp_path):
+    """configs[4]'s ray shard with the captured iteration: two ranks (gloo: both on this GPU) run scripts/train_synth.py
+    --graph under torch.distributed.run -- per iteration a forward + backward graph, the gradient exchange
+    (localrf_amd.dist.allreduce_grads through LocalTensorfs.grad_sync) on the same stream, and the Adam graph.  The loss must
+    fall as in the one-rank run, nearly every iteration must be a replay, replicas must agree (checkpoint of rank 0 loads)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "scripts", "train_synth.py"), "--graph", "--backend", "gloo",
+           "--frames", "7", "--final", "90", "--iters-per-frame", "40", "--n-max-frames", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["world"] == 2 and d["finite"] and d["iterations"] > 150
+    assert d["loss_last"] < 0.5 * d["loss_first"], (d["loss_first"], d["loss_last"])
+    st = d["graph"]
+    assert st["replays"] >= 0.8 * d["iterations"] and st["captures"] >= 3, st
+    assert d["checkpoint_roundtrip"]
