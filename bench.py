@@ -522,7 +522,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc passes for roofline.traffic")
     ap.add_argument("--child", nargs="?", const="fwd", default=None, choices=("fwd", "train"),
                     help="(internal) the timed loop only: what the PMC passes profile (fwd: eval forward; train: training step)")
-    ap.add_argument("--preroll-ms", type=float, default=150.0, help="untimed GPU clock ramp before the warm-up steps")
+    ap.add_argument("--preroll-ms", type=float, default=1500.0,
+                    help="untimed rendering before the warm-up steps: after an idle period the GPU clock of the boxes of this pool needs ~1 s of work "
+                         "to reach its sustained value (same box, round 5: 0.189 ms per step behind 150 ms of work, 0.163 ms behind 1500 or 3000 ms)")
     ap.add_argument("--grid", type=int, default=GRID, help="(internal, with --child) grid size of the profiled workload")
     ap.add_argument("--n-samples", type=int, default=N_SAMPLES_ARG, help="(internal, with --child) N_samples argument (-1 = the grid's default)")
     args = ap.parse_args()
@@ -601,7 +603,7 @@ def main():
         return field(rays, white_bg=True, is_train=False, N_samples=ns_arg)
 
     with torch.no_grad():
-        # clock ramp: the first ~10 ms of work after an idle period run at a lower GPU clock; render untimed
+        # clock ramp: the first second of work after an idle period runs at a lower GPU clock; render untimed
         # for --preroll-ms before the W warm-up steps so that K is measured at the sustained clock
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:

@@ -257,7 +257,7 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
                   const LrfSceneField* fields, float floater_thresh, int32_t chunk,
                   const float* blend_w, const float* exposure,
                   float* rays, float* rgb_f, float* depth_f, float* directions, int64_t* ij,
-                  float* rgbs, float* depth, void* stream);
+                  float* rgbs, float* depth, void* scene_workspace, size_t scene_workspace_bytes, void* stream);
 
 /* Optimiser step after the path: torch.optim.Adam with the reference's settings
  * (local_tensorfs.py:88-97,146,245; no weight decay, no amsgrad) over up to LRF_ADAM_MAX tensors in

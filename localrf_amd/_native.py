@@ -75,6 +75,7 @@ SYMBOLS = {
     "lrf_error_slot": (C.c_void_p, []),
     "lrf_debug_set_dump": (None, [C.c_void_p]),
     "lrf_debug_set_lds_lines": (None, [C.c_int]),
+    "lrf_debug_set_scene_fuse": (None, [C.c_int]),
     "lrf_debug_saved_row_offset": (C.c_int64, [C.c_int, C.c_uint64, C.c_int]),
     "lrf_debug_set_bwd_overlap": (None, [C.c_int]),
     "lrf_debug_set_train_fwd_engine": (None, [C.c_int]),
@@ -131,7 +132,7 @@ SYMBOLS = {
     "lrf_scene_blend": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_scene_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, C.c_int32, C.c_int32,
                                 C.c_int32, C.POINTER(LrfSceneField), C.c_float, C.c_int32, _f, _f,
-                                _f, _f, _f, _f, C.c_void_p, _f, _f, C.c_void_p]),
+                                _f, _f, _f, _f, C.c_void_p, _f, _f, C.c_void_p, C.c_size_t, C.c_void_p]),
     "lrf_scene_blend_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f,
                                       C.c_void_p]),
 }

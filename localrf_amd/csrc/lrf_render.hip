@@ -242,9 +242,20 @@ __device__ void pack_mlp_w32_elem(const LrfParams& p, uint32_t* __restrict__ img
 // acc/depth, floater filter, shading mask).
 // LDSL: the three density lines ([L][8] floats each, 9.6 KB at 300) are staged in LDS behind the per-wave alpha
 // slices, so a sample costs 24 texture-path loads instead of 36 (the march is bound by that path: TA 57 % busy)
-template <bool LDSL>
+// Several fields in one launch (LocalTensorfs' blended evaluation, local_tensorfs.py:440-474: every active field renders
+// every ray): the rays of the fields are one list of nf * Rf "virtual" rays, field-major -- exactly the layout of
+// lrf_scene_rays' [n_rf, R, 6] output -- and a workgroup / a tile range picks its field's DField.  All per-ray arrays
+// (counts, compaction lists, partials, unit directions, outputs) are indexed by the virtual ray.
+constexpr int LRF_MULTI_MAX = 4;
+struct MultiF { DField f[LRF_MULTI_MAX]; int nf, Rf; };
+template <bool MULTI> struct FieldArg { typedef DField type; };
+template <> struct FieldArg<true> { typedef MultiF type; };
+__device__ __forceinline__ const DField& field_of(const DField& f, int) { return f; }
+__device__ __forceinline__ const DField& field_of(const MultiF& m, int k) { return m.f[k]; }
+
+template <bool LDSL, bool MULTI = false>
 __global__ __launch_bounds__(1024) void k_march(
-    DField f, const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
+    typename FieldArg<MULTI>::type fin, const float* __restrict__ rays, const float* __restrict__ z, int R, int S,
     uint32_t flags, float floater,
     float* __restrict__ depth, float* __restrict__ acc_ws, float* __restrict__ w_all,
     int* __restrict__ ncomp, uint16_t* __restrict__ cidx, float* __restrict__ cw,
@@ -255,6 +266,9 @@ __global__ __launch_bounds__(1024) void k_march(
   const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int nw = blockDim.x >> 6;                          // rays per workgroup: 4, 8 or 16 (launch_march)
   const int ray = lb * nw + wave;
+  int fk_ = 0;
+  if constexpr (MULTI) fk_ = min((lb * nw) / fin.Rf, fin.nf - 1);   // the workgroup's field (Rf is a multiple of nw: one field per workgroup)
+  const DField& f = field_of(fin, fk_);
   const float* s_line[3] = {nullptr, nullptr, nullptr};
   if (LDSL) {                                              // lines behind the alpha slices (whole block: before any return)
     float* base = s_alpha_all + (size_t)nw * S;
@@ -890,6 +904,7 @@ static Workspace carve(void* ws, int R, int S) {
 // Test hooks (include/lrf_debug.h): process-wide, not part of the re-entrant ABI.
 static float* g_dump = nullptr;    // lrf_debug_set_dump: device buffer for the s_memtime totals of k_shade3<TIMED>
 static int g_no_lds_lines = 0;     // lrf_debug_set_lds_lines(0): k_march reads its lines from global memory
+static int g_no_scene_fuse = 0;    // lrf_debug_set_scene_fuse(0): lrf_scene_fwd renders field by field (the tests compare the two forms)
 
 static int device_cus() {                 // of the current device (one process may drive several)
   static int cache[64] = {};
@@ -950,7 +965,7 @@ static const float* sort_rays_if_asked(DField& d, const float* rays, int R, uint
 // k_march launch: lines in LDS when the three of them (+ the alpha slices) leave four workgroups per CU
 static void launch_march(const DField& d, const float* rays, const float* z, int R, int S, uint32_t flags, float floater,
                          float* depth, float* acc, float* w_all, int* ncomp, uint16_t* cidx, float* cw, float* feat,
-                         hipStream_t st) {
+                         hipStream_t st, const MultiF* mf = nullptr) {
   // 4 waves per SIMD either way (123 VGPRs): 4 / 2 / 1 workgroups of 4 / 8 / 16 rays per CU, whichever keeps
   // alpha slices + lines within the CU's 160 KB (300^3: 8 + 29 KB x 4; 500^3: 18 + 48 KB x 2; 640^3: 47 + 61 KB x 1)
   const size_t lds_l = (size_t)(d.ll[0] + d.ll[1] + d.ll[2]) * LRF_CD * sizeof(float);
@@ -968,6 +983,17 @@ static void launch_march(const DField& d, const float* rays, const float* z, int
         std::call_once(attr_once[dev & 63], [] {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
+    }
+    if (mf) {                                              // (the caller made sure that Rf is a multiple of 16 >= nw)
+      static std::once_flag attr_once_m[64];
+      int dev = 0;
+      if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess)
+        std::call_once(attr_once_m[dev & 63], [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+      hipLaunchKernelGGL((k_march<true, true>), dim3((R + nw - 1) / nw), dim3(64 * nw), lds, st,
+                         *mf, rays, z, R, S, flags, floater, depth, acc, w_all, ncomp, cidx, cw, feat);
+      return;
     }
     hipLaunchKernelGGL(k_march<true>, dim3((R + nw - 1) / nw), dim3(64 * nw), lds, st,
                        d, rays, z, R, S, flags, floater, depth, acc, w_all, ncomp, cidx, cw, feat);
@@ -1022,6 +1048,26 @@ static hipError_t launch_shade3(DField d, const float* rays, const float* z, int
     hipLaunchKernelGGL((k_shade3<8, false, false>), grid, block, lds_base, st,
                        d, rays, z, S, toff32, R, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, acc_out, SaveOut3{});
   }
+  return hipSuccess;
+}
+
+// Several fields, one launch (see MultiF): global tile offsets over all virtual rays (k_scan_tiles_n), then the colour kernel.
+static hipError_t launch_shade3_multi(const MultiF& mf, const float* rays, const float* z, int Rv, int S, uint32_t flags,
+                                      const Workspace& w, float* rgb, hipStream_t st) {
+  const size_t lds_base = (size_t)W32_ALL_U4 * sizeof(uint4) + (size_t)S * sizeof(float);
+  static std::once_flag attrm_once[64];
+  static hipError_t attrm_err[64];
+  int dev = 0;
+  hipError_t e0 = hipGetDevice(&dev);
+  if (e0 != hipSuccess) return e0;
+  std::call_once(attrm_once[dev & 63], [dev] {
+    attrm_err[dev & 63] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade3m<8, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  });
+  if (attrm_err[dev & 63] != hipSuccess) return attrm_err[dev & 63];
+  hipLaunchKernelGGL(k_scan_tiles_n<ITEM3>, dim3(1), dim3(1024), 0, st, w.ncomp, Rv, w.toff);
+  hipLaunchKernelGGL((k_shade3m<8, false>), dim3(device_cus()), dim3(512), lds_base, st,
+                     mf, rays, z, S, w.toff, Rv, w.ncomp, w.cidx, w.cw, w.part, w.pmax, flags, w.acc, rgb, (float*)nullptr, SaveOut3{});
   return hipSuccess;
 }
 
@@ -1083,6 +1129,7 @@ int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): k_wgrad_w2w3 on the caller's stream (n > 0) or on the side stream (n = 0)
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
+void lrf_debug_set_scene_fuse(int on) { g_no_scene_fuse = on ? 0 : 1; }
 // Where column `col` of saved row `row` lives, in floats from the start of the ACT (buffer 0) / GRD (buffer 1) region
 // of a training workspace (lrf_workspace_layout_bwd gives the regions): the fragment order of lrf_common.h, host side.
 // -1 for bad arguments.
@@ -1190,7 +1237,7 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
                   const LrfSceneField* fields, float floater_thresh, int32_t chunk,
                   const float* blend_w, const float* exposure,
                   float* rays, float* rgb_f, float* depth_f, float* directions, int64_t* ij,
-                  float* rgbs, float* depth, void* stream) {
+                  float* rgbs, float* depth, void* scene_workspace, size_t scene_workspace_bytes, void* stream) {
   if (!fields || !rays || !rgb_f || !depth_f || !rgbs || !depth) return set_err("lrf_scene_fwd: null argument");
   if (n_rf <= 0 || n_rf > LRF_SCENE_MAX_FIELDS) return set_err("lrf_scene_fwd: 1 <= n_rf <= LRF_SCENE_MAX_FIELDS");
   if (R < 0 || per_view <= 0 || R % per_view) return set_err("lrf_scene_fwd: R must be a multiple of per_view");
@@ -1200,6 +1247,40 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
   int rc = lrf_scene_rays(ray_ids, R, per_view, cam2world, world2rf, n_rf, focal, center, W, H, fov360, rays, directions, ij, stream);
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // Fused form: groups of up to LRF_MULTI_MAX fields in ONE march and ONE colour launch over their field-major "virtual" rays
+  // (3 launches per group instead of 2 per field; one prologue, one tail).  Needs: the whole batch in one chunk, R a multiple
+  // of 16 (a march workgroup stays inside one field), the default engine, and fields of one shape: same grid, sample count,
+  // flags, thresholds (their schedules z are then the same numbers).  `scene_workspace` (lrf_workspace_bytes(group rays, S))
+  // holds the group's per-ray state.  Same arithmetic per ray (depths bit-identical, colours to an ulp: a second compilation of the colour kernel).
+  bool fuse = scene_workspace && n_rf >= 2 && chunk >= R && R > 0 && R % 16 == 0 && !g_no_scene_fuse;
+  for (int k = 0; fuse && k < n_rf; ++k) {
+    const LrfSceneField& a = fields[k], &b = fields[0];
+    if (!a.field->cache || gen_check(a.field) || !gen_is_default(a.field->fea_pe, a.field->view_pe, a.field->feature_c ? a.field->feature_c : LRF_FEATC)) fuse = false;
+    else if (a.flags & (LRF_FLAG_MLP_VALU | LRF_FLAG_MLP_F32 | LRF_FLAG_SORT_RAYS)) fuse = false;
+    else if (a.S != b.S || a.flags != b.flags || memcmp(a.field->grid, b.field->grid, sizeof(b.field->grid))) fuse = false;
+    else if (a.field->weight_thres != b.field->weight_thres || a.field->term_T != b.field->term_T) fuse = false;
+  }
+  if (fuse && floater_thresh > 0.0f) fuse = false;             // (the floater filter's second pass: per-field path)
+  if (fuse) {
+    const int32_t S = fields[0].S;
+    if (S < 2 || S > 4096) return set_err("lrf_scene_fwd: need 2 <= S <= 4096");
+    for (int k0 = 0; k0 < n_rf; k0 += LRF_MULTI_MAX) {
+      const int nf = n_rf - k0 < LRF_MULTI_MAX ? n_rf - k0 : LRF_MULTI_MAX;
+      const int Rv = nf * R;
+      if (lrf_workspace_bytes(Rv, S) > scene_workspace_bytes) return set_err("lrf_scene_fwd: scene workspace too small");
+      const Workspace w = carve(scene_workspace, Rv, S);
+      MultiF mf;
+      mf.nf = nf; mf.Rf = R;
+      for (int k = 0; k < nf; ++k) { mf.f[k] = make_dfield(fields[k0 + k].field); mf.f[k].rdir = w.rdir; }
+      for (int k = nf; k < LRF_MULTI_MAX; ++k) mf.f[k] = mf.f[0];
+      const float* rv = rays + (size_t)k0 * R * 6;
+      launch_march(mf.f[0], rv, fields[k0].z, Rv, S, fields[k0].flags, 0.0f, depth_f + (size_t)k0 * R, w.acc, nullptr,
+                   w.ncomp, w.cidx, w.cw, nullptr, st, &mf);
+      LRF_HIP(launch_shade3_multi(mf, rv, fields[k0].z, Rv, S, fields[k0].flags, w, rgb_f + (size_t)k0 * R * 3, st));
+    }
+    LRF_HIP(hipGetLastError());
+    return lrf_scene_blend(rgb_f, depth_f, blend_w, exposure, R, per_view, n_rf, rgbs, depth, nullptr, stream);
+  }
   for (int32_t lo = 0; lo < R; lo += chunk) {
     const int32_t n = R - lo < chunk ? R - lo : chunk;
     for (int k = 0; k < n_rf; ++k) {

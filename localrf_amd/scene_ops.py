@@ -211,6 +211,14 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
         arr[k].S = int(z.shape[0])
         arr[k].flags = f._flags(bool(white_bg)) | (N.LRF_FLAG_PE_OFF if (f.fea_pe > 0 and not refine) else 0)   # local_tensorfs.py:446 passes refine=self.is_refining
         arr[k].workspace = ws.data_ptr()
+    # per-ray state of the fused form (several fields in one march + one colour launch over their field-major rays): a group
+    # of up to 4 fields of one shape, the whole batch in one chunk
+    sws, sws_bytes = None, 0
+    if n_rf >= 2 and n_chunk >= R and R % 16 == 0 and R > 0:
+        S0 = int(arr[0].S)
+        if all(int(arr[k].S) == S0 for k in range(n_rf)):
+            sws_bytes = int(N.lib().lrf_workspace_bytes(min(n_rf, 4) * R, S0))
+            sws = _scene_workspace(dev, sws_bytes)
     rays = torch.empty(n_rf, R, 6, dtype=torch.float32, device=dev)
     rgb_f = torch.empty(n_rf, R, 3, dtype=torch.float32, device=dev)
     dep_f = torch.empty(n_rf, R, dtype=torch.float32, device=dev)
@@ -222,8 +230,21 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
         N.check(N.lib().lrf_scene_fwd(ids.data_ptr(), R, int(per_view), N.ptr(c2w), N.ptr(w2rf), n_rf, N.ptr(fo), N.ptr(ce),
                                       int(W), int(H), int(bool(fov360)), arr, float(floater_thresh), int(n_chunk),
                                       N.ptr(bw), N.ptr(ex), N.ptr(rays), N.ptr(rgb_f), N.ptr(dep_f), N.ptr(dirs), ij.data_ptr(),
-                                      N.ptr(rgbs), N.ptr(depth), _stream(dev)), "lrf_scene_fwd")
+                                      N.ptr(rgbs), N.ptr(depth), None if sws is None else sws.data_ptr(), sws_bytes,
+                                      _stream(dev)), "lrf_scene_fwd")
     return rgbs, depth, dirs, ij
+
+
+_scene_ws = {}
+
+
+def _scene_workspace(dev, nbytes):
+    """One scratch buffer per device for lrf_scene_fwd's fused launches (launches on a device's stream are serialised, as with
+    the per-field workspaces)."""
+    t = _scene_ws.get(dev)
+    if t is None or t.numel() < nbytes:
+        t = _scene_ws[dev] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return t
 
 
 class _RowsGatherFn(torch.autograd.Function):

@@ -82,7 +82,7 @@ def test_build_does_not_use_the_slp_vectoriser():
 
 
 def test_shade3_shape(asm):
-    hits = _body(asm, r"k_shade3ILi8ELb[01]ELb0ELb[01]E")                     # LDS / global tile offsets x eval / SAVE
+    hits = _body(asm, r"k_shade3ILi8ELb[01]ELb0ELb[01]EE")                     # LDS / global tile offsets x eval / SAVE
     assert len(hits) == 4, [k for k, _ in hits]
     for name, body in hits:
         assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) == 135, name
@@ -97,7 +97,7 @@ def test_shade3_shape(asm):
 
 
 def test_scratch_use_is_bounded(asm):
-    for pat, limit in ((r"k_marchILb1EE", 0), (r"k_marchILb0EE", 0),
+    for pat, limit in ((r"k_marchILb1ELb0EE", 0), (r"k_marchILb0ELb0EE", 0),
                        (r"k_train_dgrad3ILi8EE", 0), (r"k_train_app3ILi8EE", 0)):
         for name, _ in _body(asm, pat):
             meta = asm[asm.index(".amdhsa_kernel " + name):]
