@@ -5,7 +5,7 @@
 // result reads the high half of a source).  On MI355X such an instruction returns a WRONG low result in lanes 48..63
 // when another wave on the same SIMD issues v_mfma_f32_16x16x32_bf16 back to back (scripts/ubench/pk_mfma.hip: exact
 // integer arithmetic, 6 % of the iterations; profiles/r08b_packed_fp32_beside_mfma.md).  That -- not a late MFMA operand
-// read -- was the cause of the run-to-run differences rounds 1 and 2 chased (DESIGN.md findings 1, 2, 9, 17): the colour
+// read -- was the cause of the run-to-run differences rounds 1 and 2 chased (docs/GFX950_FINDINGS.md findings 1, 2, 9, 17): the colour
 // kernels interpolate (packed arithmetic after vectorisation) in some waves while others run their MFMA chain.
 // tests/test_isa_checks.py rejects any packed fp32 instruction with a crossed select in the shipped ISA.
 // (Rounds 1-2 linked two units of this source, one with and one without the vectoriser; both now use the same flags,

@@ -20,7 +20,7 @@ from .scene_ops import _f32c, _stream
 
 def _i32(t, dev):
     """int32 on the device.  Host ids are staged through pinned memory: a pageable host->device copy blocks the host
-    until the stream has drained (DESIGN.md finding 7), which would serialise the iteration."""
+    until the stream has drained (docs/GFX950_FINDINGS.md finding 7), which would serialise the iteration."""
     if not torch.is_tensor(t):
         t = torch.as_tensor(t)
     if t.is_cuda:

@@ -148,7 +148,7 @@ class LocalTensorfs(SceneLifecycle):
                 stage.copy_(blending_weights)
                 blending_weights = stage.to(dev, non_blocking=True)
             # blending_weights[:, active] with a Python list uploads the index with a pageable copy, which blocks the
-            # host until the stream drains (DESIGN.md finding 7): slice when the active fields are contiguous
+            # host until the stream drains (docs/GFX950_FINDINGS.md finding 7): slice when the active fields are contiguous
             if active == list(range(active[0], active[-1] + 1)) if active else False:
                 bw = blending_weights[:, active[0]:active[-1] + 1]
             else:

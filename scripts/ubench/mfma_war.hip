@@ -1,6 +1,6 @@
 // mfma_war.hip -- when does v_mfma_f32_16x16x32_bf16 read its sources?
 //
-// DESIGN.md findings 9 / 17 blamed rare run-to-run differences of the colour kernel on "an issued MFMA reads SrcA /
+// docs/GFX950_FINDINGS.md findings 9 / 17 blamed rare run-to-run differences of the colour kernel on "an issued MFMA reads SrcA /
 // SrcB later than the compiler assumes": hipcc reloads an A-fragment register with ds_read_b128 in the very next issue
 // slot behind the MFMA that read it, and its hazard table asks for three wait states before an LDS / VALU write of a
 // 4-pass MFMA's SrcC and for none on SrcA / SrcB.  That claim was never tested in isolation.  This program does:

@@ -2,7 +2,7 @@
 // stand-alone kernel without gathers: does the layout of tests/test_mfma_chain_model.py::chain_w32 run on the hardware,
 // and what does the MFMA + LDS-fragment part of a 32-sample colour kernel cost next to the 16-sample one (library:
 // k_mlp, 86-88 us for the 725 K shaded samples of the benchmark batch)?  Compiler-scheduled builtins only: a kernel
-// that issues no gathers was deterministic with them (DESIGN.md finding 9a).
+// that issues no gathers was deterministic with them (docs/GFX950_FINDINGS.md finding 9a).
 //   hipcc --offload-arch=gfx950 -O3 -o mlp_w32 mlp_w32.hip && ./mlp_w32 [rows]
 // Lane l = (n = l & 31: sample, h = l >> 5: K half).  Fragment f, half (hi, lo), lane: 8 bf16 = A[n][8 h + j].
 //   f = ks            (0..4)   basis: A[n][slot] = basis[n][chan(h, 8 ks + j)]

@@ -460,7 +460,7 @@ def test_ray_sorting_is_invisible_to_the_caller(big):
 @pytest.mark.parametrize("engine", ["bf16x3", "f32"])
 def test_repeat_runs_are_bitwise_identical(big, engine):
     """200 renders of the same 4096 x 512 batch, with a foreign kernel (a sort) thrown in between: every render must
-    equal the first BIT FOR BIT.  Rounds 1-2 saw rare differences here (DESIGN.md finding 17); their cause was packed
+    equal the first BIT FOR BIT.  Rounds 1-2 saw rare differences here (docs/GFX950_FINDINGS.md finding 17); their cause was packed
     fp32 VALU arithmetic beside another wave's bf16 MFMAs (profiles/r08b_packed_fp32_beside_mfma.md), which the library
     no longer contains (tests/test_isa_checks.py)."""
     f, rays = big
@@ -1062,7 +1062,7 @@ def test_fuzz_forward_and_gradients_vs_aten_port(built_lib, seed):
 
 
 def test_packed_fp32_erratum_reobserved_informational(built_lib, tmp_path, capsys):
-    """INFORMATIONAL (DESIGN.md finding 17): re-runs the exact-arithmetic reproducer scripts/ubench/pk_mfma.hip on THIS box and
+    """INFORMATIONAL (docs/GFX950_FINDINGS.md finding 17): re-runs the exact-arithmetic reproducer scripts/ubench/pk_mfma.hip on THIS box and
     prints its wrong-result counts -- a v_pk_mul_f32 whose low result selects the high half of a source, beside another
     wave's bf16 MFMAs, against the same instruction beside an idle partner and against straight halves.  The library is
     protected by construction (-fno-slp-vectorize + the ISA test); this test only asserts that the controls are clean, so

@@ -6,7 +6,7 @@ __graft_entry__.build() compiles it and the device assembly is inspected.
    in lanes 48..63 when another wave of the SIMD issues bf16 MFMAs (scripts/ubench/pk_mfma.hip, exact integer
    arithmetic; profiles/r08b_packed_fp32_beside_mfma.md).  hipcc's SLP vectoriser emits exactly that form for
    "broadcast weight x pair of texels"; the library is therefore built with -fno-slp-vectorize (csrc/lrf_tu.h).  This
-   was the cause of the run-to-run differences of rounds 1-2 (DESIGN.md finding 17).
+   was the cause of the run-to-run differences of rounds 1-2 (docs/GFX950_FINDINGS.md finding 17).
 2. k_shade3 (the default colour kernel, and with SAVE the row-saving forward of the training step): 135
    v_mfma_f32_32x32x16_bf16 per tile (15 basis + 24 layer 1 + 96 layer 2), no scratch, at most 256 registers (two waves per SIMD).
 3. k_march and the two 32-sample kernels of the colour
