@@ -42,6 +42,7 @@ class _SceneRaysFn(torch.autograd.Function):
                                        N.ptr(ce), W, H, int(fov360), N.ptr(rays), N.ptr(dirs), ij.data_ptr(),
                                        _stream(dev)), "lrf_scene_rays")
         ctx.save_for_backward(ids, c2w, fo, ce)
+        ctx.set_materialize_grads(False)                         # an unused output (directions without the flow loss) costs no zero fill
         ctx.meta = (R, per_view, n_rf, W, H, int(fov360))
         ctx.mark_non_differentiable(ij)
         if squeeze:                                              # one field: its rays [R,6] as the output itself (indexing the [1,R,6]
@@ -85,6 +86,7 @@ class _SceneBlendFn(torch.autograd.Function):
                                         N.ptr(rgbs), N.ptr(depth), N.ptr(pre), _stream(dev)), "lrf_scene_blend")
         if need_bwd:
             ctx.save_for_backward(pre, bw, ex)
+        ctx.set_materialize_grads(False)                         # (depth_map unused by the loss: no zero fill, the kernel takes a null pointer)
         ctx.meta = (R, per_view, n_rf)
         return rgbs, depth
 
