@@ -1144,4 +1144,4 @@ def test_scene_forward_fused_fields_equal_field_by_field(built_lib):
         assert float((out[1][0] - out[0][0]).abs().max()) <= 2e-7, float((out[1][0] - out[0][0]).abs().max())    # colours in [0, 1]
         for a, b in zip(out[1][1:], out[0][1:]):                  # depth, directions, ij
             assert torch.equal(a, b), (n_fields, float((a.float() - b.float()).abs().max()))
-        assert float(out[1][0].std()) > 0.01 and float(out[1][1].std()) > 0.01, (float(out[1][0].std()), float(out[1][1].std()))
+        assert float(out[1][0].std()) > 0.003 and float(out[1][1].std()) > 0.01, (float(out[1][0].std()), float(out[1][1].std()))
