@@ -94,7 +94,7 @@ class CapturedIteration:
         self._side = None
         self._eager_done = False
         self.kept = {}
-        self.stats = {"eager": 0, "captures": 0, "replays": 0, "capture_host_s": 0.0, "eager_host_s": 0.0}
+        self.stats = {"eager": 0, "captures": 0, "replays": 0, "capture_host_s": 0.0, "eager_host_s": 0.0, "plans_with_intrinsics": 0}
         self.extra_signature = lambda: ()
 
     # ------------------------------------------------------------------ lifecycle state
@@ -132,6 +132,7 @@ class CapturedIteration:
         self.u2 = torch.empty(1, h, dtype=torch.float32, device=dev)
         self.start = int(start)
         self._tune_intrinsics = bool(tune_intrinsics)
+        self.stats["plans_with_intrinsics"] += int(bool(tune_intrinsics))
         self._graphs = None
         self._eager_done = False
 

@@ -177,7 +177,7 @@ def geometric_terms(lt, data, depth_map, directions, ij, cam2world_all, view_ids
 
 
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, live=None):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, live=None, lr_i_init=0):
     from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -197,7 +197,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     torch.manual_seed(seed)                                           # identical replicas under DDP
     lt = quiet(LocalTensorfs, camera_prior=None, fov=85.6, n_init_frames=min(n_init, frames), n_overlap=3, WH=(W, H),
                n_iters_per_frame=iters_per_frame, n_iters_reg=max(1, round(100 * sc)), lr_R_init=5e-3, lr_t_init=5e-4,
-               lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3, lr_decay_target_ratio=0.1,
+               lr_i_init=lr_i_init, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3, lr_decay_target_ratio=0.1,
                N_voxel_list=N_voxel_list, update_AlphaMask_list=mask_list, lr_upsample_reset=True, device=dev,
                aabb=aabb, gridSize=N_to_reso(n_init_vox, aabb), **FIELD_KW).to(dev)
     if ddp:

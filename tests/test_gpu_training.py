@@ -1240,6 +1240,14 @@ def test_captured_iteration_matches_the_eager_loop():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import train_synth
     kw = dict(frames=9, final=80, iters_per_frame=30, n_max_frames=5, dev=DEV, geo_every=5, record_all=True)
+    # ... and with the intrinsics tuned (lr_i_init > 0: focal_offset / center_rel join the captured Adam launches while the first
+    # field refines, local_tensorfs.py:218-222): the first iterations, where the two trajectories have not drifted apart yet
+    e_i = train_synth.run(graph=False, lr_i_init=1e-3, max_iters=150, **kw)
+    g_i = train_synth.run(graph=True, lr_i_init=1e-3, max_iters=150, **kw)
+    ai, bi = np.array(e_i["all_losses"]), np.array(g_i["all_losses"])
+    assert ai.shape == bi.shape and np.abs(ai[:60] - bi[:60]).max() <= 5e-3 * np.abs(ai[:60]).max(), np.abs(ai[:60] - bi[:60]).max()
+    assert abs(ai[-20:].mean() - bi[-20:].mean()) <= 0.15 * ai[-20:].mean()
+    assert g_i["graph"]["plans_with_intrinsics"] >= 1, g_i["graph"]          # the refining phase of the first field was reached
     eager = train_synth.run(graph=False, **kw)
     graph = train_synth.run(graph=True, **kw)
     assert graph["iterations"] == eager["iterations"] and graph["events"] == eager["events"], (graph["events"], eager["events"])
