@@ -4,8 +4,11 @@
 // train.py runs; every other configuration takes this engine: plain fp32 loops on the vector ALU over the parameter
 // tensors in their natural layout.  A block owns 32 samples of one ray, keeps their activation vectors in LDS as
 // [element][sample] and gives every OUTPUT unit of a layer to a thread (weight read once, 32 broadcast multiply-adds): a plain
-// tile GEMM on the VALU.  (First version: one lane per sample with private arrays -- 3-7 KB of scratch per lane, gigabytes per
-// launch, every multiply-add waiting for HBM: 155 ms per 4096 x 512 batch.)  Correct and differentiable; not tuned further.
+// tile GEMM -- on the matrix pipe since round 5 (v_mfma_f32_16x16x4_f32, exact fp32: gen_tile_dense_mfma below; the vector-ALU form
+// stays as gen_tile_dense_valu behind LRF_GEN_MFMA=0).  (First version: one lane per sample with private arrays -- 3-7 KB of scratch
+// per lane, gigabytes per launch, every multiply-add waiting for HBM: 155 ms per 4096 x 512 batch.)  Correct and differentiable;
+// 4.9 ms forward / 19.6 ms forward + backward per batch at view_pe = fea_pe = 2 (round 4: 6.5 / 36): the tile products are no longer
+// what it waits for -- a block per 32 samples re-stages everything per tile and synchronises ten times (profiles/r15_generic_engine.md).
 // It is also the LRF_FLAG_MLP_VALU debug engine of the default configuration.
 //
 // Forward (k_shade_gen): a block renders 32 (16) consecutive samples of one ray; with SAVE it leaves what the backward needs in the
@@ -47,7 +50,7 @@ __host__ __device__ inline bool gen_is_default(int fea_pe, int view_pe, int fc) 
 
 // out[i][s] = (relu) b[i] + sum_c W[i * nin + c] in[c][s]
 template <int LS>
-__device__ __forceinline__ void gen_tile_dense(const float* __restrict__ W, const float* __restrict__ b, int nout, int nin,
+__device__ __forceinline__ void gen_tile_dense_valu(const float* __restrict__ W, const float* __restrict__ b, int nout, int nin,
                                                const float* in, float* out, bool relu) {
   for (int i = threadIdx.x; i < nout; i += blockDim.x) {
     float acc[LS];
@@ -86,7 +89,7 @@ __device__ __forceinline__ void gen_tile_dense(const float* __restrict__ W, cons
 }
 // out[c][s] = sum_r W[r * ld + c] in[r][s]  (the transposed products of the backward; consecutive threads read consecutive weights)
 template <int LS>
-__device__ __forceinline__ void gen_tile_dense_t(const float* __restrict__ W, int nrow, int ncol, int ld, const float* in, float* out) {
+__device__ __forceinline__ void gen_tile_dense_t_valu(const float* __restrict__ W, int nrow, int ncol, int ld, const float* in, float* out) {
   for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
     float acc[LS];
 #pragma unroll
@@ -103,6 +106,116 @@ __device__ __forceinline__ void gen_tile_dense_t(const float* __restrict__ W, in
     for (int q = 0; q < LS / 4; ++q)
       *reinterpret_cast<float4*>(out + c * LS + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
+}
+
+// ---- the same two tile products on the matrix pipe (round 5): v_mfma_f32_16x16x4_f32, exact fp32 products and accumulation.
+// A wave owns 16 output units x LS samples (LS / 16 accumulator tiles) and walks K four inputs at a time: lane (i = lane & 15,
+// g = lane >> 4) supplies A[i][g] = the weight of unit i and input k0 + g (one dword load, 16 consecutive inputs of a row /
+// 16 consecutive units of a transposed row per four lanes) and B[g][i] = activation k0 + g of sample i from the block's
+// [element][sample] LDS image (conflict-free ds_read_b32); D[4 g + j][i] comes back as four registers per tile.  The vector-ALU
+// form above read every weight once per unit and 32-sample block and issued one FMA per product and lane (155 -> 6.5 ms
+// per 4096 x 512 batch at view_pe = fea_pe = 2 after two rounds of tuning); this one issues a 1024-product instruction per
+// 16 x 16 x 4 block.  Inputs beyond nin / rows beyond nrow enter as zeros (never as whatever the LDS holds there).
+#ifndef LRF_GEN_MFMA
+#define LRF_GEN_MFMA 1
+#endif
+#ifndef LRF_GEN_KU
+#define LRF_GEN_KU 8
+#endif
+constexpr int GEN_KU = LRF_GEN_KU;
+template <int LS>
+__device__ __forceinline__ void gen_tile_dense_mfma(const float* __restrict__ W, const float* __restrict__ b, int nout, int nin,
+                                                    const float* in, float* out, bool relu) {
+  constexpr int NTL = LS / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  for (int mt = wave; mt * 16 < nout; mt += nwave) {
+    const int u = mt * 16 + i;
+    const bool uok = u < nout;
+    const float* wr = W + (size_t)(uok ? u : 0) * nin;
+    f32x4 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = 0; k0 < nin; k0 += 4 * GEN_KU) {            // GEN_KU K-steps per iteration: their weight loads are in flight together
+      float a[GEN_KU], bv[GEN_KU][NTL];
+#pragma unroll
+      for (int q = 0; q < GEN_KU; ++q) {
+        const int k = k0 + 4 * q + g;
+        const bool kok = k < nin;
+        const int kc = kok ? k : nin - 1;                          // branch-free: every load is issued (clamped), zeros are selected afterwards
+        const float av = wr[kc];
+        a[q] = (uok && kok) ? av : 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) { const float xv = in[kc * LS + 16 * t + i]; bv[q][t] = kok ? xv : 0.0f; }
+      }
+#pragma unroll
+      for (int q = 0; q < GEN_KU; ++q)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[t] = mfma4(a[q], bv[q][t], acc[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int unit = mt * 16 + 4 * g + j;
+      if (unit < nout) {
+        const float bi = b ? b[unit] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          float v = acc[t][j] + bi;
+          if (relu) v = fmaxf(v, 0.0f);
+          out[unit * LS + 16 * t + i] = v;
+        }
+      }
+    }
+  }
+}
+template <int LS>
+__device__ __forceinline__ void gen_tile_dense_t_mfma(const float* __restrict__ W, int nrow, int ncol, int ld, const float* in, float* out) {
+  constexpr int NTL = LS / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  for (int mt = wave; mt * 16 < ncol; mt += nwave) {
+    const int c = mt * 16 + i;
+    const bool cok = c < ncol;
+    f32x4 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r0 = 0; r0 < nrow; r0 += 4 * GEN_KU) {
+      float a[GEN_KU], bv[GEN_KU][NTL];
+#pragma unroll
+      for (int q = 0; q < GEN_KU; ++q) {
+        const int r = r0 + 4 * q + g;
+        const bool rok = r < nrow;
+        const int rc = rok ? r : nrow - 1;
+        const float av = W[(size_t)rc * ld + (cok ? c : 0)];
+        a[q] = (cok && rok) ? av : 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) { const float xv = in[rc * LS + 16 * t + i]; bv[q][t] = rok ? xv : 0.0f; }
+      }
+#pragma unroll
+      for (int q = 0; q < GEN_KU; ++q)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[t] = mfma4(a[q], bv[q][t], acc[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = mt * 16 + 4 * g + j;
+      if (col < ncol) {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) out[col * LS + 16 * t + i] = acc[t][j];
+      }
+    }
+  }
+}
+template <int LS>
+__device__ __forceinline__ void gen_tile_dense(const float* __restrict__ W, const float* __restrict__ b, int nout, int nin,
+                                               const float* in, float* out, bool relu) {
+  if constexpr (LRF_GEN_MFMA) gen_tile_dense_mfma<LS>(W, b, nout, nin, in, out, relu);
+  else gen_tile_dense_valu<LS>(W, b, nout, nin, in, out, relu);
+}
+template <int LS>
+__device__ __forceinline__ void gen_tile_dense_t(const float* __restrict__ W, int nrow, int ncol, int ld, const float* in, float* out) {
+  if constexpr (LRF_GEN_MFMA) gen_tile_dense_t_mfma<LS>(W, nrow, ncol, ld, in, out);
+  else gen_tile_dense_t_valu<LS>(W, nrow, ncol, ld, in, out);
 }
 // positional_encoding (tensorBase.py:14-21) of D rows v[d][s] -> out[2 D F][s]: [sin(v_d 2^f)] then [cos(v_d 2^f)], row d * F + f inside each half
 template <int LS>
@@ -125,7 +238,13 @@ __host__ __device__ inline GenLds gen_lds(const GenCfg& g, int LS, bool bwd) {
 }
 // samples per block: 32 unless the block's LDS image would pass 150 KB
 __host__ __device__ inline int gen_tile_samples(const GenCfg& g, bool bwd) { return gen_lds(g, 32, bwd).total * 4 <= 150 * 1024 ? 32 : 16; }
-__host__ __device__ inline int gen_block_threads(const GenCfg& g) { const int t = ((g.fc > 64 ? g.fc : 64) + 63) / 64 * 64; return t > 256 ? 256 : t; }
+__host__ __device__ inline int gen_block_threads(const GenCfg& g) {
+#if LRF_GEN_MFMA
+  (void)g; return 256;                   // four waves share the 16-unit tiles of a layer (a wave per SIMD and block; 3 blocks per CU)
+#else
+  const int t = ((g.fc > 64 ? g.fc : 64) + 63) / 64 * 64; return t > 256 ? 256 : t;
+#endif
+}
 
 // the network on a block's LS samples: x rows 0..26 hold feat, dirs[s] the unit view direction of sample s (all the same ray).
 // Leaves x (with encodings), h1 = relu(..), h2v = [relu(h2) | venc], o = pre-sigmoid colours.  MLPRender_Fea_late_view.forward
@@ -141,13 +260,7 @@ __device__ __forceinline__ void gen_tile_network(const DField& f, const GenCfg& 
   __syncthreads();
   gen_tile_dense<LS>(f.w2, f.b2, g.fc, g.fc, h1, h2v, true);
   __syncthreads();
-  for (int e = threadIdx.x; e < 3 * LS; e += blockDim.x) {     // the three colours: one thread per (colour, sample)
-    const int c = e / LS, s = e % LS, ld3 = g.fc + g.inv;
-    const float* wr = f.w3 + (size_t)c * ld3;
-    float a = f.b3[c];
-    for (int u = 0; u < ld3; ++u) a += wr[u] * h2v[u * LS + s];
-    o[c * LS + s] = a;
-  }
+  gen_tile_dense<LS>(f.w3, f.b3, 3, g.fc + g.inv, h2v, o, false);   // the three colours (one 16-unit tile, three of its rows used)
   __syncthreads();
 }
 
