@@ -764,7 +764,7 @@ def main():
                 dgb = timed(gfb, 3, 1, sync)
                 work["nondefault_network"] = {
                     "what": "same grid and batch, view_pe = fea_pe = 2 (MLPRender_Fea_late_view with positional encodings): "
-                            "csrc/lrf_generic.inl, fp32 tile GEMMs on the vector ALU -- supported, not tuned",
+                            "csrc/lrf_generic.inl, fp32 tile GEMMs on v_mfma_f32_16x16x4_f32 -- supported, not tuned",
                     "rays_per_s": R_PER_GPU * 5 / dg, "ms_per_step": dg / 5 * 1e3, "forward_backward_ms": dgb / 3 * 1e3}
                 del gf
             except Exception as e:                           # noqa: BLE001
