@@ -7,7 +7,7 @@
 // tile GEMM -- on the matrix pipe since round 5 (v_mfma_f32_16x16x4_f32, exact fp32: gen_tile_dense_mfma below; the vector-ALU form
 // stays as gen_tile_dense_valu behind LRF_GEN_MFMA=0).  (First version: one lane per sample with private arrays -- 3-7 KB of scratch
 // per lane, gigabytes per launch, every multiply-add waiting for HBM: 155 ms per 4096 x 512 batch.)  Correct and differentiable;
-// 4.9 ms forward / 19.6 ms forward + backward per batch at view_pe = fea_pe = 2 (round 4: 6.5 / 36): the tile products are no longer
+// 4.1 ms forward / 18.8 ms forward + backward per batch at view_pe = fea_pe = 2 (round 4: 6.5 / 36): the tile products are no longer
 // what it waits for -- a block per 32 samples re-stages everything per tile and synchronises ten times (profiles/r15_generic_engine.md).
 // It is also the LRF_FLAG_MLP_VALU debug engine of the default configuration.
 //
@@ -298,21 +298,25 @@ __global__ __launch_bounds__(256) void k_shade_gen(
     s_u[0][tid] = u[0]; s_u[1][tid] = u[1]; s_u[2][tid] = u[2];
   }
   __syncthreads();
-  for (int e = tid; e < 72 * LS; e += blockDim.x) {           // the 72 plane x line products of every sample (tensoRF.py:153-195)
-    const int s = e % LS, pcn = e / LS, p = pcn / LRF_CA, c = pcn % LRF_CA;
-    const float u[3] = {s_u[0][s], s_u[1][s], s_u[2][s]};
-    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+  for (int e = tid; e < 18 * LS; e += blockDim.x) {           // the 72 plane x line products of every sample (tensoRF.py:153-195):
+    const int s = e % LS, pq = e / LS, p = pq / 6, c4 = 4 * (pq % 6);   // a thread forms four channels of one plane from the dense
+    const float u[3] = {s_u[0][s], s_u[1][s], s_u[2][s]};             // 24-channel texels (six 16-byte loads; the padded layout cost
+    int x0, x1, y0, y1, l0, l1; float tx, ty, tl;                       // one 4-byte load per channel and tap: 1.2 of the 4.9 ms)
     tap1d(u[MAT0[p]], f.pw[p], x0, x1, tx);
     tap1d(u[MAT1[p]], f.ph[p], y0, y1, ty);
     tap1d(u[VEC[p]],  f.ll[p], l0, l1, tl);
-    const float* pl = f.aplane[p];
-    const int pc = app_pc(c);
-    const float v = pl[((size_t)y0 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * (1.0f - ty))
-                  + pl[((size_t)y0 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * (1.0f - ty))
-                  + pl[((size_t)y1 * f.pw[p] + x0) * LRF_CAS + pc] * ((1.0f - tx) * ty)
-                  + pl[((size_t)y1 * f.pw[p] + x1) * LRF_CAS + pc] * (tx * ty);
-    const float ln = f.aline[p][(size_t)l0 * LRF_CAS + pc] * (1.0f - tl) + f.aline[p][(size_t)l1 * LRF_CAS + pc] * tl;
-    X[pcn * LS + s] = v * ln;
+    const float* pl = f.aplane2[p] + c4;
+    const float* ln = f.aline2[p] + c4;
+    const size_t r0 = (size_t)y0 * f.pw[p], r1 = (size_t)y1 * f.pw[p];
+    const float4 a = *reinterpret_cast<const float4*>(pl + (r0 + x0) * LRF_CA), b = *reinterpret_cast<const float4*>(pl + (r0 + x1) * LRF_CA);
+    const float4 c = *reinterpret_cast<const float4*>(pl + (r1 + x0) * LRF_CA), d = *reinterpret_cast<const float4*>(pl + (r1 + x1) * LRF_CA);
+    const float4 e0 = *reinterpret_cast<const float4*>(ln + (size_t)l0 * LRF_CA), e1 = *reinterpret_cast<const float4*>(ln + (size_t)l1 * LRF_CA);
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+    const int row = p * LRF_CA + c4;
+    X[(row + 0) * LS + s] = (a.x * w00 + b.x * w10 + c.x * w01 + d.x * w11) * (e0.x * (1.0f - tl) + e1.x * tl);
+    X[(row + 1) * LS + s] = (a.y * w00 + b.y * w10 + c.y * w01 + d.y * w11) * (e0.y * (1.0f - tl) + e1.y * tl);
+    X[(row + 2) * LS + s] = (a.z * w00 + b.z * w10 + c.z * w01 + d.z * w11) * (e0.z * (1.0f - tl) + e1.z * tl);
+    X[(row + 3) * LS + s] = (a.w * w00 + b.w * w10 + c.w * w01 + d.w * w11) * (e0.w * (1.0f - tl) + e1.w * tl);
   }
   __syncthreads();
   gen_tile_dense<LS>(f.basis, nullptr, LRF_APP_DIM, 72, X, x, false);     // feat = basis_mat(X) (tensoRF.py:196)
