@@ -303,6 +303,17 @@ def test_z_schedule_kernel_vs_reference_expression(built_lib):
         want = np.concatenate([a, b]) + f32(1e-1)
         d = np.abs(zt.numpy() - want)
         assert zt.shape[0] == 2 * h and d[:h].max() == 0.0 and (d[h:] <= 2.4e-7 * want[h:]).all(), (n, float(d.max()))   # the reciprocal of the inverse-depth half: within 2 ulp
+        # the reference's expression evaluated BY TORCH ON THE GPU (tensor / python scalar = tensor * (1 / h) there)
+        # is not bit-identical to the CPU evaluation the goldens record -- and the kernel follows the CPU one.  The linear half
+        # stays within an ulp; the inverse-depth half amplifies an ulp of s near s -> 1 (z = 1 / ((1 - s) + s / 1000) up to 1000:
+        # ~1e-5 relative at the far end, where the contraction has long saturated) -- the reference's own GPU / CPU difference
+        torch.manual_seed(5)
+        tg = torch.linspace(0.0, h - 1, h, device=DEV)[None] / h
+        ag = tg + torch.rand_like(tg) / h
+        sg = tg + torch.rand_like(tg) / h
+        zg = (torch.cat([ag, 1.0 / (1.0 / 1.0 * (1.0 - sg) + 1.0 / 1e3 * sg)], dim=1) + 1e-1).view(-1).cpu().numpy()
+        dg = np.abs(zt.numpy() - zg)
+        assert (dg[:h] <= 2.4e-7 * np.abs(zg[:h])).all() and (dg[h:] <= 5e-5 * np.abs(zg[h:])).all(), (n, float(dg.max()))
 
 
 # ----------------------------------------------------------------- full-size properties
