@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 5      /* 5: LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 5      /* 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -243,7 +243,11 @@ int lrf_scene_blend_bwd(const float* g_rgbs, const float* g_depth, const float* 
  * lrf_scene_blend.  `fields` is a HOST array of n_rf entries; each field brings its own z schedule (S depends on the
  * field's grid, tensorBase.py:252-262), engine flags and workspace (lrf_workspace_bytes(min(chunk, R), S) bytes; fields
  * may share one, the launches are serialised on `stream`).  Scratch supplied by the caller: rays [n_rf,R,6],
- * rgb_f [n_rf,R,3], depth_f [n_rf,R].  Outputs as lrf_scene_rays / lrf_scene_blend. */
+ * rgb_f [n_rf,R,3], depth_f [n_rf,R].  Outputs as lrf_scene_rays / lrf_scene_blend.
+ * scene_workspace (may be NULL; lrf_workspace_bytes(min(n_rf, 4) * R, S) bytes): with it, groups of up to four fields of one
+ * shape (same grid, S, flags, thresholds; default colour engine) render in ONE march and ONE colour launch over their
+ * field-major rays when the whole batch is one chunk, R % 16 == 0 and floater_thresh == 0 -- the same per-ray arithmetic
+ * (depths bit-identical, colours to an ulp); otherwise field by field. */
 #define LRF_SCENE_MAX_FIELDS 64
 typedef struct LrfSceneField {
   const LrfField* field;
