@@ -244,10 +244,10 @@ int lrf_scene_blend_bwd(const float* g_rgbs, const float* g_depth, const float* 
  * field's grid, tensorBase.py:252-262), engine flags and workspace (lrf_workspace_bytes(min(chunk, R), S) bytes; fields
  * may share one, the launches are serialised on `stream`).  Scratch supplied by the caller: rays [n_rf,R,6],
  * rgb_f [n_rf,R,3], depth_f [n_rf,R].  Outputs as lrf_scene_rays / lrf_scene_blend.
- * scene_workspace (may be NULL; lrf_workspace_bytes(min(n_rf, 4) * R, S) bytes): with it, groups of up to four fields of one
- * shape (same grid, S, flags, thresholds; default colour engine) render in ONE march and ONE colour launch over their
- * field-major rays when the whole batch is one chunk, R % 16 == 0 and floater_thresh == 0 -- the same per-ray arithmetic
- * (depths bit-identical, colours to an ulp); otherwise field by field. */
+ * scene_workspace (may be NULL; lrf_workspace_bytes(min(n_rf, 4) * min(chunk, R), S) bytes): with it, groups of up to four fields
+ * of one shape (same grid, S, flags, thresholds; default colour engine) render each chunk in ONE march and ONE colour launch over
+ * their field-major rays when chunk % 16 == 0 and floater_thresh == 0 (a ragged last chunk goes field by field) -- the same
+ * per-ray arithmetic (depths bit-identical, colours to an ulp); otherwise field by field. */
 #define LRF_SCENE_MAX_FIELDS 64
 typedef struct LrfSceneField {
   const LrfField* field;

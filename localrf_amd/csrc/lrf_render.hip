@@ -247,7 +247,10 @@ __device__ void pack_mlp_w32_elem(const LrfParams& p, uint32_t* __restrict__ img
 // lrf_scene_rays' [n_rf, R, 6] output -- and a workgroup / a tile range picks its field's DField.  All per-ray arrays
 // (counts, compaction lists, partials, unit directions, outputs) are indexed by the virtual ray.
 constexpr int LRF_MULTI_MAX = 4;
-struct MultiF { DField f[LRF_MULTI_MAX]; int nf, Rf; };
+// Rs / lo: a chunk of a larger batch -- the rays the caller sees (inputs `rays`, outputs `rgb`, `depth`) of field k's r-th ray of
+// the chunk sit at index k * Rs + lo + r of arrays laid out [n_rf][Rs]; Rs = Rf, lo = 0 when the chunk is the batch.
+struct MultiF { DField f[LRF_MULTI_MAX]; int nf, Rf, Rs, lo; };
+__device__ __forceinline__ int multi_io(const MultiF& m, int k, int vray) { return k * m.Rs + m.lo + (vray - k * m.Rf); }
 template <bool MULTI> struct FieldArg { typedef DField type; };
 template <> struct FieldArg<true> { typedef MultiF type; };
 __device__ __forceinline__ const DField& field_of(const DField& f, int) { return f; }
@@ -269,6 +272,8 @@ __global__ __launch_bounds__(1024) void k_march(
   int fk_ = 0;
   if constexpr (MULTI) fk_ = min((lb * nw) / fin.Rf, fin.nf - 1);   // the workgroup's field (Rf is a multiple of nw: one field per workgroup)
   const DField& f = field_of(fin, fk_);
+  int io_ray = ray;                                        // where the caller keeps this ray (rays in, depth out)
+  if constexpr (MULTI) io_ray = multi_io(fin, fk_, ray);
   const float* s_line[3] = {nullptr, nullptr, nullptr};
   if (LDSL) {                                              // lines behind the alpha slices (whole block: before any return)
     float* base = s_alpha_all + (size_t)nw * S;
@@ -285,9 +290,9 @@ __global__ __launch_bounds__(1024) void k_march(
   }
   if (ray >= R) return;
   float* s_alpha = s_alpha_all + (size_t)wave * S;
-  const int oray = f.perm ? f.perm[ray] : ray;             // where the caller sees this ray (ray sorting)
+  const int oray = f.perm ? f.perm[ray] : io_ray;          // where the caller sees this ray (ray sorting / a chunk of a multi-field batch)
 
-  const float* rp = rays + (size_t)ray * 6;
+  const float* rp = rays + (size_t)io_ray * 6;
   const float o[3] = {rp[0], rp[1], rp[2]};
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);      // :578-580
   const float dh[3] = {rp[3] / dn, rp[4] / dn, rp[5] / dn};
@@ -1250,11 +1255,11 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // Fused form: groups of up to LRF_MULTI_MAX fields in ONE march and ONE colour launch over their field-major "virtual" rays
-  // (3 launches per group instead of 2 per field; one prologue, one tail).  Needs: the whole batch in one chunk, R a multiple
-  // of 16 (a march workgroup stays inside one field), the default engine, and fields of one shape: same grid, sample count,
+  // (3 launches per group and chunk instead of 2 per field; one prologue, one tail).  Needs: chunks of a multiple of 16 rays
+  // (a march workgroup stays inside one field; a ragged last chunk goes field by field), the default engine, and fields of one shape: same grid, sample count,
   // flags, thresholds (their schedules z are then the same numbers).  `scene_workspace` (lrf_workspace_bytes(group rays, S))
   // holds the group's per-ray state.  Same arithmetic per ray (depths bit-identical, colours to an ulp: a second compilation of the colour kernel).
-  bool fuse = scene_workspace && n_rf >= 2 && chunk >= R && R > 0 && R % 16 == 0 && !g_no_scene_fuse;
+  bool fuse = scene_workspace && n_rf >= 2 && R > 0 && chunk % 16 == 0 && !g_no_scene_fuse;
   for (int k = 0; fuse && k < n_rf; ++k) {
     const LrfSceneField& a = fields[k], &b = fields[0];
     if (!a.field->cache || gen_check(a.field) || !gen_is_default(a.field->fea_pe, a.field->view_pe, a.field->feature_c ? a.field->feature_c : LRF_FEATC)) fuse = false;
@@ -1266,19 +1271,31 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
   if (fuse) {
     const int32_t S = fields[0].S;
     if (S < 2 || S > 4096) return set_err("lrf_scene_fwd: need 2 <= S <= 4096");
-    for (int k0 = 0; k0 < n_rf; k0 += LRF_MULTI_MAX) {
-      const int nf = n_rf - k0 < LRF_MULTI_MAX ? n_rf - k0 : LRF_MULTI_MAX;
-      const int Rv = nf * R;
-      if (lrf_workspace_bytes(Rv, S) > scene_workspace_bytes) return set_err("lrf_scene_fwd: scene workspace too small");
-      const Workspace w = carve(scene_workspace, Rv, S);
-      MultiF mf;
-      mf.nf = nf; mf.Rf = R;
-      for (int k = 0; k < nf; ++k) { mf.f[k] = make_dfield(fields[k0 + k].field); mf.f[k].rdir = w.rdir; }
-      for (int k = nf; k < LRF_MULTI_MAX; ++k) mf.f[k] = mf.f[0];
-      const float* rv = rays + (size_t)k0 * R * 6;
-      launch_march(mf.f[0], rv, fields[k0].z, Rv, S, fields[k0].flags, 0.0f, depth_f + (size_t)k0 * R, w.acc, nullptr,
-                   w.ncomp, w.cidx, w.cw, nullptr, st, &mf);
-      LRF_HIP(launch_shade3_multi(mf, rv, fields[k0].z, Rv, S, fields[k0].flags, w, rgb_f + (size_t)k0 * R * 3, st));
+    for (int32_t lo = 0; lo < R; lo += chunk) {                // chunk by chunk, as the field-by-field form (:440)
+      const int32_t n = R - lo < chunk ? R - lo : chunk;
+      if (n % 16) {                                            // a ragged last chunk: field by field
+        for (int k = 0; k < n_rf; ++k) {
+          const LrfSceneField& sf = fields[k];
+          rc = render_fwd_impl(sf.field, rays + ((size_t)k * R + lo) * 6, sf.z, n, sf.S, sf.flags, floater_thresh,
+                               rgb_f + ((size_t)k * R + lo) * 3, depth_f + (size_t)k * R + lo, nullptr, nullptr, sf.workspace, st, nullptr);
+          if (rc != 0 && rc != 2) return rc;
+        }
+        continue;
+      }
+      for (int k0 = 0; k0 < n_rf; k0 += LRF_MULTI_MAX) {
+        const int nf = n_rf - k0 < LRF_MULTI_MAX ? n_rf - k0 : LRF_MULTI_MAX;
+        const int Rv = nf * n;
+        if (lrf_workspace_bytes(Rv, S) > scene_workspace_bytes) return set_err("lrf_scene_fwd: scene workspace too small");
+        const Workspace w = carve(scene_workspace, Rv, S);
+        MultiF mf;
+        mf.nf = nf; mf.Rf = n; mf.Rs = R; mf.lo = lo;
+        for (int k = 0; k < nf; ++k) { mf.f[k] = make_dfield(fields[k0 + k].field); mf.f[k].rdir = w.rdir; }
+        for (int k = nf; k < LRF_MULTI_MAX; ++k) mf.f[k] = mf.f[0];
+        const float* rv = rays + (size_t)k0 * R * 6;           // field k of the group: rays [k0 + k][lo + r], outputs likewise (multi_io)
+        launch_march(mf.f[0], rv, fields[k0].z, Rv, S, fields[k0].flags, 0.0f, depth_f + (size_t)k0 * R, w.acc, nullptr,
+                     w.ncomp, w.cidx, w.cw, nullptr, st, &mf);
+        LRF_HIP(launch_shade3_multi(mf, rv, fields[k0].z, Rv, S, fields[k0].flags, w, rgb_f + (size_t)k0 * R * 3, st));
+      }
     }
     LRF_HIP(hipGetLastError());
     return lrf_scene_blend(rgb_f, depth_f, blend_w, exposure, R, per_view, n_rf, rgbs, depth, nullptr, stream);

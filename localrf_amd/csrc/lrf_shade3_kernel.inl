@@ -136,7 +136,11 @@ __global__ __launch_bounds__(NW * 64) void LRF_SHADE3_NAME(
     const size_t ci = (size_t)w_ray * S + j0 + (n < cnt ? n : 0);
     hd.k = cidx[ci];
     hd.wgt = (n < cnt && h == 0) ? cw[ci] : 0.0f;              // the two K halves of a sample hold the same colour: count it once
+#if LRF_SHADE3_MULTI
+    const float* rp = rays + (size_t)multi_io(mf, fk, w_ray) * 6;       // (a chunk of a larger batch: the caller's ray index)
+#else
     const float* rp = rays + (size_t)w_ray * 6;
+#endif
     const float4 dq = *reinterpret_cast<const float4*>(f.rdir + (size_t)w_ray * 4);     // d / |d| as k_march formed it (tensorBase.py:578-580)
     hd.o[0] = rp[0]; hd.o[1] = rp[1]; hd.o[2] = rp[2]; hd.d[0] = dq.x; hd.d[1] = dq.y; hd.d[2] = dq.z;
     return hd;
@@ -319,7 +323,11 @@ __global__ __launch_bounds__(NW * 64) void LRF_SHADE3_NAME(
   // waves share one L1 and these lines were never read before in this launch; the stores only have to be acknowledged.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#if LRF_SHADE3_MULTI
+  for (int r = ra + tid; r < rb; r += NT) finalize_ray<false>(r, (int)toff[r + 1] - (int)toff[r], pmax, flags, acc, part, rgb_out, acc_out, multi_io(mf, min(r / mf.Rf, mf.nf - 1), r));
+#else
   for (int r = ra + tid; r < rb; r += NT) finalize_ray<false>(r, (int)toff[r + 1] - (int)toff[r], pmax, flags, acc, part, rgb_out, acc_out, f.perm ? f.perm[r] : r);
+#endif
   LRF_TICK(7);
   if (TIMED && f.dump && lane == 0) {
     unsigned long long* dp = reinterpret_cast<unsigned long long*>(f.dump) + ((size_t)blockIdx.x * NW + wave) * 8;

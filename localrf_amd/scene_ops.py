@@ -214,12 +214,12 @@ def scene_forward(ray_ids, cam2world, world2rf, focal, center, per_view, W, H, f
         arr[k].flags = f._flags(bool(white_bg)) | (N.LRF_FLAG_PE_OFF if (f.fea_pe > 0 and not refine) else 0)   # local_tensorfs.py:446 passes refine=self.is_refining
         arr[k].workspace = ws.data_ptr()
     # per-ray state of the fused form (several fields in one march + one colour launch over their field-major rays): a group
-    # of up to 4 fields of one shape, the whole batch in one chunk
+    # of up to 4 fields of one shape, chunk by chunk (chunks of a multiple of 16 rays)
     sws, sws_bytes = None, 0
-    if n_rf >= 2 and n_chunk >= R and R % 16 == 0 and R > 0:
+    if n_rf >= 2 and n_chunk % 16 == 0 and R > 0:
         S0 = int(arr[0].S)
         if all(int(arr[k].S) == S0 for k in range(n_rf)):
-            sws_bytes = int(N.lib().lrf_workspace_bytes(min(n_rf, 4) * R, S0))
+            sws_bytes = int(N.lib().lrf_workspace_bytes(min(n_rf, 4) * n_chunk, S0))
             sws = _scene_workspace(dev, sws_bytes)
     rays = torch.empty(n_rf, R, 6, dtype=torch.float32, device=dev)
     rgb_f = torch.empty(n_rf, R, 3, dtype=torch.float32, device=dev)

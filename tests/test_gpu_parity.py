@@ -1144,14 +1144,21 @@ def test_scene_forward_fused_fields_equal_field_by_field(built_lib):
         bw = torch.rand(V, n_fields, generator=g) + 0.1
         bw = bw / bw.sum(1, keepdim=True)
         out = {}
-        for fuse in (1, 0):
-            lib.lrf_debug_set_scene_fuse(fuse)
+        for fuse in (1, 0, 2):                                       # 2: fused, in chunks (3 x 160 rays + a ragged 32: min_chunk lowered for it)
+            lib.lrf_debug_set_scene_fuse(1 if fuse else 0)
+            mc = lt.min_chunk
+            if fuse == 2:
+                lt.min_chunk = 1
             try:
                 with torch.no_grad():
-                    out[fuse] = [t.clone() for t in lt(ray_ids, view_ids, 48, 36, is_train=False, blending_weights=bw, chunk=4096)]
+                    out[fuse] = [t.clone() for t in lt(ray_ids, view_ids, 48, 36, is_train=False, blending_weights=bw,
+                                                       chunk=4096 if fuse != 2 else 160 * n_fields)]
             finally:
                 lib.lrf_debug_set_scene_fuse(1)
+                lt.min_chunk = mc
         torch.cuda.synchronize()
+        for a, b in zip(out[2], out[1]):                            # chunked fused = unchunked fused, bit for bit (same kernels, same per-ray order)
+            assert torch.equal(a, b), (n_fields, "chunked", float((a.float() - b.float()).abs().max()))
         assert float((out[1][0] - out[0][0]).abs().max()) <= 2e-7, float((out[1][0] - out[0][0]).abs().max())    # colours in [0, 1]
         for a, b in zip(out[1][1:], out[0][1:]):                  # depth, directions, ij
             assert torch.equal(a, b), (n_fields, float((a.float() - b.float()).abs().max()))
