@@ -494,7 +494,9 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
     const float* __restrict__ crgb, const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
     const float* __restrict__ rpart, int pmax, float* __restrict__ g_rays,
     BinGeom bg, uint16_t* __restrict__ tid /* [3][nmax] plane-tile id of every density entry, 0xffff = none */,
-    int* __restrict__ hist /* += entries per tile */, uint32_t nmax) {
+    int* __restrict__ hist /* += entries per tile */, uint32_t nmax,
+    unsigned* __restrict__ vmax_bits /* max over samples, planes, channels of |g line| and |g plane| as float bits (atomicMax): every
+                                        contribution the fixed-point density scatter adds is at most this (k_scatter_fix) */) {
   extern __shared__ float s_all[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
     }
   }
   // density scatter (tile ids for the binned scatter kernel) + position gradient
+  float vmax = 0.0f;
   for (int k = lane; k < S; k += 64) {
     const float gf = s_alpha[k];                               // (0 for the last sample)
     const size_t ei = (size_t)ray * S + k;                     // entry index = sample id
@@ -656,6 +659,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
           const float P = (v00 * (1.0f - tx) + v10 * tx) * (1.0f - ty) + (v01 * (1.0f - tx) + v11 * tx) * ty;
           const float Lv = e0 * (1.0f - tl) + e1 * tl;
           const float dP = gf * Lv, dL = gf * P;
+          vmax = fmaxf(vmax, fmaxf(fabsf(dP), fabsf(dL)));
           gix += dP * ((v10 - v00) * (1.0f - ty) + (v11 - v01) * ty);
           giy += dP * ((v01 - v00) * (1.0f - tx) + (v11 - v10) * tx);
           gil += dL * (e1 - e0);
@@ -668,6 +672,9 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
 #pragma unroll
     for (int a = 0; a < 3; ++a) { go3[a] += gx3[a]; gdh[a] += gx3[a] * zk; }
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+  if (lane == 0 && vmax > 0.0f) atomicMax(vmax_bits, __float_as_uint(vmax));
   // appearance partials of this ray's tiles (written by k_train_dgrad3); with rpart == null they are added
   // afterwards by k_rays_add_rpart, so that this kernel does not have to wait for the data-gradient kernel
   const int nt = rpart ? 2 * ((nsh + ITEM3 - 1) / ITEM3) : 0;          // 16-row tiles of the ray (k_shade3<SAVE>)
@@ -828,6 +835,16 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
 // ScatterDst), x fastest; round 3 flushed into a channel-last gradient image that one more kernel unpacked (a 35-70 MB
 // memset + read + transpose per step).
 struct ScatterDst { float* plane[3]; float* line[3]; };
+#ifdef LRF_SCATTER_PROF          // experiment build: s_memtime totals of wave 0 of every workgroup -> g_scat_prof[APP][block][12]
+__device__ unsigned long long g_scat_prof[2][2048][12];
+#define SP_TICK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sp_tk[i] += now_ - sp_last; sp_last = now_; } while (0)
+#define SP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SP_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define SP_TICK(i) do {} while (0)
+#define SP_WAIT_VM() do {} while (0)
+#define SP_WAIT_LGKM() do {} while (0)
+#endif
 template <int C, bool APP, int NT, bool LINES>
 __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, ScatterDst dst, const float* __restrict__ rays,
                                                        const float* __restrict__ z, int S, const int* __restrict__ offs,
@@ -842,6 +859,11 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
   int a = (int)(E0 + E * blockIdx.x / gridDim.x);
   const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
   if (a >= b) return;
+#ifdef LRF_SCATTER_PROF
+  unsigned long long sp_tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_last = __builtin_readcyclecounter();
+  const unsigned long long sp_t0 = sp_last;
+  sp_tk[9] = (unsigned long long)(b - a);
+#endif
   int lo = bin_lo, hi = bin_hi;                        // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
   int bin = lo;
@@ -870,6 +892,10 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
     }
     for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) s_acc[i] = 0.0f;
     __syncthreads();
+    SP_TICK(0);
+#ifdef LRF_SCATTER_PROF
+    sp_tk[8] += 1;
+#endif
     const float* lnp = APP ? f.aline[p] : f.dline[p];
     const float* plp = APP ? f.aplane[p] : f.dplane[p];
     // Two phases per 64 entries of a wave.  A: lane = entry -- list / row lookup, sample position,
@@ -895,6 +921,10 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
         lpk = (l0 << 1) | (l1 - l0);
         ppk = y0 * f.pw[p] + x0;                       // (LINES) texel index of the base tap in the plane itself
       }
+      SP_WAIT_VM(); SP_TICK(1);
+#ifdef LRF_SCATTER_PROF
+      sp_tk[10] += 1;
+#endif
       const int n_here = min(64, seg_end - e0);
       // A group of LPE lanes takes LPE consecutive entries IN LIST ORDER: the list keeps consecutive
       // samples of a ray adjacent, and those mostly share their base texel, so their contributions
@@ -970,6 +1000,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
           if (curl >= 0) flushl(curl);
           curl = lp;
         }
+        SP_WAIT_LGKM(); SP_TICK(4);
         const float w00 = (1.0f - sx) * (1.0f - sy), w10 = sx * (1.0f - sy), w01 = (1.0f - sx) * sy, w11 = sx * sy;
         constexpr int CS = APP ? LRF_CAS : C;               // channel stride of the cache / gradient image
         const float* r0 = lnp + (size_t)(lp >> 1) * CS;
@@ -1003,6 +1034,7 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
             for (int j = 0; j < CPL; ++j) { v00[j] = q00[CPL * sub + j]; v10[j] = q10[CPL * sub + j]; v01[j] = q01[CPL * sub + j]; v11[j] = q11[CPL * sub + j]; }
           }
         }
+        SP_WAIT_VM(); SP_TICK(2);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
           const float Lv = e0v[j] * (1.0f - sl) + e1v[j] * sl;
@@ -1015,11 +1047,14 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
             lac[1][j] += dL * sl;
           }
         }
+        SP_TICK(3);
       }
       if (cur >= 0) flush(cur);
       if (LINES && curl >= 0) flushl(curl);
+      SP_WAIT_LGKM(); SP_TICK(4);
     }
     __syncthreads();
+    SP_TICK(5);
     float* gpl = dst.plane[p];
     for (int i = threadIdx.x; i < BCELL * BCELL * C; i += NT) {       // x fastest: 33 consecutive floats of one channel row
       const int c = i / (BCELL * BCELL), cell = i % (BCELL * BCELL);
@@ -1030,9 +1065,17 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
         atomic_add_f32(gpl + ((size_t)c * f.ph[p] + y) * f.pw[p] + x, v);
     }
     __syncthreads();
+    SP_TICK(6);
     a = seg_end;
   }
   if (LINES && lplane >= 0) flush_line();
+  SP_TICK(7);
+#ifdef LRF_SCATTER_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    sp_tk[11] = __builtin_readcyclecounter() - sp_t0;
+    for (int i = 0; i < 12; ++i) g_scat_prof[APP ? 1 : 0][blockIdx.x][i] = sp_tk[i];
+  }
+#endif
 }
 
 // line gradients: LINE_WGS workgroups per line, each accumulates its slice of the entries
@@ -1137,6 +1180,202 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, ScatterDst dst, c
   }
 }
 
+// ---------------------------------------------------------------- density scatter on 64-bit fixed point (round 6)
+// What the phase profile of k_scatter_plane said (profiles/r17_scatter_phases.md): per 64 entries a wave spends 2.3 K cycles on
+// positions and taps, 2.7 K waiting for gathers and 10.3 K in "shuffles + LDS adds" -- and replacing the compare-and-swap pairs
+// by fire-and-forget integer adds (wrong sums, timing only) took just 14 % off the kernel: what costs is the machinery around
+// the adds -- seven cross-lane reads per entry to hand phase A's lane-per-entry results to phase B's lane groups, run merging,
+// per-group flush branches.  This kernel has none of it: lane = entry from the list read to the last add, all eight channels
+// in the lane (taps as two float4 each: the widest loads the texture path offers), and every contribution is ONE
+// ds_add_u64 of a fixed-point value -- no return value, no retry loop, same-cell adds of neighbouring lanes (consecutive
+// samples of a ray) serialised by the LDS itself.  Accumulators are channel-major ([C][cell]: lanes of one instruction hit
+// different banks unless they share the cell).
+// Fixed point: every contribution is at most vmax = max |g line|, |g plane| (reduced by k_bwd_ray, which forms those products
+// for the position gradient), a cell receives at most 4 n of them from the n entries of the segment, so with
+// scale = 2^(min(50, 62 - bits(4 n)) - exponent(vmax)) no sum leaves 63 bits and no addend leaves 51 (the conversion below is
+// exact there).  The quantum is vmax 2^-50 .. 2^-38: sums are exact to far below fp32's own rounding of each product, and --
+// integer adds being associative -- independent of the order the entries arrive in: a workgroup's tile and line sums are
+// bit-reproducible (what still varies from run to run is the order of the fp32 atomics that add them into the gradient).
+constexpr int FIX_NT = 1024;
+__device__ __forceinline__ unsigned long long fix64(float v, double scale) {
+  // v * scale + 1.5 * 2^52: the low mantissa bits of the sum hold rint(v * scale) in two's complement (|v * scale| < 2^51)
+  const double x = fma((double)v, scale, 6755399441055744.0);
+  return (unsigned long long)(__double_as_longlong(x) - 0x4338000000000000ll);
+}
+__device__ __forceinline__ int fix_shift(unsigned n_contrib, int vex) { return min(50, 62 - (32 - __builtin_clz(n_contrib))) - vex; }
+// runs of equal keys among consecutive lanes of a 16-lane row: position of the lane in its run and whether it is the run's
+// last lane (which then holds the inclusive sum of seg_sum).  Lanes that are not `valid` form runs of their own.
+struct SegRun { bool f1, f2, f4, f8, tail; };
+template <int D>
+__device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true); }   // lane i <- lane i - D of its row, 0 where there is none
+__device__ __forceinline__ SegRun seg_run(int key, bool valid, int lane) {
+  if (!valid) key = -1 - lane;
+  const int prev = row_shr_i<1>(key);
+  const unsigned long long starts = __ballot((lane & 15) == 0 || prev != key);
+  const int leader = 63 - __builtin_clzll(starts & (~0ull >> (63 - lane)));
+  const int pos = lane - leader;
+  SegRun r;
+  r.f1 = pos >= 1; r.f2 = pos >= 2; r.f4 = pos >= 4; r.f8 = pos >= 8;
+  r.tail = valid && (lane == 63 || ((starts >> (lane + 1)) & 1ull));
+  return r;
+}
+__device__ __forceinline__ float seg_sum(float v, const SegRun& r) {
+  v += r.f1 ? __int_as_float(row_shr_i<1>(__float_as_int(v))) : 0.0f;
+  v += r.f2 ? __int_as_float(row_shr_i<2>(__float_as_int(v))) : 0.0f;
+  v += r.f4 ? __int_as_float(row_shr_i<4>(__float_as_int(v))) : 0.0f;
+  v += r.f8 ? __int_as_float(row_shr_i<8>(__float_as_int(v))) : 0.0f;
+  return v;
+}
+template <int C, bool APP, int NT>
+__global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, ScatterDst dst, const float* __restrict__ rays,
+                                                     const float* __restrict__ z, int S, const int* __restrict__ offs,
+                                                     const uint32_t* __restrict__ list, const float* __restrict__ gf,
+                                                     const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
+                                                     const unsigned* __restrict__ vmax_bits, int bin_lo, int bin_hi) {
+  static_assert(!APP && C == LRF_CD, "density only (the appearance tile does not fit as 64-bit cells)");
+  constexpr int CELLS = BCELL * BCELL;
+  extern __shared__ unsigned long long s_fx[];          // [C][CELLS] tile, then [C][L_p] line
+  unsigned long long* s_fl = s_fx + C * CELLS;
+  const long long E0 = offs[bin_lo], E = (long long)offs[bin_hi] - E0;
+  int a = (int)(E0 + E * blockIdx.x / gridDim.x);
+  const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
+  if (a >= b) return;
+#ifdef LRF_SCATTER_PROF
+  unsigned long long sp_tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_last = __builtin_readcyclecounter();
+  const unsigned long long sp_t0 = sp_last;
+  sp_tk[9] = (unsigned long long)(b - a);
+#endif
+  int vex = 0;
+  (void)frexpf(__uint_as_float(*vmax_bits), &vex);      // vmax < 2^vex
+  vex = max(-120, min(127, vex));
+  int lo = bin_lo, hi = bin_hi;                         // largest bin with offs[bin] <= a
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
+  int bin = lo;
+  int lplane = -1, shL = 0;                             // plane whose line gradient s_fl holds, its scale
+  auto flush_line = [&]() {                             // whole workgroup; s_fl -> += the gradient of line `lplane` ([C][L])
+    __syncthreads();
+    float* gln = dst.line[lplane];
+    const int nl = f.ll[lplane] * C;
+    const double inv = ldexp(1.0, -shL);
+    for (int i = threadIdx.x; i < nl; i += NT) {
+      const long long q = (long long)s_fl[i];
+      if (q != 0) atomic_add_f32(gln + i, (float)((double)q * inv));
+    }
+    __syncthreads();
+  };
+  while (a < b) {
+    while (offs[bin + 1] <= a) ++bin;
+    const int seg_end = min(b, offs[bin + 1]);
+    const int p = bin >= bg.base[2] ? 2 : (bin >= bg.base[1] ? 1 : 0);
+    const int t = bin - bg.base[p];
+    const int tx0 = (t % bg.tx[p]) * BTILE, ty0 = (t / bg.tx[p]) * BTILE;
+    const int pw = f.pw[p], ph = f.ph[p], ll = f.ll[p];
+    if (p != lplane) {
+      if (lplane >= 0) flush_line();
+      lplane = p;
+      // this workgroup's entries of plane p: at most two contributions each to a line cell
+      const int pend = min(b, offs[min(bin_hi, p == 2 ? bg.total : bg.base[p + 1])]);
+      shL = fix_shift(2u * (unsigned)(pend - a), vex);
+      for (int i = threadIdx.x; i < ll * C; i += NT) s_fl[i] = 0ull;
+    }
+    for (int i = threadIdx.x; i < C * CELLS; i += NT) s_fx[i] = 0ull;
+    __syncthreads();
+    SP_TICK(0);
+#ifdef LRF_SCATTER_PROF
+    sp_tk[8] += 1;
+#endif
+    const int shT = fix_shift(4u * (unsigned)(seg_end - a), vex);
+    const double scT = ldexp(1.0, shT), scL = ldexp(1.0, shL);
+    const float* lnp = f.dline[p];
+    const float* plp = f.dplane[p];
+    const int am0 = MAT0[p], am1 = MAT1[p], av = VEC[p];
+    const int lane = threadIdx.x & 63;
+    for (int e0 = a + (int)(threadIdx.x & ~63u); e0 < seg_end; e0 += NT) {      // (whole waves: the run sums below are wave operations)
+      const int e = e0 + lane;
+      const bool valid = e < seg_end;
+      const uint32_t cid = list[valid ? e : seg_end - 1];
+      const float g = valid ? gf[cid] : 0.0f;
+      float u[3];
+      cid_point(f, rays, z, S, cid, u);
+      int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
+      tap1d(u[am0], pw, x0, x1, tx);
+      tap1d(u[am1], ph, y0, y1, ty);
+      tap1d(u[av],  ll, l0, l1, tl);
+      const int c00 = (y0 - ty0) * BCELL + (x0 - tx0), cx = x1 - x0, cy = (y1 - y0) * BCELL;
+      const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+      float e0v[C], e1v[C], v00[C], v10[C], v01[C], v11[C];
+      const float* r0 = lnp + (size_t)l0 * C;
+      const float* r1 = lnp + (size_t)l1 * C;
+      const float* q00 = plp + ((size_t)y0 * pw + x0) * C;
+      const float* q10 = q00 + (size_t)cx * C;
+      const float* q01 = q00 + (size_t)(y1 - y0) * pw * C;
+      const float* q11 = q01 + (size_t)cx * C;
+#pragma unroll
+      for (int h = 0; h < C / 4; ++h) {
+        ld4g(r0 + 4 * h, e0v + 4 * h);  ld4g(r1 + 4 * h, e1v + 4 * h);
+        ld4g(q00 + 4 * h, v00 + 4 * h); ld4g(q10 + 4 * h, v10 + 4 * h);
+        ld4g(q01 + 4 * h, v01 + 4 * h); ld4g(q11 + 4 * h, v11 + 4 * h);
+      }
+      SP_WAIT_VM(); SP_TICK(1);
+#ifdef LRF_SCATTER_PROF
+      sp_tk[10] += 1;
+#endif
+      // Consecutive entries are mostly consecutive samples of one ray, and in the contracted far field dozens of them share
+      // their cell: left alone, the adds of one instruction pile up on a handful of addresses and the LDS serialises them
+      // (measured: 52 cycles per ds_add_u64 instruction against 11 for distinct addresses).  So the lanes of a RUN -- equal
+      // cell and tap steps, inside one 16-lane row -- are summed across lanes first (inclusive segmented scan, four DPP
+      // row shifts per value) and only the run's last lane adds.
+      const SegRun rt = seg_run((c00 << 2) | (cx << 1) | (cy ? 1 : 0), valid, lane);
+      const SegRun rl = seg_run((l0 << 1) | (l1 - l0), valid, lane);
+      unsigned long long* tc = s_fx + c00;
+      unsigned long long* lc0 = s_fl + l0;
+      unsigned long long* lc1 = s_fl + l1;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float Lv = e0v[c] * (1.0f - tl) + e1v[c] * tl;
+        const float dP = g * Lv;
+        const float t00 = seg_sum(dP * w00, rt), t10 = seg_sum(dP * w10, rt), t01 = seg_sum(dP * w01, rt), t11 = seg_sum(dP * w11, rt);
+        if (rt.tail) {
+          atomicAdd(tc + c * CELLS, fix64(t00, scT));
+          atomicAdd(tc + c * CELLS + cx, fix64(t10, scT));
+          atomicAdd(tc + c * CELLS + cy, fix64(t01, scT));
+          atomicAdd(tc + c * CELLS + cy + cx, fix64(t11, scT));
+        }
+        const float P = v00[c] * w00 + v10[c] * w10 + v01[c] * w01 + v11[c] * w11;
+        const float dL = g * P;
+        const float s0 = seg_sum(dL * (1.0f - tl), rl), s1 = seg_sum(dL * tl, rl);
+        if (rl.tail) {
+          atomicAdd(lc0 + c * ll, fix64(s0, scL));
+          atomicAdd(lc1 + c * ll, fix64(s1, scL));
+        }
+      }
+      SP_WAIT_LGKM(); SP_TICK(4);
+    }
+    __syncthreads();
+    SP_TICK(5);
+    float* gpl = dst.plane[p];
+    const double invT = ldexp(1.0, -shT);
+    for (int i = threadIdx.x; i < C * CELLS; i += NT) {          // x fastest: 33 consecutive floats of one channel row
+      const long long q = (long long)s_fx[i];
+      if (q == 0) continue;
+      const int c = i / CELLS, cell = i % CELLS;
+      const int x = tx0 + cell % BCELL, y = ty0 + cell / BCELL;
+      if (x < pw && y < ph) atomic_add_f32(gpl + ((size_t)c * ph + y) * pw + x, (float)((double)q * invT));
+    }
+    __syncthreads();
+    SP_TICK(6);
+    a = seg_end;
+  }
+  if (lplane >= 0) flush_line();
+  SP_TICK(7);
+#ifdef LRF_SCATTER_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    sp_tk[11] = __builtin_readcyclecounter() - sp_t0;
+    for (int i = 0; i < 12; ++i) g_scat_prof[0][blockIdx.x][i] = sp_tk[i];
+  }
+#endif
+}
+
 #include "lrf_train32.inl"
 
 struct BwdWorkspace {
@@ -1172,7 +1411,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.nmax = (uint32_t)rows;                                     // rows >= R*S
   b.rowinfo = reinterpret_cast<uint32_t*>(take(rows));
   b.tid = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
-  b.hist = reinterpret_cast<int*>(take(2 * BIN_MAX));           // histogram, then the fill pass's cursors: cleared by one memset
+  b.hist = reinterpret_cast<int*>(take(2 * BIN_MAX + 8));       // histogram, then the fill pass's cursors, then max|contribution| (k_bwd_ray): cleared by one memset
   b.cursor = b.hist + BIN_MAX;
   b.offs = reinterpret_cast<int*>(take(BIN_MAX + 1));
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
@@ -1195,6 +1434,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
 // lrf_train32.inl.)
 static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 + k_train_app3 without row stores / position gradient and X / dz1 products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
+static int g_scatter_fix = 1;       // lrf_debug_set_train_fwd_engine(16 | ...): the density scatter with fp32 compare-and-swap adds (k_scatter_plane<8>, rounds 2-5) instead of k_scatter_fix; the tests compare the two
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
                                     const BwdWorkspace& b, float* rgb, hipStream_t st) {
@@ -1213,7 +1453,7 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_dgrad_dbg = (e >> 5) & 7; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : 1; lrf::g_dgrad_dbg = (e >> 5) & 7; }
 
 namespace lrf {
 // floats per row of weight-gradient operands when the backward runs the generic engine (any non-default network, or
@@ -1308,6 +1548,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CD, false, FIX_NT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
       lds_attr_err[dev_id & 63] = e;
@@ -1367,26 +1609,34 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                        b.grd, b.rowinfo, b.relu_bits, b.act, b.wpart, g_dgrad_dbg & 5);
   }
   if (ss) LRF_HIP(hipEventRecord(ss->app[0], st));         // go / dfeat rows: the weight-gradient kernel may start
+  const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
+  const size_t lds_ap = sizeof(float) * BCELL * BCELL * LRF_CA, lds_al = sizeof(float) * LRF_CA * ll_max;
+  const bool fuse_a = g_scatter_fused && lds_ap + lds_al <= 158 * 1024;
   LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * 2 * BIN_MAX, st));
   hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
                      d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
                      b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3);
 
   // ---- side stream: per-ray backward, density scatter
-  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * 2 * BIN_MAX, sb));
+  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));
+  unsigned* vmax_d = reinterpret_cast<unsigned*>(b.hist + 2 * BIN_MAX);
   hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
                      d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
-                     (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax);
-  hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
-  const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
+                     (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax, vmax_d);
   // line gradients ride on the plane pass when tile + line accumulators fit in LDS (g_scatter_fused; appearance at 640^3 does not)
   const size_t lds_dp = sizeof(float) * BCELL * BCELL * LRF_CD, lds_dl = sizeof(float) * LRF_CD * ll_max;
-  const size_t lds_ap = sizeof(float) * BCELL * BCELL * LRF_CA, lds_al = sizeof(float) * LRF_CA * ll_max;
-  const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024, fuse_a = g_scatter_fused && lds_ap + lds_al <= 158 * 1024;
-  if (fuse_d) {
+  const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024;
+  const bool fix_d = g_scatter_fix && g_scatter_fused && 2 * (lds_dp + lds_dl) <= 158 * 1024;   // 64-bit fixed-point accumulators: twice the bytes
+  if (fix_d) {
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
+    hipLaunchKernelGGL((k_scatter_fix<LRF_CD, false, FIX_NT>), dim3(cus), dim3(FIX_NT), 2 * (lds_dp + lds_dl), sb,
+                       d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, vmax_d, 0, bg.total);
+  } else if (fuse_d) {
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
     hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512, true>), dim3(cus * LRF_DPLANE_MULT), dim3(512), lds_dp + lds_dl, sb,
                        d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, 0, bg.total);
   } else {
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
     hipLaunchKernelGGL((k_scatter_plane<LRF_CD, false, 512, false>), dim3(cus * LRF_DPLANE_MULT), dim3(512), lds_dp, sb,
                        d, bg, dst_d, rays, z, S, b.offs, b.list, b.feat, b.rowinfo, b.grd, 0, bg.total);
     hipLaunchKernelGGL((k_scatter_line<LRF_CD, false, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_dl, sb,

@@ -969,18 +969,24 @@ static const float* sort_rays_if_asked(DField& d, const float* rays, int R, uint
   return w.rays_s;
 }
 
-// k_march launch: lines in LDS when the three of them (+ the alpha slices) leave four workgroups per CU
+// rays per k_march workgroup with the density lines in LDS (4, 8 or 16), 0 when alpha slices + lines do not fit (grids of
+// about 900^3 and above) or lrf_debug_set_lds_lines(0): k_march<false> then reads the lines from global memory
+static int march_lds_rays(const int32_t ll[3], int S) {
+  if (g_no_lds_lines) return 0;
+  const size_t lds_l = (size_t)(ll[0] + ll[1] + ll[2]) * LRF_CD * sizeof(float);
+  for (int cand = 4; cand <= 16; cand *= 2)
+    if (((size_t)cand * S * sizeof(float) + lds_l) * (16 / cand) <= 156 * 1024) return cand;
+  return 0;
+}
+// k_march launch: lines in LDS when the three of them (+ the alpha slices) leave four workgroups per CU.  mf (the fused
+// multi-field form) exists with the lines in LDS only: lrf_scene_fwd does not fuse when march_lds_rays() is 0.
 static void launch_march(const DField& d, const float* rays, const float* z, int R, int S, uint32_t flags, float floater,
                          float* depth, float* acc, float* w_all, int* ncomp, uint16_t* cidx, float* cw, float* feat,
                          hipStream_t st, const MultiF* mf = nullptr) {
   // 4 waves per SIMD either way (123 VGPRs): 4 / 2 / 1 workgroups of 4 / 8 / 16 rays per CU, whichever keeps
   // alpha slices + lines within the CU's 160 KB (300^3: 8 + 29 KB x 4; 500^3: 18 + 48 KB x 2; 640^3: 47 + 61 KB x 1)
   const size_t lds_l = (size_t)(d.ll[0] + d.ll[1] + d.ll[2]) * LRF_CD * sizeof(float);
-  int nw = 0;
-  if (!g_no_lds_lines) {
-    for (int cand = 4; cand <= 16 && !nw; cand *= 2)
-      if (((size_t)cand * S * sizeof(float) + lds_l) * (16 / cand) <= 156 * 1024) nw = cand;
-  }
+  const int nw = march_lds_rays(d.ll, S);
   if (nw) {
     const size_t lds = (size_t)nw * S * sizeof(float) + lds_l;
     if (lds > 64 * 1024) {
@@ -1136,6 +1142,11 @@ int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): k_wgrad_w2w3 on the caller's stream (n > 0) or on the side stream (n = 0)
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
+#ifdef LRF_SCATTER_PROF
+int lrf_debug_scatter_prof(unsigned long long* host_out /* [2][2048][12] */) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lrf::g_scat_prof), sizeof(unsigned long long) * 2 * 2048 * 12);
+}
+#endif
 void lrf_debug_set_scene_fuse(int on) { g_no_scene_fuse = on ? 0 : 1; }
 // Where column `col` of saved row `row` lives, in floats from the start of the ACT (buffer 0) / GRD (buffer 1) region
 // of a training workspace (lrf_workspace_layout_bwd gives the regions): the fragment order of lrf_common.h, host side.
@@ -1268,6 +1279,11 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
     else if (a.field->weight_thres != b.field->weight_thres || a.field->term_T != b.field->term_T) fuse = false;
   }
   if (fuse && floater_thresh > 0.0f) fuse = false;             // (the floater filter's second pass: per-field path)
+  if (fuse) {                                                  // k_march<MULTI> keeps the density lines in LDS: no such form without them
+    const int32_t* g = fields[0].field->grid;                  // (line p runs along axis VEC[p]: the three lengths are the three grid sizes)
+    const int32_t ll[3] = {g[0], g[1], g[2]};
+    if (!march_lds_rays(ll, fields[0].S)) fuse = false;
+  }
   if (fuse) {
     const int32_t S = fields[0].S;
     if (S < 2 || S > 4096) return set_err("lrf_scene_fwd: need 2 <= S <= 4096");

@@ -165,6 +165,13 @@ class CapturedIteration:
             field.jitter_override = None
             lt.freeze_intrinsics = frozen
         total.backward()
+        if lt.grad_sync is not None:
+            # Data parallel: with a regulariser in the loss autograd leaves the density tensors' .grad in a tensor of its own
+            # (regulariser + render), not in the flat buffer the exchange reduces in place.  Bringing them back HERE -- under
+            # capture too -- makes the copy a node of every replay and makes the Adam graph captured next bake the flat
+            # buffer's addresses: what the ranks reduce is what Adam reads (outside the graph the copy ran,
+            # but the captured Adam kept reading the rank-local stray and the replicas drifted apart).
+            field.rebucket_grads()
         self.kept = {k: v.detach() for k, v in kept.items()}
 
     def _adam(self):
@@ -207,12 +214,16 @@ class CapturedIteration:
         return g
 
     # ------------------------------------------------------------------ one iteration
-    def step(self, view_list, ray_ids, scalars=None, all_poses_active=False, pose_ids=(), tune_intrinsics=False, start=0):
+    def step(self, view_list, ray_ids, scalars=None, all_poses_active=False, pose_ids=(), tune_intrinsics=False, start=0,
+             global_views=None):
         """view_list: the batch's view ids (host ints, n_views of them); ray_ids: host int64 [batch] pixel ids, view-major;
         scalars: {name: float}; all_poses_active: every pose of `pose_ids` receives a gradient this iteration (the flow loss
         differentiates through all assembled frames) -- otherwise only the sampled views' poses are stepped; pose_ids /
         tune_intrinsics: what scene.step_begin returned; start: first frame of the pose assembly (the flow loss's
-        starting_frame_id; every sampled view must be >= start)."""
+        starting_frame_id; every sampled view must be >= start); global_views (data parallel): the view ids of the WHOLE
+        batch before localrf_amd.dist.shard_views -- the gradient exchange hands every rank the summed pose / exposure
+        gradients of all of them, so all of them are stepped on every rank, as the eager path does (has-gradient flags,
+        MAX over ranks); default: view_list."""
         lt = self.scene
         sig = self._signature(start, pose_ids, tune_intrinsics)
         if sig != self._sig:
@@ -231,7 +242,8 @@ class CapturedIteration:
             active = None
         else:
             active = set(self._always)
-            for v in set(int(x) for x in views.tolist()):
+            stepped = views if global_views is None else np.asarray(global_views, dtype=np.int64).reshape(-1)
+            for v in set(int(x) for x in stepped.tolist()):
                 active.update(self._pose_params.get(v, ()))
         self.plan.host_scalars(host["adam"], active)
         self.inputs.push(k)

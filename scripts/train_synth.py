@@ -243,6 +243,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     while training and (max_iters is None or it < max_iters):
         view_ids, ray_idx, (vv, pp) = data.sample(batch)
         if gs is not None:                                             # the captured iteration: the same schedule calls around one replay
+            all_views = view_ids.tolist()                              # every rank steps the poses of the whole batch's views
             if ddp:
                 ray_idx, view_ids = shard_views(ray_idx, view_ids, rank, world)
             phase["reg"] = bool(lt.regularize)
@@ -250,7 +251,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             start = max(data.active_frames_bounds[0] - 1, 0)
             pose_ids, tune = lt.step_begin(True, zero_grad=False)
             kept = gs.step(view_ids.tolist(), ray_idx.numpy(), {"reg_w": reg_w}, all_poses_active=phase["reg"] and geo,
-                           pose_ids=pose_ids, tune_intrinsics=tune, start=start)
+                           pose_ids=pose_ids, tune_intrinsics=tune, start=start, global_views=all_views)
             lt.step_schedule()
             can_add_rf = lt.step_finish()
             loss = kept["photo"]
@@ -366,6 +367,19 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     torch.cuda.synchronize(dev)
     if live is not None:                                               # (probes: the live objects of the run)
         live.update(scene=lt, captured=gs, data=data)
+    # data parallel: replicas must hold the SAME parameters -- every rank applied the same reduced gradients.  max |p - p of
+    # rank 0| over ranks, by group (field tensors, poses, exposures / intrinsics / the rest)
+    divergence = None
+    if ddp:
+        divergence = {"field": 0.0, "poses": 0.0, "other": 0.0}
+        for name, p in lt.named_parameters():
+            mine = p.detach().float().cpu() if dist.get_backend() == "gloo" else p.detach().float().clone()
+            ref = mine.clone()
+            dist.broadcast(ref, src=0)
+            d = (mine - ref).abs().max().reshape(1) if mine.numel() else torch.zeros(1, device=mine.device)
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)
+            key = "field" if name.startswith("tensorfs.") else ("poses" if name.startswith(("r_c2w.", "t_c2w.")) else "other")
+            divergence[key] = max(divergence[key], float(d))
     # checkpoint round trip into the reference's key set (local_tensorfs.py:326-356)
     sd = {k: v.detach().clone() for k, v in lt.state_dict().items()}
     lt2 = quiet(LocalTensorfs, **{**lt.get_kwargs(), "device": dev})
@@ -389,7 +403,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             "graph": (dict(gs.stats) if gs is not None else None), "all_losses": all_losses,
             "param_checksum": float(sum(p.detach().double().abs().sum() for p in lt.parameters())),
             "checkpoint_roundtrip": bool(same), "checkpoint_keys_follow_reference": bool(keys_ok), "world": world,
-            "final_resolution": res}
+            "final_resolution": res, "replica_divergence": divergence}
 
 
 def main():

@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void k(int iters, float* out) {
     int a;
     if (PATTERN == 0) a = (threadIdx.x + it * 256) & (N - 1);              // conflict-free, distinct
     else if (PATTERN == 1) { s = s * 1664525u + 1013904223u; a = (s >> 8) & (N - 1); }  // random
-    else { s = s * 1664525u + 1013904223u; a = (((s >> 8) & 1023) * 8 + (threadIdx.x & 7)) & (N - 1); } // 8-lane groups on random texels
+    else if (PATTERN == 2) { s = s * 1664525u + 1013904223u; a = (((s >> 8) & 1023) * 8 + (threadIdx.x & 7)) & (N - 1); } // 8-lane groups on random texels
+    else { uint32_t g = (threadIdx.x >> 2) * 2654435761u + blockIdx.x * 40503u + it * 97u; g = g * 1664525u + 1013904223u;     // 4-lane groups, lane owns 64-bit slot j of a random 24-float texel
+           a = (((g >> 8) % 340) * 24 + (threadIdx.x & 3) * 6 + 2 * (it % 3)) & (N - 1); }
     if (MODE == 0) atomicAdd(&acc[a], 1.0f);                                // ds_add_f32
     else if (MODE == 1) atomicAdd(reinterpret_cast<unsigned*>(&acc[a]), 1u);  // ds_add_u32
     else if (MODE == 2) r += (float)atomicAdd(reinterpret_cast<unsigned*>(&acc[a]), 1u);  // ds_add_rtn_u32
@@ -27,6 +29,17 @@ __global__ __launch_bounds__(256) void k(int iters, float* out) {
       do { assumed = old; old = atomicCAS(p, assumed, __float_as_uint(__uint_as_float(assumed) + 1.0f)); } while (old != assumed);
     } else if (MODE == 7) atomicAdd(reinterpret_cast<double*>(&acc[(a >> 1) << 1]), 1.0);          // ds_add_f64
     else if (MODE == 8) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(a >> 1) << 1]), 1ull);  // ds_add_u64
+    else if (MODE == 9) r += (float)atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(a >> 1) << 1]), 1ull);  // ds_add_rtn_u64
+    else if (MODE == 10) {                                                   // CAS-loop on 64 bits: two fp32 adds (the scatter kernels' form up to round 5)
+      unsigned long long* p = reinterpret_cast<unsigned long long*>(&acc[(a >> 1) << 1]);
+      unsigned long long old = *p, assumed;
+      do {
+        assumed = old;
+        const unsigned long long nv = (unsigned long long)__float_as_uint(__uint_as_float((unsigned)assumed) + 1.0f) |
+                                      ((unsigned long long)__float_as_uint(__uint_as_float((unsigned)(assumed >> 32)) + 1.0f) << 32);
+        old = atomicCAS(p, assumed, nv);
+      } while (old != assumed);
+    }
     else { float v = acc[a]; acc[a] = v + 1.0f; }                           // non-atomic rmw
   }
   __syncthreads();
@@ -54,7 +67,9 @@ int main() {
   run<2, 0>("ds_add_rtn_u32 distinct"); run<2, 1>("ds_add_rtn_u32 random");
   run<4, 1>("ds_add_rtn_f32 random");
   run<6, 0>("CAS-loop f32 distinct"); run<6, 1>("CAS-loop f32 random"); run<6, 2>("CAS-loop f32 8-lane texel");
-  run<7, 1>("ds_add_f64 random"); run<8, 1>("ds_add_u64 random");
+  run<7, 1>("ds_add_f64 random"); run<8, 1>("ds_add_u64 random"); run<8, 0>("ds_add_u64 distinct"); run<8, 3>("ds_add_u64 4-lane texel");
+  run<9, 1>("ds_add_rtn_u64 random"); run<10, 1>("CAS-loop 2xf32 (b64) random"); run<10, 3>("CAS-loop 2xf32 (b64) 4-lane texel");
+  run<1, 3>("ds_add_u32 4-lane texel"); run<6, 3>("CAS-loop f32 4-lane texel");
   run<3, 0>("ds_write distinct"); run<3, 1>("ds_write random");
   run<5, 0>("rmw non-atomic distinct"); run<5, 1>("rmw non-atomic random");
   return 0;

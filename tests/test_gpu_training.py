@@ -1304,7 +1304,10 @@ def test_two_rank_progressive_loop_with_captured_iterations(tmp_path):
     """configs[4]'s ray shard with the captured iteration: two ranks (gloo: both on this GPU) run scripts/train_synth.py
     --graph under torch.distributed.run -- per iteration a forward + backward graph, the gradient exchange
     (localrf_amd.dist.allreduce_grads through LocalTensorfs.grad_sync) on the same stream, and the Adam graph.  The loss must
-    fall as in the one-rank run, nearly every iteration must be a replay, replicas must agree (checkpoint of rank 0 loads)."""
+    fall as in the one-rank run, nearly every iteration must be a replay, and the replicas must hold IDENTICAL parameters at
+    the end (max |p - p of rank 0| over ranks = 0 for the field, the poses and everything else: every rank applied the same
+    reduced gradients -- with the regulariser in the loss (strayed density gradients) and with views only the other rank
+    sampled, the two ways the captured path let replicas drift apart before round 6)."""
     import json
     import os
     import socket
@@ -1328,3 +1331,4 @@ def test_two_rank_progressive_loop_with_captured_iterations(tmp_path):
     st = d["graph"]
     assert st["replays"] >= 0.8 * d["iterations"] and st["captures"] >= 3, st
     assert d["checkpoint_roundtrip"]
+    assert d["replica_divergence"] == {"field": 0.0, "poses": 0.0, "other": 0.0}, d["replica_divergence"]
