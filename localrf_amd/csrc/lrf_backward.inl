@@ -1192,8 +1192,8 @@ __global__ __launch_bounds__(NT) void k_scatter_line(DField f, ScatterDst dst, c
 // different banks unless they share the cell).
 // Fixed point: every contribution is at most vmax = max |g line|, |g plane| (reduced by k_bwd_ray, which forms those products
 // for the position gradient), a cell receives at most 4 n of them from the n entries of the segment, so with
-// scale = 2^(min(50, 62 - bits(4 n)) - exponent(vmax)) no sum leaves 63 bits and no addend leaves 51 (the conversion below is
-// exact there).  The quantum is vmax 2^-50 .. 2^-38: sums are exact to far below fp32's own rounding of each product, and --
+// scale = 2^(min(46, 62 - bits(4 n)) - exponent(vmax)) no sum leaves 63 bits and no addend (the sum of a run of up to 16 lanes)
+// leaves 51 (the conversion below is exact there).  The quantum is vmax 2^-46 .. 2^-38: sums are exact to far below fp32's own rounding of each product, and --
 // integer adds being associative -- independent of the order the entries arrive in: a workgroup's tile and line sums are
 // bit-reproducible (what still varies from run to run is the order of the fp32 atomics that add them into the gradient).
 constexpr int FIX_NT = 1024;
@@ -1202,10 +1202,10 @@ __device__ __forceinline__ unsigned long long fix64(float v, double scale) {
   const double x = fma((double)v, scale, 6755399441055744.0);
   return (unsigned long long)(__double_as_longlong(x) - 0x4338000000000000ll);
 }
-__device__ __forceinline__ int fix_shift(unsigned n_contrib, int vex) { return min(50, 62 - (32 - __builtin_clz(n_contrib))) - vex; }
+__device__ __forceinline__ int fix_shift(unsigned n_contrib, int vex) { return min(46, 62 - (32 - __builtin_clz(n_contrib))) - vex; }   // (46: one add carries the sum of up to 16 lanes)
 // runs of equal keys among consecutive lanes of a 16-lane row: position of the lane in its run and whether it is the run's
 // last lane (which then holds the inclusive sum of seg_sum).  Lanes that are not `valid` form runs of their own.
-struct SegRun { bool f1, f2, f4, f8, tail; };
+struct SegRun { float m1, m2, m4, m8; bool tail; };
 template <int D>
 __device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true); }   // lane i <- lane i - D of its row, 0 where there is none
 __device__ __forceinline__ SegRun seg_run(int key, bool valid, int lane) {
@@ -1215,16 +1215,28 @@ __device__ __forceinline__ SegRun seg_run(int key, bool valid, int lane) {
   const int leader = 63 - __builtin_clzll(starts & (~0ull >> (63 - lane)));
   const int pos = lane - leader;
   SegRun r;
-  r.f1 = pos >= 1; r.f2 = pos >= 2; r.f4 = pos >= 4; r.f8 = pos >= 8;
+  r.m1 = pos >= 1 ? 1.0f : 0.0f; r.m2 = pos >= 2 ? 1.0f : 0.0f; r.m4 = pos >= 4 ? 1.0f : 0.0f; r.m8 = pos >= 8 ? 1.0f : 0.0f;
   r.tail = valid && (lane == 63 || ((starts >> (lane + 1)) & 1ull));
   return r;
 }
-__device__ __forceinline__ float seg_sum(float v, const SegRun& r) {
-  v += r.f1 ? __int_as_float(row_shr_i<1>(__float_as_int(v))) : 0.0f;
-  v += r.f2 ? __int_as_float(row_shr_i<2>(__float_as_int(v))) : 0.0f;
-  v += r.f4 ? __int_as_float(row_shr_i<4>(__float_as_int(v))) : 0.0f;
-  v += r.f8 ? __int_as_float(row_shr_i<8>(__float_as_int(v))) : 0.0f;
-  return v;
+// Inclusive sums over the lanes of the run up to this one, four values at once: v += mask * (v of the lane 1, 2, 4, 8 below).
+// The shifted value is MULTIPLIED by the lane's 0 / 1 mask, not selected: with `cond ? dpp(v) : 0` the compiler predicates
+// the DPP move on cond, and a DPP read from a lane that EXEC disables returns 0 -- the run's first lane (cond false) then
+// contributes nothing (scripts/ubench/seg_sum.hip checks both forms against a host loop).  Written as v_fmac_f32 with a DPP
+// source: the compiler's form of fmaf(dpp(v), m, v) is v_mov_b32_dpp + v_fmac_f32 + hazard nops, 2.6 issue slots per value
+// and step (500 of the kernel's 1000 per 64 entries); here it is one, and the steps of one value are four instructions
+// apart, so no DPP read follows the VALU write of its register closer than the two wait states it needs (s_nop 1 covers
+// whatever the compiler placed in front).
+__device__ __forceinline__ void seg_sum4(float& v0, float& v1, float& v2, float& v3, const SegRun& r) {
+#define LRF_STEP(N, M) \
+  "v_fmac_f32_dpp %0, %0, " M " row_shr:" N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_fmac_f32_dpp %1, %1, " M " row_shr:" N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_fmac_f32_dpp %2, %2, " M " row_shr:" N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+  "v_fmac_f32_dpp %3, %3, " M " row_shr:" N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm volatile("s_nop 1\n\t" LRF_STEP("1", "%4") LRF_STEP("2", "%5") LRF_STEP("4", "%6") LRF_STEP("8", "%7")
+               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)
+               : "v"(r.m1), "v"(r.m2), "v"(r.m4), "v"(r.m8));
+#undef LRF_STEP
 }
 template <int C, bool APP, int NT>
 __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, ScatterDst dst, const float* __restrict__ rays,
@@ -1324,29 +1336,38 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       // their cell: left alone, the adds of one instruction pile up on a handful of addresses and the LDS serialises them
       // (measured: 52 cycles per ds_add_u64 instruction against 11 for distinct addresses).  So the lanes of a RUN -- equal
       // cell and tap steps, inside one 16-lane row -- are summed across lanes first (inclusive segmented scan, four DPP
-      // row shifts per value) and only the run's last lane adds.
+      // row shifts per value: seg_sum4) and only the run's last lane adds.
       const SegRun rt = seg_run((c00 << 2) | (cx << 1) | (cy ? 1 : 0), valid, lane);
       const SegRun rl = seg_run((l0 << 1) | (l1 - l0), valid, lane);
       unsigned long long* tc = s_fx + c00;
       unsigned long long* lc0 = s_fl + l0;
       unsigned long long* lc1 = s_fl + l1;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float Lv = e0v[c] * (1.0f - tl) + e1v[c] * tl;
-        const float dP = g * Lv;
-        const float t00 = seg_sum(dP * w00, rt), t10 = seg_sum(dP * w10, rt), t01 = seg_sum(dP * w01, rt), t11 = seg_sum(dP * w11, rt);
-        if (rt.tail) {
-          atomicAdd(tc + c * CELLS, fix64(t00, scT));
-          atomicAdd(tc + c * CELLS + cx, fix64(t10, scT));
-          atomicAdd(tc + c * CELLS + cy, fix64(t01, scT));
-          atomicAdd(tc + c * CELLS + cy + cx, fix64(t11, scT));
+      for (int c = 0; c < C; c += 2) {
+        float t[2][4], sl[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float Lv = e0v[c + j] * (1.0f - tl) + e1v[c + j] * tl;
+          const float dP = g * Lv;
+          t[j][0] = dP * w00; t[j][1] = dP * w10; t[j][2] = dP * w01; t[j][3] = dP * w11;
+          seg_sum4(t[j][0], t[j][1], t[j][2], t[j][3], rt);
+          const float P = v00[c + j] * w00 + v10[c + j] * w10 + v01[c + j] * w01 + v11[c + j] * w11;
+          const float dL = g * P;
+          sl[2 * j] = dL * (1.0f - tl); sl[2 * j + 1] = dL * tl;
         }
-        const float P = v00[c] * w00 + v10[c] * w10 + v01[c] * w01 + v11[c] * w11;
-        const float dL = g * P;
-        const float s0 = seg_sum(dL * (1.0f - tl), rl), s1 = seg_sum(dL * tl, rl);
-        if (rl.tail) {
-          atomicAdd(lc0 + c * ll, fix64(s0, scL));
-          atomicAdd(lc1 + c * ll, fix64(s1, scL));
+        seg_sum4(sl[0], sl[1], sl[2], sl[3], rl);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (rt.tail) {
+            atomicAdd(tc + (c + j) * CELLS, fix64(t[j][0], scT));
+            atomicAdd(tc + (c + j) * CELLS + cx, fix64(t[j][1], scT));
+            atomicAdd(tc + (c + j) * CELLS + cy, fix64(t[j][2], scT));
+            atomicAdd(tc + (c + j) * CELLS + cy + cx, fix64(t[j][3], scT));
+          }
+          if (rl.tail) {
+            atomicAdd(lc0 + (c + j) * ll, fix64(sl[2 * j], scL));
+            atomicAdd(lc1 + (c + j) * ll, fix64(sl[2 * j + 1], scL));
+          }
         }
       }
       SP_WAIT_LGKM(); SP_TICK(4);
