@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 5      /* 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 6      /* 6: lrf_batch_gather, lrf_loss_combine_*; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -377,6 +377,33 @@ int lrf_depth_loss_bwd(const float* depth, const float* gt, int32_t V, int32_t n
 int lrf_photo_loss_fwd(const float* rgb, const float* target, const float* w, const float* w_mean, int32_t R, float* loss, float* aux, void* stream);
 int lrf_photo_loss_bwd(const float* rgb, const float* target, const float* w, const float* aux, const float* g_loss /* device [1] */,
                        int32_t R, float* g_rgb, void* stream);
+
+/* Batch assembly (train.py:352-358, 385-420 index the dataset tensors with the batch's (view, pixel) ids, one ATen gather
+ * and one mask expression per tensor): target colours, both optical flows with their masks (forward: the view is not the
+ * last image; backward: not the first) and inverse depths of V x n pixels in one launch.  Dataset tensors [n_images, HW, 3 | 2 |
+ * 2 | 1] float32, a NULL tensor (or output) is skipped; view_ids int64 [V] (negative ids count from the end); pix int64 [V, n]:
+ * pixel ids inside the view. */
+typedef struct {
+  const float* images; const float* fwd_flow; const float* bwd_flow; const float* invdepths;
+  const int64_t* view_ids; const int64_t* pix;
+  int32_t V, n, HW, n_images;
+} LrfBatchGather;
+int lrf_batch_gather(const LrfBatchGather* a, float* target /* [V n, 3] */, float* fwd_flow /* [V n, 2] */, float* fwd_mask /* [V n] */,
+                     float* bwd_flow, float* bwd_mask, float* invdepth /* [V n] */, void* stream);
+
+/* Loss assembly (train.py:425-437: loss + flow * w_flow * reg / ((W + H) / 2) + depth * w_depth * reg + L1 ...):
+ * total = sum_k w_k sum_j x_k[j] with w_k = a_k + b_k s[0] -- s a device scalar (the schedule weight of the iteration), x_k a
+ * device scalar or a vector of n_k partial sums (the per-view sums of lrf_flow_loss_fwd / lrf_depth_loss_fwd, added in index
+ * order).  One launch each way instead of a dozen scalar kernels; w_out [count] carries the weights to the backward,
+ * g[k] = g_total[0] w_k = d total / d x_k[j]. */
+#define LRF_LOSS_TERMS_MAX 8
+typedef struct {
+  const float* x[LRF_LOSS_TERMS_MAX]; int32_t n[LRF_LOSS_TERMS_MAX];
+  float a[LRF_LOSS_TERMS_MAX], b[LRF_LOSS_TERMS_MAX];
+  int32_t count; const float* s;
+} LrfLossTerms;
+int lrf_loss_combine_fwd(const LrfLossTerms* t, float* total /* device [1] */, float* w_out /* device [count] */, void* stream);
+int lrf_loss_combine_bwd(const float* w, const float* g_total /* device [1] */, int32_t count, float* g /* device [count] */, void* stream);
 
 /* Row gather out[v,:] = src[idx[v],:] (src [F,K], idx int64 [V], negative ids count from the end) and its backward
  * g_src[f,:] = sum_{v: idx[v]=f} g_out[v,:] in v order (no atomics): the per-view poses / exposures a batch picks out of the per-frame

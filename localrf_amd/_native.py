@@ -67,6 +67,18 @@ class LrfFlowLoss(C.Structure):
 
 
 LRF_LOSS_MAX_PER_VIEW = 4096
+LRF_LOSS_TERMS_MAX = 8
+
+
+class LrfBatchGather(C.Structure):
+    _fields_ = [("images", _f), ("fwd_flow", _f), ("bwd_flow", _f), ("invdepths", _f), ("view_ids", C.c_void_p), ("pix", C.c_void_p),
+                ("V", C.c_int32), ("n", C.c_int32), ("HW", C.c_int32), ("n_images", C.c_int32)]
+
+
+class LrfLossTerms(C.Structure):
+    _fields_ = [("x", _f * LRF_LOSS_TERMS_MAX), ("n", C.c_int32 * LRF_LOSS_TERMS_MAX), ("a", C.c_float * LRF_LOSS_TERMS_MAX),
+                ("b", C.c_float * LRF_LOSS_TERMS_MAX), ("count", C.c_int32), ("s", _f)]
+
 
 # every symbol include/lrf.h and include/lrf_debug.h declare: (restype, argtypes)
 SYMBOLS = {
@@ -104,6 +116,9 @@ SYMBOLS = {
     "lrf_adam_step": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "lrf_photo_loss_fwd": (C.c_int, [_f, _f, _f, _f, C.c_int32, _f, _f, C.c_void_p]),
     "lrf_photo_loss_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, _f, C.c_void_p]),
+    "lrf_batch_gather": (C.c_int, [C.POINTER(LrfBatchGather), _f, _f, _f, _f, _f, _f, C.c_void_p]),
+    "lrf_loss_combine_fwd": (C.c_int, [C.POINTER(LrfLossTerms), _f, _f, C.c_void_p]),
+    "lrf_loss_combine_bwd": (C.c_int, [_f, _f, C.c_int32, _f, C.c_void_p]),
     "lrf_rows_gather": (C.c_int, [_f, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_rows_gather_bwd": (C.c_int, [_f, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_adam_step_dev": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, _f, C.c_float, C.c_float, C.c_float, C.c_void_p]),
@@ -157,7 +172,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if h.lrf_abi_version() != 5:
+        if h.lrf_abi_version() != 6:
             raise NativeError("localrf_amd: ABI version mismatch")
         _lib = h
     return _lib

@@ -538,3 +538,70 @@ extern "C" int lrf_rows_gather_bwd(const float* g_out, const int64_t* idx, int32
   LRF_HIP(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------- batch assembly, loss assembly (round 6)
+// What surrounds the three loss kernels in an iteration of train.py:352-437 is a few dozen one-line tensor expressions: the
+// (view, pixel) indexing of the images, flows and inverse depths, the flow masks, the schedule weights, the sums.  Through
+// ATen each is a launch (or three, with its backward): 45 of the 94 kernels of a captured iteration of the regularised
+// phase, ~0.2 ms of its 1.35 (profiles/r17_graph_iteration_timeline_64.md).  Two kernels take their place.
+namespace lrf {
+__global__ __launch_bounds__(256) void k_batch_gather(LrfBatchGather a, float* __restrict__ target, float* __restrict__ fwd_flow,
+                                                      float* __restrict__ fwd_mask, float* __restrict__ bwd_flow,
+                                                      float* __restrict__ bwd_mask, float* __restrict__ invdepth) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.V * a.n) return;
+  long long v = reinterpret_cast<const long long*>(a.view_ids)[i / a.n];
+  if (v < 0) v += a.n_images;                                 // (negative ids count from the end, as tensor indexing does)
+  const long long px = reinterpret_cast<const long long*>(a.pix)[i];
+  const size_t q = (size_t)v * a.HW + (size_t)px;
+  if (a.images && target) { target[3 * (size_t)i] = a.images[3 * q]; target[3 * (size_t)i + 1] = a.images[3 * q + 1]; target[3 * (size_t)i + 2] = a.images[3 * q + 2]; }
+  if (a.fwd_flow && fwd_flow) { fwd_flow[2 * (size_t)i] = a.fwd_flow[2 * q]; fwd_flow[2 * (size_t)i + 1] = a.fwd_flow[2 * q + 1]; }
+  if (a.bwd_flow && bwd_flow) { bwd_flow[2 * (size_t)i] = a.bwd_flow[2 * q]; bwd_flow[2 * (size_t)i + 1] = a.bwd_flow[2 * q + 1]; }
+  if (a.invdepths && invdepth) invdepth[i] = a.invdepths[q];
+  if (fwd_mask) fwd_mask[i] = v < a.n_images - 1 ? 1.0f : 0.0f;
+  if (bwd_mask) bwd_mask[i] = v > 0 ? 1.0f : 0.0f;
+}
+// total = sum_k w_k sum_j x_k[j],  w_k = a_k + b_k s: one wave, term k's values summed in index order by lane k
+__global__ __launch_bounds__(64) void k_loss_combine_fwd(LrfLossTerms t, float* __restrict__ total, float* __restrict__ w_out) {
+  const int k = threadIdx.x;
+  float v = 0.0f, w = 0.0f;
+  if (k < t.count) {
+    w = t.a[k] + t.b[k] * (t.s ? t.s[0] : 0.0f);
+    float acc = 0.0f;
+    for (int j = 0; j < t.n[k]; ++j) acc += t.x[k][j];
+    v = acc * w;
+    w_out[k] = w;
+  }
+  float tot = 0.0f;                                           // ordered: term 0 first
+  for (int j = 0; j < t.count; ++j) tot += __shfl(v, j, 64);
+  if (k == 0) total[0] = tot;
+}
+__global__ __launch_bounds__(64) void k_loss_combine_bwd(const float* __restrict__ w, const float* __restrict__ g_total, int count, float* __restrict__ g) {
+  if ((int)threadIdx.x < count) g[threadIdx.x] = g_total[0] * w[threadIdx.x];
+}
+}  // namespace lrf
+
+extern "C" int lrf_batch_gather(const LrfBatchGather* a, float* target, float* fwd_flow, float* fwd_mask, float* bwd_flow,
+                                float* bwd_mask, float* invdepth, void* stream) {
+  using namespace lrf;
+  if (!a || !a->view_ids || !a->pix || a->V <= 0 || a->n <= 0 || a->HW <= 0 || a->n_images <= 0) return set_err("lrf_batch_gather: bad argument");
+  hipLaunchKernelGGL(k_batch_gather, dim3((a->V * a->n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a,
+                     target, fwd_flow, fwd_mask, bwd_flow, bwd_mask, invdepth);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int lrf_loss_combine_fwd(const LrfLossTerms* t, float* total, float* w_out, void* stream) {
+  using namespace lrf;
+  if (!t || !total || !w_out || t->count <= 0 || t->count > LRF_LOSS_TERMS_MAX) return set_err("lrf_loss_combine_fwd: bad argument");
+  for (int k = 0; k < t->count; ++k) if (!t->x[k] || t->n[k] <= 0) return set_err("lrf_loss_combine_fwd: null or empty term");
+  hipLaunchKernelGGL(k_loss_combine_fwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), *t, total, w_out);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int lrf_loss_combine_bwd(const float* w, const float* g_total, int32_t count, float* g, void* stream) {
+  using namespace lrf;
+  if (!w || !g_total || !g || count <= 0 || count > LRF_LOSS_TERMS_MAX) return set_err("lrf_loss_combine_bwd: bad argument");
+  hipLaunchKernelGGL(k_loss_combine_bwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), w, g_total, count, g);
+  LRF_HIP(hipGetLastError());
+  return 0;
+}

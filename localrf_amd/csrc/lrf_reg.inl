@@ -14,7 +14,12 @@
 namespace lrf {
 
 constexpr int L1_TPB = 256;
-constexpr int L1_QCHUNK = 256;       // plane texels per workgroup in the line-gradient pass
+constexpr int L1_QCHUNK = 256;       // plane texels per workgroup in the line-gradient pass, at most
+constexpr int L1_QCHUNK_MIN = 8;
+// plane texels per workgroup of the line-gradient pass: about 512 workgroups per plane whatever the grid (a fixed 256 left a
+// 64^3 field -- 4096 texels per plane -- with 16 workgroups of 64 busy lanes: 30-60 us per plane for 0.26 MFLOP, a tenth of
+// the captured iteration of the regularised phase)
+__host__ __device__ inline int l1_qchunk(int hw) { const int q = (hw + 511) / 512; return q < L1_QCHUNK_MIN ? L1_QCHUNK_MIN : (q > L1_QCHUNK ? L1_QCHUNK : q); }
 
 struct L1Geo {
   const float* plane[3]; const float* line[3];
@@ -71,11 +76,22 @@ __global__ __launch_bounds__(L1_TPB) void k_l1_mean(const float* __restrict__ pa
   if (threadIdx.x == 0) out[0] = s / (float)n;
 }
 
+// The three planes' passes are one launch each (blockIdx -> plane through the block offsets in L1Blk).
+struct L1Blk { int first[4]; int nchunk[3]; int qc[3]; size_t lpart_off[3]; };
+__device__ __forceinline__ int l1_plane_of(const int first[4], int& blk) {
+  const int p = (int)blockIdx.x >= first[2] ? 2 : ((int)blockIdx.x >= first[1] ? 1 : 0);
+  blk = (int)blockIdx.x - first[p];
+  return p;
+}
+struct L1Out { float* plane[3]; float* line[3]; };
+
 // g_plane_p[c, q] = scale * sum_r dfeat[q L + r] line_p[c, r]: one wavefront per texel q
-__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_plane(L1Geo G, int p, const float* __restrict__ dfeat,
-                                                         const float* __restrict__ g_out, float* __restrict__ g_plane) {
+__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_plane(L1Geo G, L1Blk B, const float* __restrict__ dfeat,
+                                                         const float* __restrict__ g_out, L1Out out) {
+  int blk;
+  const int p = l1_plane_of(B.first, blk);
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * (L1_TPB / 64) + (threadIdx.x >> 6);
+  const int q = blk * (L1_TPB / 64) + (threadIdx.x >> 6);
   if (q >= G.hw[p]) return;
   const int L = G.ll[p];
   float acc[LRF_CD];
@@ -90,15 +106,18 @@ __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_plane(L1Geo G, int p, const f
 #pragma unroll
   for (int c = 0; c < LRF_CD; ++c) {
     const float s = wave_sum(acc[c]);
-    if (lane == 0) g_plane[(size_t)c * G.hw[p] + q] = s * scale;
+    if (lane == 0) out.plane[p][(size_t)c * G.hw[p] + q] = s * scale;
   }
 }
 
-// lpart[chunk][c][r] = sum over the chunk's texels q of dfeat[q L + r] plane_p[c, q]
-__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line(L1Geo G, int p, const float* __restrict__ dfeat,
+// lpart_p[chunk][c][r] = sum over the chunk's texels q of dfeat[q L + r] plane_p[c, q]
+__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line(L1Geo G, L1Blk B, const float* __restrict__ dfeat,
                                                         float* __restrict__ lpart) {
+  int blk;
+  const int p = l1_plane_of(B.first, blk);
   const int L = G.ll[p];
-  const int q0 = blockIdx.x * L1_QCHUNK, q1 = min(q0 + L1_QCHUNK, G.hw[p]);
+  const int q0 = blk * B.qc[p], q1 = min(q0 + B.qc[p], G.hw[p]);
+  float* lp = lpart + B.lpart_off[p];
   for (int r = threadIdx.x; r < L; r += L1_TPB) {
     float acc[LRF_CD];
 #pragma unroll
@@ -109,18 +128,34 @@ __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line(L1Geo G, int p, const fl
       for (int c = 0; c < LRF_CD; ++c) acc[c] += v * G.plane[p][(size_t)c * G.hw[p] + q];   // wave-uniform operand
     }
 #pragma unroll
-    for (int c = 0; c < LRF_CD; ++c) lpart[((size_t)blockIdx.x * LRF_CD + c) * L + r] = acc[c];
+    for (int c = 0; c < LRF_CD; ++c) lp[((size_t)blk * LRF_CD + c) * L + r] = acc[c];
   }
 }
 
-__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line_reduce(const float* __restrict__ lpart, int nchunk, int L,
-                                                               long long n, const float* __restrict__ g_out,
-                                                               float* __restrict__ g_line) {
-  const int i = blockIdx.x * L1_TPB + threadIdx.x;           // (c, r)
-  if (i >= LRF_CD * L) return;
+// g_line_p[c, r] = scale * sum over the chunks of lpart_p: 16 outputs per workgroup, 16 threads per output, thread j adds
+// the chunks k = j (mod 16) in order and the 16 partial sums are added in order -- fixed order: deterministic.  (One thread per
+// output walking all ~512 chunks: 119 us at 64^3, where the whole launch has 512 outputs.)
+constexpr int L1_RED_OUT = 16, L1_RED_GRP = L1_TPB / L1_RED_OUT;
+__global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line_reduce(L1Geo G, L1Blk B, const float* __restrict__ lpart,
+                                                               const float* __restrict__ g_out, L1Out out) {
+  __shared__ float s_part[L1_RED_GRP][L1_RED_OUT];
+  int blk;
+  const int p = l1_plane_of(B.first, blk);
+  const int L = G.ll[p], n_out = LRF_CD * L;
+  const int o = threadIdx.x % L1_RED_OUT, j = threadIdx.x / L1_RED_OUT;
+  const int i = blk * L1_RED_OUT + o;                        // (c, r)
+  const float* lp = lpart + B.lpart_off[p];
   float acc = 0.0f;
-  for (int k = 0; k < nchunk; ++k) acc += lpart[(size_t)k * LRF_CD * L + i];   // fixed order: deterministic
-  g_line[i] = acc * (g_out[0] / (float)n);
+  if (i < n_out)
+    for (int k = j; k < B.nchunk[p]; k += L1_RED_GRP) acc += lp[(size_t)k * n_out + i];
+  s_part[j][o] = acc;
+  __syncthreads();
+  if (j == 0 && i < n_out) {
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < L1_RED_GRP; ++q) t += s_part[q][o];
+    out.line[p][i] = t * (g_out[0] / (float)G.n);
+  }
 }
 
 static int l1_geo(const float* const plane[3], const float* const line[3], const int32_t hw[3], const int32_t ll[3],
@@ -141,15 +176,18 @@ static int l1_blocks(long long n) {
   return (int)(want < cap ? want : cap);
 }
 static int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
-static int l1_chunks(const int32_t hw[3]) { return (max3(hw[0], hw[1], hw[2]) + L1_QCHUNK - 1) / L1_QCHUNK; }
+static size_t l1_lpart_floats(const int32_t hw[3], const int32_t ll[3]) {          // the three planes' partial blocks
+  size_t n = 0;
+  for (int p = 0; p < 3; ++p) n += (size_t)((hw[p] + l1_qchunk(hw[p]) - 1) / l1_qchunk(hw[p])) * LRF_CD * (size_t)ll[p];
+  return n;
+}
 
 }  // namespace lrf
 
 extern "C" size_t lrf_density_l1_workspace(const int32_t hw[3], const int32_t ll[3]) {
   using namespace lrf;
   const long long n = (long long)hw[0] * ll[0];
-  const size_t lmax = (size_t)max3(ll[0], ll[1], ll[2]);
-  return sizeof(float) * ((size_t)n + (size_t)device_cus() * 16 + (size_t)l1_chunks(hw) * LRF_CD * lmax) + 1024;
+  return sizeof(float) * ((size_t)n + (size_t)device_cus() * 16 + l1_lpart_floats(hw, ll)) + 1024;
 }
 
 extern "C" int lrf_density_l1_fwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
@@ -179,15 +217,25 @@ extern "C" int lrf_density_l1_bwd(const float* const plane[3], const float* cons
   const float* dfeat = static_cast<const float*>(workspace);
   float* lpart = const_cast<float*>(dfeat) + G.n + (size_t)device_cus() * 16;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  L1Out out;
+  L1Blk Bp, Bl, Br;                                          // block offsets of the plane / line / reduce launches
+  Bp.first[0] = Bl.first[0] = Br.first[0] = 0;
+  size_t off = 0;
   for (int p = 0; p < 3; ++p) {
     if (!g_plane[p] || !g_line[p]) return set_err("lrf_density_l1_bwd: null gradient pointer");
-    hipLaunchKernelGGL(k_l1_bwd_plane, dim3((G.hw[p] + L1_TPB / 64 - 1) / (L1_TPB / 64)), dim3(L1_TPB), 0, st,
-                       G, p, dfeat, g_out, g_plane[p]);
-    const int nchunk = (G.hw[p] + L1_QCHUNK - 1) / L1_QCHUNK;
-    hipLaunchKernelGGL(k_l1_bwd_line, dim3(nchunk), dim3(L1_TPB), 0, st, G, p, dfeat, lpart);
-    hipLaunchKernelGGL(k_l1_bwd_line_reduce, dim3((LRF_CD * G.ll[p] + L1_TPB - 1) / L1_TPB), dim3(L1_TPB), 0, st,
-                       lpart, nchunk, G.ll[p], G.n, g_out, g_line[p]);
+    out.plane[p] = g_plane[p]; out.line[p] = g_line[p];
+    const int qc = l1_qchunk(G.hw[p]), nchunk = (G.hw[p] + qc - 1) / qc;
+    Bp.first[p + 1] = Bp.first[p] + (G.hw[p] + L1_TPB / 64 - 1) / (L1_TPB / 64);
+    Bl.first[p + 1] = Bl.first[p] + nchunk;
+    Br.first[p + 1] = Br.first[p] + (LRF_CD * G.ll[p] + L1_RED_OUT - 1) / L1_RED_OUT;
+    Bp.qc[p] = Bl.qc[p] = Br.qc[p] = qc;
+    Bp.nchunk[p] = Bl.nchunk[p] = Br.nchunk[p] = nchunk;
+    Bp.lpart_off[p] = Bl.lpart_off[p] = Br.lpart_off[p] = off;
+    off += (size_t)nchunk * LRF_CD * (size_t)G.ll[p];
   }
+  hipLaunchKernelGGL(k_l1_bwd_plane, dim3(Bp.first[3]), dim3(L1_TPB), 0, st, G, Bp, dfeat, g_out, out);
+  hipLaunchKernelGGL(k_l1_bwd_line, dim3(Bl.first[3]), dim3(L1_TPB), 0, st, G, Bl, dfeat, lpart);
+  hipLaunchKernelGGL(k_l1_bwd_line_reduce, dim3(Br.first[3]), dim3(L1_TPB), 0, st, G, Br, lpart, g_out, out);
   LRF_HIP(hipGetLastError());
   return 0;
 }

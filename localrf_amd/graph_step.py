@@ -72,10 +72,11 @@ class StaticInputs:
 class StepInputs:
     """What the loss function of a captured iteration sees besides the render's outputs (all static device tensors)."""
 
-    def __init__(self, ray_ids, view_ids, frame, scalars, cam2world_all, start, n_views):
+    def __init__(self, ray_ids, view_ids, frame, scalars, cam2world_all, start, n_views, frame32=None):
         self.ray_ids, self.view_ids, self.frame = ray_ids, view_ids, frame    # int64 [B], int64 [V], int64 [V] = view - start
         self.scalars = scalars                                    # {name: 0-dim float32 tensor}
         self.cam2world_all, self.start, self.n_views = cam2world_all, start, n_views   # get_cam2world(starting_id=start)
+        self.frame32 = frame32                                    # int32 [2, V]: (view - start, view == frames assembled - 1): losses.flow_loss(frame_ids=)
 
 
 class CapturedIteration:
@@ -125,7 +126,8 @@ class CapturedIteration:
         self._always = {id(p) for _, p in pairs} - {q for pr in self._pose_params.values() for q in pr}
         h = int(field.nSamples) // 6
         fields = {"ray_ids": ((self.batch,), torch.int64), "view_ids": ((self.n_views,), torch.int64),
-                  "frame": ((self.n_views,), torch.int64), "adam": ((len(self.plan), 2), torch.float32),
+                  "frame": ((self.n_views,), torch.int64), "frame32": ((2, self.n_views), torch.int32),
+                  "adam": ((len(self.plan), 2), torch.float32),
                   "scalars": ((max(1, len(self.scalar_names)),), torch.float32)}
         self.inputs = StaticInputs(dev, fields)
         self.u1 = torch.empty(1, h, dtype=torch.float32, device=dev)
@@ -160,7 +162,7 @@ class CapturedIteration:
                                             world2rf=[w.detach() for w in lt.world2rf])
             sc = {n: d["scalars"][i] for i, n in enumerate(self.scalar_names)}
             total, kept = self.loss_fn(rgb, depth, directions, ij,
-                                       StepInputs(d["ray_ids"], d["view_ids"], d["frame"], sc, c2w_all, self.start, self.n_views))
+                                       StepInputs(d["ray_ids"], d["view_ids"], d["frame"], sc, c2w_all, self.start, self.n_views, d["frame32"]))
         finally:
             field.jitter_override = None
             lt.freeze_intrinsics = frozen
@@ -172,7 +174,7 @@ class CapturedIteration:
             # buffer's addresses: what the ranks reduce is what Adam reads (outside the graph the copy ran,
             # but the captured Adam kept reading the rank-local stray and the replicas drifted apart).
             field.rebucket_grads()
-        self.kept = {k: v.detach() for k, v in kept.items()}
+        self.kept = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in kept.items()}
 
     def _adam(self):
         self.plan.launch(self.inputs.dev["adam"])
@@ -234,6 +236,8 @@ class CapturedIteration:
         views = np.asarray(view_list, dtype=np.int64).reshape(-1)
         host["view_ids"][:] = views
         host["frame"][:] = views - self.start
+        host["frame32"][0] = views - self.start
+        host["frame32"][1] = views == (len(lt.r_c2w) - self.start) - 1   # (train.py:396 compares the ABSOLUTE id with the slice's length: losses.flow_loss)
         if views.min() < self.start:
             raise IndexError("a sampled view lies before the first assembled frame")
         for i, n in enumerate(self.scalar_names):

@@ -212,18 +212,26 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     phase = {"reg": False}
 
     def graph_loss(rgb_map, depth_map, directions, ij, inp):
+        # the same loss as the eager branch below, written with the two assembly kernels (losses.batch_gather / combine): the
+        # dozen (view, pixel) gathers, mask expressions and scalar products of train.py:352-437 are 45 of the 94 launches of a
+        # captured iteration of the regularised phase when each goes through ATen
         V = inp.n_views
         psel = inp.ray_ids.reshape(V, -1)
-        target = data.images[inp.view_ids[:, None], psel].reshape(-1, 3)
-        loss = geo_losses.photometric_loss(rgb_map, target)
-        total, kept = loss, {"photo": loss}
-        if phase["reg"] and geo:
-            fl, dl = geometric_terms(lt, data, depth_map, directions, ij, inp.cam2world_all, inp.view_ids, inp.start, inp.view_ids, psel, W, H)
-            total = total + fl * (inp.scalars["reg_w"] / ((W + H) / 2)) + dl * (0.1 * inp.scalars["reg_w"])
-            kept.update(flow=fl, depth=dl)
-        if phase["reg"]:
-            tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)
-            total = total + tv + l1
+        n = int(psel.shape[1])
+        want_geo = phase["reg"] and geo
+        rows = geo_losses.batch_gather(inp.view_ids, psel, images=data.images, fwd_flow=data.fwd_flow if want_geo else None,
+                                       bwd_flow=data.bwd_flow if want_geo else None, invdepths=data.invdepths if want_geo else None)
+        loss = geo_losses.photometric_loss(rgb_map, rows["target"])
+        terms, kept = [(loss, 1.0, 0.0)], {"photo": loss}
+        if want_geo:
+            fl = geo_losses.flow_loss(depth_map, directions, ij, inp.cam2world_all, inp.view_ids, inp.start, rows["fwd_flow"], rows["fwd_mask"],
+                                      rows["bwd_flow"], rows["bwd_mask"], lt.focal(W), lt.center(W, H), per_view=True, frame_ids=inp.frame32)
+            dl = geo_losses.depth_loss(depth_map, rows["invdepths"], V, per_view=True)
+            terms += [(fl, 0.0, 1.0 / ((W + H) / 2) / (V * n)), (dl, 0.0, 0.1 / (V * n))]      # opt.py: loss weights 1 and 0.1, times reg_w
+            kept.update(flow=fl, depth=dl, geo_norm=float(V * n))
+        if phase["reg"] and lt.rf_iter[-1] < lt.n_iters and L1_weight > 0:                      # local_tensorfs.py:361-375
+            terms.append((lt.tensorfs[-1].density_L1(), L1_weight, 0.0))
+        total = loss if len(terms) == 1 else geo_losses.combine(terms, inp.scalars["reg_w"])
         return total, kept
 
     gs = None
@@ -256,7 +264,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             can_add_rf = lt.step_finish()
             loss = kept["photo"]
             if phase["reg"] and geo:
-                geo_vals.append((float(kept["flow"]), float(kept["depth"])) if it % geo_every == 0 else None)
+                geo_vals.append((float(kept["flow"].sum()) / kept["geo_norm"], float(kept["depth"].sum()) / kept["geo_norm"]) if it % geo_every == 0 else None)
         else:
             # indices go up through pinned memory: indexing a device tensor with host indices (or any pageable
             # host->device copy, as train.py:352-358 does) blocks the host until the stream has drained

@@ -1332,3 +1332,62 @@ def test_two_rank_progressive_loop_with_captured_iterations(tmp_path):
     assert st["replays"] >= 0.8 * d["iterations"] and st["captures"] >= 3, st
     assert d["checkpoint_roundtrip"]
     assert d["replica_divergence"] == {"field": 0.0, "poses": 0.0, "other": 0.0}, d["replica_divergence"]
+
+
+@pytest.mark.gpu
+def test_batch_and_loss_assembly_kernels_vs_torch_expressions(built_lib):
+    """lrf_batch_gather against the reference's tensor indexing and mask expressions (train.py:352-358,385-420: values
+    bit-identical, negative view ids included); lrf_loss_combine_* and the per-view forms of flow_loss / depth_loss against
+    the scalar chain of train.py:425-437 written in torch: same total (fp32 summation order), same gradients in every leaf."""
+    from localrf_amd import losses
+    g = torch.Generator().manual_seed(11)
+    F_, HW, V, n = 9, 640, 5, 37
+    images, fwd, bwd = torch.rand(F_, HW, 3, generator=g).to(DEV), torch.randn(F_, HW, 2, generator=g).to(DEV), torch.randn(F_, HW, 2, generator=g).to(DEV)
+    inv = torch.rand(F_, HW, generator=g).to(DEV)
+    views = torch.tensor([0, 3, 8, -1, 4], device=DEV)
+    pix = torch.randint(0, HW, (V, n), generator=g).to(DEV)
+    rows = losses.batch_gather(views, pix, images=images, fwd_flow=fwd, bwd_flow=bwd, invdepths=inv)
+    va = views % F_
+    assert torch.equal(rows["target"], images[va[:, None], pix].reshape(-1, 3))
+    assert torch.equal(rows["fwd_flow"], fwd[va[:, None], pix].reshape(-1, 2)) and torch.equal(rows["bwd_flow"], bwd[va[:, None], pix].reshape(-1, 2))
+    assert torch.equal(rows["invdepths"], inv[va[:, None], pix].reshape(-1))
+    assert torch.equal(rows["fwd_mask"], (va < F_ - 1).float()[:, None].expand(V, n).reshape(-1))
+    assert torch.equal(rows["bwd_mask"], (va > 0).float()[:, None].expand(V, n).reshape(-1))
+    only = losses.batch_gather(views, pix, images=images)
+    assert set(only) == {"target"} and torch.equal(only["target"], rows["target"])
+    # combine: scalars and vectors of partial sums, weights a + b s
+    s = torch.tensor(0.37, device=DEV)
+    base = [torch.randn((), generator=g), torch.randn(V, generator=g), torch.randn(V, generator=g), torch.rand((), generator=g)]
+    coef = [(1.0, 0.0), (0.0, 1.0 / 56 / (V * n)), (0.0, 0.1 / (V * n)), (1e-2, 0.0)]
+    xs = [b.to(DEV).requires_grad_(True) for b in base]
+    total = losses.combine([(x, a, b) for x, (a, b) in zip(xs, coef)], s)
+    gs = torch.autograd.grad(total * 2.5, xs)
+    ys = [b.to(DEV).requires_grad_(True) for b in base]
+    ref = sum(y.sum() * (a + b * s) for y, (a, b) in zip(ys, coef))
+    gr = torch.autograd.grad(ref * 2.5, ys)
+    assert abs(float(total) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    for a_, b_ in zip(gs, gr):
+        assert a_.shape == b_.shape and float((a_ - b_).abs().max()) <= 1e-6 * max(1e-6, float(b_.abs().max()))
+    # per-view sums through combine == the means through the scalar chain, values and gradients
+    from util import load_golden
+    gg = load_golden("geo_losses")
+    res = {}
+    for form in ("mean", "per_view"):
+        a = _geo_inputs(gg)
+        d = torch.from_numpy(gg["depth"]).to(DEV).requires_grad_(True)
+        Vg = int(d.shape[0]); ng = int(d.numel() // Vg)
+        if form == "mean":
+            fl = losses.flow_loss(**a)
+            dl = losses.depth_loss(d, torch.from_numpy(gg["invdepths"]).to(DEV), Vg)
+            tot = fl * (s / 56) + dl * (0.1 * s)
+        else:
+            fl = losses.flow_loss(per_view=True, **a)
+            dl = losses.depth_loss(d, torch.from_numpy(gg["invdepths"]).to(DEV), Vg, per_view=True)
+            assert fl.shape == (Vg,) and dl.shape == (Vg,)
+            tot = losses.combine([(fl, 0.0, 1.0 / 56 / (Vg * ng)), (dl, 0.0, 0.1 / (Vg * ng))], s)
+        tot.backward()
+        res[form] = (float(tot), a["depth_map"].grad.clone(), a["cam2world"].grad.clone(), d.grad.clone())
+    m, p = res["mean"], res["per_view"]
+    assert abs(m[0] - p[0]) <= 2e-6 * abs(m[0])
+    for x, y in zip(m[1:], p[1:]):
+        assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())
