@@ -60,6 +60,9 @@ constexpr int BIN_MAX = 2048;            // max tiles over the three planes (640
 #define LRF_DPLANE_MULT 4
 #endif
 constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
+#ifndef LRF_FIX_APP_MAX_BINS
+#define LRF_FIX_APP_MAX_BINS 400          // plane tiles (all three planes) up to which the appearance scatter runs on fixed point too (300^3: 300, 500^3: 768)
+#endif
 #ifndef LRF_SCATTER_CAS64
 #define LRF_SCATTER_CAS64 1
 #endif
@@ -1244,14 +1247,22 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
                                                      const uint32_t* __restrict__ list, const float* __restrict__ gf,
                                                      const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
                                                      const unsigned* __restrict__ vmax_bits, int bin_lo, int bin_hi) {
-  static_assert(!APP && C == LRF_CD, "density only (the appearance tile does not fit as 64-bit cells)");
+  // APP (C = 24): the appearance tensors, EIGHT channels per sweep over the workgroup's share (three sweeps): a 24-channel
+  // tile of 64-bit cells would be 209 KB.  The sample's d(loss)/d(feature) is then per channel (the dX row k_train_app3
+  // left), the taps come from the dense 24-channel caches (aplane2 / aline2: 32-byte pieces at 32 * sweep), vmax is
+  // k_train_app3's max |dX line|, |dX plane|.  Positions and runs are formed again in every sweep (~a quarter of a
+  // sweep's instructions); in return the kernel needs 89-111 KB of LDS at any grid size (the compare-and-swap kernel's
+  // fp32 tile + line accumulators no longer fit at 640^3) and its sums are exact.
+  constexpr int CH = LRF_CD;                            // channels per sweep
+  static_assert(C % CH == 0 && (APP ? C == LRF_CA : C == LRF_CD), "8 channels per sweep");
   constexpr int CELLS = BCELL * BCELL;
-  extern __shared__ unsigned long long s_fx[];          // [C][CELLS] tile, then [C][L_p] line
-  unsigned long long* s_fl = s_fx + C * CELLS;
+  extern __shared__ unsigned long long s_fx[];          // [CH][CELLS] tile, then [CH][L_p] line
+  unsigned long long* s_fl = s_fx + CH * CELLS;
   const long long E0 = offs[bin_lo], E = (long long)offs[bin_hi] - E0;
-  int a = (int)(E0 + E * blockIdx.x / gridDim.x);
+  const int a_first = (int)(E0 + E * blockIdx.x / gridDim.x);
   const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
-  if (a >= b) return;
+  if (a_first >= b) return;
+  int a = a_first;
 #ifdef LRF_SCATTER_PROF
   unsigned long long sp_tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_last = __builtin_readcyclecounter();
   const unsigned long long sp_t0 = sp_last;
@@ -1262,12 +1273,15 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
   vex = max(-120, min(127, vex));
   int lo = bin_lo, hi = bin_hi;                         // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
-  int bin = lo;
+  const int bin_first = lo;
+  for (int sweep = 0; sweep < C / CH; ++sweep) {
+  a = a_first;
+  int bin = bin_first;
   int lplane = -1, shL = 0;                             // plane whose line gradient s_fl holds, its scale
   auto flush_line = [&]() {                             // whole workgroup; s_fl -> += the gradient of line `lplane` ([C][L])
     __syncthreads();
-    float* gln = dst.line[lplane];
-    const int nl = f.ll[lplane] * C;
+    float* gln = dst.line[lplane] + (size_t)sweep * CH * f.ll[lplane];
+    const int nl = f.ll[lplane] * CH;
     const double inv = ldexp(1.0, -shL);
     for (int i = threadIdx.x; i < nl; i += NT) {
       const long long q = (long long)s_fl[i];
@@ -1288,9 +1302,9 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       // this workgroup's entries of plane p: at most two contributions each to a line cell
       const int pend = min(b, offs[min(bin_hi, p == 2 ? bg.total : bg.base[p + 1])]);
       shL = fix_shift(2u * (unsigned)(pend - a), vex);
-      for (int i = threadIdx.x; i < ll * C; i += NT) s_fl[i] = 0ull;
+      for (int i = threadIdx.x; i < ll * CH; i += NT) s_fl[i] = 0ull;
     }
-    for (int i = threadIdx.x; i < C * CELLS; i += NT) s_fx[i] = 0ull;
+    for (int i = threadIdx.x; i < CH * CELLS; i += NT) s_fx[i] = 0ull;
     __syncthreads();
     SP_TICK(0);
 #ifdef LRF_SCATTER_PROF
@@ -1298,15 +1312,28 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
 #endif
     const int shT = fix_shift(4u * (unsigned)(seg_end - a), vex);
     const double scT = ldexp(1.0, shT), scL = ldexp(1.0, shL);
-    const float* lnp = f.dline[p];
-    const float* plp = f.dplane[p];
+    const float* lnp = APP ? f.aline2[p] + CH * sweep : f.dline[p];      // the sweep's 8 channels of a texel: 32 bytes, 16-byte aligned
+    const float* plp = APP ? f.aplane2[p] + CH * sweep : f.dplane[p];
     const int am0 = MAT0[p], am1 = MAT1[p], av = VEC[p];
     const int lane = threadIdx.x & 63;
     for (int e0 = a + (int)(threadIdx.x & ~63u); e0 < seg_end; e0 += NT) {      // (whole waves: the run sums below are wave operations)
       const int e = e0 + lane;
       const bool valid = e < seg_end;
-      const uint32_t cid = list[valid ? e : seg_end - 1];
-      const float g = valid ? gf[cid] : 0.0f;
+      const uint32_t row = list[valid ? e : seg_end - 1];
+      const uint32_t cid = APP ? rowinfo[row] : row;
+      float dx[CH];                                     // d(loss)/d(feature of channel c): one scalar for the density, the row's dX for the appearance
+      if (APP) {
+        const float* dxp = grd_dx_row(grd, row) + p * LRF_CA + CH * sweep;
+        ld4g(dxp, dx); ld4g(dxp + 4, dx + 4);
+      } else {
+        const float g = gf[cid];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) dx[c] = g;
+      }
+      if (!valid) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) dx[c] = 0.0f;
+      }
       float u[3];
       cid_point(f, rays, z, S, cid, u);
       int x0, x1, y0, y1, l0, l1; float tx, ty, tl;
@@ -1315,15 +1342,15 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       tap1d(u[av],  ll, l0, l1, tl);
       const int c00 = (y0 - ty0) * BCELL + (x0 - tx0), cx = x1 - x0, cy = (y1 - y0) * BCELL;
       const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
-      float e0v[C], e1v[C], v00[C], v10[C], v01[C], v11[C];
-      const float* r0 = lnp + (size_t)l0 * C;
+      float e0v[CH], e1v[CH], v00[CH], v10[CH], v01[CH], v11[CH];
+      const float* r0 = lnp + (size_t)l0 * C;                 // (C = the texel's channel stride in its cache)
       const float* r1 = lnp + (size_t)l1 * C;
       const float* q00 = plp + ((size_t)y0 * pw + x0) * C;
       const float* q10 = q00 + (size_t)cx * C;
       const float* q01 = q00 + (size_t)(y1 - y0) * pw * C;
       const float* q11 = q01 + (size_t)cx * C;
 #pragma unroll
-      for (int h = 0; h < C / 4; ++h) {
+      for (int h = 0; h < CH / 4; ++h) {
         ld4g(r0 + 4 * h, e0v + 4 * h);  ld4g(r1 + 4 * h, e1v + 4 * h);
         ld4g(q00 + 4 * h, v00 + 4 * h); ld4g(q10 + 4 * h, v10 + 4 * h);
         ld4g(q01 + 4 * h, v01 + 4 * h); ld4g(q11 + 4 * h, v11 + 4 * h);
@@ -1343,16 +1370,16 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       unsigned long long* lc0 = s_fl + l0;
       unsigned long long* lc1 = s_fl + l1;
 #pragma unroll
-      for (int c = 0; c < C; c += 2) {
+      for (int c = 0; c < CH; c += 2) {
         float t[2][4], sl[4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float Lv = e0v[c + j] * (1.0f - tl) + e1v[c + j] * tl;
-          const float dP = g * Lv;
+          const float dP = dx[c + j] * Lv;
           t[j][0] = dP * w00; t[j][1] = dP * w10; t[j][2] = dP * w01; t[j][3] = dP * w11;
           seg_sum4(t[j][0], t[j][1], t[j][2], t[j][3], rt);
           const float P = v00[c + j] * w00 + v10[c + j] * w10 + v01[c + j] * w01 + v11[c + j] * w11;
-          const float dL = g * P;
+          const float dL = dx[c + j] * P;
           sl[2 * j] = dL * (1.0f - tl); sl[2 * j + 1] = dL * tl;
         }
         seg_sum4(sl[0], sl[1], sl[2], sl[3], rl);
@@ -1374,9 +1401,9 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
     }
     __syncthreads();
     SP_TICK(5);
-    float* gpl = dst.plane[p];
+    float* gpl = dst.plane[p] + (size_t)sweep * CH * ph * pw;
     const double invT = ldexp(1.0, -shT);
-    for (int i = threadIdx.x; i < C * CELLS; i += NT) {          // x fastest: 33 consecutive floats of one channel row
+    for (int i = threadIdx.x; i < CH * CELLS; i += NT) {         // x fastest: 33 consecutive floats of one channel row
       const long long q = (long long)s_fx[i];
       if (q == 0) continue;
       const int c = i / CELLS, cell = i % CELLS;
@@ -1388,11 +1415,12 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
     a = seg_end;
   }
   if (lplane >= 0) flush_line();
+  }                                                     // sweep
   SP_TICK(7);
 #ifdef LRF_SCATTER_PROF
   if (threadIdx.x == 0 && blockIdx.x < 2048) {
     sp_tk[11] = __builtin_readcyclecounter() - sp_t0;
-    for (int i = 0; i < 12; ++i) g_scat_prof[0][blockIdx.x][i] = sp_tk[i];
+    for (int i = 0; i < 12; ++i) g_scat_prof[APP ? 1 : 0][blockIdx.x][i] = sp_tk[i];
   }
 #endif
 }
@@ -1440,7 +1468,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.tileinfo = reinterpret_cast<int4*>(take(rows / 16 * 4));
   b.toff32 = reinterpret_cast<int*>(take((size_t)R + 1));
   b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
-  b.hist2 = reinterpret_cast<int*>(take(2 * BIN_MAX));
+  b.hist2 = reinterpret_cast<int*>(take(2 * BIN_MAX + 8));      // (+ max|contribution| of the appearance scatter, k_train_app3)
   b.cursor2 = b.hist2 + BIN_MAX;
   b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
   b.list2 = reinterpret_cast<uint32_t*>(take(3 * rows));
@@ -1455,7 +1483,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
 // lrf_train32.inl.)
 static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 + k_train_app3 without row stores / position gradient and X / dz1 products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
-static int g_scatter_fix = 1;       // lrf_debug_set_train_fwd_engine(16 | ...): the density scatter with fp32 compare-and-swap adds (k_scatter_plane<8>, rounds 2-5) instead of k_scatter_fix; the tests compare the two
+static int g_scatter_fix = 3;       // bit 0: density, bit 1: appearance (up to LRF_FIX_APP_MAX_BINS plane tiles; bit 2: at any size) through k_scatter_fix.  lrf_debug_set_train_fwd_engine(16 | ...): both through the compare-and-swap kernels of rounds 2-5 (the tests compare the two); 256: the density alone; 512: the appearance at any grid size
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
                                     const BwdWorkspace& b, float* rgb, hipStream_t st) {
@@ -1474,7 +1502,7 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : 1; lrf::g_dgrad_dbg = (e >> 5) & 7; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : ((e & 512) ? 7 : 3)); lrf::g_dgrad_dbg = (e >> 5) & 7; }
 
 namespace lrf {
 // floats per row of weight-gradient operands when the backward runs the generic engine (any non-default network, or
@@ -1571,6 +1599,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CD, false, FIX_NT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CA, true, FIX_NT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
       lds_attr_err[dev_id & 63] = e;
@@ -1633,10 +1663,11 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
   const size_t lds_ap = sizeof(float) * BCELL * BCELL * LRF_CA, lds_al = sizeof(float) * LRF_CA * ll_max;
   const bool fuse_a = g_scatter_fused && lds_ap + lds_al <= 158 * 1024;
-  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * 2 * BIN_MAX, st));
+  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * (2 * BIN_MAX + 8), st));
+  unsigned* vmax_a = reinterpret_cast<unsigned*>(b.hist2 + 2 * BIN_MAX);
   hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
                      d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
-                     b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3);
+                     b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a);
 
   // ---- side stream: per-ray backward, density scatter
   LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));
@@ -1648,6 +1679,11 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const size_t lds_dp = sizeof(float) * BCELL * BCELL * LRF_CD, lds_dl = sizeof(float) * LRF_CD * ll_max;
   const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024;
   const bool fix_d = g_scatter_fix && g_scatter_fused && 2 * (lds_dp + lds_dl) <= 158 * 1024;   // 64-bit fixed-point accumulators: twice the bytes
+  // the appearance scatter sweeps its share three times (8 channels each: the same LDS), i.e. zeroes and flushes three tiles
+  // per bin: it wins where the bins are few (forward + backward at 64^3 1.28 -> 1.14 ms, at 300^3 1.382 -> 1.325 with both
+  // kernels against 1.332 with the density one alone) and loses where they are many (500^3: 1.549 against 1.494, 640^3: 1.742
+  // against 1.706: profiles/r17_fixed_point_scatter.md) -- there the compare-and-swap kernel stays
+  const bool fix_a = fix_d && (g_scatter_fix & 2) && (bg.total <= LRF_FIX_APP_MAX_BINS || (g_scatter_fix & 4));
   if (fix_d) {
     hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
     hipLaunchKernelGGL((k_scatter_fix<LRF_CD, false, FIX_NT>), dim3(cus), dim3(FIX_NT), 2 * (lds_dp + lds_dl), sb,
@@ -1718,7 +1754,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int npass = (flags & LRF_FLAG_PLANE_EVENTS) ? 3 : 1;
   for (int q = 0; q < npass; ++q) {
     const int blo = npass == 1 ? 0 : bg.base[q], bhi = (npass == 1 || q == 2) ? bg.total : bg.base[q + 1];
-    if (fuse_a) {
+    if (fix_a) {
+      hipLaunchKernelGGL((k_scatter_fix<LRF_CA, true, FIX_NT>), dim3(cus), dim3(FIX_NT), 2 * (lds_dp + lds_dl), st,
+                         d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, vmax_a, blo, bhi);
+    } else if (fuse_a) {
       hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,
                          d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, blo, bhi);
     } else {
@@ -1727,7 +1766,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     }
     if (npass == 3 && q < 2 && sx) LRF_HIP(hipEventRecord(sx->bucket[3 + q], st));    // app_plane[q] is final (its line only if fused: bucket 2)
   }
-  if (!fuse_a)
+  if (!fuse_a && !fix_a)
     hipLaunchKernelGGL((k_scatter_line<LRF_CA, true, 1024>), dim3(3 * LINE_WGS), dim3(1024), lds_al, st,
                        d, dst_a, rays, z, R, S, w.toff, b.feat, b.rowinfo, b.grd);
 

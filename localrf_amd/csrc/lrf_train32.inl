@@ -81,9 +81,12 @@ __device__ void pack_mlp_w32_t_elem(const LrfParams& p, uint32_t* __restrict__ i
 // Two channels per instruction: the float4 of a tap is two aligned register pairs, the arithmetic below is written on
 // float2 vectors with straight halves (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32; finding 17 concerns crossed low selects
 // only, which this form cannot produce) -- 16 packed operations per pair of channels instead of ~50 scalar ones.
+// vm: running max of |dX line| and |dX plane| -- the bound every contribution of the fixed-point appearance scatter obeys
+// (k_scatter_fix<24, true>: what it adds to a plane tap is dX line times a bilinear weight, to a line cell dX plane times a
+// linear weight)
 template <int p>
 __device__ __forceinline__ void app12_position_grad(const DField& f, const int i0[3], const int i1[3], const float t[3],
-                                                    const float gm[3], int h, const float dX[12], float gu[3], float X[12]) {
+                                                    const float gm[3], int h, const float dX[12], float gu[3], float X[12], float& vm) {
   const int x0 = i0[MAT0[p]], x1 = i1[MAT0[p]], y0 = i0[MAT1[p]], y1 = i1[MAT1[p]];
   const int l0 = i0[VEC[p]], l1 = i1[VEC[p]];
   const f32x2v tx = {t[MAT0[p]], t[MAT0[p]]}, ty = {t[MAT1[p]], t[MAT1[p]]}, tl = {t[VEC[p]], t[VEC[p]]};
@@ -114,6 +117,8 @@ __device__ __forceinline__ void app12_position_grad(const DField& f, const int i
       const f32x2v x2 = P * Lv;
       X[4 * i + 2 * c] = x2[0]; X[4 * i + 2 * c + 1] = x2[1];
       const f32x2v dP = d * Lv, dL = d * P;
+      vm = fmaxf(fmaxf(vm, fabsf(dP[0])), fabsf(dP[1]));
+      vm = fmaxf(fmaxf(vm, fabsf(dL[0])), fabsf(dL[1]));
       gix = dP * dxp + gix;
       giy = dP * dy + giy;
       gil = dL * de + gil;
@@ -373,8 +378,10 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     const int* __restrict__ toff, int R, const int4* __restrict__ tileinfo, const uint16_t* __restrict__ cidx,
     float* __restrict__ grd /* in: dfeat blocks, out: dX blocks */, float* __restrict__ rpart, int pmax, float* __restrict__ wpart,
     BinGeom bg, uint16_t* __restrict__ tile_id /* [3][nmax] plane-tile id of every row, 0xffff = none */, int* __restrict__ hist, uint32_t nmax,
-    int dbg /* timing experiments: 1 no row stores, 2 no position gradient / X */) {
+    int dbg /* timing experiments: 1 no row stores, 2 no position gradient / X */,
+    unsigned* __restrict__ vmax_bits /* max |dX line|, |dX plane| over the batch as float bits (atomicMax), or null */) {
   constexpr int NT = NW * 64;
+  float vmax = 0.0f;
   extern __shared__ uint4 s_dyn4[];
   uint4* img = s_dyn4;                                        // fragment q (0..5) = W32T_BAS + q of the transposed image
   uint4* s_sel = s_dyn4 + APP3_IMG_U4;                        // the eight 0 / 1 selectors, [selector][lane]
@@ -542,9 +549,9 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
       }
     }
     if (!(dbg & 2)) {                                          // every lane gathers (rows beyond the tile's count sit on the tile's first sample and carry dX = dfeat = 0):
-      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu, X);  // no branch between the matrix products and the gathers, the compiler interleaves them
-      app12_position_grad<1>(f, i0, i1, t, gm, h, dX + 12, gu, X + 12);
-      app12_position_grad<2>(f, i0, i1, t, gm, h, dX + 24, gu, X + 24);
+      app12_position_grad<0>(f, i0, i1, t, gm, h, dX, gu, X, vmax);  // no branch between the matrix products and the gathers, the compiler interleaves them
+      app12_position_grad<1>(f, i0, i1, t, gm, h, dX + 12, gu, X + 12, vmax);
+      app12_position_grad<2>(f, i0, i1, t, gm, h, dX + 24, gu, X + 24, vmax);
     }
     // ---- dbasis += dfeat^T X, plane by plane
     {
@@ -598,6 +605,11 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
   for (int i = threadIdx.x; i < bg.total; i += NT) {
     const int v = s_h[i];
     if (v) atomicAdd(&hist[i], v);
+  }
+  if (vmax_bits) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(vmax_bits, __float_as_uint(vmax));
   }
   // ---- dbasis partial of the workgroup (as k_train_dgrad3's dW1 block)
   f32x4* s_red = reinterpret_cast<f32x4*>(s_dyn4);           // [wave slot][12 float4 of the 48 accumulator registers][lane]
