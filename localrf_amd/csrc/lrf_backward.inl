@@ -677,7 +677,9 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
-  if (lane == 0 && vmax > 0.0f) atomicMax(vmax_bits, __float_as_uint(vmax));
+  // one atomic per wave on ONE word is 4096 memory-side atomics in a row (~12 ns each: 32 us of this kernel when first
+  // measured): the maximum only grows, so a wave whose value does not exceed what the word already holds has nothing to add
+  if (lane == 0 && __float_as_uint(vmax) > __hip_atomic_load(vmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(vmax_bits, __float_as_uint(vmax));
   // appearance partials of this ray's tiles (written by k_train_dgrad3); with rpart == null they are added
   // afterwards by k_rays_add_rpart, so that this kernel does not have to wait for the data-gradient kernel
   const int nt = rpart ? 2 * ((nsh + ITEM3 - 1) / ITEM3) : 0;          // 16-row tiles of the ray (k_shade3<SAVE>)

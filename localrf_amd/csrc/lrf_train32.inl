@@ -609,7 +609,8 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
   if (vmax_bits) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
-    if ((threadIdx.x & 63) == 0 && vmax > 0.0f) atomicMax(vmax_bits, __float_as_uint(vmax));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(vmax) > __hip_atomic_load(vmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))   // (the maximum only grows: k_bwd_ray)
+      atomicMax(vmax_bits, __float_as_uint(vmax));
   }
   // ---- dbasis partial of the workgroup (as k_train_dgrad3's dW1 block)
   f32x4* s_red = reinterpret_cast<f32x4*>(s_dyn4);           // [wave slot][12 float4 of the 48 accumulator registers][lane]

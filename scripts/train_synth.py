@@ -443,6 +443,9 @@ def main():
         if not first:
             bar()
     ge.build()
+    if os.environ.get("LRF_TRAIN_ENG"):                                 # A/B of backward engines (lrf_debug_set_train_fwd_engine bits, include/lrf_debug.h)
+        from localrf_amd import _native
+        _native.lib().lrf_debug_set_train_fwd_engine(int(os.environ["LRF_TRAIN_ENG"], 0))
     if ddp and first:
         bar()
     out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
