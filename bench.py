@@ -227,7 +227,7 @@ def size_workloads(dev, sync, use_pmc):
                 rec["traffic"] = sum(v["traffic_bytes"] for v in rec["kernels"].values())
         out[f"fwd_{g}"] = rec
         if g == 500:
-            opt = FusedAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+            opt = FusedAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), pack_field=f)
             gr, gd = torch.randn(R_PER_GPU, 3, device=dev), torch.randn(R_PER_GPU, device=dev)
 
             def step():
@@ -627,7 +627,7 @@ def main():
 
     # ---- training step, every N: forward with a graph, backward, gradient all-reduce (RCCL), FusedAdam
     sd_init = {k: v.detach().clone() for k, v in field.state_dict().items()}     # the workloads below render the untrained field again
-    opt = FusedAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    opt = FusedAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), pack_field=field)
     gr = torch.randn(R_PER_GPU, 3, device=dev)
     gd = torch.randn(R_PER_GPU, device=dev)
     reduced = [0]

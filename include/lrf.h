@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 6      /* 6: lrf_batch_gather, lrf_loss_combine_*; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 6      /* 6: lrf_batch_gather, lrf_loss_combine_*, lrf_adam_step_pack; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -281,6 +281,16 @@ int lrf_adam_step(const LrfAdamTensor* tensors /* host array */, int32_t count, 
  * whose .grad is None: local_tensorfs.py:229-243 steps the poses of sampled views only). */
 int lrf_adam_step_dev(const LrfAdamTensor* tensors /* host array */, int32_t count, const float* dev_scalars, float beta1, float beta2,
                       float eps, void* stream);
+
+/* The optimiser step FUSED with the layout refresh (local_tensorfs.py:146,245 step the field's optimiser, and
+ * the next forward re-reads every parameter to rebuild the channel-last cache): the same update as lrf_adam_step /
+ * lrf_adam_step_dev (dev_scalars NULL: the host fields of the structs) for the tensors of the table, and behind it `cache` --
+ * the layout cache of the field whose parameters `p` names (lrf_cache_bytes, as lrf_pack_field fills it) -- holds the NEW
+ * values: the field's twelve plane / line tensors are stepped and written channel-last by one kernel (tensors of `p` that
+ * are not in the table are only repacked), the other tensors of the table by the table kernel, then the colour network's
+ * images are rebuilt.  Equivalent to lrf_adam_step[_dev] followed by lrf_pack_field. */
+int lrf_adam_step_pack(const LrfAdamTensor* tensors /* host array */, int32_t count, const float* dev_scalars /* or NULL */,
+                       float beta1, float beta2, float eps, const LrfParams* p, void* cache, void* stream);
 
 /* density_L1 regulariser (tensoRF.py:83-92), on by default while
  * rf_iter < n_iters_reg (opt.py:111, local_tensorfs.py:361-375):

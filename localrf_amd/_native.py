@@ -114,6 +114,7 @@ SYMBOLS = {
     "lrf_sample_ray_contracted": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_z_schedule": (C.c_int, [C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_adam_step": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "lrf_adam_step_pack": (C.c_int, [C.POINTER(LrfAdamTensor), C.c_int32, _f, C.c_float, C.c_float, C.c_float, C.POINTER(LrfParams), C.c_void_p, C.c_void_p]),
     "lrf_photo_loss_fwd": (C.c_int, [_f, _f, _f, _f, C.c_int32, _f, _f, C.c_void_p]),
     "lrf_photo_loss_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, _f, C.c_void_p]),
     "lrf_batch_gather": (C.c_int, [C.POINTER(LrfBatchGather), _f, _f, _f, _f, _f, _f, C.c_void_p]),

@@ -126,7 +126,8 @@ class SceneLifecycle(torch.nn.Module):
         self.world2rf.append(world2rf.clone().detach())
         self.rf_iter.append(0)
         self.rf_optimizer = FusedAdam(
-            self.tensorfs[-1].get_optparam_groups(self.rf_lr_init, self.rf_lr_basis), betas=_ADAM_BETAS)
+            self.tensorfs[-1].get_optparam_groups(self.rf_lr_init, self.rf_lr_basis), betas=_ADAM_BETAS,
+            pack_field=self.tensorfs[-1])                        # the step refreshes the field's layout cache itself (lrf_adam_step_pack)
 
     def append_frame(self):
         """New frame initialised from the previous pose (local_tensorfs.py:148-177)."""
@@ -237,7 +238,7 @@ class SceneLifecycle(torch.nn.Module):
             if self.lr_upsample_reset:
                 self.rf_optimizer = FusedAdam(
                     self.tensorfs[-1].get_optparam_groups(self.rf_lr_init, self.rf_lr_basis),
-                    betas=_ADAM_BETAS)
+                    betas=_ADAM_BETAS, pack_field=self.tensorfs[-1])
         if self.rf_iter[-1] in self.update_AlphaMask_list:      # :264-266
             self.tensorfs[-1].updateAlphaMask(tuple((self.tensorfs[-1].gridSize / 2).int().tolist()))
 

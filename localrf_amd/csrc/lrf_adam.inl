@@ -15,15 +15,18 @@ constexpr int ADAM_TPB = 256, ADAM_VEC = 4, ADAM_CHUNK = ADAM_TPB * ADAM_VEC * 4
 struct AdamTable {
   LrfAdamTensor t[LRF_ADAM_MAX];
   int first_block[LRF_ADAM_MAX + 1];   // prefix sum of per-tensor block counts
+  short row[LRF_ADAM_MAX];             // the tensor's row of dev_scalars (its index in the caller's table)
   int count;
 };
 
+// (every operation spelt out with its rounding: the compiler contracts a * b + c into an fma where it sees fit, and it saw fit
+// differently in k_adam_multi and in k_adam_pack -- the two kernels must produce the same bits)
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
                                       float step_size, float bc2_sqrt) {
-  m = m + (g - m) * (1.0f - b1);
-  v = v * b2 + (1.0f - b2) * g * g;
-  const float denom = sqrtf(v) / bc2_sqrt + eps;
-  p = p - step_size * (m / denom);
+  m = __fmaf_rn(__fsub_rn(g, m), __fsub_rn(1.0f, b1), m);
+  v = __fmaf_rn(v, b2, __fmul_rn(__fmul_rn(__fsub_rn(1.0f, b2), g), g));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+  p = __fmaf_rn(-step_size, __fdiv_rn(m, denom), p);
 }
 
 // dev_scalars (lrf_adam_step_dev): [count][2] = {step_size, bc2_sqrt} per tensor in DEVICE memory, read at execution time -- the
@@ -34,8 +37,8 @@ __global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1
   while (ti + 1 < tab.count && (int)blockIdx.x >= tab.first_block[ti + 1]) ++ti;   // <= 64 uniform steps
   LrfAdamTensor T = tab.t[ti];
   if (dev_scalars) {
-    T.step_size = dev_scalars[2 * ti];
-    T.bc2_sqrt = dev_scalars[2 * ti + 1];
+    T.step_size = dev_scalars[2 * tab.row[ti]];
+    T.bc2_sqrt = dev_scalars[2 * tab.row[ti] + 1];
     if (!(T.bc2_sqrt > 0.0f)) return;                // not stepped this iteration (a view nobody sampled: torch skips .grad None)
   }
   const long long base = (long long)((int)blockIdx.x - tab.first_block[ti]) * ADAM_CHUNK;
@@ -81,6 +84,7 @@ static int adam_step_impl(const LrfAdamTensor* tensors, int32_t count, const flo
     if (!t.p || !t.g || !t.m || !t.v || t.n < 0) return set_err("lrf_adam_step: null tensor pointer or negative size");
     if (t.n > (int64_t)2000000000) return set_err("lrf_adam_step: tensor too large");
     tab.t[i] = t;
+    tab.row[i] = (short)i;
     tab.first_block[i] = blocks;
     blocks += (int)((t.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
   }
@@ -100,4 +104,142 @@ extern "C" int lrf_adam_step_dev(const LrfAdamTensor* tensors, int32_t count, co
                                  float eps, void* stream) {
   if (!dev_scalars) return lrf::set_err("lrf_adam_step_dev: null scalar table");
   return adam_step_impl(tensors, count, dev_scalars, beta1, beta2, eps, stream);
+}
+
+// ---------------------------------------------------------------- Adam fused with the layout refresh (round 6)
+// The twelve plane / line tensors of a field are 99.9 % of its parameters, and every one of their texels is rewritten by
+// Adam at the end of an iteration and re-read by the layout refresh (k_pack_planes) at the start of the next: 106 + 84 us and
+// 674 + 400 MB of counter traffic per step at 500^3.  Here the thread that steps element (c, y, x) keeps the new value and the
+// workgroup -- 128 consecutive texels of one row, all channels -- writes the channel-last records itself: the parameter is
+// read once instead of three times (Adam, and the padded + dense appearance caches each re-read it), and written as before.
+namespace lrf {
+
+struct AdamPackSeg {
+  LrfAdamTensor t;            // p: the parameter [C][H][W]; g == null: not stepped this launch (only packed)
+  float* dst0; float* dst1;   // density: dst0 [H][W][8]; appearance: dst0 padded [H][W][32] (app_pc), dst1 dense [H][W][24]
+  int C, H, W, row;           // row of dev_scalars, -1 = the host fields of t
+};
+struct AdamPackTab { AdamPackSeg s[12]; int first_block[13]; };
+
+template <int C>
+__device__ __forceinline__ void adam_pack_block(const AdamPackSeg& sg, int blk, float b1, float b2, float eps,
+                                                const float* __restrict__ dev_scalars, float* s_t) {
+  constexpr bool APPC = C == LRF_CA;
+  constexpr int CS = APPC ? LRF_CAS : LRF_CD, ld = CS + 4;   // records stay 16-byte aligned in LDS
+  const int nbx = (sg.W + 127) / 128;
+  const int y = blk / nbx, x0 = (blk % nbx) * 128, t = threadIdx.x;
+  const int nx = min(128, sg.W - x0);
+  float step_size = sg.t.step_size, bc2 = sg.t.bc2_sqrt;
+  if (dev_scalars && sg.row >= 0) { step_size = dev_scalars[2 * sg.row]; bc2 = dev_scalars[2 * sg.row + 1]; }
+  const bool adam = sg.t.g != nullptr && bc2 > 0.0f;
+  if (t < nx) {
+    const size_t i0 = (size_t)y * sg.W + x0 + t, cs = (size_t)sg.H * sg.W;
+    float pv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) pv[c] = sg.t.p[i0 + c * cs];
+    if (adam) {
+      float gv[C], mv[C], vv[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) { gv[c] = sg.t.g[i0 + c * cs]; mv[c] = sg.t.m[i0 + c * cs]; vv[c] = sg.t.v[i0 + c * cs]; }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        adam1(pv[c], gv[c], mv[c], vv[c], b1, b2, eps, step_size, bc2);
+        sg.t.p[i0 + c * cs] = pv[c]; sg.t.m[i0 + c * cs] = mv[c]; sg.t.v[i0 + c * cs] = vv[c];
+      }
+    }
+    float* d = s_t + t * ld;
+    if (APPC) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { d[8 * q + 6] = 0.0f; d[8 * q + 7] = 0.0f; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) d[APPC ? app_pc(c) : c] = pv[c];
+  }
+  __syncthreads();
+  {
+    float4* out = reinterpret_cast<float4*>(sg.dst0 + ((size_t)y * sg.W + x0) * CS);
+    constexpr int q4 = CS / 4;
+    for (int i = t; i < nx * q4; i += 128) out[i] = *reinterpret_cast<const float4*>(&s_t[(i / q4) * ld + 4 * (i % q4)]);
+  }
+  if (APPC) {                                                // the dense 24-channel record: channel c sits at app_pc(c) of the padded one
+    float4* out = reinterpret_cast<float4*>(sg.dst1 + ((size_t)y * sg.W + x0) * LRF_CA);
+    constexpr int q4 = LRF_CA / 4;
+    for (int i = t; i < nx * q4; i += 128) {
+      const float* r = s_t + (i / q4) * ld;
+      const int c0 = 4 * (i % q4);
+      out[i] = make_float4(r[app_pc(c0)], r[app_pc(c0 + 1)], r[app_pc(c0 + 2)], r[app_pc(c0 + 3)]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void k_adam_pack(AdamPackTab tab, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
+  __shared__ __attribute__((aligned(16))) float s_t[128 * (LRF_CAS + 4)];
+  int k = 0;
+  while (k + 1 < 12 && (int)blockIdx.x >= tab.first_block[k + 1]) ++k;
+  const AdamPackSeg& sg = tab.s[k];
+  const int blk = (int)blockIdx.x - tab.first_block[k];
+  if (sg.C == LRF_CA) adam_pack_block<LRF_CA>(sg, blk, b1, b2, eps, dev_scalars, s_t);
+  else                adam_pack_block<LRF_CD>(sg, blk, b1, b2, eps, dev_scalars, s_t);
+}
+
+}  // namespace lrf
+
+extern "C" int lrf_adam_step_pack(const LrfAdamTensor* tensors, int32_t count, const float* dev_scalars, float beta1, float beta2,
+                                  float eps, const LrfParams* p, void* cache, void* stream) {
+  using namespace lrf;
+  if (count < 0 || count > LRF_ADAM_MAX) return set_err("lrf_adam_step_pack: count must be in [0, LRF_ADAM_MAX]");
+  if ((count && !tensors) || !p || !cache) return set_err("lrf_adam_step_pack: null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const Layout L = make_layout(p->grid);
+  float* base = reinterpret_cast<float*>(cache);
+  AdamPackTab pt;
+  bool taken[LRF_ADAM_MAX] = {};
+  int blocks = 0;
+  for (int q = 0; q < 3; ++q) {
+    const float* prm[4] = {p->density_plane[q], p->density_line[q], p->app_plane[q], p->app_line[q]};
+    float* d0[4] = {base + L.dplane[q], base + L.dline[q], base + L.aplane[q], base + L.aline[q]};
+    float* d1[4] = {nullptr, nullptr, base + L.aplane2[q], base + L.aline2[q]};
+    const int Cs[4] = {LRF_CD, LRF_CD, LRF_CA, LRF_CA}, Hs[4] = {L.ph[q], 1, L.ph[q], 1}, Ws[4] = {L.pw[q], L.ll[q], L.pw[q], L.ll[q]};
+    for (int k = 0; k < 4; ++k) {
+      AdamPackSeg& sg = pt.s[4 * q + k];
+      if (!prm[k]) return set_err("lrf_adam_step_pack: null parameter pointer");
+      sg.t = LrfAdamTensor{const_cast<float*>(prm[k]), nullptr, nullptr, nullptr, (int64_t)Cs[k] * Hs[k] * Ws[k], 0.0f, 0.0f};
+      sg.row = -1;
+      for (int j = 0; j < count; ++j)
+        if (tensors[j].p == prm[k]) {
+          if (!tensors[j].g || !tensors[j].m || !tensors[j].v || tensors[j].n != sg.t.n) return set_err("lrf_adam_step_pack: a field tensor's Adam entry has null state or another size");
+          sg.t = tensors[j]; sg.row = dev_scalars ? j : -1; taken[j] = true;
+          break;
+        }
+      sg.dst0 = d0[k]; sg.dst1 = d1[k]; sg.C = Cs[k]; sg.H = Hs[k]; sg.W = Ws[k];
+      pt.first_block[4 * q + k] = blocks;
+      blocks += Hs[k] * ((Ws[k] + 127) / 128);
+    }
+  }
+  pt.first_block[12] = blocks;
+  // the small tensors (basis, colour network, per-frame poses / exposures ...): the table kernel
+  AdamTable tab;
+  tab.count = 0;
+  int tb = 0;
+  for (int j = 0; j < count; ++j) {
+    if (taken[j]) continue;
+    const LrfAdamTensor& t = tensors[j];
+    if (!t.p || !t.g || !t.m || !t.v || t.n < 0) return set_err("lrf_adam_step_pack: null tensor pointer or negative size");
+    if (t.n > (int64_t)2000000000) return set_err("lrf_adam_step_pack: tensor too large");
+    tab.t[tab.count] = t; tab.row[tab.count] = (short)j; tab.first_block[tab.count] = tb;
+    tb += (int)((t.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    ++tab.count;
+  }
+  tab.first_block[tab.count] = tb;
+  if (tb) hipLaunchKernelGGL(k_adam_multi, dim3(tb), dim3(ADAM_TPB), 0, st, tab, beta1, beta2, eps, dev_scalars);
+  hipLaunchKernelGGL(k_adam_pack, dim3(blocks), dim3(128), 0, st, pt, beta1, beta2, eps, dev_scalars);
+  // the fragment-ordered images of the colour network, from the weights the table kernel just stepped (slice 18 of k_pack_planes)
+  PackTab none = {};
+  PackMlp pm;
+  pm.mlp = base + L.mlp; pm.mlpb = reinterpret_cast<uint32_t*>(base + L.mlpb); pm.mlpw = reinterpret_cast<uint32_t*>(base + L.mlpw);
+  pm.mlpwt = reinterpret_cast<uint32_t*>(base + L.mlpwt);
+  pm.mode = gen_is_default(p->fea_pe, p->view_pe, p->feature_c ? p->feature_c : LRF_FEATC) ? 0 : 1;
+  hipLaunchKernelGGL(k_pack_planes, dim3(8, 8, 1), dim3(128), 0, st, none, *p, pm, 18);
+  LRF_HIP(hipGetLastError());
+  return 0;
 }

@@ -49,8 +49,9 @@ __device__ void pack_mlp_w32_t_elem(const LrfParams& p, uint32_t* __restrict__ i
 // The whole layout cache in ONE launch: all plane / line tensors of a field (the appearance ones twice: padded and dense;
 // blockIdx.z < 18 selects; a line [C,L,1] is a plane with H = 1) and, in slice 18, the four fragment-ordered images of the
 // colour network (they were four launches of ~5 us each, three of them in front of every training forward).
-__global__ __launch_bounds__(128) void k_pack_planes(PackTab tab, LrfParams p, PackMlp pm) {
-  if (blockIdx.z == 18) {
+__global__ __launch_bounds__(128) void k_pack_planes(PackTab tab, LrfParams p, PackMlp pm, int z0 /* first slice of this launch: 0, or 18 = the network images only (lrf_adam_step_pack) */) {
+  const int zsl = (int)blockIdx.z + z0;
+  if (zsl == 18) {
     const int nthr = gridDim.x * gridDim.y * 128;
     for (int idx = (blockIdx.y * gridDim.x + blockIdx.x) * 128 + threadIdx.x; idx < 26880; idx += nthr) {   // >= the largest image (IMGB_ALL * 4 = 26624)
       if (pm.mode == 0) {
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(128) void k_pack_planes(PackTab tab, LrfParams p, P
     }
     return;
   }
-  const PackSeg sg = tab.s[blockIdx.z];
+  const PackSeg sg = tab.s[zsl];
   const float* __restrict__ src = sg.src;
   float* __restrict__ dst = sg.dst;
   const int C = sg.C, H = sg.H, W = sg.W, CS = sg.CS, app = sg.app;
@@ -1188,7 +1189,7 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
   pm.mlp = base + L.mlp; pm.mlpb = reinterpret_cast<uint32_t*>(base + L.mlpb); pm.mlpw = reinterpret_cast<uint32_t*>(base + L.mlpw);
   pm.mlpwt = reinterpret_cast<uint32_t*>(base + L.mlpwt);
   pm.mode = gen_is_default(p->fea_pe, p->view_pe, p->feature_c ? p->feature_c : LRF_FEATC) ? 0 : 1;   // the generic engine reads the parameter tensors themselves
-  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 19), dim3(128), 0, st, tab, *p, pm);
+  hipLaunchKernelGGL(k_pack_planes, dim3((wmax + 127) / 128, hmax, 19), dim3(128), 0, st, tab, *p, pm, 0);
   LRF_HIP(hipGetLastError());
   return 0;
 }

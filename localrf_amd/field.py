@@ -395,6 +395,22 @@ class TensorVMSplit(torch.nn.Module):
         N.check(lib.lrf_pack_field(C.byref(cp), self._cache.data_ptr(), st), "lrf_pack_field")
         self._cache_key = key
 
+    def _fused_step_target(self):
+        """(LrfParams, parameter list, cache) for lrf_adam_step_pack -- the optimiser step that leaves the layout cache holding
+        the stepped values (localrf_amd.optim.FusedAdam(pack_field=...)) -- or None while no cache of the current grid's size
+        exists (the first forward, after an upsample / a device move): then the step runs alone and the next forward packs."""
+        if self._cache is None or self._cache_key is None:
+            return None
+        cp, ps = self._c_params()
+        if self._cache.device != ps[0].device or self._cache.numel() * 4 != N.lib().lrf_cache_bytes(cp.grid):
+            return None
+        return cp, ps, self._cache
+
+    def _mark_cache_fresh(self):
+        """The cache was just rewritten from the parameters as they are now (lrf_adam_step_pack): _ensure_cache's key."""
+        ps = self._param_list()
+        self._cache_key = tuple((p.data_ptr(), p._version) for p in ps) + tuple(self._grid_host) + tuple(self._aabb_host)
+
     def _c_field(self):
         """LrfField struct for the current cache / alpha mask (rebuilt only when they change)."""
         mask = self.alphaMask

@@ -9,6 +9,7 @@ Same constructor arguments, param_groups (lr decay by `group["lr"] *= f` works a
 local_tensorfs.py:224-247) and per-parameter state keys (`step`, `exp_avg`, `exp_avg_sq`) as
 torch.optim.Adam, so state dicts interchange.  No CPU fallback: parameters must live on the GPU.
 Cited lines are relative to /root/reference/localTensoRF."""
+import ctypes as C
 import math
 
 import torch
@@ -17,8 +18,23 @@ from torch.autograd.graph import increment_version
 from . import _native as N
 
 
+def _pack_target(fields):
+    """The one field whose layout cache a launch over these optimisers' tensors can rewrite (FusedAdam.pack_field), with what
+    lrf_adam_step_pack needs, or None: no such field, more than one, or no cache of the current grid's size yet."""
+    fs = {id(f): f for f in fields if f is not None}
+    if len(fs) != 1:
+        return None
+    (field,) = fs.values()
+    tgt = field._fused_step_target()
+    return None if tgt is None else (field, tgt)
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, pack_field=None):
+        """pack_field: the localrf_amd TensorVMSplit whose parameters this optimiser steps -- its layout cache is then rewritten
+        by the step itself (lrf_adam_step_pack: the plane / line tensors are stepped and written channel-last by one kernel)
+        instead of by the next forward; an attribute, may be set or changed later (append_rf moves on to a new field)."""
+        self.pack_field = pack_field
         if weight_decay != 0 or amsgrad:
             raise ValueError("FusedAdam implements the reference's configuration: weight_decay=0, amsgrad=False")
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
@@ -64,7 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
                 bc1 = 1.0 - b1 ** step
                 bc2_sqrt = math.sqrt(1.0 - b2 ** step)
                 g = p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.contiguous().float()
-                out.append((p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"] / bc1, bc2_sqrt, (b1, b2), group["eps"]))
+                out.append((p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"] / bc1, bc2_sqrt, (b1, b2), group["eps"], self.pack_field))
         return out
 
     @staticmethod
@@ -79,9 +95,16 @@ class FusedAdam(torch.optim.Optimizer):
             for lo in range(0, len(es), N.LRF_ADAM_MAX):
                 part = es[lo:lo + N.LRF_ADAM_MAX]
                 tab = (N.LrfAdamTensor * len(part))()
-                for t, (p, g, m, v, step_size, bc2_sqrt, _, _) in zip(tab, part):
+                for t, (p, g, m, v, step_size, bc2_sqrt, _, _, _) in zip(tab, part):
                     t.p, t.g, t.m, t.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
                     t.n, t.step_size, t.bc2_sqrt = p.numel(), step_size, bc2_sqrt
+                fused = _pack_target(e[8] for e in part) if len(es) <= N.LRF_ADAM_MAX else None
+                if fused is not None:                         # the step writes the field's layout cache too
+                    field, (cp, keep, cache) = fused
+                    N.check(lib.lrf_adam_step_pack(tab, len(part), None, b1, b2, eps, C.byref(cp), cache.data_ptr(), st), "lrf_adam_step_pack")
+                    increment_version([e[0] for e in part])
+                    field._mark_cache_fresh()
+                    continue
                 N.check(lib.lrf_adam_step(tab, len(part), b1, b2, eps, st), "lrf_adam_step")
                 # the kernel rewrote the parameters behind autograd's back: bump their versions so
                 # layout caches keyed on (data_ptr, _version) (TensorVMSplit._ensure_cache) and
@@ -160,6 +183,13 @@ class StaticAdamPlan:
                     s = opt.state[p]
                     t.p, t.g, t.m, t.v = p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()
                     t.n, t.step_size, t.bc2_sqrt = p.numel(), 0.0, 0.0
+                fused = _pack_target(self.pairs[i][0].pack_field for i in part) if len(idx) <= N.LRF_ADAM_MAX else None
+                if fused is not None:                         # the step leaves the field's layout cache holding the stepped values
+                    field, (cp, keep, cache) = fused
+                    N.check(lib.lrf_adam_step_pack(tab, len(part), scalars_dev[part[0]:].data_ptr(), b1, b2, eps, C.byref(cp), cache.data_ptr(), st),
+                            "lrf_adam_step_pack")
+                    self._packed_field = field
+                    continue
                 N.check(lib.lrf_adam_step_dev(tab, len(part), scalars_dev[part[0]:].data_ptr(), b1, b2, eps, st), "lrf_adam_step_dev")
 
     def host_scalars(self, out, active=None):
@@ -180,5 +210,9 @@ class StaticAdamPlan:
             out[i, 1] = math.sqrt(1.0 - b2 ** step)
 
     def bump_versions(self):
-        """The replayed kernels rewrote the parameters behind autograd's back (see FusedAdam._launch)."""
+        """The replayed kernels rewrote the parameters behind autograd's back (see FusedAdam._launch) -- and, when the launch was
+        lrf_adam_step_pack, the field's layout cache with them."""
         increment_version([p for _, p in self.pairs])
+        f = getattr(self, "_packed_field", None)
+        if f is not None:
+            f._mark_cache_fresh()

@@ -1391,3 +1391,53 @@ def test_batch_and_loss_assembly_kernels_vs_torch_expressions(built_lib):
     assert abs(m[0] - p[0]) <= 2e-6 * abs(m[0])
     for x, y in zip(m[1:], p[1:]):
         assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(24, 20, 28), (150, 131, 140)])
+def test_adam_step_fused_with_the_layout_refresh(built_lib, grid):
+    """lrf_adam_step_pack (FusedAdam(pack_field=field)): parameters and Adam state bit-identical to the plain fused step, the
+    layout cache it leaves bit-identical to what lrf_pack_field builds from the stepped parameters (ragged widths: 131 = one
+    full 128-texel block + 3), a tensor without gradient repacked but not stepped, the next forward takes the cache as it is
+    (no repack) and renders what the two-pass path renders; a later in-place edit still invalidates the cache."""
+    import ctypes as C
+    from localrf_amd import FusedAdam
+    from localrf_amd import _native as N
+    from util import make_field, make_rays, quiet
+    fa = quiet(make_field, list(grid), "cpu", seed=5).to(DEV)
+    fb = quiet(make_field, list(grid), "cpu", seed=5).to(DEV)
+    oa = FusedAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    ob = FusedAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), pack_field=fb)
+    rays = make_rays(96, 3).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    for it in range(3):
+        grads = {n: torch.randn(p.shape, generator=g).to(DEV) * 0.1 for n, p in fa.named_parameters()}
+        for f in (fa, fb):
+            with torch.no_grad():
+                out = f(rays, N_samples=64)                     # builds / takes the cache
+            for n, p in f.named_parameters():
+                p.grad = None if (n == "density_line.1" and it == 1) else grads[n].clone()
+        key_before = fb._cache_key
+        oa.step()
+        ob.step()
+        assert fb._cache_key is not None and fb._cache_key != key_before          # marked fresh for the NEW parameter versions
+        for (n, p), (_, q) in zip(fa.named_parameters(), fb.named_parameters()):
+            assert torch.equal(p, q), n
+            if p in oa.state and "exp_avg" in oa.state[p]:
+                assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]), n
+        # the cache the fused step left == a fresh pack of the same parameters
+        cp, keep = fb._c_params()
+        fresh = fb._cache.clone()                                # (the alignment gaps between the cache's sections are nobody's: same bytes on both sides)
+        N.check(built_lib.lrf_pack_field(C.byref(cp), fresh.data_ptr(), torch.cuda.current_stream().cuda_stream), "lrf_pack_field")
+        torch.cuda.synchronize()
+        assert torch.equal(fresh.view(torch.int32), fb._cache.view(torch.int32)), it
+        key = fb._cache_key
+        with torch.no_grad():
+            ra, _ = fa(rays, N_samples=64)
+            rb, _ = fb(rays, N_samples=64)
+        assert fb._cache_key == key                              # the forward took the cache as the step left it
+        assert torch.equal(ra, rb)
+    with torch.no_grad():
+        fb.app_plane[0].mul_(1.5)
+        rc, _ = fb(rays, N_samples=64)
+    assert fb._cache_key != key and not torch.equal(rb, rc)
