@@ -60,9 +60,6 @@ constexpr int BIN_MAX = 2048;            // max tiles over the three planes (640
 #define LRF_DPLANE_MULT 4
 #endif
 constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
-#ifndef LRF_FIX_APP_MAX_BINS
-#define LRF_FIX_APP_MAX_BINS 400          // plane tiles (all three planes) up to which the appearance scatter runs on fixed point too (300^3: 300, 500^3: 768)
-#endif
 #ifndef LRF_SCATTER_CAS64
 #define LRF_SCATTER_CAS64 1
 #endif
@@ -1249,22 +1246,22 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
                                                      const uint32_t* __restrict__ list, const float* __restrict__ gf,
                                                      const uint32_t* __restrict__ rowinfo, const float* __restrict__ grd,
                                                      const unsigned* __restrict__ vmax_bits, int bin_lo, int bin_hi) {
-  // APP (C = 24): the appearance tensors, EIGHT channels per sweep over the workgroup's share (three sweeps): a 24-channel
-  // tile of 64-bit cells would be 209 KB.  The sample's d(loss)/d(feature) is then per channel (the dX row k_train_app3
-  // left), the taps come from the dense 24-channel caches (aplane2 / aline2: 32-byte pieces at 32 * sweep), vmax is
-  // k_train_app3's max |dX line|, |dX plane|.  Positions and runs are formed again in every sweep (~a quarter of a
-  // sweep's instructions); in return the kernel needs 89-111 KB of LDS at any grid size (the compare-and-swap kernel's
-  // fp32 tile + line accumulators no longer fit at 640^3) and its sums are exact.
+  // APP (C = 24): the appearance tensors, EIGHT channels per sweep over a tile's entries (three sweeps per tile, back to back:
+  // a 24-channel tile of 64-bit cells would be 209 KB; the line accumulators hold all 24 channels).  The sample's
+  // d(loss)/d(feature) is then per channel (the dX row k_train_app3 left), the taps come from the dense 24-channel caches
+  // (aplane2 / aline2: 32-byte pieces at 32 * sweep), vmax is k_train_app3's max |dX line|, |dX plane|.  Positions and
+  // runs are formed again in every sweep (~a quarter of a sweep's instructions).  (Sweeping the workgroup's whole SHARE
+  // three times instead -- 8-channel line accumulators -- fetched every 128-byte line of taps and dX rows three times from
+  // beyond L2: 1.57 GB of counter traffic for the two scatter kernels against 0.88 GB with the compare-and-swap kernels.)
   constexpr int CH = LRF_CD;                            // channels per sweep
   static_assert(C % CH == 0 && (APP ? C == LRF_CA : C == LRF_CD), "8 channels per sweep");
   constexpr int CELLS = BCELL * BCELL;
-  extern __shared__ unsigned long long s_fx[];          // [CH][CELLS] tile, then [CH][L_p] line
+  extern __shared__ unsigned long long s_fx[];          // [CH][CELLS] tile (of the sweep), then [C][L_p] line
   unsigned long long* s_fl = s_fx + CH * CELLS;
   const long long E0 = offs[bin_lo], E = (long long)offs[bin_hi] - E0;
-  const int a_first = (int)(E0 + E * blockIdx.x / gridDim.x);
+  int a = (int)(E0 + E * blockIdx.x / gridDim.x);
   const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
-  if (a_first >= b) return;
-  int a = a_first;
+  if (a >= b) return;
 #ifdef LRF_SCATTER_PROF
   unsigned long long sp_tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_last = __builtin_readcyclecounter();
   const unsigned long long sp_t0 = sp_last;
@@ -1275,15 +1272,12 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
   vex = max(-120, min(127, vex));
   int lo = bin_lo, hi = bin_hi;                         // largest bin with offs[bin] <= a
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= a) lo = mid; else hi = mid; }
-  const int bin_first = lo;
-  for (int sweep = 0; sweep < C / CH; ++sweep) {
-  a = a_first;
-  int bin = bin_first;
+  int bin = lo;
   int lplane = -1, shL = 0;                             // plane whose line gradient s_fl holds, its scale
   auto flush_line = [&]() {                             // whole workgroup; s_fl -> += the gradient of line `lplane` ([C][L])
     __syncthreads();
-    float* gln = dst.line[lplane] + (size_t)sweep * CH * f.ll[lplane];
-    const int nl = f.ll[lplane] * CH;
+    float* gln = dst.line[lplane];
+    const int nl = f.ll[lplane] * C;
     const double inv = ldexp(1.0, -shL);
     for (int i = threadIdx.x; i < nl; i += NT) {
       const long long q = (long long)s_fl[i];
@@ -1304,14 +1298,15 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       // this workgroup's entries of plane p: at most two contributions each to a line cell
       const int pend = min(b, offs[min(bin_hi, p == 2 ? bg.total : bg.base[p + 1])]);
       shL = fix_shift(2u * (unsigned)(pend - a), vex);
-      for (int i = threadIdx.x; i < ll * CH; i += NT) s_fl[i] = 0ull;
+      for (int i = threadIdx.x; i < ll * C; i += NT) s_fl[i] = 0ull;
     }
-    for (int i = threadIdx.x; i < CH * CELLS; i += NT) s_fx[i] = 0ull;
-    __syncthreads();
-    SP_TICK(0);
 #ifdef LRF_SCATTER_PROF
     sp_tk[8] += 1;
 #endif
+    for (int sweep = 0; sweep < C / CH; ++sweep) {
+    for (int i = threadIdx.x; i < CH * CELLS; i += NT) s_fx[i] = 0ull;
+    __syncthreads();
+    SP_TICK(0);
     const int shT = fix_shift(4u * (unsigned)(seg_end - a), vex);
     const double scT = ldexp(1.0, shT), scL = ldexp(1.0, shL);
     const float* lnp = APP ? f.aline2[p] + CH * sweep : f.dline[p];      // the sweep's 8 channels of a texel: 32 bytes, 16-byte aligned
@@ -1369,8 +1364,8 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       const SegRun rt = seg_run((c00 << 2) | (cx << 1) | (cy ? 1 : 0), valid, lane);
       const SegRun rl = seg_run((l0 << 1) | (l1 - l0), valid, lane);
       unsigned long long* tc = s_fx + c00;
-      unsigned long long* lc0 = s_fl + l0;
-      unsigned long long* lc1 = s_fl + l1;
+      unsigned long long* lc0 = s_fl + (size_t)sweep * CH * ll + l0;
+      unsigned long long* lc1 = s_fl + (size_t)sweep * CH * ll + l1;
 #pragma unroll
       for (int c = 0; c < CH; c += 2) {
         float t[2][4], sl[4];
@@ -1414,10 +1409,10 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
     }
     __syncthreads();
     SP_TICK(6);
+    }                                                   // sweep
     a = seg_end;
   }
   if (lplane >= 0) flush_line();
-  }                                                     // sweep
   SP_TICK(7);
 #ifdef LRF_SCATTER_PROF
   if (threadIdx.x == 0 && blockIdx.x < 2048) {
@@ -1485,7 +1480,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
 // lrf_train32.inl.)
 static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 + k_train_app3 without row stores / position gradient and X / dz1 products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
-static int g_scatter_fix = 3;       // bit 0: density, bit 1: appearance (up to LRF_FIX_APP_MAX_BINS plane tiles; bit 2: at any size) through k_scatter_fix.  lrf_debug_set_train_fwd_engine(16 | ...): both through the compare-and-swap kernels of rounds 2-5 (the tests compare the two); 256: the density alone; 512: the appearance at any grid size
+static int g_scatter_fix = 3;       // bit 0: density, bit 1: appearance (where its accumulators fit in LDS) through k_scatter_fix.  lrf_debug_set_train_fwd_engine(16 | ...): both through the compare-and-swap kernels of rounds 2-5 (the tests compare the two); 256: the density alone
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
                                     const BwdWorkspace& b, float* rgb, hipStream_t st) {
@@ -1504,7 +1499,7 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : ((e & 512) ? 7 : 3)); lrf::g_dgrad_dbg = (e >> 5) & 7; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : 3); lrf::g_dgrad_dbg = (e >> 5) & 7; }
 
 namespace lrf {
 // floats per row of weight-gradient operands when the backward runs the generic engine (any non-default network, or
@@ -1681,11 +1676,11 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const size_t lds_dp = sizeof(float) * BCELL * BCELL * LRF_CD, lds_dl = sizeof(float) * LRF_CD * ll_max;
   const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024;
   const bool fix_d = g_scatter_fix && g_scatter_fused && 2 * (lds_dp + lds_dl) <= 158 * 1024;   // 64-bit fixed-point accumulators: twice the bytes
-  // the appearance scatter sweeps its share three times (8 channels each: the same LDS), i.e. zeroes and flushes three tiles
-  // per bin: it wins where the bins are few (forward + backward at 64^3 1.28 -> 1.14 ms, at 300^3 1.382 -> 1.325 with both
-  // kernels against 1.332 with the density one alone) and loses where they are many (500^3: 1.549 against 1.494, 640^3: 1.742
-  // against 1.706: profiles/r17_fixed_point_scatter.md) -- there the compare-and-swap kernel stays
-  const bool fix_a = fix_d && (g_scatter_fix & 2) && (bg.total <= LRF_FIX_APP_MAX_BINS || (g_scatter_fix & 4));
+  // the appearance scatter runs on fixed point too where an 8-channel tile + 24-channel line accumulators of 64-bit cells fit
+  // in LDS (lines up to 479 cells): forward + backward 1.26 -> 1.12 ms at 64^3, 1.36 -> 1.29 at 300^3, on par with the
+  // compare-and-swap kernel at 400^3-460^3 (profiles/r17_fixed_point_scatter.md); above that the compare-and-swap kernel stays
+  const size_t lds_fa = 2 * lds_dp + sizeof(unsigned long long) * LRF_CA * ll_max;
+  const bool fix_a = fix_d && (g_scatter_fix & 2) && lds_fa <= 158 * 1024;
   if (fix_d) {
     hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
     hipLaunchKernelGGL((k_scatter_fix<LRF_CD, false, FIX_NT>), dim3(cus), dim3(FIX_NT), 2 * (lds_dp + lds_dl), sb,
@@ -1757,7 +1752,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   for (int q = 0; q < npass; ++q) {
     const int blo = npass == 1 ? 0 : bg.base[q], bhi = (npass == 1 || q == 2) ? bg.total : bg.base[q + 1];
     if (fix_a) {
-      hipLaunchKernelGGL((k_scatter_fix<LRF_CA, true, FIX_NT>), dim3(cus), dim3(FIX_NT), 2 * (lds_dp + lds_dl), st,
+      hipLaunchKernelGGL((k_scatter_fix<LRF_CA, true, FIX_NT>), dim3(cus), dim3(FIX_NT), lds_fa, st,
                          d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, vmax_a, blo, bhi);
     } else if (fuse_a) {
       hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,
