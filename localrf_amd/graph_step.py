@@ -269,7 +269,11 @@ class CapturedIteration:
             if self._graphs is None:
                 t0 = time.perf_counter()
                 self._zero_grads()                                # gradients are created inside the capture: static addresses in its pool
-                field._cache_key = None                           # the layout refresh (lrf_pack_field) is the graph's first node
+                # the layout refresh: written by the Adam launch itself when the field's optimiser steps it fused
+                # (lrf_adam_step_pack: the cache is fresh from the eager iteration just run, and every replay leaves it fresh
+                # for the next) -- otherwise lrf_pack_field is the graph's first node
+                if not self.plan.packs(field):
+                    field._cache_key = None
                 if sync is None:
                     self._graphs = (self._capture(lambda: (self._forward_backward(), self._adam())),)
                 else:

@@ -158,6 +158,23 @@ class StaticAdamPlan:
     def __len__(self):
         return len(self.pairs)
 
+    def _classes(self):
+        classes = {}
+        for i, (opt, p) in enumerate(self.pairs):
+            grp = self._group[(id(opt), id(p))]
+            classes.setdefault((tuple(grp["betas"]), grp["eps"], p.device), []).append(i)
+        return classes
+
+    def packs(self, field):
+        """Whether launch() would step this field through lrf_adam_step_pack right now, i.e. leave its layout cache holding
+        the stepped values (the captured iteration then needs no refresh node in front of its forward)."""
+        for idx in self._classes().values():
+            if len(idx) <= N.LRF_ADAM_MAX:
+                t = _pack_target(self.pairs[i][0].pack_field for i in idx)
+                if t is not None and t[0] is field:
+                    return True
+        return False
+
     def launch(self, scalars_dev):
         """Enqueue (or capture) the launches.  scalars_dev: float32 [len(self), 2] on the device.  Every parameter must
         hold its gradient (.grad) at this point: the pointers are baked into the launch."""
