@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   // first pass of the density scatter's counting sort (it was a kernel of its own that re-derived every sample's position):
   // the workgroup's histogram over the plane tiles, behind the four per-ray arrays (one per wave was measured: four times the
   // global atomics at the end, 80 -> 120 us)
-  int* s_h = reinterpret_cast<int*>(s_all + (size_t)16 * S);
+  int* s_h = reinterpret_cast<int*>(s_all + (size_t)14 * S);      // (per wave: alpha, w, gw [S] floats + idx [S] shorts = 14 S bytes x 4 waves / 4)
   for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
   __syncthreads();
   auto flush_hist = [&]() {                                    // every wave of the workgroup, behind the one barrier at the end
@@ -514,10 +514,12 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
     }
   };
   if (ray >= R) { flush_hist(); return; }                      // (a wave without a ray still meets the others at that barrier)
-  float* s_alpha = s_all + (size_t)wave * 4 * S;
+  float* s_alpha = s_all + (size_t)wave * 3 * S;
   float* s_w = s_alpha + S;
   float* s_gw = s_w + S;
-  int* s_idx = reinterpret_cast<int*>(s_gw + S);
+  // compact index of a sample among the ray's shaded ones (< S <= 2048) or -1, as shorts behind the three float arrays of all
+  // four waves: 29.9 KB per workgroup at S = 512 instead of 34 KB -- five workgroups per CU instead of four
+  short* s_idx = reinterpret_cast<short*>(s_all + (size_t)12 * S) + (size_t)wave * S;
   const float* rp = rays + (size_t)ray * 6;
   const float o[3] = {rp[0], rp[1], rp[2]};
   const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   const int nsh = ncomp[ray];
 
   for (int k = lane; k < S; k += 64) s_idx[k] = -1;
-  for (int j = lane; j < nsh; j += 64) s_idx[cidx[(size_t)ray * S + j]] = j;
+  for (int j = lane; j < nsh; j += 64) s_idx[cidx[(size_t)ray * S + j]] = (short)j;
   // alpha per sample (same arithmetic as k_march)
   for (int k = lane; k < S; k += 64) {
     float alpha = 0.0f;
@@ -1589,7 +1591,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line<LRF_CD, false, 1024>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_ray),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 16 * LRF_MAX_S_TRAIN * 4 + BIN_MAX * 4);
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 14 * LRF_MAX_S_TRAIN * 4 + BIN_MAX * 4);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_dgrad3<8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8>),
@@ -1669,7 +1671,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // ---- side stream: per-ray backward, density scatter
   LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));
   unsigned* vmax_d = reinterpret_cast<unsigned*>(b.hist + 2 * BIN_MAX);
-  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)16 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
+  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)14 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
                      d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
                      (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax, vmax_d);
   // line gradients ride on the plane pass when tile + line accumulators fit in LDS (g_scatter_fused; appearance at 640^3 does not)
