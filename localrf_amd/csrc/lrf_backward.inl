@@ -179,7 +179,7 @@ __device__ __forceinline__ float4 row_load4(const float* p) {
 // gradients unchanged (74 tests), forward+backward 1.94 vs 1.79 ms.  The scatters are bound by their LDS adds, not by
 // those gathers.  Not adopted.)
 __device__ __forceinline__ void load_dx6(const float* __restrict__ grd, size_t row, int p, int sub, float dv[6]) {
-  const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, row) + p * LRF_CA + 6 * sub);
+  const float2* dx2 = reinterpret_cast<const float2*>(grd_dx_row(grd, row) + p * LRF_CA + 6 * sub);       // (rows order: lrf_common.h)
 #pragma unroll
   for (int h = 0; h < 3; ++h) { const float2 t2 = row_load2_b<16>(dx2 + h); dv[2 * h] = t2.x; dv[2 * h + 1] = t2.y; }
 }
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       const uint32_t cid = APP ? rowinfo[row] : row;
       float dx[CH];                                     // d(loss)/d(feature of channel c): one scalar for the density, the row's dX for the appearance
       if (APP) {
-        const float* dxp = grd_dx_row(grd, row) + p * LRF_CA + CH * sweep;
+        const float* dxp = grd_dx8(grd, row, p, sweep);
         ld4g(dxp, dx); ld4g(dxp + 4, dx + 4);
       } else {
         const float g = gf[cid];
@@ -1662,18 +1662,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const size_t ll_max = (size_t)max(L.ll[0], max(L.ll[1], L.ll[2]));
   const size_t lds_ap = sizeof(float) * BCELL * BCELL * LRF_CA, lds_al = sizeof(float) * LRF_CA * ll_max;
   const bool fuse_a = g_scatter_fused && lds_ap + lds_al <= 158 * 1024;
-  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * (2 * BIN_MAX + 8), st));
-  unsigned* vmax_a = reinterpret_cast<unsigned*>(b.hist2 + 2 * BIN_MAX);
-  hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
-                     d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
-                     b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a);
-
-  // ---- side stream: per-ray backward, density scatter
-  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));
-  unsigned* vmax_d = reinterpret_cast<unsigned*>(b.hist + 2 * BIN_MAX);
-  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)14 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
-                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
-                     (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax, vmax_d);
   // line gradients ride on the plane pass when tile + line accumulators fit in LDS (g_scatter_fused; appearance at 640^3 does not)
   const size_t lds_dp = sizeof(float) * BCELL * BCELL * LRF_CD, lds_dl = sizeof(float) * LRF_CD * ll_max;
   const bool fuse_d = g_scatter_fused && lds_dp + lds_dl <= 64 * 1024;
@@ -1683,6 +1671,18 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // compare-and-swap kernel at 400^3-460^3 (profiles/r17_fixed_point_scatter.md); above that the compare-and-swap kernel stays
   const size_t lds_fa = 2 * lds_dp + sizeof(unsigned long long) * LRF_CA * ll_max;
   const bool fix_a = fix_d && (g_scatter_fix & 2) && lds_fa <= 158 * 1024;
+  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * (2 * BIN_MAX + 8), st));
+  unsigned* vmax_a = reinterpret_cast<unsigned*>(b.hist2 + 2 * BIN_MAX);
+  hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
+                     d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
+                     b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a, fix_a ? 1 : 0);
+
+  // ---- side stream: per-ray backward, density scatter
+  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));
+  unsigned* vmax_d = reinterpret_cast<unsigned*>(b.hist + 2 * BIN_MAX);
+  hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)14 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
+                     d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,
+                     (const float*)nullptr, w.pmax, g_rays, bg, b.tid, b.hist, b.nmax, vmax_d);
   if (fix_d) {
     hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, sb, bg, b.nmax, R, S, w.toff, 0, b.tid, b.hist, b.cursor, b.offs, b.list);
     hipLaunchKernelGGL((k_scatter_fix<LRF_CD, false, FIX_NT>), dim3(cus), dim3(FIX_NT), 2 * (lds_dp + lds_dl), sb,

@@ -124,8 +124,15 @@ __host__ __device__ inline Layout make_layout(const int32_t grid[3]) {
 //   t * 16 * LD + (c / 16) * 256 + ((c / 4 % 4) * 16 + s) * 4 + c % 4            (frag_off below)
 // so that a producer's store instruction (lane (s, g) holds columns 16 b + 4 g .. + 3 of row s) writes 1 KB contiguous
 // instead of sixteen 64-byte pieces apart, and the weight-gradient kernel stages whole blocks with contiguous loads.
-// Exception: the dX block of a GRD tile is row-major inside the tile (16 rows x 80 floats behind the 3 fragment
-// blocks, natural channel order): the binned scatter kernels read it one row at a time (grd_dx_row).
+// Exception: the dX block of a GRD tile (16 x 80 floats behind the 3 fragment blocks), in one of two orders chosen per
+// backward pass (lrf_render_bwd: the order its appearance scatter wants):
+//   rows    row-major inside the tile, natural channel order (rounds 2-5): k_scatter_plane<24> / k_scatter_line<24> read the 96
+//           bytes of a (row, plane) pair at once (grd_dx_row);
+//   groups  [plane 3][channel group 3][row 16][8 channels]: the 32 bytes a (row, plane) pair contributes to one 8-channel sweep
+//           of k_scatter_fix<24> lie beside those of the tile's other rows -- consecutive entries of the scatter are consecutive
+//           samples of a ray, i.e. consecutive rows -- so a 128-byte line serves four entries of a sweep.  With row-major
+//           rows each of the three sweeps fetched the row's line again: 1.4 GB of counter traffic for that kernel, 273 us
+//           against 229 (grd_dx8).
 constexpr int ACT_FEAT = 0, ACT_LD = 32;
 constexpr int GRD_GO = 0, GRD_DFEAT = 16, GRD_DX = 48, GRD_LD = 128;
 static_assert(ACT_FEAT % 16 == 0 && ACT_LD % 16 == 0, "fragment blocks are 16 columns");
@@ -139,6 +146,10 @@ __device__ __forceinline__ float* frag_lane_base(float* buf, size_t tile, int ld
 }
 __device__ __forceinline__ const float* grd_dx_row(const float* grd, size_t row) {
   return grd + (row >> 4) * (size_t)(16 * GRD_LD) + GRD_DX * 16 + (row & 15) * (GRD_LD - GRD_DX);
+}
+// (groups order) the eight channels 8 grp .. 8 grp + 7 of plane p of row `row`: 32 bytes, 16-byte aligned
+__device__ __forceinline__ const float* grd_dx8(const float* grd, size_t row, int p, int grp) {
+  return grd + (row >> 4) * (size_t)(16 * GRD_LD) + GRD_DX * 16 + (((p * 3 + grp) * 16 + (int)(row & 15)) << 3);
 }
 
 struct DField {

@@ -1157,7 +1157,7 @@ int64_t lrf_debug_saved_row_offset(int buffer, uint64_t row, int col) {
   if (buffer == 0) return (col < 0 || col >= ACT_LD) ? -1 : (int64_t)frag_off((size_t)row, col, ACT_LD);
   if (buffer == 1) {
     if (col < 0 || col >= GRD_LD) return -1;
-    if (col >= GRD_DX) return (int64_t)((row >> 4) * (uint64_t)(16 * GRD_LD) + GRD_DX * 16 + (row & 15) * (GRD_LD - GRD_DX) + (col - GRD_DX));
+    if (col >= GRD_DX) return (int64_t)((row >> 4) * (uint64_t)(16 * GRD_LD) + GRD_DX * 16 + (row & 15) * (GRD_LD - GRD_DX) + (col - GRD_DX));   // (the row-major order of the dX block; the other one: lrf_common.h)
     return (int64_t)frag_off((size_t)row, col, GRD_LD);
   }
   return -1;

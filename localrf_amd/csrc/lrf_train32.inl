@@ -379,7 +379,8 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     float* __restrict__ grd /* in: dfeat blocks, out: dX blocks */, float* __restrict__ rpart, int pmax, float* __restrict__ wpart,
     BinGeom bg, uint16_t* __restrict__ tile_id /* [3][nmax] plane-tile id of every row, 0xffff = none */, int* __restrict__ hist, uint32_t nmax,
     int dbg /* timing experiments: 1 no row stores, 2 no position gradient / X */,
-    unsigned* __restrict__ vmax_bits /* max |dX line|, |dX plane| over the batch as float bits (atomicMax), or null */) {
+    unsigned* __restrict__ vmax_bits /* max |dX line|, |dX plane| over the batch as float bits (atomicMax), or null */,
+    int dx_groups /* order of the dX block (lrf_common.h): 1 = [plane][channel group][row][8] for k_scatter_fix<24>, 0 = row-major */) {
   constexpr int NT = NW * 64;
   float vmax = 0.0f;
   extern __shared__ uint4 s_dyn4[];
@@ -500,16 +501,20 @@ __global__ __launch_bounds__(NW * 64) void k_train_app3(
     int k_n = k;
     if (more) k_n = index_of(pr + 1, ti_n);
     if (!(dbg & 1)) {
-      // dX block of the two tiles (row-major inside a tile, natural channel order: the scatter kernels read it a row at a
-      // time).  A lane holds 3 x 48 B of its row: stored directly that is nine instructions of 64 scattered 16-byte pieces
-      // (65 of the kernel's 160 us); staged through this wave's LDS tile instead, every store instruction writes 1 KB contiguous.
-      float* sp = s_stg + n * (GRD_LD - GRD_DX) + 12 * h;
+      // dX block of the two tiles, in the order this pass's appearance scatter reads it (lrf_common.h: rows, or [plane][channel
+      // group of 8][row][8]).  A lane holds 3 x 48 B of its row: stored directly that is nine instructions of 64 scattered
+      // 16-byte pieces (65 of the kernel's 160 us); staged through this wave's LDS tile in the global order instead, every
+      // store instruction writes 1 KB contiguous.
+      float* tile_s = s_stg + (n >> 4) * (16 * (GRD_LD - GRD_DX));
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          *reinterpret_cast<float4*>(sp + p * LRF_CA + 4 * i) = make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]);
-      *reinterpret_cast<float4*>(s_stg + n * (GRD_LD - GRD_DX) + 72 + 4 * h) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the rows' pad columns
+        for (int i = 0; i < 3; ++i) {
+          const int c = 12 * h + 4 * i;                        // the float4's first channel: 0, 4, .. 20 -- inside one group of 8
+          float* d = dx_groups ? tile_s + ((((p * 3 + (c >> 3)) * 16 + (n & 15)) << 3) + (c & 7)) : tile_s + (n & 15) * (GRD_LD - GRD_DX) + p * LRF_CA + c;
+          *reinterpret_cast<float4*>(d) = make_float4(dX[12 * p + 4 * i], dX[12 * p + 4 * i + 1], dX[12 * p + 4 * i + 2], dX[12 * p + 4 * i + 3]);
+        }
+      *reinterpret_cast<float4*>(dx_groups ? tile_s + 9 * 128 + ((n & 15) << 3) + 4 * h : tile_s + (n & 15) * (GRD_LD - GRD_DX) + 72 + 4 * h) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the pad columns
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
