@@ -1611,7 +1611,9 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 14 * LRF_MAX_S_TRAIN * 4 + BIN_MAX * 4);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_dgrad3<8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8>),
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_train_app3<8, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CD, false, FIX_NT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1690,9 +1692,14 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const bool fix_a = fix_d && (g_scatter_fix & 2) && lds_fa <= 158 * 1024;
   LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * (2 * BIN_MAX + 8), st));
   unsigned* vmax_a = reinterpret_cast<unsigned*>(b.hist2 + 2 * BIN_MAX);
-  hipLaunchKernelGGL((k_train_app3<8>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
-                     d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
-                     b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a, fix_a ? 1 : 0);
+  if (fix_a)
+    hipLaunchKernelGGL((k_train_app3<8, true>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
+                       d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
+                       b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a);
+  else
+    hipLaunchKernelGGL((k_train_app3<8, false>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
+                       d.mlpwt, rays, z, S, w.toff, R, b.tileinfo, w.cidx,
+                       b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a);
 
   // ---- side stream: per-ray backward, density scatter
   LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));

@@ -372,15 +372,15 @@ __global__ __launch_bounds__(NW * 64) void k_train_dgrad3(
 // 48 accumulator registers per wave, one [32][96] block per workgroup at WP_BAS (k_wgrad_reduce).
 constexpr int APP3_IMG_U4 = (W32T_NFRAG - W32T_BAS) * 128;       // the six basis^T fragments
 constexpr int APP3_STG_FLOATS = 32 * (GRD_LD - GRD_DX);          // dX rows of a pair of tiles, per wave
-template <int NW>
+template <int NW, bool DXG = false /* order of the dX block (lrf_common.h): true = [plane][channel group][row][8] for k_scatter_fix<24>, false = row-major */>
 __global__ __launch_bounds__(NW * 64) void k_train_app3(
     DField f, const uint4* __restrict__ imt, const float* __restrict__ rays, const float* __restrict__ z, int S,
     const int* __restrict__ toff, int R, const int4* __restrict__ tileinfo, const uint16_t* __restrict__ cidx,
     float* __restrict__ grd /* in: dfeat blocks, out: dX blocks */, float* __restrict__ rpart, int pmax, float* __restrict__ wpart,
     BinGeom bg, uint16_t* __restrict__ tile_id /* [3][nmax] plane-tile id of every row, 0xffff = none */, int* __restrict__ hist, uint32_t nmax,
     int dbg /* timing experiments: 1 no row stores, 2 no position gradient / X */,
-    unsigned* __restrict__ vmax_bits /* max |dX line|, |dX plane| over the batch as float bits (atomicMax), or null */,
-    int dx_groups /* order of the dX block (lrf_common.h): 1 = [plane][channel group][row][8] for k_scatter_fix<24>, 0 = row-major */) {
+    unsigned* __restrict__ vmax_bits /* max |dX line|, |dX plane| over the batch as float bits (atomicMax), or null */) {
+  constexpr bool dx_groups = DXG;
   constexpr int NT = NW * 64;
   float vmax = 0.0f;
   extern __shared__ uint4 s_dyn4[];

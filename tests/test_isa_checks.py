@@ -98,7 +98,8 @@ def test_shade3_shape(asm):
 
 def test_scratch_use_is_bounded(asm):
     for pat, limit in ((r"k_marchILb1ELb0EE", 0), (r"k_marchILb0ELb0EE", 0),
-                       (r"k_train_dgrad3ILi8EE", 0), (r"k_train_app3ILi8EE", 0)):
+                       (r"k_train_dgrad3ILi8EE", 0), (r"k_train_app3ILi8ELb0EE", 0), (r"k_train_app3ILi8ELb1EE", 0),
+                       (r"k_scatter_fixILi8ELb0ELi1024EE", 0), (r"k_scatter_fixILi24ELb1ELi1024EE", 0), (r"k_adam_packE", 0)):
         for name, _ in _body(asm, pat):
             meta = asm[asm.index(".amdhsa_kernel " + name):]
             meta = meta[:meta.index(".end_amdhsa_kernel")]
@@ -110,7 +111,7 @@ def test_colour_backward_kernels_shape(asm):
     """k_train_dgrad3: 96 (W2^T) + 24 (W1^T) MFMAs of the data chain, 4 + 16 selector transposes (feat^T, dz1^T), 24 for dW1.
     k_train_app3: 18 (basis^T), 4 + 12 selector transposes (dfeat^T, X^T per plane), 18 for dbasis.  All on the 32x32x16
     instruction, at most 256 registers (two waves per SIMD)."""
-    for pat, n in ((r"k_train_dgrad3ILi8EE", 96 + 24 + 4 + 16 + 24), (r"k_train_app3ILi8EE", 18 + 4 + 12 + 18)):
+    for pat, n in ((r"k_train_dgrad3ILi8EE", 96 + 24 + 4 + 16 + 24), (r"k_train_app3ILi8ELb0EE", 18 + 4 + 12 + 18), (r"k_train_app3ILi8ELb1EE", 18 + 4 + 12 + 18)):
         name, body = _body(asm, pat)[0]
         assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) == n, (name, len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)))
         meta = asm[asm.index(name + ":"):]
