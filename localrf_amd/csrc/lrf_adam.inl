@@ -12,12 +12,16 @@ namespace lrf {
 
 constexpr int ADAM_TPB = 256, ADAM_VEC = 4, ADAM_CHUNK = ADAM_TPB * ADAM_VEC * 4;   // 4096 elements per block
 
-struct AdamTable {
-  LrfAdamTensor t[LRF_ADAM_MAX];
-  int first_block[LRF_ADAM_MAX + 1];   // prefix sum of per-tensor block counts
-  short row[LRF_ADAM_MAX];             // the tensor's row of dev_scalars (its index in the caller's table)
+template <int CAP>
+struct AdamTableT {
+  LrfAdamTensor t[CAP];
+  int first_block[CAP + 1];            // prefix sum of per-tensor block counts
+  short row[CAP];                      // the tensor's row of dev_scalars (its index in the caller's table)
   int count;
 };
+typedef AdamTableT<LRF_ADAM_MAX> AdamTable;
+constexpr int ADAM_SMALL_CAP = 44;      // small tensors k_adam_pack takes along (kernel arguments stay under 4 KB beside its own table)
+typedef AdamTableT<ADAM_SMALL_CAP> AdamTableS;
 
 // (every operation spelt out with its rounding: the compiler contracts a * b + c into an fma where it sees fit, and it saw fit
 // differently in k_adam_multi and in k_adam_pack -- the two kernels must produce the same bits)
@@ -32,21 +36,23 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 // dev_scalars (lrf_adam_step_dev): [count][2] = {step_size, bc2_sqrt} per tensor in DEVICE memory, read at execution time -- the
 // launch can sit in a captured hipGraph whose replays step with the learning rates / bias corrections (and skip the tensors,
 // bc2_sqrt <= 0) the host wrote before each replay.
-__global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
+template <int TPB, class TAB>
+__device__ __forceinline__ void adam_table_block(const TAB& tab, int blk, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
+  constexpr int CHUNK = TPB * ADAM_VEC * 4;
   int ti = 0;
-  while (ti + 1 < tab.count && (int)blockIdx.x >= tab.first_block[ti + 1]) ++ti;   // <= 64 uniform steps
+  while (ti + 1 < tab.count && blk >= tab.first_block[ti + 1]) ++ti;   // <= 64 uniform steps
   LrfAdamTensor T = tab.t[ti];
   if (dev_scalars) {
     T.step_size = dev_scalars[2 * tab.row[ti]];
     T.bc2_sqrt = dev_scalars[2 * tab.row[ti] + 1];
     if (!(T.bc2_sqrt > 0.0f)) return;                // not stepped this iteration (a view nobody sampled: torch skips .grad None)
   }
-  const long long base = (long long)((int)blockIdx.x - tab.first_block[ti]) * ADAM_CHUNK;
+  const long long base = (long long)(blk - tab.first_block[ti]) * CHUNK;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(T.p) | reinterpret_cast<uintptr_t>(T.g) |
                         reinterpret_cast<uintptr_t>(T.m) | reinterpret_cast<uintptr_t>(T.v)) & 15) == 0;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const long long i = base + ((long long)it * ADAM_TPB + threadIdx.x) * ADAM_VEC;
+    const long long i = base + ((long long)it * TPB + threadIdx.x) * ADAM_VEC;
     if (i >= T.n) break;
     if (vec_ok && i + ADAM_VEC <= T.n) {
       float4 p = *reinterpret_cast<float4*>(T.p + i), m = *reinterpret_cast<float4*>(T.m + i),
@@ -66,6 +72,9 @@ __global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1
       }
     }
   }
+}
+__global__ __launch_bounds__(ADAM_TPB) void k_adam_multi(AdamTable tab, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
+  adam_table_block<ADAM_TPB>(tab, (int)blockIdx.x, b1, b2, eps, dev_scalars);
 }
 
 }  // namespace lrf
@@ -132,8 +141,42 @@ __device__ __forceinline__ void adam_pack_block(const AdamPackSeg& sg, int blk, 
   float step_size = sg.t.step_size, bc2 = sg.t.bc2_sqrt;
   if (dev_scalars && sg.row >= 0) { step_size = dev_scalars[2 * sg.row]; bc2 = dev_scalars[2 * sg.row + 1]; }
   const bool adam = sg.t.g != nullptr && bc2 > 0.0f;
-  if (t < nx) {
-    const size_t i0 = (size_t)y * sg.W + x0 + t, cs = (size_t)sg.H * sg.W;
+  const size_t cs = (size_t)sg.H * sg.W;
+  if (APPC) {                                                // the pad slots of the padded record
+    float* d = s_t + t * ld;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { d[8 * q + 6] = 0.0f; d[8 * q + 7] = 0.0f; }
+  }
+  // Rows whose start is 16-byte aligned in all four arrays (W a multiple of 4: 64, 220, 300, 500, 640 ...): a thread takes
+  // FOUR consecutive texels of C / 4 channels (c = slice, slice + 4, ...) with 16-byte loads and stores -- 24 of each per array
+  // for the appearance tensors instead of 96 of four bytes; otherwise (97^3, 331^3: odd widths) one texel, all channels.
+  const bool vec = (sg.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(sg.t.p) | reinterpret_cast<uintptr_t>(sg.t.g) |
+                                        reinterpret_cast<uintptr_t>(sg.t.m) | reinterpret_cast<uintptr_t>(sg.t.v)) & 15) == 0;
+  if (vec) {
+    const int q = t & 31, slice = t >> 5;                    // texels x0 + 4 q .. + 3, channels slice, slice + 4, ...
+    if (4 * q < nx) {
+      const size_t i0 = (size_t)y * sg.W + x0 + 4 * q;
+#pragma unroll
+      for (int k = 0; k < C / 4; ++k) {
+        const int c = slice + 4 * k;
+        const size_t i = i0 + c * cs;
+        float4 p = *reinterpret_cast<const float4*>(sg.t.p + i);
+        if (adam) {
+          float4 m = *reinterpret_cast<const float4*>(sg.t.m + i), v = *reinterpret_cast<const float4*>(sg.t.v + i);
+          const float4 g = *reinterpret_cast<const float4*>(sg.t.g + i);
+          adam1(p.x, g.x, m.x, v.x, b1, b2, eps, step_size, bc2);
+          adam1(p.y, g.y, m.y, v.y, b1, b2, eps, step_size, bc2);
+          adam1(p.z, g.z, m.z, v.z, b1, b2, eps, step_size, bc2);
+          adam1(p.w, g.w, m.w, v.w, b1, b2, eps, step_size, bc2);
+          *reinterpret_cast<float4*>(sg.t.p + i) = p; *reinterpret_cast<float4*>(sg.t.m + i) = m; *reinterpret_cast<float4*>(sg.t.v + i) = v;
+        }
+        const int slot = APPC ? app_pc(c) : c;
+        float* d = s_t + (4 * q) * ld + slot;
+        d[0] = p.x; d[ld] = p.y; d[2 * ld] = p.z; d[3 * ld] = p.w;
+      }
+    }
+  } else if (t < nx) {
+    const size_t i0 = (size_t)y * sg.W + x0 + t;
     float pv[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) pv[c] = sg.t.p[i0 + c * cs];
@@ -148,10 +191,6 @@ __device__ __forceinline__ void adam_pack_block(const AdamPackSeg& sg, int blk, 
       }
     }
     float* d = s_t + t * ld;
-    if (APPC) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { d[8 * q + 6] = 0.0f; d[8 * q + 7] = 0.0f; }
-    }
 #pragma unroll
     for (int c = 0; c < C; ++c) d[APPC ? app_pc(c) : c] = pv[c];
   }
@@ -172,8 +211,15 @@ __device__ __forceinline__ void adam_pack_block(const AdamPackSeg& sg, int blk, 
   }
 }
 
-__global__ __launch_bounds__(128) void k_adam_pack(AdamPackTab tab, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
+// blocks [0, first_block[12]): the field's twelve tensors; behind them the table kernel's blocks for the small tensors
+// (2048 elements each at 128 threads)
+constexpr int ADAM_PACK_CHUNK = 128 * ADAM_VEC * 4;
+__global__ __launch_bounds__(128) void k_adam_pack(AdamPackTab tab, AdamTableS small, float b1, float b2, float eps, const float* __restrict__ dev_scalars) {
   __shared__ __attribute__((aligned(16))) float s_t[128 * (LRF_CAS + 4)];
+  if ((int)blockIdx.x >= tab.first_block[12]) {
+    adam_table_block<128>(small, (int)blockIdx.x - tab.first_block[12], b1, b2, eps, dev_scalars);
+    return;
+  }
   int k = 0;
   while (k + 1 < 12 && (int)blockIdx.x >= tab.first_block[k + 1]) ++k;
   const AdamPackSeg& sg = tab.s[k];
@@ -217,22 +263,42 @@ extern "C" int lrf_adam_step_pack(const LrfAdamTensor* tensors, int32_t count, c
     }
   }
   pt.first_block[12] = blocks;
-  // the small tensors (basis, colour network, per-frame poses / exposures ...): the table kernel
-  AdamTable tab;
-  tab.count = 0;
-  int tb = 0;
+  // the small tensors (basis, colour network, per-frame poses / exposures ...): the table kernel's blocks behind the field's in
+  // the same launch (up to ADAM_SMALL_CAP of them; more -- dozens of per-frame optimisers in one call -- go through k_adam_multi)
+  int n_small = 0;
   for (int j = 0; j < count; ++j) {
     if (taken[j]) continue;
     const LrfAdamTensor& t = tensors[j];
     if (!t.p || !t.g || !t.m || !t.v || t.n < 0) return set_err("lrf_adam_step_pack: null tensor pointer or negative size");
     if (t.n > (int64_t)2000000000) return set_err("lrf_adam_step_pack: tensor too large");
-    tab.t[tab.count] = t; tab.row[tab.count] = (short)j; tab.first_block[tab.count] = tb;
-    tb += (int)((t.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
-    ++tab.count;
+    ++n_small;
   }
-  tab.first_block[tab.count] = tb;
-  if (tb) hipLaunchKernelGGL(k_adam_multi, dim3(tb), dim3(ADAM_TPB), 0, st, tab, beta1, beta2, eps, dev_scalars);
-  hipLaunchKernelGGL(k_adam_pack, dim3(blocks), dim3(128), 0, st, pt, beta1, beta2, eps, dev_scalars);
+  AdamTableS small;
+  small.count = 0;
+  small.first_block[0] = 0;
+  int tb = 0;
+  if (n_small <= ADAM_SMALL_CAP) {
+    for (int j = 0; j < count; ++j) {
+      if (taken[j]) continue;
+      small.t[small.count] = tensors[j]; small.row[small.count] = (short)j; small.first_block[small.count] = tb;
+      tb += (int)((tensors[j].n + ADAM_PACK_CHUNK - 1) / ADAM_PACK_CHUNK);
+      ++small.count;
+    }
+    small.first_block[small.count] = tb;
+  } else {
+    AdamTable tab;
+    tab.count = 0;
+    int nb = 0;
+    for (int j = 0; j < count; ++j) {
+      if (taken[j]) continue;
+      tab.t[tab.count] = tensors[j]; tab.row[tab.count] = (short)j; tab.first_block[tab.count] = nb;
+      nb += (int)((tensors[j].n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+      ++tab.count;
+    }
+    tab.first_block[tab.count] = nb;
+    if (nb) hipLaunchKernelGGL(k_adam_multi, dim3(nb), dim3(ADAM_TPB), 0, st, tab, beta1, beta2, eps, dev_scalars);
+  }
+  hipLaunchKernelGGL(k_adam_pack, dim3(blocks + tb), dim3(128), 0, st, pt, small, beta1, beta2, eps, dev_scalars);
   // the fragment-ordered images of the colour network, from the weights the table kernel just stepped (slice 18 of k_pack_planes)
   PackTab none = {};
   PackMlp pm;
