@@ -70,6 +70,13 @@ constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
 #define LRF_DENS_LPE 4                   // lanes per entry of the density scatter (8 channels): 4 lanes x one pair each (64-bit CAS), 259 -> 224 us against 8 lanes x one channel
 #endif
 
+// A workgroup of a scatter kernel pays ~13-24 K cycles per tile it VISITS (zero the accumulators, flush them, three barriers)
+// and ~8-10 K per 1024 entries.  Shares of equal ENTRIES leave the workgroups whose share crosses a dozen sparse tiles 3-5
+// times behind the rest once the field is trained (profiles/r17_scatter_trained_phases.md: appearance, 621 entries per
+// workgroup on average, 1.4 visits -- and one workgroup with 12 visits = the kernel's 187 us).  Shares are therefore cut at
+// equal COST, a bin counting SCATTER_VISIT_COST entries more than it holds: k_bin_fill leaves the prefix sums of that cost
+// behind the entry offsets, share_entry maps a position on the cost axis back to an entry.
+constexpr int SCATTER_VISIT_COST = 2048;
 struct BinGeom { int tx[3], ty[3], base[3], total; };
 __host__ __device__ inline BinGeom make_bins(const Layout& L) {
   BinGeom b; int off = 0;
@@ -775,6 +782,18 @@ __device__ __forceinline__ void cid_point_r(const DField& f, const float* __rest
   sample_point(f, o, dh, z[k], x, u);
 }
 
+// entry index of position c on the cost axis of bins [bin_lo, bin_hi) (offs: entry offsets, coffs = offs + BIN_MAX + 1: cost
+// offsets; the first SCATTER_VISIT_COST units of a non-empty bin are its visit, the rest its entries)
+__device__ __forceinline__ int share_entry(const int* __restrict__ offs, int bin_lo, int bin_hi, long long c) {
+  const int* coffs = offs + BIN_MAX + 1;
+  if (c >= coffs[bin_hi]) return offs[bin_hi];
+  int lo = bin_lo, hi = bin_hi;                        // largest bin with coffs[bin] <= c
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (coffs[mid] <= c) lo = mid; else hi = mid; }
+  const int cnt = offs[lo + 1] - offs[lo];
+  const long long within = c - coffs[lo] - (cnt ? SCATTER_VISIT_COST : 0);
+  return offs[lo] + (int)max(0ll, min((long long)cnt, within));
+}
+
 // pass 1: tile id of every entry in every plane + global histogram
 // (The histogram pass of the counting sort is not a kernel: k_bwd_ray (density) and k_train_app3 (appearance) hold every
 // entry's taps anyway, write its three tile ids and count them in LDS histograms.)
@@ -787,29 +806,33 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
   __shared__ int s_h[BIN_MAX];
   __shared__ int s_off[BIN_MAX];
   __shared__ int s_wsum[4];
+  __shared__ int s_wnz[4];
   const uint32_t n = app ? (uint32_t)toff[R] * 16u : (uint32_t)R * (uint32_t)S;
   const uint32_t b0 = blockIdx.x * (uint32_t)BIN_CHUNK;
   if (b0 >= n && blockIdx.x != 0) return;                      // (block 0 always writes the offsets)
   {                                                            // exclusive scan of hist[0 .. total): 8 consecutive tiles per thread
     constexpr int PT = BIN_MAX / 256;
     const int t0 = threadIdx.x * PT, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int v[PT], sum = 0;
+    int v[PT], sum = 0, nz = 0;
 #pragma unroll
-    for (int i = 0; i < PT; ++i) { v[i] = t0 + i < bg.total ? hist[t0 + i] : 0; sum += v[i]; }
-    int incl = sum;
+    for (int i = 0; i < PT; ++i) { v[i] = t0 + i < bg.total ? hist[t0 + i] : 0; sum += v[i]; nz += v[i] ? 1 : 0; }
+    int incl = sum, incz = nz;                                   // (the second scan: non-empty bins in front -- the cost offsets of block 0)
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - sum;
-    for (int q = 0; q < wave; ++q) base += s_wsum[q];
-#pragma unroll
-    for (int i = 0; i < PT; ++i) { if (t0 + i < BIN_MAX) s_off[t0 + i] = base; base += v[i]; }
-    if (blockIdx.x == 0) {
-#pragma unroll
-      for (int i = 0; i < PT; ++i) if (t0 + i < bg.total) offs[t0 + i] = s_off[t0 + i];
-      if (threadIdx.x == 255) offs[bg.total] = base;           // = the number of entries
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64), tz = __shfl_up(incz, d, 64);
+      if (lane >= d) { incl += t; incz += tz; }
     }
+    if (lane == 63) { s_wsum[wave] = incl; s_wnz[wave] = incz; }
+    __syncthreads();
+    int base = incl - sum, basez = incz - nz;
+    for (int q = 0; q < wave; ++q) { base += s_wsum[q]; basez += s_wnz[q]; }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      if (t0 + i < BIN_MAX) s_off[t0 + i] = base;
+      if (blockIdx.x == 0 && t0 + i < bg.total) { offs[t0 + i] = base; offs[BIN_MAX + 1 + t0 + i] = base + basez * SCATTER_VISIT_COST; }
+      base += v[i]; basez += v[i] ? 1 : 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 255) { offs[bg.total] = base; offs[BIN_MAX + 1 + bg.total] = base + basez * SCATTER_VISIT_COST; }   // = the number of entries / the total cost
   }
   if (b0 >= n) return;
   for (int i = threadIdx.x; i < bg.total; i += 256) s_h[i] = 0;
@@ -874,9 +897,9 @@ __global__ __launch_bounds__(NT) void k_scatter_plane(DField f, BinGeom bg, Scat
   float* s_lacc = s_acc + BCELL * BCELL * C;
   // this launch's share of the list: the entries of bins [bin_lo, bin_hi) -- all of them (0, bg.total), or one plane's
   // when lrf_render_bwd runs the pass per plane (LRF_FLAG_PLANE_EVENTS: plane p's gradient is final behind its launch)
-  const long long E0 = offs[bin_lo], E = (long long)offs[bin_hi] - E0;
-  int a = (int)(E0 + E * blockIdx.x / gridDim.x);
-  const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
+  const long long C0 = offs[BIN_MAX + 1 + bin_lo], Cn = (long long)offs[BIN_MAX + 1 + bin_hi] - C0;      // equal COST per workgroup (SCATTER_VISIT_COST)
+  int a = share_entry(offs, bin_lo, bin_hi, C0 + Cn * blockIdx.x / gridDim.x);
+  const int b = share_entry(offs, bin_lo, bin_hi, C0 + Cn * (blockIdx.x + 1) / gridDim.x);
   if (a >= b) return;
 #ifdef LRF_SCATTER_PROF
   unsigned long long sp_tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_last = __builtin_readcyclecounter();
@@ -1275,9 +1298,9 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
   constexpr int CELLS = BCELL * BCELL;
   extern __shared__ unsigned long long s_fx[];          // [CH][CELLS] tile (of the sweep), then [C][L_p] line
   unsigned long long* s_fl = s_fx + CH * CELLS;
-  const long long E0 = offs[bin_lo], E = (long long)offs[bin_hi] - E0;
-  int a = (int)(E0 + E * blockIdx.x / gridDim.x);
-  const int b = (int)(E0 + E * (blockIdx.x + 1) / gridDim.x);
+  const long long C0 = offs[BIN_MAX + 1 + bin_lo], Cn = (long long)offs[BIN_MAX + 1 + bin_hi] - C0;      // equal COST per workgroup (SCATTER_VISIT_COST)
+  int a = share_entry(offs, bin_lo, bin_hi, C0 + Cn * blockIdx.x / gridDim.x);
+  const int b = share_entry(offs, bin_lo, bin_hi, C0 + Cn * (blockIdx.x + 1) / gridDim.x);
   if (a >= b) return;
 #ifdef LRF_SCATTER_PROF
   unsigned long long sp_tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sp_last = __builtin_readcyclecounter();
@@ -1477,7 +1500,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.tid = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
   b.hist = reinterpret_cast<int*>(take(2 * BIN_MAX + 8));       // histogram, then the fill pass's cursors, then max|contribution| (k_bwd_ray): cleared by one memset
   b.cursor = b.hist + BIN_MAX;
-  b.offs = reinterpret_cast<int*>(take(BIN_MAX + 1));
+  b.offs = reinterpret_cast<int*>(take(2 * (BIN_MAX + 1)));     // entry offsets | cost offsets (k_bin_fill)
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.relu_bits = reinterpret_cast<uint32_t*>(take(rows / 16 * 128));
   b.tileinfo = reinterpret_cast<int4*>(take(rows / 16 * 4));
@@ -1485,7 +1508,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
   b.hist2 = reinterpret_cast<int*>(take(2 * BIN_MAX + 8));      // (+ max|contribution| of the appearance scatter, k_train_app3)
   b.cursor2 = b.hist2 + BIN_MAX;
-  b.offs2 = reinterpret_cast<int*>(take(BIN_MAX + 1));
+  b.offs2 = reinterpret_cast<int*>(take(2 * (BIN_MAX + 1)));
   b.list2 = reinterpret_cast<uint32_t*>(take(3 * rows));
   b.gen = gen_ld ? take(rows * (size_t)gen_ld) : nullptr;
   b.bytes = off;
