@@ -76,7 +76,10 @@ constexpr int LINE_WGS = LRF_LINE_WGS;   // workgroups per line
 // workgroup on average, 1.4 visits -- and one workgroup with 12 visits = the kernel's 187 us).  Shares are therefore cut at
 // equal COST, a bin counting SCATTER_VISIT_COST entries more than it holds: k_bin_fill leaves the prefix sums of that cost
 // behind the entry offsets, share_entry maps a position on the cost axis back to an entry.
-constexpr int SCATTER_VISIT_COST = 2048;
+#ifndef LRF_SCATTER_VISIT_COST
+#define LRF_SCATTER_VISIT_COST 2048
+#endif
+constexpr int SCATTER_VISIT_COST = LRF_SCATTER_VISIT_COST;
 struct BinGeom { int tx[3], ty[3], base[3], total; };
 __host__ __device__ inline BinGeom make_bins(const Layout& L) {
   BinGeom b; int off = 0;
