@@ -17,8 +17,11 @@ ap.add_argument("--samples", type=int, default=1536)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--rounds", type=int, default=2)
+ap.add_argument("--overlap", type=int, default=None, help="lrf_debug_set_bwd_overlap argument (0: the backward's two branches on one stream)")
 a = ap.parse_args()
 lib = N.lib()
+if a.overlap is not None:
+    lib.lrf_debug_set_bwd_overlap(a.overlap)
 engs = [int(x) for x in a.eng.split(",")]
 g = load_golden("field_small_train_grad")
 rel = lambda x, y: float(np.abs(x - y).max() / max(np.abs(y).max(), 1e-12))
