@@ -545,39 +545,65 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
 
   for (int k = lane; k < S; k += 64) s_idx[k] = -1;
   for (int j = lane; j < nsh; j += 64) s_idx[cidx[(size_t)ray * S + j]] = (short)j;
-  // alpha per sample (same arithmetic as k_march)
-  for (int k = lane; k < S; k += 64) {
-    float alpha = 0.0f;
-    const float fk = feat[(size_t)ray * S + k];
-    if (k < S - 1 && fk > -INFINITY) {
-      const float sigma = feature2density(fk, f.density_shift, relu);
-      alpha = 1.0f - expf(-sigma * (z[k + 1] - z[k]) * f.distance_scale);
+  // alpha per sample (same arithmetic as k_march).  This kernel is one latency chain per wave (every ray's wave is resident at
+  // once: its duration is the time ONE wave needs): the loops over the ray's 64-sample chunks therefore issue the loads of
+  // four chunks together instead of paying a round trip per chunk (k_bwd_ray 63 -> us in a captured 300^3 iteration).
+  const float* frow = feat + (size_t)ray * S;
+  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    float fk4[4], z04[4], z14[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = ((c0 + u) << 6) + lane, kc = min(k, S - 1);
+      fk4[u] = frow[kc]; z04[u] = z[kc]; z14[u] = z[min(k + 1, S - 1)];
     }
-    if (k == S - 1) alpha = 1.0f;
-    s_alpha[k] = alpha;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = ((c0 + u) << 6) + lane;
+      if (k < S) {
+        float alpha = 0.0f;
+        if (k < S - 1 && fk4[u] > -INFINITY) {
+          const float sigma = feature2density(fk4[u], f.density_shift, relu);
+          alpha = 1.0f - expf(-sigma * (z14[u] - z04[u]) * f.distance_scale);
+        }
+        if (k == S - 1) alpha = 1.0f;
+        s_alpha[k] = alpha;
+      }
+    }
   }
   // weights and d(loss)/d(w_k);  total = sum_k gw_k w_k
   float carry = 1.0f, tot = 0.0f, dsum = 0.0f;
-  for (int c = 0; c < nchunk; ++c) {
-    const int k = (c << 6) + lane;
-    const float alpha = k < S ? s_alpha[k] : 0.0f;
-    const float v = k < S ? (1.0f - alpha + 1e-10f) : 1.0f;
-    float excl, total;
-    wave_scan_prod(v, lane, excl, total);
-    const float T = carry * excl;
-    carry *= total;
-    const float w = alpha * T;
-    if (k < S) {
-      float gw = gd * z[k] / dn - gsum;
-      const int j = s_idx[k];
+  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    float zk4[4], col4[4];                                     // z and g_rgb . colour of four chunks' samples, requested together
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = ((c0 + u) << 6) + lane;
+      zk4[u] = z[min(k, S - 1)];
+      col4[u] = 0.0f;
+      const int j = k < S ? (int)s_idx[k] : -1;
       if (j >= 0) {
         const float* cp = crgb + ((size_t)ray * S + j) * 3;
-        gw += gr[0] * cp[0] + gr[1] * cp[1] + gr[2] * cp[2];
+        col4[u] = gr[0] * cp[0] + gr[1] * cp[1] + gr[2] * cp[2];
       }
-      s_w[k] = w;
-      s_gw[k] = gw;
-      tot += gw * w;
-      dsum += w * z[k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u;
+      if (c >= nchunk) break;
+      const int k = (c << 6) + lane;
+      const float alpha = k < S ? s_alpha[k] : 0.0f;
+      const float v = k < S ? (1.0f - alpha + 1e-10f) : 1.0f;
+      float excl, total;
+      wave_scan_prod(v, lane, excl, total);
+      const float T = carry * excl;
+      carry *= total;
+      const float w = alpha * T;
+      if (k < S) {
+        const float gw = (gd * zk4[u] / dn - gsum) + col4[u];
+        s_w[k] = w;
+        s_gw[k] = gw;
+        tot += gw * w;
+        dsum += w * zk4[u];
+      }
     }
   }
   tot = wave_sum(tot);
@@ -588,7 +614,17 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
   float go3[3] = {0.0f, 0.0f, 0.0f}, gdh[3] = {0.0f, 0.0f, 0.0f};
   float run = 0.0f;
   carry = 1.0f;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    float fk4[4], z04[4], z14[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = ((c0 + u) << 6) + lane, kc = min(k, S - 1);
+      fk4[u] = frow[kc]; z04[u] = z[kc]; z14[u] = z[min(k + 1, S - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+    const int c = c0 + u;
+    if (c >= nchunk) break;
     const int k = (c << 6) + lane;
     const float alpha = k < S ? s_alpha[k] : 0.0f;
     const float vk = k < S ? (1.0f - alpha + 1e-10f) : 1.0f;
@@ -606,19 +642,20 @@ __global__ __launch_bounds__(256) void k_bwd_ray(
     const float chunk_total = __shfl(incl, 63, 64);
     float gf = 0.0f;
     if (k < S - 1) {
-      const float fk = feat[(size_t)ray * S + k];
+      const float fk = fk4[u];
       if (fk > -INFINITY) {
         const float suffix = tot - (run + incl);
         const float dalpha = s_gw[k] * Tk - suffix / vk;
         const float y = fk + f.density_shift;
         const float dsig_df = relu ? (fk > 0.0f ? 1.0f : 0.0f) : (y > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-y)));
-        gf = dalpha * (z[k + 1] - z[k]) * f.distance_scale * (1.0f - alpha) * dsig_df;
+        gf = dalpha * (z14[u] - z04[u]) * f.distance_scale * (1.0f - alpha) * dsig_df;
       }
     }
     run += chunk_total;
     if (k < S) {
       s_alpha[k] = gf;                     // alpha of sample k is not needed any more
       feat[(size_t)ray * S + k] = gf;      // consumed by the binned scatter kernels
+    }
     }
   }
   // density scatter (tile ids for the binned scatter kernel) + position gradient
