@@ -908,6 +908,17 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
   }
 }
 
+// Histogram + cursors + max|contribution| word of both counting sorts, cleared by ONE launch on the caller's stream in front
+// of the fork.  NOT hipMemsetAsync: the runtime's fill reads its pattern from a staging ring that a host running several
+// iterations ahead of the device can wrap -- profiles/r18_memset_fault.md: in the progressive loop the density histogram came
+// back filled with a stale 16-byte pattern instead of zeros (once, at the first capture behind a lifecycle event), the fill
+// pass then indexed the entry list 4 GB out of bounds: "Memory access fault by GPU node".
+constexpr int BIN_CLEAR_WORDS = 2 * BIN_MAX + 8;
+__global__ __launch_bounds__(256) void k_clear_bins(int* __restrict__ h0, int* __restrict__ h1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < BIN_CLEAR_WORDS) { h0[i] = 0; h1[i] = 0; }
+}
+
 // Plane gradients.  The entry lists are sorted by tile; workgroup w owns the w-th equal share
 // of the concatenated list (a few tiles hold 12 % of all samples each, so one workgroup per
 // tile is badly unbalanced), accumulates tile by tile in LDS and flushes each tile once.
@@ -1542,7 +1553,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.nmax = (uint32_t)rows;                                     // rows >= R*S
   b.rowinfo = reinterpret_cast<uint32_t*>(take(rows));
   b.tid = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
-  b.hist = reinterpret_cast<int*>(take(2 * BIN_MAX + 8));       // histogram, then the fill pass's cursors, then max|contribution| (k_bwd_ray): cleared by one memset
+  b.hist = reinterpret_cast<int*>(take(BIN_CLEAR_WORDS));       // histogram, then the fill pass's cursors, then max|contribution| (k_bwd_ray): cleared by k_clear_bins
   b.cursor = b.hist + BIN_MAX;
   b.offs = reinterpret_cast<int*>(take(2 * (BIN_MAX + 1)));     // entry offsets | cost offsets (k_bin_fill)
   b.list = reinterpret_cast<uint32_t*>(take(3 * rows));
@@ -1550,7 +1561,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
   b.tileinfo = reinterpret_cast<int4*>(take(rows / 16 * 4));
   b.toff32 = reinterpret_cast<int*>(take((size_t)R + 1));
   b.tid2 = reinterpret_cast<uint16_t*>(take((3 * rows + 1) / 2 + 2));
-  b.hist2 = reinterpret_cast<int*>(take(2 * BIN_MAX + 8));      // (+ max|contribution| of the appearance scatter, k_train_app3)
+  b.hist2 = reinterpret_cast<int*>(take(BIN_CLEAR_WORDS));      // (+ max|contribution| of the appearance scatter, k_train_app3)
   b.cursor2 = b.hist2 + BIN_MAX;
   b.offs2 = reinterpret_cast<int*>(take(2 * (BIN_MAX + 1)));
   b.list2 = reinterpret_cast<uint32_t*>(take(3 * rows));
@@ -1706,7 +1717,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // gradients it produces are added to d/d(rays) afterwards by k_rays_add_rpart), so the texture / LDS-atomic bound
   // per-ray work runs under the row-traffic bound colour-network backward instead of behind it.
   SideStream* sx = side_stream();                          // also holds the bucket events of lrf_render_bwd_wait
-  SideStream* ss = g_bwd_overlap ? sx : nullptr;
+  // Under stream capture the two branches go on ONE stream: ROCm runs the branches of a graph one after the other anyway
+  // (DESIGN.md s4e), and every cross-stream edge of the captured fork / join costs ~10 us of idle time in the replay (four of
+  // them per backward: profiles/r18_graph_iteration_timeline.md).
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap_status);
+  const bool capturing = cap_status == hipStreamCaptureStatusActive;
+  SideStream* ss = (g_bwd_overlap && !capturing) ? sx : nullptr;
   // the side stream and its fork / join events are per device: host threads that enqueue backward passes on the same
   // device take turns (enqueueing is ~0.3 ms of host time; the kernels themselves still overlap on the GPU)
   std::unique_lock<std::mutex> side_lock;
@@ -1718,6 +1735,7 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     dst_d.plane[q] = g->density_plane[q]; dst_d.line[q] = g->density_line[q];
     dst_a.plane[q] = g->app_plane[q]; dst_a.line[q] = g->app_line[q];
   }
+  hipLaunchKernelGGL(k_clear_bins, dim3((BIN_CLEAR_WORDS + 255) / 256), dim3(256), 0, st, b.hist, b.hist2);     // (in front of the fork: both branches count into these)
   hipStream_t sb = st;
   if (ss) {
     LRF_HIP(hipEventRecord(ss->fork, st));
@@ -1757,7 +1775,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // compare-and-swap kernel at 400^3-460^3 (profiles/r17_fixed_point_scatter.md); above that the compare-and-swap kernel stays
   const size_t lds_fa = 2 * lds_dp + sizeof(unsigned long long) * LRF_CA * ll_max;
   const bool fix_a = fix_d && (g_scatter_fix & 2) && lds_fa <= 158 * 1024;
-  LRF_HIP(hipMemsetAsync(b.hist2, 0, sizeof(int) * (2 * BIN_MAX + 8), st));
   unsigned* vmax_a = reinterpret_cast<unsigned*>(b.hist2 + 2 * BIN_MAX);
   if (fix_a)
     hipLaunchKernelGGL((k_train_app3<8, true>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
@@ -1769,7 +1786,6 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                        b.grd, b.rpart, w.pmax, b.wpart, bg, b.tid2, b.hist2, b.nmax, g_dgrad_dbg & 3, vmax_a);
 
   // ---- side stream: per-ray backward, density scatter
-  LRF_HIP(hipMemsetAsync(b.hist, 0, sizeof(int) * (2 * BIN_MAX + 8), sb));
   unsigned* vmax_d = reinterpret_cast<unsigned*>(b.hist + 2 * BIN_MAX);
   hipLaunchKernelGGL(k_bwd_ray, dim3((R + 3) / 4), dim3(256), (size_t)14 * S * sizeof(float) + (size_t)bg.total * sizeof(int), sb,
                      d, rays, z, R, S, flags, b.feat, w.ncomp, w.cidx, b.crgb, g_rgb, g_depth,

@@ -320,3 +320,17 @@ def test_untaped_chunk_honours_the_caller_beyond_the_workspace_bound(built_lib):
     assert s._untaped_chunk(4096, [F(2214)]) == 4096            # the caller's chunk, exactly
     s.min_chunk = 1
     assert s._untaped_chunk(4096, [F(2214)]) == 4096
+
+
+def test_no_runtime_fill_or_copy_in_the_library_sources():
+    """profiles/r18_memset_fault.md: a hipMemsetAsync in the backward filled the counting sort's histogram with a stale
+    pattern when the host ran iterations ahead of the device (memory access fault in the captured progressive loop).  The
+    library clears and moves its buffers with its own kernels; nothing in csrc may call the runtime's fill / copy."""
+    src_dir = os.path.join(ROOT, "localrf_amd", "csrc")
+    bad = []
+    for name in sorted(os.listdir(src_dir)):
+        if not name.endswith((".hip", ".inl", ".h")):
+            continue
+        text = re.sub(r"//[^\n]*", "", open(os.path.join(src_dir, name)).read())
+        bad += [(name, m.group(0)) for m in re.finditer(r"\bhipMem(set\w*|cpy\w*Async)\s*\(", text)]   # (a blocking debug read-back is fine)
+    assert not bad, bad
