@@ -270,34 +270,62 @@ __device__ __forceinline__ float relu_gate(float x, uint32_t bits, int k) {
 // Rows behind the chunk's end read tile r0 again; their go and mask bits are zeroed in LDS, so they contribute nothing.
 // (Measured and dropped: 64-row steps double-buffered in LDS, four alternating waves staging step i + 1 while all eight
 // multiply step i, one barrier per step -- 228 us against 200 us: twice the barriers, and the staging waves hold the others up.)
-constexpr int W23_KT = 128, W23_CS = W23_KT + 8, W23_NT = 9;
-constexpr size_t W23_LDS = (size_t)(8 * 128) * 16 + 128 * 4 + 2 * (size_t)(W23_NT * 16) * W23_CS * 2 + (size_t)6 * W23_KT * 2
-                         + (size_t)LRF_FEATC * (W23_KT / 32) * 4;
+// KT rows per step.  128: the form above -- 27 accumulator tiles + operands are ~240 registers, two waves per SIMD is all the
+// register file holds, and all eight wait at both barriers of a step while nobody multiplies (the matrix pipe is busy 53 % of
+// the kernel, profiles/r18_pmc_train.md).  64: the step's operands are DOUBLE-BUFFERED in LDS (2 x 43.6 KB) and every wave
+// stages its share of step i + 1 itself -- a 16-row tile's layer 1 is split over two waves, four unit tiles each -- but waves
+// 0-3 stage first and multiply second while waves 4-7 (the other wave of each SIMD) multiply first and stage second: one
+// barrier per step, and on every SIMD one wave's VALU / LDS staging runs under the other's MFMAs.
+// (Measured and dropped, round 6: four-wave workgroups owning half of the units each, two per CU, single-buffered 64-row
+// steps -- the rows staged twice per CU: forward + backward 1.19 -> 1.30 ms.)
+constexpr int W23_NT = 9;
+__host__ __device__ constexpr size_t w23_lds(int KT) {
+  return (size_t)(8 * 128) * 16 + 128 * 4
+       + (KT == 64 ? 2 : 1) * (2 * (size_t)(W23_NT * 16) * (KT + 8) * 2 + (size_t)6 * KT * 2 + (size_t)LRF_FEATC * (KT / 32) * 4);
+}
+template <int KT>
 __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ mlpb, const float* __restrict__ feat /* act + 16 * ACT_FEAT */, int lda,
                                                     const float* __restrict__ go /* grd + 16 * GRD_GO */, int ldg,
                                                     const uint32_t* __restrict__ relu_bits, const float* __restrict__ w3 /* [3][131] */,
                                                     const float* __restrict__ w2 /* [128][128] */, const float* __restrict__ b2,
                                                     const int* __restrict__ toff, int R, float* __restrict__ wpart) {
-  constexpr int KT = W23_KT, NT = W23_NT, WB = NT * 16, CS = W23_CS;
+  constexpr int NT = W23_NT, WB = NT * 16, CS = KT + 8;
+  constexpr bool DB = KT == 64;                                   // double-buffered step operands
+  constexpr int TPS = KT / 16, WPT = 8 / TPS, MT1 = 8 / WPT;     // tiles per step, waves per tile, layer-1 unit tiles per wave
+  constexpr int WPG = KT / 64;                                    // waves per lane group of mask dwords
+  constexpr int BUF_BYTES = 2 * WB * CS * 2 + 6 * KT * 2 + LRF_FEATC * (KT / 32) * 4;
   extern __shared__ uint4 s_w23[];
   uint4* s_w1 = s_w23;                                              // W1 fragments [t' 8][hi, lo][lane 64]
   float* s_b1 = reinterpret_cast<float*>(s_w1 + 8 * 128);
-  __bf16* s_bh = reinterpret_cast<__bf16*>(s_b1 + 128);            // [144 columns][CS rows]
+  char* s_buf0 = reinterpret_cast<char*>(s_b1 + 128);
+  __bf16* s_bh = reinterpret_cast<__bf16*>(s_buf0);                // [144 columns][CS rows]
   __bf16* s_bl = s_bh + WB * CS;
   __bf16* s_ga = s_bl + WB * CS;                                    // [colour 3][hi, lo][KT rows]: go, pre-split
   uint32_t* s_mt = reinterpret_cast<uint32_t*>(s_ga + 6 * KT);     // [unit 128][KT / 32]: bit (row % 32) of dword row / 32 = m2[row][unit]
+  auto use_buf = [&](int b) {                                       // (DB) point the four arrays at buffer b
+    s_bh = reinterpret_cast<__bf16*>(s_buf0 + (size_t)b * BUF_BYTES);
+    s_bl = s_bh + WB * CS;
+    s_ga = s_bl + WB * CS;
+    s_mt = reinterpret_cast<uint32_t*>(s_ga + 6 * KT);
+  };
   const int rows = toff[R] * 16;
   const int WGRAD_CH = wgrad_chunk_rows(rows);
-  const int r0 = blockIdx.x * WGRAD_CH;
+  const int chunk = (int)blockIdx.x;
+  const int r0 = chunk * WGRAD_CH;
   if (r0 >= rows) return;
   const int r1 = min(r0 + WGRAD_CH, rows);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int mt = wave;                                              // this wave's M-tile: units 16 mt .. 16 mt + 15
   for (int q = tid; q < 8 * 128; q += 512) s_w1[q] = mlpb[IMGB_W1 + q];
   if (tid < 128) s_b1[tid] = reinterpret_cast<const float*>(mlpb + IMGB_TAIL)[TAIL_B1 + tid];
-  for (int q = tid; q < 16 * CS; q += 512) {                        // the bias block of B: column 128 = 1, 129 .. 143 = 0
-    s_bh[128 * CS + q] = (__bf16)(q < CS ? 1.0f : 0.0f);
-    s_bl[128 * CS + q] = (__bf16)0.0f;
+  for (int b = 0; b < (DB ? 2 : 1); ++b) {
+    use_buf(b);
+    for (int q = tid; q < 16 * CS; q += 512) {                      // the bias block of B: column 128 = 1, 129 .. 143 = 0
+      s_bh[128 * CS + q] = (__bf16)(q < CS ? 1.0f : 0.0f);
+      s_bl[128 * CS + q] = (__bf16)0.0f;
+    }
   }
+  use_buf(0);
   f32x4 acc[3][NT];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -312,41 +340,42 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
   Pre pre;
   auto fetch = [&](Pre& p, int rb) {
     {                                                      // feat of this wave's tile, as the forward's D registers: blocks 0, 1 of the row
-      int tile = (rb >> 4) + wave;
+      int tile = (rb >> 4) + (wave % TPS);
       if (tile * 16 >= r1) tile = r0 >> 4;
       const float* fp = feat + (size_t)tile * (size_t)(16 * lda) + (lane << 2);
       p.f0 = row_load4(fp);
       p.f1 = row_load4(fp + 256);
     }
-    {                                                      // go / (dhat, 1) of row rb + tid % 128: lane groups 0 and 1 of the go block
+    {                                                      // go / (dhat, 1) of row rb + tid % KT: lane groups 0 and 1 of the go block (KT = 64: waves 4-7 repeat 0-3's, branch-free)
       const int row = rb + (tid & (KT - 1));
       const int rowc = row < r1 ? row : r0;
       const float* gp = go + (size_t)(rowc >> 4) * (size_t)(16 * ldg) + ((rowc & 15) << 2);
       p.go = *reinterpret_cast<const float4*>(gp);
       p.dh = *reinterpret_cast<const float4*>(gp + 64);
       // layer-2 mask dword (row, lane group gg = tid / 128): tile row / 16, lane (row % 16) + 16 gg
-      p.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * (tid >> 7)];
+      p.m = relu_bits[((size_t)(rowc >> 4) * 2 + 1) * 64 + (rowc & 15) + 16 * ((tid / KT) & 3)];
     }
   };
   auto stage = [&](const Pre& p, int rb) {
-    __syncthreads();                                       // previous step's products have read LDS
+    if (!DB) __syncthreads();                              // previous step's products have read LDS
     // ---- layer 1 of the forward on this wave's 16 rows (the 16-sample fragments of the exact-order engines; k_shade3 sums the same products in another order: relu(h1) differs from the forward's in the last bit at most)
-    f32x4 h1[8];
+    const int tl = wave % TPS, mb = (wave / TPS) * MT1;      // this wave's tile of the step, its first unit tile
+    f32x4 h1[MT1];
 #pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&s_b1[16 * t1 + 4 * g]);
+    for (int t1 = 0; t1 < MT1; ++t1) h1[t1] = *reinterpret_cast<const f32x4*>(&s_b1[16 * (mb + t1) + 4 * g]);
     {
       const float v[8] = {p.f0.x, p.f0.y, p.f0.z, p.f0.w, p.f1.x, p.f1.y, p.f1.z, p.f1.w};
       bf16x8 bh, bl;
       split8(v, bh, bl);
-      gemm_step<8>(s_w1, 0, 1, lane, bh, bl, h1);
+      gemm_step<MT1>(s_w1, mb, 1, lane, bh, bl, h1);
     }
 #pragma unroll
-    for (int t1 = 0; t1 < 8; ++t1)
+    for (int t1 = 0; t1 < MT1; ++t1)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = fmaxf(h1[t1][r], 0.0f);
         const __bf16 h = (__bf16)v;
-        const int at = (16 * t1 + 4 * g + r) * CS + 16 * wave + i;
+        const int at = (16 * (mb + t1) + 4 * g + r) * CS + 16 * tl + i;
         s_bh[at] = h;
         s_bl[at] = (__bf16)(v - (float)h);
       }
@@ -363,9 +392,9 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
         for (int a = 0; a < 4; ++a) xv[c][a] += gv[c] * dv[a];
       }
     }
-    {                                                      // mask bits, transposed: wave w holds lane group gg = w / 2 of rows 64 (w % 2) + lane
+    if (wave < 4 * WPG) {                                  // mask bits, transposed: wave w holds lane group gg = w / WPG of rows 64 (w % WPG) + lane
       const uint32_t m = ok ? p.m : 0u;
-      const int gg = wave >> 1, half = wave & 1;
+      const int gg = wave / WPG, half = wave % WPG;
 #pragma unroll
       for (int b = 0; b < 32; ++b) {                       // bit b = unit 16 (b / 4) + 4 gg + b % 4
         const unsigned long long bal = __ballot((m >> b) & 1u);
@@ -375,10 +404,10 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
         }
       }
     }
-    __syncthreads();
+    if (!DB) __syncthreads();
   };
   auto compute = [&]() {
-#pragma unroll 1
+#pragma unroll (DB ? 2 : 1)
     for (int kk = 0; kk < KT / 32; ++kk) {
       uint4 ar[3][2];
 #pragma unroll
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
         ar[c][1] = *reinterpret_cast<const uint4*>(&s_ga[(2 * c + 1) * KT + 32 * kk + 8 * g]);
       }
       // rows 32 kk + 8 g + j, j = 0 .. 7: bit j of this byte says whether unit 16 wave + i was active in row j
-      const uint32_t byte = (s_mt[(16 * wave + i) * (KT / 32) + kk] >> (8 * g)) & 0xffu;
+      const uint32_t byte = (s_mt[(16 * mt + i) * (KT / 32) + kk] >> (8 * g)) & 0xffu;
       uint32_t pm[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {                        // K slots 2 q, 2 q + 1 share a dword of the operand
@@ -426,17 +455,37 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
     }
   };
   fetch(pre, r0);
-  for (int rb = r0; rb < r1; rb += KT) {
-    stage(pre, rb);
-    fetch(pre, rb + KT);
-    compute();
+  if constexpr (!DB) {
+    for (int rb = r0; rb < r1; rb += KT) {
+      stage(pre, rb);
+      fetch(pre, rb + KT);
+      compute();
+    }
+  } else {
+    __syncthreads();                                       // the W1 fragments and b1 are in LDS
+    stage(pre, r0);                                        // step 0 into buffer 0
+    fetch(pre, r0 + KT);
+    __syncthreads();
+    int cur = 0;
+    for (int rb = r0; rb < r1; rb += KT, cur ^= 1) {
+      const bool more = rb + KT < r1;
+      if (wave < 4) {                                      // stage step i + 1, then multiply step i ...
+        if (more) { use_buf(cur ^ 1); stage(pre, rb + KT); fetch(pre, rb + 2 * KT); }
+        use_buf(cur); compute();
+      } else {                                             // ... while the SIMD's other wave does it the other way round
+        use_buf(cur); compute();
+        if (more) { use_buf(cur ^ 1); stage(pre, rb + KT); fetch(pre, rb + 2 * KT); }
+      }
+      __syncthreads();
+    }
+    use_buf(0);
   }
   // ---- epilogue, once per chunk: acc[c][n][r] = T_c[u = 16 wave + 4 g + r][v = 16 n + i]
-  float* o2 = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W2;
-  float* o3 = wpart + (size_t)blockIdx.x * WP_FLOATS + WP_W3;
+  float* o2 = wpart + (size_t)chunk * WP_FLOATS + WP_W2;
+  float* o3 = wpart + (size_t)chunk * WP_FLOATS + WP_W3;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int u = 16 * wave + 4 * g + r;
+    const int u = 16 * mt + 4 * g + r;
     const float w3r = w3[u], w3g = w3[131 + u], w3b = w3[262 + u];
     float d3[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -465,7 +514,7 @@ __global__ __launch_bounds__(512) void k_wgrad_w2w3(const uint4* __restrict__ ml
       }
   }
   __syncthreads();
-  if (tid < 12) o3[(tid >> 2) * 144 + LRF_FEATC + (tid & 3)] = s_x[tid] + s_x[12 + tid];
+  if (tid < 12) o3[(tid >> 2) * 144 + LRF_FEATC + (tid & 3)] = s_x[tid] + (KT > 64 ? s_x[12 + tid] : 0.0f);
 }
 
 // dst[m*dst_ld + n] += sum_chunks part[chunk][off + m*ld + n_off + n]   (chunks in a fixed order) for
@@ -1577,6 +1626,7 @@ static BwdWorkspace carve_bwd(void* ws, int R, int S, const int32_t grid[3], int
 static int g_dgrad_dbg = 0;         // lrf_debug_set_train_fwd_engine bits 32 / 64 / 128: k_train_dgrad3 + k_train_app3 without row stores / position gradient and X / dz1 products (timing only)
 static int g_scatter_fused = 1;     // lrf_debug_set_train_fwd_engine(8 | ...): separate plane / line scatter kernels (measurement)
 static int g_scatter_fix = 3;       // bit 0: density, bit 1: appearance (where its accumulators fit in LDS) through k_scatter_fix.  lrf_debug_set_train_fwd_engine(16 | ...): both through the compare-and-swap kernels of rounds 2-5 (the tests compare the two); 256: the density alone
+static int g_wgrad_kt = 64;          // rows per step of k_wgrad_w2w3 (lrf_debug_set_train_fwd_engine(512 | ...): 128, one workgroup per CU)
 static int g_wgrad_split = 1;       // lrf_debug_set_bwd_overlap(1 + 2 * (n + 1)): n > 0 = k_wgrad_w2w3 on the caller's stream, 0 = on the side stream
 static hipError_t launch_shade_save(DField d, const float* rays, const float* z, int S, int R, uint32_t flags, const Workspace& w,
                                     const BwdWorkspace& b, float* rgb, hipStream_t st) {
@@ -1595,7 +1645,7 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : 3); lrf::g_dgrad_dbg = (e >> 5) & 7; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : 3); lrf::g_dgrad_dbg = (e >> 5) & 7; lrf::g_wgrad_kt = (e & 512) ? 128 : 64; }
 
 namespace lrf {
 // floats per row of weight-gradient operands when the backward runs the generic engine (any non-default network, or
@@ -1697,8 +1747,10 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CA, true, FIX_NT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)W23_LDS);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3<128>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)w23_lds(128));
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3<64>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)w23_lds(64));
       lds_attr_err[dev_id & 63] = e;
     });
     LRF_HIP(lds_attr_err[dev_id & 63]);
@@ -1823,8 +1875,12 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     gemm(ro.dz2, gc.fc, ro.h1, gc.fc + 1, g->w2, gc.fc, g->b2);
     gemm(ro.go, 3, ro.h2v, gc.fc + gc.inv + 1, g->w3, gc.fc + gc.inv, g->b3);
   } else {
-    hipLaunchKernelGGL(k_wgrad_w2w3, dim3(nch_max), dim3(512), W23_LDS, w23_on_st ? st : sb, d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
-                       b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
+    if (g_wgrad_kt == 64)
+      hipLaunchKernelGGL(k_wgrad_w2w3<64>, dim3(nch_max), dim3(512), w23_lds(64), w23_on_st ? st : sb, d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
+                         b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
+    else
+      hipLaunchKernelGGL(k_wgrad_w2w3<128>, dim3(nch_max), dim3(512), w23_lds(128), w23_on_st ? st : sb, d.mlpb, b.act + 16 * ACT_FEAT, ACT_LD, b.grd + 16 * GRD_GO, GRD_LD,
+                         b.relu_bits, p->w3, p->w2, p->b2, w.toff, R, b.wpart);
   }
   if (ss) LRF_HIP(hipEventRecord(ss->app[1], st));          // the caller's-stream partials (dW1, dbasis[, dW2, dW3]) are complete behind this
   {

@@ -650,6 +650,33 @@ def test_gradient_scatter_engines_agree_and_meet_the_reference(built_lib, name):
         check_grads(dens, {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in dens}, 1e-4, subset=subset or None, gmax=gmax)
 
 
+@pytest.mark.parametrize("name", ["field_small_train_grad", "field_128_train_grad"])
+def test_weight_gradient_kernel_forms_agree(built_lib, name):
+    """k_wgrad_w2w3 in its double-buffered 64-row form (the default) and in the single-buffered 128-row form of rounds 4-5
+    (lrf_debug_set_train_fwd_engine(512 | ...)): the same three-term products summed in another order -- every network
+    gradient within 2e-6 of its tensor's maximum, and three runs of the default bit-identical among themselves (the partial
+    blocks are reduced in a fixed order: a race between a step's staging and its products would show here)."""
+    g = load_golden(name)
+    f = quiet(field_from_golden, g, DEV) if name == "field_small_train_grad" else field_from_seed(g, DEV)
+    ns = int(g["N_samples"]) if "N_samples" in g else int(g["nSamples"])
+    z = torch.from_numpy(oracle.z_schedule(ns, np.float32, jitter=(g["U"], g["U2"])))
+    gr, gd = torch.from_numpy(g["g_rgb"]).to(DEV), torch.from_numpy(g["g_depth"]).to(DEV)
+    runs = []
+    try:
+        for eng in (1, 1, 1, 513):
+            built_lib.lrf_debug_set_train_fwd_engine(eng)
+            _, _, grads, _ = _train_grads(f, g["rays"], z, gr, gd)
+            runs.append({n: v.clone() for n, v in grads.items() if "mlp" in n})
+    finally:
+        built_lib.lrf_debug_set_train_fwd_engine(1)
+    assert len(runs[0]) == 6, sorted(runs[0])
+    for n, v in runs[0].items():
+        if "mlp.0" not in n:                          # (layer 1's gradient comes from k_train_dgrad3's per-workgroup partials)
+            assert torch.equal(v, runs[1][n]) and torch.equal(v, runs[2][n]), n
+        den = float(runs[3][n].abs().max())
+        assert float((v - runs[3][n]).abs().max()) <= 2e-6 * den, (n, float((v - runs[3][n]).abs().max()) / den)
+
+
 @pytest.mark.parametrize("name,min_forced", [("field_500_train_grad", 10000), ("field_640_train_grad", 5000)])
 def test_backward_at_training_sizes_vs_reference_autograd_golden(built_lib, name, min_forced):
     """BASELINE configs[4]'s own sizes against the REFERENCE: 500^3 (512 rays) and the reference's default end size 640^3
