@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 6      /* 6: lrf_batch_gather, lrf_loss_combine_*, lrf_adam_step_pack; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 7      /* 7: lrf_density_l1_bwd_acc; 6: lrf_batch_gather, lrf_loss_combine_*, lrf_adam_step_pack; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
@@ -305,6 +305,12 @@ int lrf_density_l1_fwd(const float* const plane[3], const float* const line[3], 
 int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
                        const int32_t ll[3], const void* workspace, const float* g_out /* device [1] */,
                        float* const g_plane[3], float* const g_line[3], void* stream);
+/* The same, ADDED to what g_plane / g_line hold (every element has one writer; stream order behind whoever filled them): the
+ * regulariser's gradient lands in the buffers lrf_render_bwd scattered into -- one autograd node for render + regulariser,
+ * no gradient-accumulation passes over the six density tensors between them (TensorVMSplit.fuse_density_L1). */
+int lrf_density_l1_bwd_acc(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                           const int32_t ll[3], const void* workspace, const float* g_out /* device [1] */,
+                           float* const g_plane[3], float* const g_line[3], void* stream);
 
 /* Pose assembly: LocalTensorfs.get_cam2world (local_tensorfs.py:292-299) with sixD_to_mtx
  * (utils/utils.py:381-388): per frame a 6D rotation [3,2] (Gram-Schmidt -> columns b1, b2, b1 x b2)

@@ -128,6 +128,8 @@ SYMBOLS = {
                                      C.c_float, C.c_int32, C.c_void_p, _f, C.c_void_p]),
     "lrf_density_l1_bwd": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.c_void_p, _f, C.POINTER(_f), C.POINTER(_f), C.c_void_p]),
+    "lrf_density_l1_bwd_acc": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.c_void_p, _f, C.POINTER(_f), C.POINTER(_f), C.c_void_p]),
     "lrf_pose_assemble": (C.c_int, [C.POINTER(_f), C.POINTER(_f), C.c_int32, C.c_int32, _f, C.c_void_p]),
     "lrf_pose_assemble_bwd": (C.c_int, [C.POINTER(_f), C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
     "lrf_dense_alpha": (C.c_int, [C.POINTER(LrfField), _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_float,
@@ -173,7 +175,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if h.lrf_abi_version() != 6:
+        if h.lrf_abi_version() != 7:
             raise NativeError("localrf_amd: ABI version mismatch")
         _lib = h
     return _lib

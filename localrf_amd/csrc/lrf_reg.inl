@@ -86,8 +86,9 @@ __device__ __forceinline__ int l1_plane_of(const int first[4], int& blk) {
 struct L1Out { float* plane[3]; float* line[3]; };
 
 // g_plane_p[c, q] = scale * sum_r dfeat[q L + r] line_p[c, r]: one wavefront per texel q
+// (acc: add to what `out` holds -- lrf_density_l1_bwd_acc, every element has one writer -- instead of storing)
 __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_plane(L1Geo G, L1Blk B, const float* __restrict__ dfeat,
-                                                         const float* __restrict__ g_out, L1Out out) {
+                                                         const float* __restrict__ g_out, L1Out out, int acc_out) {
   int blk;
   const int p = l1_plane_of(B.first, blk);
   const int lane = threadIdx.x & 63;
@@ -106,7 +107,10 @@ __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_plane(L1Geo G, L1Blk B, const
 #pragma unroll
   for (int c = 0; c < LRF_CD; ++c) {
     const float s = wave_sum(acc[c]);
-    if (lane == 0) out.plane[p][(size_t)c * G.hw[p] + q] = s * scale;
+    if (lane == 0) {
+      float* o = out.plane[p] + (size_t)c * G.hw[p] + q;
+      *o = acc_out ? *o + s * scale : s * scale;
+    }
   }
 }
 
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line(L1Geo G, L1Blk B, const 
 // output walking all ~512 chunks: 119 us at 64^3, where the whole launch has 512 outputs.)
 constexpr int L1_RED_OUT = 16, L1_RED_GRP = L1_TPB / L1_RED_OUT;
 __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line_reduce(L1Geo G, L1Blk B, const float* __restrict__ lpart,
-                                                               const float* __restrict__ g_out, L1Out out) {
+                                                               const float* __restrict__ g_out, L1Out out, int acc_out) {
   __shared__ float s_part[L1_RED_GRP][L1_RED_OUT];
   int blk;
   const int p = l1_plane_of(B.first, blk);
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(L1_TPB) void k_l1_bwd_line_reduce(L1Geo G, L1Blk B,
     float t = 0.0f;
 #pragma unroll
     for (int q = 0; q < L1_RED_GRP; ++q) t += s_part[q][o];
-    out.line[p][i] = t * (g_out[0] / (float)G.n);
+    const float r = t * (g_out[0] / (float)G.n);
+    out.line[p][i] = acc_out ? out.line[p][i] + r : r;
   }
 }
 
@@ -207,9 +212,9 @@ extern "C" int lrf_density_l1_fwd(const float* const plane[3], const float* cons
   return 0;
 }
 
-extern "C" int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
-                                  const int32_t ll[3], const void* workspace, const float* g_out,
-                                  float* const g_plane[3], float* const g_line[3], void* stream) {
+static int density_l1_bwd_impl(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                               const int32_t ll[3], const void* workspace, const float* g_out,
+                               float* const g_plane[3], float* const g_line[3], void* stream, int acc_out) {
   using namespace lrf;
   L1Geo G;
   if (!plane || !line || !hw || !ll || !workspace || !g_out || !g_plane || !g_line || l1_geo(plane, line, hw, ll, G))
@@ -233,11 +238,21 @@ extern "C" int lrf_density_l1_bwd(const float* const plane[3], const float* cons
     Bp.lpart_off[p] = Bl.lpart_off[p] = Br.lpart_off[p] = off;
     off += (size_t)nchunk * LRF_CD * (size_t)G.ll[p];
   }
-  hipLaunchKernelGGL(k_l1_bwd_plane, dim3(Bp.first[3]), dim3(L1_TPB), 0, st, G, Bp, dfeat, g_out, out);
+  hipLaunchKernelGGL(k_l1_bwd_plane, dim3(Bp.first[3]), dim3(L1_TPB), 0, st, G, Bp, dfeat, g_out, out, acc_out);
   hipLaunchKernelGGL(k_l1_bwd_line, dim3(Bl.first[3]), dim3(L1_TPB), 0, st, G, Bl, dfeat, lpart);
-  hipLaunchKernelGGL(k_l1_bwd_line_reduce, dim3(Br.first[3]), dim3(L1_TPB), 0, st, G, Br, lpart, g_out, out);
+  hipLaunchKernelGGL(k_l1_bwd_line_reduce, dim3(Br.first[3]), dim3(L1_TPB), 0, st, G, Br, lpart, g_out, out, acc_out);
   LRF_HIP(hipGetLastError());
   return 0;
+}
+extern "C" int lrf_density_l1_bwd(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                                  const int32_t ll[3], const void* workspace, const float* g_out,
+                                  float* const g_plane[3], float* const g_line[3], void* stream) {
+  return density_l1_bwd_impl(plane, line, hw, ll, workspace, g_out, g_plane, g_line, stream, 0);
+}
+extern "C" int lrf_density_l1_bwd_acc(const float* const plane[3], const float* const line[3], const int32_t hw[3],
+                                      const int32_t ll[3], const void* workspace, const float* g_out,
+                                      float* const g_plane[3], float* const g_line[3], void* stream) {
+  return density_l1_bwd_impl(plane, line, hw, ll, workspace, g_out, g_plane, g_line, stream, 1);
 }
 
 // ---------------------------------------------------------------------------------------------

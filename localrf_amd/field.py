@@ -87,12 +87,27 @@ class _RenderFn(torch.autograd.Function):
             ctx.ws, ctx.versions = None, field._param_versions()
         ctx.field, ctx.flags = field, flags
         ctx.save_for_backward(rays, z)
-        return rgb, depth
+        # TensorVMSplit.fuse_density_L1: the regulariser's value is a third output of THIS node, so that its gradient is added
+        # by this node's backward into the buffers the render gradient was scattered into (lrf_density_l1_bwd_acc) -- with a
+        # node of its own autograd sums the two contributions to each of the six density tensors in six more passes, and
+        # .grad ends up outside the flat gradient buffer (rebucket_grads)
+        ctx.l1 = None
+        l1 = None
+        if getattr(field, "fuse_density_L1", False):
+            ctx.set_materialize_grads(False)
+            dens = tuple(p.detach() for p in params[:6])
+            l1, l1_ws = _DensityL1Fn.run_forward(field, dens)
+            ctx.l1 = (l1_ws, dens)
+        return rgb, depth, l1
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth):
+    def backward(ctx, g_rgb, g_depth, g_l1=None):
         rays, z = ctx.saved_tensors
         ws = ctx.ws
+        if g_rgb is None or g_depth is None:                 # (fuse_density_L1: gradients are not materialised)
+            R = rays.shape[0]
+            g_rgb = torch.zeros(R, 3, device=rays.device) if g_rgb is None else g_rgb
+            g_depth = torch.zeros(R, device=rays.device) if g_depth is None else g_depth
         if ctx.versions is not None and ctx.versions != ctx.field._param_versions():
             # the reference's autograd raises here too ("modified by an inplace operation"): the
             # gradients of the recorded forward cannot be formed from updated parameters
@@ -101,6 +116,9 @@ class _RenderFn(torch.autograd.Function):
                 "between forward and backward of the same render graph")
         g_rays, g_params = ctx.field._native_backward(rays, z, ctx.flags, g_rgb, g_depth, saved_ws=ws)
         ctx.ws = None                            # a second backward through this graph recomputes
+        if ctx.l1 is not None and g_l1 is not None:          # the regulariser's gradient on top (same stream: behind the scatters)
+            l1_ws, dens = ctx.l1
+            _DensityL1Fn.run_backward(l1_ws, dens, g_l1, g_params[:6], accumulate=True)
         return (None, g_rays, None, None, None) + tuple(g_params)
 
 
@@ -120,9 +138,9 @@ class _DensityL1Fn(torch.autograd.Function):
         return pp, lp, hw, ll
 
     @staticmethod
-    def forward(ctx, field, *tensors):
+    def run_forward(field, tensors):
+        """(value [] , workspace) of the six detached density tensors."""
         lib = N.lib()
-        tensors = tuple(t.detach() for t in tensors)
         pp, lp, hw, ll = _DensityL1Fn._args(tensors)
         dev = tensors[0].device
         ws = torch.empty(lib.lrf_density_l1_workspace(hw, ll), dtype=torch.uint8, device=dev)
@@ -131,19 +149,31 @@ class _DensityL1Fn(torch.autograd.Function):
         N.check(lib.lrf_density_l1_fwd(pp, lp, hw, ll, float(field.density_shift),
                                        1 if field.fea2denseAct == "relu" else 0, ws.data_ptr(), N.ptr(out), st),
                 "lrf_density_l1_fwd")
-        ctx.save_for_backward(ws, *tensors)
-        return out[0]
+        return out[0], ws
 
     @staticmethod
-    def backward(ctx, g_out):
-        ws, *tensors = ctx.saved_tensors
+    def run_backward(ws, tensors, g_out, grads, accumulate=False):
+        """d value / d tensors times g_out into `grads` (stored, or added to what they hold)."""
         pp, lp, hw, ll = _DensityL1Fn._args(tensors)
-        grads = [torch.empty_like(t) for t in tensors]
         gp = (C.c_void_p * 3)(*[g.data_ptr() for g in grads[:3]])
         gl = (C.c_void_p * 3)(*[g.data_ptr() for g in grads[3:]])
         g = g_out.detach().reshape(1).contiguous().float()
         st = torch.cuda.current_stream(g.device).cuda_stream
-        N.check(N.lib().lrf_density_l1_bwd(pp, lp, hw, ll, ws.data_ptr(), N.ptr(g), gp, gl, st), "lrf_density_l1_bwd")
+        fn = N.lib().lrf_density_l1_bwd_acc if accumulate else N.lib().lrf_density_l1_bwd
+        N.check(fn(pp, lp, hw, ll, ws.data_ptr(), N.ptr(g), gp, gl, st), "lrf_density_l1_bwd")
+
+    @staticmethod
+    def forward(ctx, field, *tensors):
+        tensors = tuple(t.detach() for t in tensors)
+        out, ws = _DensityL1Fn.run_forward(field, tensors)
+        ctx.save_for_backward(ws, *tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ws, *tensors = ctx.saved_tensors
+        grads = [torch.empty_like(t) for t in tensors]
+        _DensityL1Fn.run_backward(ws, tensors, g_out, grads)
         return (None, *grads)
 
 
@@ -845,7 +875,9 @@ class TensorVMSplit(torch.nn.Module):
                 raise N.NativeError("floater_thresh > 0 is an eval-only filter (train.py:107,139)")
             if out is not None:
                 raise ValueError("out= is only valid when no gradient is recorded")
-            return _RenderFn.apply(self, rays_chunk, z, flags, 0.0, *self._param_list())
+            rgb, depth, l1 = _RenderFn.apply(self, rays_chunk, z, flags, 0.0, *self._param_list())
+            self._fused_l1 = None if l1 is None else (l1, self._param_versions())
+            return rgb, depth
         return self._native_forward(rays_chunk, z, flags, float(floater_thresh), out=out)
 
     def render_weights(self, rays_chunk, N_samples=-1, floater_thresh=0, white_bg=True):
@@ -876,6 +908,11 @@ class TensorVMSplit(torch.nn.Module):
         registers instead of materialising 8 x g^3 floats per plane (same arithmetic and the
         reference's per-plane flattening orders)."""
         self._require_gpu(self.density_plane[0])
+        fused = getattr(self, "_fused_l1", None)
+        if fused is not None:                    # fuse_density_L1: the value the last taped forward of this field computed,
+            self._fused_l1 = None                # once, and only for the parameters it was computed from
+            if fused[1] == self._param_versions() and torch.is_grad_enabled():
+                return fused[0]
         return _DensityL1Fn.apply(self, *self.density_plane, *self.density_line)
 
     def _tv_loss(self, reg, planes, lines):

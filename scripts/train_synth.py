@@ -177,7 +177,8 @@ def geometric_terms(lt, data, depth_map, directions, ij, cam2world_all, view_ids
 
 
 def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=4096, max_iters=None, seed=0,
-        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, live=None, lr_i_init=0):
+        dev="cuda:0", ddp=False, log=None, max_drift=0.25, n_max_frames=12, geo=True, geo_every=25, graph=False, record_all=False, live=None, lr_i_init=0,
+        fuse_l1=True):
     from localrf_amd import LocalTensorfs, losses as geo_losses
     from localrf_amd.dist import allreduce_grads, shard_views
     from localrf_amd.rays import N_to_reso
@@ -238,7 +239,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     if graph:
         from localrf_amd.graph_step import CapturedIteration
         gs = CapturedIteration(lt, W, H, batch // world, 16 // world, graph_loss, scalar_names=("reg_w",), optimize_poses=True)
-        gs.extra_signature = lambda: (phase["reg"],)
+        gs.extra_signature = lambda: (phase["reg"], bool(getattr(lt.tensorfs[-1], "fuse_density_L1", False)))
     n_added, last_add, it = 0, 0, 0
     drift, drift_prev = LateScalar(), 0.0
     all_losses = []
@@ -250,6 +251,9 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     res = int(lt.tensorfs[-1].gridSize[0])
     while training and (max_iters is None or it < max_iters):
         view_ids, ray_idx, (vv, pp) = data.sample(batch)
+        # the regulariser's gradient rides on the render's backward (TensorVMSplit.fuse_density_L1) whenever this iteration's
+        # loss will contain it: local_tensorfs.py:361-375
+        lt.tensorfs[-1].fuse_density_L1 = bool(fuse_l1 and lt.regularize and lt.rf_iter[-1] < lt.n_iters and L1_weight > 0)
         if gs is not None:                                             # the captured iteration: the same schedule calls around one replay
             all_views = view_ids.tolist()                              # every rank steps the poses of the whole batch's views
             if ddp:
@@ -423,6 +427,7 @@ def main():
     ap.add_argument("--n-max-frames", type=int, default=12, help="frames per field before refinement (the reference: 100)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--graph", action="store_true", help="the iteration as one replayed hipGraph (localrf_amd/graph_step.py)")
+    ap.add_argument("--no-fuse-l1", action="store_true", help="density_L1 as an autograd node of its own (A/B of TensorVMSplit.fuse_density_L1)")
     ap.add_argument("--no-geo", action="store_true", help="without the optical-flow / monocular-depth losses")
     ap.add_argument("--backend", default="nccl", help="under torchrun: nccl (= RCCL, one rank per GPU) or gloo (ranks may share a GPU)")
     args = ap.parse_args()
@@ -449,7 +454,7 @@ def main():
     if ddp and first:
         bar()
     out = run(frames=args.frames, final=args.final, iters_per_frame=args.iters_per_frame, max_iters=args.max_iters, n_max_frames=args.n_max_frames,
-              dev=f"cuda:{local}", ddp=ddp, geo=not args.no_geo, graph=args.graph, log=lambda m: print(m, file=sys.stderr, flush=True))
+              dev=f"cuda:{local}", ddp=ddp, geo=not args.no_geo, graph=args.graph, fuse_l1=not args.no_fuse_l1, log=lambda m: print(m, file=sys.stderr, flush=True))
     if not ddp or int(os.environ["RANK"]) == 0:
         print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o)))
         if args.json:

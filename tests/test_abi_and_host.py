@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     for name in declared:
         assert getattr(built_lib, name) is not None
-    assert built_lib.lrf_abi_version() == 6
+    assert built_lib.lrf_abi_version() == 7
 
 
 def test_cache_and_workspace_sizes(built_lib):

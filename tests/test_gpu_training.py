@@ -337,6 +337,49 @@ def test_density_l1_kernel_vs_reference_formula(grid, act):
     assert all(p.grad is None for n, p in f.named_parameters() if "density" not in n)
 
 
+def test_density_l1_riding_on_the_render_backward():
+    """TensorVMSplit.fuse_density_L1: the regulariser as a third output of the render's autograd node.  Same loss value and
+    the same gradients as the two separate nodes (the density tensors: render + regulariser, each summed in the same order,
+    added in one more place -- 1e-6 of the tensor's maximum), .grad of every parameter still a view of the ONE flat gradient
+    buffer (what the data-parallel exchange reduces in place: no rebucket_grads copy), the flag off or the value unused: the
+    plain paths."""
+    from util import make_field, make_rays
+    f = quiet(make_field, [40, 36, 44], "cpu", seed=5).to(DEV)
+    rays = make_rays(512, 3).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    gr, gd = torch.randn(512, 3, generator=gen).to(DEV), torch.randn(512, generator=gen).to(DEV)
+    z = f.z_schedule(False, -1, DEV)
+    f.z_override = z.clone()
+
+    def run(fuse, use_l1=True):
+        f.fuse_density_L1 = fuse
+        for p in f.parameters():
+            p.grad = None
+        rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=-1)
+        total = (rgb * gr).sum() + (depth * gd).sum()
+        l1 = f.density_L1() if use_l1 else None
+        if use_l1:
+            total = total + 0.37 * l1
+        total.backward()
+        return (None if l1 is None else float(l1.detach())), {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None}, f.grad_bucket()
+    try:
+        v0, g0, b0 = run(False)
+        v1, g1, b1 = run(True)
+        _, g2, b2 = run(True, use_l1=False)            # fused forward, value never used: the render's gradients alone
+        _, g3, _ = run(False, use_l1=False)
+    finally:
+        f.fuse_density_L1 = False
+        f.z_override = None
+    assert v0 == v1
+    assert b0 is None and b1 is not None and b2 is not None      # separate nodes: autograd's sums live outside the flat buffer
+    assert set(g0) == set(g1) == set(g2)
+    for n in g0:
+        den = float(g0[n].abs().max())
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-6 * den, (n, float((g0[n] - g1[n]).abs().max()) / den)
+        assert float((g2[n] - g3[n]).abs().max()) <= 1e-6 * float(g3[n].abs().max()), n
+    assert any(float((g1[n] - g2[n]).abs().max()) > 0 for n in g1 if "density" in n)   # the regulariser did contribute
+
+
 def test_pose_assemble_kernel_vs_torch_chain():
     """lrf_pose_assemble/_bwd against stack + sixD_to_mtx + cat (local_tensorfs.py:292-299), more
     frames than one launch holds, one frame used twice."""
