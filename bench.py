@@ -777,8 +777,9 @@ def main():
                     fb = lambda: field(big, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)   # noqa: E731
                     per = sorted(timed(fb, 1, 1 if i == 0 else 0, sync) for i in range(9))     # each step on its own: the median
                     d_big = per[4]                                                                  # is not moved by a one-off stall
-                work["batch_65536"] = {"what": "same field and sample count, 65536 rays per call (three launches: the tile offsets of "
-                                               "this many rays do not fit in LDS beside the weight image); median of 9 single steps",
+                work["batch_65536"] = {"what": "same field and sample count, 65536 rays per call: four chunks of 16384 rays alternating over two "
+                                               "streams (lrf_render_fwd's large-batch mode; three launches per chunk: the tile offsets of this many "
+                                               "rays do not fit in LDS beside the weight image); median of 9 single steps",
                                        "rays_per_s": 16 * R_PER_GPU / d_big, "ms_per_step": d_big * 1e3, "ms_min_max": [per[0] * 1e3, per[-1] * 1e3]}
                 del big
             except Exception as e:                           # noqa: BLE001

@@ -87,6 +87,7 @@ SYMBOLS = {
     "lrf_error_slot": (C.c_void_p, []),
     "lrf_debug_set_dump": (None, [C.c_void_p]),
     "lrf_debug_set_lds_lines": (None, [C.c_int]),
+    "lrf_debug_set_pipe_chunk": (None, [C.c_int]),
     "lrf_debug_set_scene_fuse": (None, [C.c_int]),
     "lrf_debug_saved_row_offset": (C.c_int64, [C.c_int, C.c_uint64, C.c_int]),
     "lrf_debug_set_bwd_overlap": (None, [C.c_int]),

@@ -912,6 +912,7 @@ static Workspace carve(void* ws, int R, int S) {
 // Test hooks (include/lrf_debug.h): process-wide, not part of the re-entrant ABI.
 static float* g_dump = nullptr;    // lrf_debug_set_dump: device buffer for the s_memtime totals of k_shade3<TIMED>
 static int g_no_lds_lines = 0;     // lrf_debug_set_lds_lines(0): k_march reads its lines from global memory
+static int g_pipe_chunk = 16384;    // lrf_debug_set_pipe_chunk: rays per chunk of lrf_render_fwd's large-batch mode (0: one pass over the whole batch, as rounds 1-5)
 static int g_no_scene_fuse = 0;    // lrf_debug_set_scene_fuse(0): lrf_scene_fwd renders field by field (the tests compare the two forms)
 
 static int device_cus() {                 // of the current device (one process may drive several)
@@ -1143,6 +1144,7 @@ int lrf_abi_version(void) { return LRF_ABI_VERSION; }
 void lrf_debug_set_dump(float* buf) { g_dump = buf; }
 void lrf_debug_set_bwd_overlap(int on) { g_bwd_overlap = (on & 1) ? 1 : 0; if (on > 1) g_wgrad_split = (on >> 1) - 1; }   // on = 1 + 2 * (n + 1): k_wgrad_w2w3 on the caller's stream (n > 0) or on the side stream (n = 0)
 void lrf_debug_set_lds_lines(int on) { g_no_lds_lines = on ? 0 : 1; }
+void lrf_debug_set_pipe_chunk(int rays) { g_pipe_chunk = rays > 0 ? rays : 0; }
 #ifdef LRF_SCATTER_PROF
 int lrf_debug_scatter_prof(unsigned long long* host_out /* [2][2048][12] */) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lrf::g_scat_prof), sizeof(unsigned long long) * 2 * 2048 * 12);
@@ -1194,7 +1196,19 @@ int lrf_pack_field(const LrfParams* p, void* cache, void* stream) {
   return 0;
 }
 
-size_t lrf_workspace_bytes(int32_t R, int32_t S) { return carve(nullptr, R, S).bytes; }
+// Large batches (full-frame evaluation: renderer.py:65-77 renders an image 4096 rays at a time) go through the two kernels
+// in chunks of g_pipe_chunk rays that alternate over the caller's stream and the side stream: a chunk's k_march and the
+// tail of its k_shade3 run beside the other stream's colour kernel (k_shade3 is one persistent workgroup per CU bound by
+// instruction issue at 46 %; k_march is latency / L2 bound).  65536 rays at configs[1]: 2.38 ms in one pass, 2.49 / 2.30 /
+// 2.24 / 2.26 / 2.30 ms in chunks of 4096 / 8192 / 16384 / 24576 / 32768 (scripts/pipe_chunk_probe.py; 262144 rays: 9.55 ->
+// 8.69 ms = 30.2 M rays/s); below two chunks of 16384 one pass is as fast or faster.  Every chunk has a workspace of its own
+// inside the caller's.
+static int pipe_chunks(int R) { return (g_pipe_chunk > 0 && R >= 2 * g_pipe_chunk) ? (R + g_pipe_chunk - 1) / g_pipe_chunk : 1; }
+size_t lrf_workspace_bytes(int32_t R, int32_t S) {
+  const size_t whole = carve(nullptr, R, S).bytes;
+  const int nc = pipe_chunks(R);
+  return nc > 1 ? std::max(whole, (size_t)nc * carve(nullptr, g_pipe_chunk, S).bytes) : whole;
+}
 
 // One batch of rays through k_march and the colour stage on `st`; ev (optional, lrf_render_fwd_profile): 4 events =
 // start, after k_march, after the colour kernel(s), end.
@@ -1242,8 +1256,26 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
 int lrf_render_fwd(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
                    uint32_t flags, float floater_thresh, float* rgb, float* depth,
                    float* weight_out, float* acc_out, void* workspace, void* stream) {
-  const int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out,
-                                 workspace, reinterpret_cast<hipStream_t>(stream), nullptr);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nc = (f && rays && rgb && depth && workspace && R > 0) ? pipe_chunks(R) : 1;
+  SideStream* ss = nc > 1 ? side_stream() : nullptr;
+  if (!ss) {
+    const int rc = render_fwd_impl(f, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out, workspace, st, nullptr);
+    return rc == 2 ? 0 : rc;
+  }
+  std::lock_guard<std::mutex> lk(ss->mu);
+  LRF_HIP(hipEventRecord(ss->fork, st));
+  LRF_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+  const size_t wb = carve(nullptr, g_pipe_chunk, S).bytes;
+  int rc = 0;
+  for (int c = 0; c < nc && (rc == 0 || rc == 2); ++c) {
+    const int r0 = c * g_pipe_chunk, rn = std::min(g_pipe_chunk, R - r0);
+    rc = render_fwd_impl(f, rays + (size_t)r0 * 6, z, rn, S, flags, floater_thresh, rgb + (size_t)r0 * 3, depth + r0,
+                         weight_out ? weight_out + (size_t)r0 * S : nullptr, acc_out ? acc_out + r0 : nullptr,
+                         static_cast<char*>(workspace) + (size_t)c * wb, (c & 1) ? ss->s : st, nullptr);
+  }
+  LRF_HIP(hipEventRecord(ss->join, ss->s));                  // (also after an error: the side stream is joined again)
+  LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   return rc == 2 ? 0 : rc;
 }
 

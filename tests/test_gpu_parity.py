@@ -650,6 +650,30 @@ def test_gradient_scatter_engines_agree_and_meet_the_reference(built_lib, name):
         check_grads(dens, {n: torch.from_numpy(g["grad." + n]).to(DEV) for n in dens}, 1e-4, subset=subset or None, gmax=gmax)
 
 
+@pytest.mark.parametrize("sort", [False, True])
+def test_large_batches_in_chunks_over_two_streams(built_lib, sort):
+    """lrf_render_fwd's large-batch mode (chunks alternating over the caller's stream and the side stream, a workspace each):
+    bit-identical to one pass over the whole batch -- rays are independent -- with a ragged last chunk, with and without ray
+    sorting, and the caller's stream is joined again (the result is read right behind the call on it)."""
+    from util import make_field, make_rays
+    f = quiet(make_field, [48, 40, 44], "cpu", seed=4).to(DEV)
+    f.sort_rays = sort
+    rays = torch.cat([make_rays(2048, 11 + i) for i in range(5)], 0)[:9000].to(DEV)
+    out = {}
+    try:
+        for chunk in (0, 2048):
+            built_lib.lrf_debug_set_pipe_chunk(chunk)
+            f._ws = None
+            with torch.no_grad():
+                rgb, depth = f(rays, white_bg=True, is_train=False, N_samples=96)
+            out[chunk] = (rgb.clone(), depth.clone())
+    finally:
+        built_lib.lrf_debug_set_pipe_chunk(16384)
+        f._ws = None
+    assert float(out[0][0].std()) > 0.01
+    assert torch.equal(out[0][0], out[2048][0]) and torch.equal(out[0][1], out[2048][1])
+
+
 @pytest.mark.parametrize("name", ["field_small_train_grad", "field_128_train_grad"])
 def test_weight_gradient_kernel_forms_agree(built_lib, name):
     """k_wgrad_w2w3 in its double-buffered 64-row form (the default) and in the single-buffered 128-row form of rounds 4-5
