@@ -784,6 +784,24 @@ def main():
                 del big
             except Exception as e:                           # noqa: BLE001
                 work["batch_65536"] = {"error": repr(e)}
+            try:                                             # the headline's batches, alternating over two streams (a workspace per stream)
+                sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+                rays_b = make_rays(R_PER_GPU, 9).to(dev)
+                state = {"k": 0}
+
+                def two():
+                    state["k"] ^= 1
+                    with torch.cuda.stream(sa if state["k"] else sb):
+                        field(rays if state["k"] else rays_b, white_bg=True, is_train=False, N_samples=N_SAMPLES_ARG)
+                with torch.no_grad():
+                    sa.wait_stream(torch.cuda.current_stream(dev)); sb.wait_stream(torch.cuda.current_stream(dev))
+                    per2 = sorted(timed(two, 40, 6 if i == 0 else 0, sync) / 40 for i in range(5))
+                work["two_streams_4096"] = {"what": "the headline's 4096-ray batches issued alternately on two streams (TensorVMSplit keeps a workspace per "
+                                                    "stream): k_march of one batch and the tail of its k_shade3 run beside the other stream's colour kernel; "
+                                                    "not the headline (one stream, one batch at a time); median of 5 x 40 batches",
+                                            "rays_per_s": R_PER_GPU / per2[2], "ms_per_batch": per2[2] * 1e3, "ms_min_max": [per2[0] * 1e3, per2[-1] * 1e3]}
+            except Exception as e:                           # noqa: BLE001
+                work["two_streams_4096"] = {"error": repr(e)}
             try:
                 lt, ray_ids, view_ids, bw = config3_scene(dev)
                 with torch.no_grad():

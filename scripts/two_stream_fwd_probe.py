@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Eval forward of BASELINE configs[1] issued on ONE stream against the same number of batches alternating over TWO streams
-(two field objects: separate workspaces): does k_march of one batch run beside k_shade3 of another?
+(one field: TensorVMSplit keeps a workspace per stream): does k_march of one batch run beside k_shade3 of another?
 python scripts/two_stream_fwd_probe.py [--grid 300] [--batches 200]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,8 @@ ap.add_argument("--samples", type=int, default=512)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--batches", type=int, default=200)
 a = ap.parse_args()
-fs = [quiet(make_field, [a.grid] * 3, "cpu", seed=0).to("cuda:0") for _ in range(2)]
+f0 = quiet(make_field, [a.grid] * 3, "cpu", seed=0).to("cuda:0")
+fs = [f0, f0]
 rays = [make_rays(a.rays, 1 + i).cuda() for i in range(2)]
 streams = [torch.cuda.Stream() for _ in range(2)]
 
