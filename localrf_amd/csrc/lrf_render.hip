@@ -1253,10 +1253,10 @@ static int render_fwd_impl(const LrfField* f, const float* rays, const float* z,
   return 0;
 }
 
-int lrf_render_fwd(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
-                   uint32_t flags, float floater_thresh, float* rgb, float* depth,
-                   float* weight_out, float* acc_out, void* workspace, void* stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// render_fwd_impl, large batches in chunks over two streams (see lrf_workspace_bytes); 0 or an error code
+static int render_fwd_pipelined(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                                uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                                float* weight_out, float* acc_out, void* workspace, hipStream_t st) {
   const int nc = (f && rays && rgb && depth && workspace && R > 0) ? pipe_chunks(R) : 1;
   SideStream* ss = nc > 1 ? side_stream() : nullptr;
   if (!ss) {
@@ -1277,6 +1277,13 @@ int lrf_render_fwd(const LrfField* f, const float* rays, const float* z, int32_t
   LRF_HIP(hipEventRecord(ss->join, ss->s));                  // (also after an error: the side stream is joined again)
   LRF_HIP(hipStreamWaitEvent(st, ss->join, 0));
   return rc == 2 ? 0 : rc;
+}
+
+int lrf_render_fwd(const LrfField* f, const float* rays, const float* z, int32_t R, int32_t S,
+                   uint32_t flags, float floater_thresh, float* rgb, float* depth,
+                   float* weight_out, float* acc_out, void* workspace, void* stream) {
+  return render_fwd_pipelined(f, rays, z, R, S, flags, floater_thresh, rgb, depth, weight_out, acc_out, workspace,
+                              reinterpret_cast<hipStream_t>(stream));
 }
 
 // LocalTensorfs.forward without a tape (local_tensorfs.py:397-499) as ONE call: the rays of every active field, the
@@ -1325,9 +1332,9 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
       if (n % 16) {                                            // a ragged last chunk: field by field
         for (int k = 0; k < n_rf; ++k) {
           const LrfSceneField& sf = fields[k];
-          rc = render_fwd_impl(sf.field, rays + ((size_t)k * R + lo) * 6, sf.z, n, sf.S, sf.flags, floater_thresh,
-                               rgb_f + ((size_t)k * R + lo) * 3, depth_f + (size_t)k * R + lo, nullptr, nullptr, sf.workspace, st, nullptr);
-          if (rc != 0 && rc != 2) return rc;
+          rc = render_fwd_pipelined(sf.field, rays + ((size_t)k * R + lo) * 6, sf.z, n, sf.S, sf.flags, floater_thresh,
+                                    rgb_f + ((size_t)k * R + lo) * 3, depth_f + (size_t)k * R + lo, nullptr, nullptr, sf.workspace, st);
+          if (rc) return rc;
         }
         continue;
       }
@@ -1353,9 +1360,9 @@ int lrf_scene_fwd(const int64_t* ray_ids, int32_t R, int32_t per_view, const flo
     const int32_t n = R - lo < chunk ? R - lo : chunk;
     for (int k = 0; k < n_rf; ++k) {
       const LrfSceneField& sf = fields[k];
-      rc = render_fwd_impl(sf.field, rays + ((size_t)k * R + lo) * 6, sf.z, n, sf.S, sf.flags, floater_thresh,
-                           rgb_f + ((size_t)k * R + lo) * 3, depth_f + (size_t)k * R + lo, nullptr, nullptr, sf.workspace, st, nullptr);
-      if (rc != 0 && rc != 2) return rc;
+      rc = render_fwd_pipelined(sf.field, rays + ((size_t)k * R + lo) * 6, sf.z, n, sf.S, sf.flags, floater_thresh,   // (chunks of 32768 rays and more: over two streams)
+                                rgb_f + ((size_t)k * R + lo) * 3, depth_f + (size_t)k * R + lo, nullptr, nullptr, sf.workspace, st);
+      if (rc) return rc;
     }
   }
   return lrf_scene_blend(rgb_f, depth_f, blend_w, exposure, R, per_view, n_rf, rgbs, depth, nullptr, stream);

@@ -166,7 +166,11 @@ class CapturedIteration:
         finally:
             field.jitter_override = None
             lt.freeze_intrinsics = frozen
-        total.backward()
+        # (the seed of the backward: autograd's own ones_like is a fill launch per iteration -- 4.8 us of a captured replay)
+        one = getattr(self, "_one", None)
+        if one is None or one.device != total.device or one.dtype != total.dtype or one.shape != total.shape:
+            one = self._one = torch.ones_like(total)
+        total.backward(gradient=one)
         if lt.grad_sync is not None:
             # Data parallel: with a regulariser in the loss autograd leaves the density tensors' .grad in a tensor of its own
             # (regulariser + render), not in the flat buffer the exchange reduces in place.  Bringing them back HERE -- under

@@ -1096,6 +1096,37 @@ def test_trajectory_replay_vs_reference_golden():
     assert e_rgb < 5e-4 and e_dep < 1e-3
 
 
+def test_full_frame_scene_forward_in_chunks_over_two_streams(built_lib):
+    """A whole view through LocalTensorfs.forward without a tape (renderer.py:65-77 hands the scene an image at a time; one
+    active field: lrf_scene_fwd's per-field path): chunks of 32768 rays and more are rendered in pieces of 16384 alternating
+    over two streams -- bit-identical to the one-pass form (lrf_debug_set_pipe_chunk(0)), ragged last piece included."""
+    from localrf_amd import LocalTensorfs
+    W, H = 256, 164                                              # 41984 rays: 16384 + 16384 + 9216
+    aabb = 2 * torch.tensor([[-1.0, -1, -1], [1, 1, 1]]).to(DEV)
+    torch.manual_seed(3)
+    lt = quiet(LocalTensorfs, fov=85.6, n_init_frames=3, n_overlap=1, WH=(W, H), n_iters_per_frame=600, n_iters_reg=100,
+               lr_R_init=5e-3, lr_t_init=5e-4, lr_i_init=0, lr_exposure_init=1e-3, rf_lr_init=0.02, rf_lr_basis=1e-3,
+               lr_decay_target_ratio=0.1, N_voxel_list={}, update_AlphaMask_list=[], camera_prior=None, device=DEV,
+               lr_upsample_reset=True, aabb=aabb, gridSize=[40, 44, 36], **FIELD_KW).to(DEV)
+    ray_ids = torch.arange(W * H, device=DEV)
+    view_ids = torch.tensor([1], device=DEV)
+    out = {}
+    try:
+        for chunk in (0, 16384):
+            built_lib.lrf_debug_set_pipe_chunk(chunk)
+            for f in lt.tensorfs:
+                f._ws = None
+            with torch.no_grad():
+                out[chunk] = [t.clone() for t in lt(ray_ids, view_ids, W, H, is_train=False, white_bg=True, chunk=65536)]
+    finally:
+        built_lib.lrf_debug_set_pipe_chunk(16384)
+        for f in lt.tensorfs:
+            f._ws = None
+    assert float(out[0][0].std()) > 1e-3
+    for a, b in zip(out[0], out[16384]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("chunk,min_chunk,test_id", [(16384, 65536, False), (192, 1, False), (4096, 65536, True)])
 def test_scene_forward_single_native_call_equals_the_per_field_path(chunk, min_chunk, test_id):
     """lrf_scene_fwd (what LocalTensorfs.forward calls when no gradient is recorded: rays of every active field, the
