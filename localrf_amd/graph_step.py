@@ -53,12 +53,15 @@ class StaticInputs:
         self._np = [{n: h.numpy()[o:o + b].view(_NP[dt]).reshape(sh) for n, (o, b, sh, dt) in offs.items()} for h in self._host]
         self._ev = [None] * ring
         self._next = 0
+        self.wait_s = 0.0
 
     def stage(self):
         k = self._next
         self._next = (k + 1) % len(self._host)
         if self._ev[k] is not None:
+            t0 = time.perf_counter()
             self._ev[k].synchronize()                             # (a copy issued `ring` iterations ago: long done)
+            self.wait_s += time.perf_counter() - t0               # ~0 over a run = the host never waited: the loop is host-bound
         return k, self._np[k]
 
     def push(self, k):
@@ -129,6 +132,8 @@ class CapturedIteration:
                   "frame": ((self.n_views,), torch.int64), "frame32": ((2, self.n_views), torch.int32),
                   "adam": ((len(self.plan), 2), torch.float32),
                   "scalars": ((max(1, len(self.scalar_names)),), torch.float32)}
+        if getattr(self, "inputs", None) is not None:
+            self.stats["stage_wait_s"] = self.stats.get("stage_wait_s", 0.0) + self.inputs.wait_s
         self.inputs = StaticInputs(dev, fields)
         self.u1 = torch.empty(1, h, dtype=torch.float32, device=dev)
         self.u2 = torch.empty(1, h, dtype=torch.float32, device=dev)
@@ -284,7 +289,9 @@ class CapturedIteration:
                     self._graphs = (self._capture(self._forward_backward), self._capture(self._adam))
                 self.stats["captures"] += 1
                 self.stats["capture_host_s"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
             self._graphs[0].replay()
+            self.stats["replay_host_s"] = self.stats.get("replay_host_s", 0.0) + time.perf_counter() - t0    # (launch + any back-pressure of the queue)
             if sync is not None:
                 field._grad_fresh = True                          # (set by the backward's Python, which a replay does not run)
                 sync(lt)

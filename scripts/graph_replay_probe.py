@@ -27,6 +27,12 @@ if gs._graphs is not None:
     for _ in range(300): g.replay()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 300 * 1e3
     print(f"graph replay back to back: {dt:.4f} ms per iteration at {out['final_resolution']}^3, nodes unknown")
+    # sustained: blocks of 500 replays, seconds apart from the start -- does the chip hold its clock when it is never idle?
+    for blk in range(8):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(500): g.replay()
+        torch.cuda.synchronize()
+        print(f"  sustained block {blk}: {(time.perf_counter() - t0) / 500 * 1e3:.4f} ms per replay", flush=True)
     # the same work launched eagerly, for the GPU time of the kernels alone (host-bound or not, the stream drains at the end)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()

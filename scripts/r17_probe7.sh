@@ -10,6 +10,8 @@ for E in ${ENGS:-1}; do
   python - <<PY
 import json
 d = json.load(open("$O/train_graph_eng$E.json"))
-print("eng $E", {k: round(v, 3) for k, v in d["ms_per_iteration_by_resolution"].items()}, "loss", d["loss_last"])
+print("eng $E", {k: round(v, 3) for k, v in d["ms_per_iteration_by_resolution"].items()}, "loss", d["loss_last"], "host: %.2f s inside replay(), waited %.2f (input ring) + %.2f (late reads) s of %.2f s" % (d["graph"].get("replay_host_s", -1), d["graph"].get("stage_wait_s", -1), d.get("late_reads_wait_s", -1), sum(d["ms_per_iteration_by_resolution"][k] * d["iterations_by_resolution"][k] for k in d["iterations_by_resolution"]) / 1e3))
+print("   host ms per iteration:", {r: {k: round(x, 3) for k, x in v.items()} for r, v in d.get("host_ms_per_iteration_by_resolution", {}).items()})
+print("   pace:", " ".join("%d:%.2f" % (a, b) for a, b in d.get("ms_per_iteration_by_250", [])))
 PY
 done

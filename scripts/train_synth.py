@@ -157,10 +157,44 @@ class LateScalar:
             self.ev = torch.cuda.Event()
         self.ev.record()
 
+    waited = 0.0                                                      # (class-wide: seconds the host spent waiting in value())
+
     def value(self):
         if self.ev is not None:
+            t0 = time.perf_counter()
             self.ev.synchronize()
+            LateScalar.waited += time.perf_counter() - t0
         return float(self.pin[0])
+
+
+class LateLog:
+    """Logged device values read one logging period late (the captured loop): put(tensors, sink) enqueues their copy into
+    pinned memory behind the replay that produced them; the values reach `sink(floats)` at the next put() / flush().  A
+    float(tensor) per logged value drains the stream -- the GPU then idles for the host's share of an iteration, every 25
+    iterations, twice in the regularised phase."""
+
+    def __init__(self, width=4):
+        self.pin = torch.zeros(width, pin_memory=True)
+        self.ev = None
+        self.pending = None
+
+    def flush(self):
+        if self.pending is not None:
+            t0 = time.perf_counter()
+            self.ev.synchronize()
+            LateScalar.waited += time.perf_counter() - t0
+            n, sink = self.pending
+            sink([float(x) for x in self.pin[:n]])
+            self.pending = None
+
+    def put(self, tensors, sink):
+        self.flush()
+        for i, t in enumerate(tensors):
+            self.pin[i:i + 1].copy_(t.detach().reshape(-1)[:1] if t.numel() == 1 else t.detach().sum().reshape(1), non_blocking=True)
+        if self.ev is None:
+            self.ev = torch.cuda.Event()
+        self.ev.record()
+        self.pending = (len(tensors), sink)
 
 
 def geometric_terms(lt, data, depth_map, directions, ij, cam2world_all, view_ids, start, vsel, psel, W, H):
@@ -244,13 +278,19 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
     drift, drift_prev = LateScalar(), 0.0
     all_losses = []
     losses, per_res, events, geo_vals, geo_curve = [], {}, [], [], []
+    late_geo, late_loss = LateLog(), LateLog()
+    LateScalar.waited = 0.0
     torch.cuda.reset_peak_memory_stats(dev)
     mem_marks = []
     training = True
     t_mark, it_mark = time.perf_counter(), 0
-    res = int(lt.tensorfs[-1].gridSize[0])
+    res = int(lt.tensorfs[-1]._grid_host[0])                          # (the host copy: gridSize itself is a device tensor, as in the reference -- reading it drains the stream)
+    pace = []
+    host_t = {}                                                        # res -> seconds of host time by section of the loop body (captured loop)
     while training and (max_iters is None or it < max_iters):
+        tq0 = time.perf_counter()
         view_ids, ray_idx, (vv, pp) = data.sample(batch)
+        tq1 = time.perf_counter()
         # the regulariser's gradient rides on the render's backward (TensorVMSplit.fuse_density_L1) whenever this iteration's
         # loss will contain it: local_tensorfs.py:361-375
         lt.tensorfs[-1].fuse_density_L1 = bool(fuse_l1 and lt.regularize and lt.rf_iter[-1] < lt.n_iters and L1_weight > 0)
@@ -262,13 +302,21 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             reg_w = lt.lr_factor ** lt.rf_iter[-1]
             start = max(data.active_frames_bounds[0] - 1, 0)
             pose_ids, tune = lt.step_begin(True, zero_grad=False)
+            tq2 = time.perf_counter()
             kept = gs.step(view_ids.tolist(), ray_idx.numpy(), {"reg_w": reg_w}, all_poses_active=phase["reg"] and geo,
                            pose_ids=pose_ids, tune_intrinsics=tune, start=start, global_views=all_views)
+            tq3 = time.perf_counter()
             lt.step_schedule()
             can_add_rf = lt.step_finish()
+            tq4 = time.perf_counter()
+            ht = host_t.setdefault(res, [0.0, 0.0, 0.0, 0.0, 0.0, 0])
+            ht[0] += tq1 - tq0; ht[1] += tq2 - tq1; ht[2] += tq3 - tq2; ht[3] += tq4 - tq3; ht[5] += 1
             loss = kept["photo"]
             if phase["reg"] and geo:
-                geo_vals.append((float(kept["flow"].sum()) / kept["geo_norm"], float(kept["depth"].sum()) / kept["geo_norm"]) if it % geo_every == 0 else None)
+                geo_vals.append(None)
+                if it % geo_every == 0:                                # (read one period late: no drain)
+                    slot, norm = len(geo_vals) - 1, kept["geo_norm"]
+                    late_geo.put([kept["flow"], kept["depth"]], lambda v, slot=slot, norm=norm: geo_vals.__setitem__(slot, (v[0] / norm, v[1] / norm)))
         else:
             # indices go up through pinned memory: indexing a device tensor with host indices (or any pageable
             # host->device copy, as train.py:352-358 does) blocks the host until the stream has drained
@@ -325,7 +373,7 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                                 "rot_step_deg": float(torch.rad2deg(torch.acos(cosang))[ok].mean()) if ok.any() else 0.0}
                     geo_curve.append({**diag, "it": it, "field": len(lt.tensorfs) - 1, "rf_iter": int(lt.rf_iter[-1]), "refining": bool(lt.is_refining),
                                       "reg_w": float(reg_w), "flow": geo_vals[-1][0], "depth": geo_vals[-1][1], "photo": float(loss.detach()),
-                                      "frames": [lo, hi], "res": int(lt.tensorfs[-1].gridSize[0]),
+                                      "frames": [lo, hi], "res": int(lt.tensorfs[-1]._grid_host[0]),
                                       "pose_err": float(rel.norm(dim=-1).mean()), "est_step": float(step_est), "true_step": 0.04})
             if lt.regularize:
                 tv, l1 = lt.get_reg_loss(None, 0.0, 0.0, L1_weight)         # train.py:425-429, opt.py:111-113
@@ -361,8 +409,12 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                 training = False
         if record_all:                                                 # (tests: every iteration's photometric loss; synchronises)
             all_losses.append(float(loss.detach()))
+        if gs is not None:
+            host_t[res][4] += time.perf_counter() - tq4                # (drift read, frame / field appends of this iteration)
         it += 1
-        new_res = int(lt.tensorfs[-1].gridSize[0])
+        if it % 250 == 0:
+            pace.append((it, time.perf_counter()))                     # (the host's pace: at most four iterations ahead of the GPU)
+        new_res = int(lt.tensorfs[-1]._grid_host[0])                   # (host copy: int(gridSize[0]) here drained the stream on EVERY iteration -- host and GPU took turns, 0.15 ms of every captured iteration)
         if new_res != res or not training or (max_iters is not None and it == max_iters):
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t_mark
@@ -372,11 +424,18 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
                 e["s"] += dt
             mem_marks.append((it, torch.cuda.memory_allocated(dev)))
             t_mark, it_mark, res = time.perf_counter(), it, new_res
-        if it % 25 == 0:
+        if it % 25 == 0 and gs is not None:                               # the captured loop logs one period late
+            def sink(v, it=it, res=res, nf=len(lt.tensorfs), nfr=len(lt.r_c2w)):
+                losses.append(v[0])
+                if log and rank == 0:
+                    log(f"it {it} loss {v[0]:.4f} res {res} fields {nf} frames {nfr}")
+            late_loss.put([loss], sink)
+        elif it % 25 == 0:
             losses.append(float(loss.detach()))
             if log and rank == 0:
                 log(f"it {it} loss {losses[-1]:.4f} res {res} fields {len(lt.tensorfs)} frames {len(lt.r_c2w)}")
     torch.cuda.synchronize(dev)
+    late_geo.flush(); late_loss.flush()
     if live is not None:                                               # (probes: the live objects of the run)
         live.update(scene=lt, captured=gs, data=data)
     # data parallel: replicas must hold the SAME parameters -- every rank applied the same reduced gradients.  max |p - p of
@@ -412,7 +471,10 @@ def run(frames=24, W=64, H=48, n_init=5, final=300, iters_per_frame=60, batch=40
             "geometric_losses": {"iterations_with_them": len(geo_vals), "flow_first_last": [v[0] for v in geo_vals if v][:1] + [v[0] for v in geo_vals if v][-1:],
                                  "depth_first_last": [v[1] for v in geo_vals if v][:1] + [v[1] for v in geo_vals if v][-1:]},
             "geo_curve": geo_curve, "geo_by_field": geo_by_field(geo_curve),
-            "graph": (dict(gs.stats) if gs is not None else None), "all_losses": all_losses,
+            "late_reads_wait_s": LateScalar.waited,
+            "ms_per_iteration_by_250": [[b[0], round(1e3 * (b[1] - a[1]) / 250, 4)] for a, b in zip(pace, pace[1:])],
+            "host_ms_per_iteration_by_resolution": {str(r): {"sample": 1e3 * v[0] / max(1, v[5]), "prepare": 1e3 * v[1] / max(1, v[5]), "step": 1e3 * v[2] / max(1, v[5]),
+                                                             "schedule": 1e3 * v[3] / max(1, v[5]), "rest": 1e3 * v[4] / max(1, v[5])} for r, v in host_t.items()}, "graph": (dict(gs.stats, stage_wait_s=gs.stats.get("stage_wait_s", 0.0) + (gs.inputs.wait_s if getattr(gs, "inputs", None) is not None else 0.0)) if gs is not None else None), "all_losses": all_losses,
             "param_checksum": float(sum(p.detach().double().abs().sum() for p in lt.parameters())),
             "checkpoint_roundtrip": bool(same), "checkpoint_keys_follow_reference": bool(keys_ok), "world": world,
             "final_resolution": res, "replica_divergence": divergence}
