@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void seg_sum4(float& v0, float& v1, float& v2, float&
                : "v"(r.m1), "v"(r.m2), "v"(r.m4), "v"(r.m8));
 #undef LRF_STEP
 }
-template <int C, bool APP, int NT>
+template <int C, bool APP, int NT, int CH = LRF_CD>
 __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, ScatterDst dst, const float* __restrict__ rays,
                                                      const float* __restrict__ z, int S, const int* __restrict__ offs,
                                                      const uint32_t* __restrict__ list, const float* __restrict__ gf,
@@ -1397,8 +1397,9 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
   // runs are formed again in every sweep (~a quarter of a sweep's instructions).  (Sweeping the workgroup's whole SHARE
   // three times instead -- 8-channel line accumulators -- fetched every 128-byte line of taps and dX rows three times from
   // beyond L2: 1.57 GB of counter traffic for the two scatter kernels against 0.88 GB with the compare-and-swap kernels.)
-  constexpr int CH = LRF_CD;                            // channels per sweep
-  static_assert(C % CH == 0 && (APP ? C == LRF_CA : C == LRF_CD), "8 channels per sweep");
+  // CH: channels per sweep.  8, or 4 for the appearance tensors of grids whose lines do not fit beside an 8-channel tile (lines of
+  // 480 .. 640 cells: six sweeps per tile, the tile 34.8 KB; the dX block's 8-channel groups are read in halves)
+  static_assert(C % CH == 0 && (CH == 8 || (APP && CH == 4)) && (APP ? C == LRF_CA : C == LRF_CD), "8 (or 4) channels per sweep");
   constexpr int CELLS = BCELL * BCELL;
   extern __shared__ unsigned long long s_fx[];          // [CH][CELLS] tile (of the sweep), then [C][L_p] line
   unsigned long long* s_fl = s_fx + CH * CELLS;
@@ -1465,8 +1466,12 @@ __global__ __launch_bounds__(NT) void k_scatter_fix(DField f, BinGeom bg, Scatte
       const uint32_t cid = APP ? rowinfo[row] : row;
       float dx[CH];                                     // d(loss)/d(feature of channel c): one scalar for the density, the row's dX for the appearance
       if (APP) {
-        const float* dxp = grd_dx8(grd, row, p, sweep);
-        ld4g(dxp, dx); ld4g(dxp + 4, dx + 4);
+        if constexpr (CH == 8) {
+          const float* dxp = grd_dx8(grd, row, p, sweep);
+          ld4g(dxp, dx); ld4g(dxp + 4, dx + 4);
+        } else {
+          ld4g(grd_dx8(grd, row, p, sweep >> 1) + 4 * (sweep & 1), dx);
+        }
       } else {
         const float g = gf[cid];
 #pragma unroll
@@ -1645,7 +1650,7 @@ static hipError_t launch_shade_save(DField d, const float* rays, const float* z,
 
 }  // namespace lrf
 
-extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : 3); lrf::g_dgrad_dbg = (e >> 5) & 7; lrf::g_wgrad_kt = (e & 512) ? 128 : 64; }
+extern "C" void lrf_debug_set_train_fwd_engine(int e) { lrf::g_scatter_fused = (e & 8) ? 0 : 1; lrf::g_scatter_fix = (e & 16) ? 0 : ((e & 256) ? 1 : ((e & 1024) ? 7 : 3)); lrf::g_dgrad_dbg = (e >> 5) & 7; lrf::g_wgrad_kt = (e & 512) ? 128 : 64; }
 
 namespace lrf {
 // floats per row of weight-gradient operands when the backward runs the generic engine (any non-default network, or
@@ -1747,6 +1752,8 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CA, true, FIX_NT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_fix<LRF_CA, true, FIX_NT, 4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3<128>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)w23_lds(128));
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_w2w3<64>),
@@ -1826,7 +1833,11 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   // in LDS (lines up to 479 cells): forward + backward 1.26 -> 1.12 ms at 64^3, 1.36 -> 1.29 at 300^3, on par with the
   // compare-and-swap kernel at 400^3-460^3 (profiles/r17_fixed_point_scatter.md); above that the compare-and-swap kernel stays
   const size_t lds_fa = 2 * lds_dp + sizeof(unsigned long long) * LRF_CA * ll_max;
-  const bool fix_a = fix_d && (g_scatter_fix & 2) && lds_fa <= 158 * 1024;
+  const bool fix_a8 = fix_d && (g_scatter_fix & 2) && lds_fa <= 158 * 1024;
+  // ... and with FOUR channels per sweep (six sweeps, a 34.8 KB tile) where only that leaves room for the lines: 480 .. 640 cells
+  const size_t lds_fa4 = lds_dp + sizeof(unsigned long long) * LRF_CA * ll_max;
+  const bool fix_a4 = fix_d && (g_scatter_fix & 2) && !fix_a8 && !(g_scatter_fix & 4) && lds_fa4 <= 158 * 1024;
+  const bool fix_a = fix_a8 || fix_a4;
   unsigned* vmax_a = reinterpret_cast<unsigned*>(b.hist2 + 2 * BIN_MAX);
   if (fix_a)
     hipLaunchKernelGGL((k_train_app3<8, true>), dim3(n_dgrad_wg), dim3(512), app3_lds_bytes(S, 8, bg.total), st, d,
@@ -1916,8 +1927,11 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
   const int npass = (flags & LRF_FLAG_PLANE_EVENTS) ? 3 : 1;
   for (int q = 0; q < npass; ++q) {
     const int blo = npass == 1 ? 0 : bg.base[q], bhi = (npass == 1 || q == 2) ? bg.total : bg.base[q + 1];
-    if (fix_a) {
+    if (fix_a8) {
       hipLaunchKernelGGL((k_scatter_fix<LRF_CA, true, FIX_NT>), dim3(cus), dim3(FIX_NT), lds_fa, st,
+                         d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, vmax_a, blo, bhi);
+    } else if (fix_a4) {
+      hipLaunchKernelGGL((k_scatter_fix<LRF_CA, true, FIX_NT, 4>), dim3(cus), dim3(FIX_NT), lds_fa4, st,
                          d, bg, dst_a, rays, z, S, b.offs2, b.list2, b.feat, b.rowinfo, b.grd, vmax_a, blo, bhi);
     } else if (fuse_a) {
       hipLaunchKernelGGL((k_scatter_plane<LRF_CA, true, LRF_APP_NT, true>), dim3(cus), dim3(LRF_APP_NT), lds_ap + lds_al, st,

@@ -99,7 +99,7 @@ def test_shade3_shape(asm):
 def test_scratch_use_is_bounded(asm):
     for pat, limit in ((r"k_marchILb1ELb0EE", 0), (r"k_marchILb0ELb0EE", 0),
                        (r"k_train_dgrad3ILi8EE", 0), (r"k_train_app3ILi8ELb0EE", 0), (r"k_train_app3ILi8ELb1EE", 0),
-                       (r"k_scatter_fixILi8ELb0ELi1024EE", 0), (r"k_scatter_fixILi24ELb1ELi1024EE", 0), (r"k_adam_packE", 0)):
+                       (r"k_scatter_fixILi8ELb0ELi1024ELi8EE", 0), (r"k_scatter_fixILi24ELb1ELi1024ELi8EE", 0), (r"k_adam_packE", 0)):
         for name, _ in _body(asm, pat):
             meta = asm[asm.index(".amdhsa_kernel " + name):]
             meta = meta[:meta.index(".end_amdhsa_kernel")]
