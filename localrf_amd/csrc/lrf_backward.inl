@@ -936,13 +936,26 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
 #pragma unroll
     for (int p = 0; p < 3; ++p) tv[q][p] = i < n ? tid[(size_t)p * nmax + i] : (unsigned short)0xffff;
   }
+  // rank of every entry among its block's entries of the same tile.  A wave's 64 entries are consecutive samples (or rows) of
+  // a ray and mostly share their tile: one returning LDS atomic per lane put up to 64 lanes on one address -- serialised,
+  // ~100 us of the density pass on a field without empty space.  The lanes of a RUN of equal ids take their ranks from ONE
+  // atomic of the run's first lane (its length), the others add their position in the run.
   int rank[PER][3];
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int q = 0; q < PER; ++q)
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      rank[q][p] = -1;
-      if (tv[q][p] != 0xffff) rank[q][p] = atomicAdd(&s_h[bg.base[p] + tv[q][p]], 1);
+      const int key = tv[q][p];
+      const int prev = __shfl_up(key, 1, 64);
+      const unsigned long long starts = __ballot(lane == 0 || prev != key);
+      const int leader = 63 - __builtin_clzll(starts & (~0ull >> (63 - lane)));
+      const unsigned long long above = lane == 63 ? 0ull : (starts >> (lane + 1));
+      const int len = (above ? lane + 1 + __builtin_ctzll(above) : 64) - leader;      // (read by the run's first lane only)
+      int base = 0;
+      if (lane == leader && key != 0xffff) base = atomicAdd(&s_h[bg.base[p] + key], len);
+      base = __shfl(base, leader, 64);
+      rank[q][p] = key != 0xffff ? base + (lane - leader) : -1;
     }
   __syncthreads();
   for (int i = threadIdx.x; i < bg.total; i += 256)          // (all of a thread's atomics in flight together: measured, slower -- 16.7 against 13.6 us)
