@@ -101,13 +101,16 @@ typedef struct LrfField {
 } LrfField;
 
 /* Gradients wrt the reference's parameters, in the reference's (state-dict) layout.
- * Accumulated into (+=); caller zeroes. */
+ * Accumulated into (+=); the caller zeroes them -- or (ABI 7) names ONE range that holds all of them (the flat gradient
+ * buffer of localrf_amd: parameters' gradients and d/d rays) and lrf_render_bwd clears it with the launch that clears its own
+ * bins: zero_base (16-byte aligned) / zero_floats (a multiple of 4), NULL / 0 = the caller cleared. */
 typedef struct LrfGrads {
   float* density_plane[3];
   float* density_line[3];
   float* app_plane[3];
   float* app_line[3];
   float* basis; float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;
+  float* zero_base; int64_t zero_floats;
 } LrfGrads;
 
 int         lrf_abi_version(void);

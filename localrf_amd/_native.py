@@ -44,7 +44,8 @@ class LrfSceneField(C.Structure):
 class LrfGrads(C.Structure):
     _fields_ = [("density_plane", _f * 3), ("density_line", _f * 3),
                 ("app_plane", _f * 3), ("app_line", _f * 3),
-                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f)]
+                ("basis", _f), ("w1", _f), ("b1", _f), ("w2", _f), ("b2", _f), ("w3", _f), ("b3", _f),
+                ("zero_base", _f), ("zero_floats", C.c_int64)]
 
 
 LRF_ADAM_MAX = 64

@@ -975,10 +975,22 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
 // iterations ahead of the device can wrap -- profiles/r18_memset_fault.md: in the progressive loop the density histogram came
 // back filled with a stale 16-byte pattern instead of zeros (once, at the first capture behind a lifecycle event), the fill
 // pass then indexed the entry list 4 GB out of bounds: "Memory access fault by GPU node".
+// The same launch clears the caller's gradient buffer when LrfGrads names it (zero_base / zero_floats: one range that holds
+// every gradient the backward adds into): blocks behind the bins' take 2048 float4 each.
 constexpr int BIN_CLEAR_WORDS = 2 * BIN_MAX + 8;
-__global__ __launch_bounds__(256) void k_clear_bins(int* __restrict__ h0, int* __restrict__ h1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < BIN_CLEAR_WORDS) { h0[i] = 0; h1[i] = 0; }
+constexpr int BIN_CLEAR_BLOCKS = (BIN_CLEAR_WORDS + 255) / 256, ZERO_F4_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void k_clear_bins(int* __restrict__ h0, int* __restrict__ h1, float4* __restrict__ zero_base, long long zero_f4) {
+  if (blockIdx.x < BIN_CLEAR_BLOCKS) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < BIN_CLEAR_WORDS) { h0[i] = 0; h1[i] = 0; }
+    return;
+  }
+  const long long b0 = (long long)(blockIdx.x - BIN_CLEAR_BLOCKS) * ZERO_F4_PER_BLOCK;
+#pragma unroll
+  for (int k = 0; k < ZERO_F4_PER_BLOCK / 256; ++k) {
+    const long long i = b0 + k * 256 + threadIdx.x;
+    if (i < zero_f4) zero_base[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
 }
 
 // Plane gradients.  The entry lists are sorted by tile; workgroup w owns the w-th equal share
@@ -1807,7 +1819,13 @@ extern "C" int lrf_render_bwd(const LrfField* f, const LrfParams* p, const float
     dst_d.plane[q] = g->density_plane[q]; dst_d.line[q] = g->density_line[q];
     dst_a.plane[q] = g->app_plane[q]; dst_a.line[q] = g->app_line[q];
   }
-  hipLaunchKernelGGL(k_clear_bins, dim3((BIN_CLEAR_WORDS + 255) / 256), dim3(256), 0, st, b.hist, b.hist2);     // (in front of the fork: both branches count into these)
+  if (g->zero_floats < 0 || (g->zero_floats & 3) || (g->zero_floats && (!g->zero_base || (reinterpret_cast<uintptr_t>(g->zero_base) & 15))))
+    return set_err("lrf_render_bwd: LrfGrads.zero_base / zero_floats must name a 16-byte aligned range of a multiple of 4 floats (or NULL / 0)");
+  {
+    const long long zf4 = g->zero_floats / 4;
+    const unsigned nblk_clear = (unsigned)(BIN_CLEAR_BLOCKS + (zf4 + ZERO_F4_PER_BLOCK - 1) / ZERO_F4_PER_BLOCK);
+    hipLaunchKernelGGL(k_clear_bins, dim3(nblk_clear), dim3(256), 0, st, b.hist, b.hist2, reinterpret_cast<float4*>(g->zero_base), zf4);     // (in front of the fork: both branches count into these)
+  }
   hipStream_t sb = st;
   if (ss) {
     LRF_HIP(hipEventRecord(ss->fork, st));

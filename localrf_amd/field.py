@@ -569,7 +569,9 @@ class TensorVMSplit(torch.nn.Module):
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + (n + 63) // 64 * 64)
-        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        # lrf_render_bwd clears the buffer itself (LrfGrads.zero_base, with the launch that clears its bins) -- except for an
+        # empty batch, where it is not called
+        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev) if R > 0 else torch.zeros(offs[-1], dtype=torch.float32, device=dev)
         grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(keep)]
         g_rays = flat[offs[-2]:offs[-2] + R * 6].view(R, 6)
         # (the view tensors themselves are NOT kept: autograd adopts an incoming gradient as .grad without a copy only while
@@ -602,6 +604,8 @@ class TensorVMSplit(torch.nn.Module):
             cg.app_plane[i] = grads[6 + i].data_ptr()
             cg.app_line[i] = grads[9 + i].data_ptr()
         (cg.basis, cg.w1, cg.b1, cg.w2, cg.b2, cg.w3, cg.b3) = [g.data_ptr() for g in grads[12:]]
+        flat = self._grad_flat["flat"]
+        cg.zero_base, cg.zero_floats = flat.data_ptr(), flat.numel()          # (offsets are multiples of 64 floats: so is the total)
         nbytes = lib.lrf_workspace_bytes_bwd_cfg(R, S, cp.grid, int(self.fea_pe), int(self.view_pe), int(self.featureC), flags)
         if saved_ws is not None:                 # filled by lrf_render_fwd_train for exactly this call
             ws = saved_ws

@@ -59,7 +59,7 @@ class _SceneRaysFn(torch.autograd.Function):
         g_rays = _f32c(g_rays)
         g_dirs = None if g_dirs is None else _f32c(g_dirs)
         g_c2w = torch.empty(V, 3, 4, dtype=torch.float32, device=dev)
-        g_intr = torch.zeros(V, 3, dtype=torch.float32, device=dev)
+        g_intr = torch.empty(V, 3, dtype=torch.float32, device=dev)        # (every entry is written: k_scene_rays_bwd, one block per view)
         g_w2rf = torch.empty(V, n_rf, 3, dtype=torch.float32, device=dev)
         N.check(N.lib().lrf_scene_rays_bwd(ids.data_ptr(), R, per_view, N.ptr(c2w), n_rf, N.ptr(fo), N.ptr(ce),
                                            W, H, fov360, N.ptr(g_rays), N.ptr(g_dirs), N.ptr(g_c2w),
