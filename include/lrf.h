@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LRF_ABI_VERSION 7      /* 7: lrf_density_l1_bwd_acc; 6: lrf_batch_gather, lrf_loss_combine_*, lrf_adam_step_pack; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
+#define LRF_ABI_VERSION 7      /* 7: lrf_density_l1_bwd_acc, LrfGrads.zero_base / zero_floats; 6: lrf_batch_gather, lrf_loss_combine_*, lrf_adam_step_pack; 5: lrf_scene_fwd takes a scene workspace (fused multi-field launches), LRF_FLAG_PLANE_EVENTS, lrf_render_bwd_wait buckets 3 / 4, lrf_adam_step_dev, lrf_photo_loss_*, lrf_rows_gather*; 4: lrf_z_schedule, training rows = feat + gradient row only (ACT_LD 32), network configuration in LrfParams / LrfField, lrf_workspace_bytes_bwd_cfg; 3: lrf_render_bwd_wait, unknown flag bits rejected */
 #define LRF_MAX_S 4096         /* samples per ray accepted by lrf_render_fwd */
 #define LRF_MAX_S_TRAIN 2048   /* ... by lrf_render_fwd_train / lrf_render_bwd (16 B of LDS per sample and ray) */
 
