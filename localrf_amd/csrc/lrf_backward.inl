@@ -971,10 +971,10 @@ __global__ __launch_bounds__(256) void k_bin_fill(BinGeom bg, uint32_t nmax, int
 }
 
 // Histogram + cursors + max|contribution| word of both counting sorts, cleared by ONE launch on the caller's stream in front
-// of the fork.  NOT hipMemsetAsync: the runtime's fill reads its pattern from a staging ring that a host running several
-// iterations ahead of the device can wrap -- profiles/r18_memset_fault.md: in the progressive loop the density histogram came
-// back filled with a stale 16-byte pattern instead of zeros (once, at the first capture behind a lifecycle event), the fill
-// pass then indexed the entry list 4 GB out of bounds: "Memory access fault by GPU node".
+// of the fork.  NOT hipMemsetAsync: the runtime's fill reads its pattern from a staging slot, and in the captured progressive
+// loop the density histogram came back filled with a stale 16-byte pattern -- another dispatch's kernel arguments -- instead
+// of zeros (in the first graph behind a lifecycle event, profiles/r18_memset_fault.md); the fill pass then indexed the entry
+// list 4 GB out of bounds: "Memory access fault by GPU node".
 // The same launch clears the caller's gradient buffer when LrfGrads names it (zero_base / zero_floats: one range that holds
 // every gradient the backward adds into): blocks behind the bins' take 2048 float4 each.
 constexpr int BIN_CLEAR_WORDS = 2 * BIN_MAX + 8;

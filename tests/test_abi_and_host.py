@@ -324,7 +324,7 @@ def test_untaped_chunk_honours_the_caller_beyond_the_workspace_bound(built_lib):
 
 def test_no_runtime_fill_or_copy_in_the_library_sources():
     """profiles/r18_memset_fault.md: a hipMemsetAsync in the backward filled the counting sort's histogram with a stale
-    pattern when the host ran iterations ahead of the device (memory access fault in the captured progressive loop).  The
+    pattern -- another dispatch's kernel arguments -- instead of zeros (memory access fault in the captured progressive loop).  The
     library clears and moves its buffers with its own kernels; nothing in csrc may call the runtime's fill / copy."""
     src_dir = os.path.join(ROOT, "localrf_amd", "csrc")
     bad = []
